@@ -1,0 +1,101 @@
+"""Deterministic synthetic frames / weights / descriptor banks.
+
+There is no dataset or checkpoint on the GPU box, and torch's RNG streams differ
+between CPU and GPU, so everything synthetic is produced by an integer hash
+(splitmix64 over the element index) that gives bit-identical float32 values on
+any machine.  Golden fixtures (tests/golden) are generated from, and checked
+against, exactly these tensors.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _MASK
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform(seed: int, shape, lo: float = -1.0, hi: float = 1.0) -> np.ndarray:
+    """float32 array, uniform in [lo, hi), exactly reproducible."""
+    n = int(np.prod(shape))
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = _splitmix64(idx ^ _splitmix64(np.full(1, seed, dtype=np.uint64)))
+    u = (h >> np.uint64(40)).astype(np.float64) * (1.0 / (1 << 24))  # 24-bit mantissa: exact in f32
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def normalish(seed: int, shape, std: float = 1.0) -> np.ndarray:
+    """Sum of four uniforms, scaled to the requested std (bell-shaped, bounded)."""
+    acc = np.zeros(int(np.prod(shape)), dtype=np.float64)
+    for j in range(4):
+        acc += uniform(seed * 4 + j, (acc.size,)).astype(np.float64)
+    # var of one U(-1,1) = 1/3 -> sum of 4 has std sqrt(4/3)
+    return (acc * (std / np.sqrt(4.0 / 3.0))).astype(np.float32).reshape(shape)
+
+
+def frames(seed: int, n: int, cfg) -> np.ndarray:
+    """[n, C, H, W] float32 in [-1, 1): what vit_transform (infer/src/transform.py:37-42,
+    Normalize(0.5, 0.5)) hands to the model."""
+    return uniform(seed, (n, cfg.channels, cfg.image_size, cfg.image_size))
+
+
+def encoder_weights(seed: int, cfg) -> dict:
+    """Random-init weights in the canonical naming of vsc_hip/weights.py.
+
+    The q/k projections are drawn wider than HF's 0.02 so the softmax is not
+    near-uniform (a flat softmax would hide attention bugs)."""
+    d, m = cfg.width, cfg.mlp_dim
+    s = seed * 1000
+    w = {}
+
+    def nxt():
+        nonlocal s
+        s += 1
+        return s
+
+    w["patch.weight"] = normalish(nxt(), (d, cfg.channels, cfg.patch_size, cfg.patch_size), 0.03)
+    if cfg.patch_bias:
+        w["patch.bias"] = normalish(nxt(), (d,), 0.02)
+    w["cls"] = normalish(nxt(), (d,), 0.3)
+    w["pos"] = normalish(nxt(), (cfg.tokens, d), 0.3)
+    if cfg.pre_ln:
+        w["ln_pre.weight"] = 1.0 + normalish(nxt(), (d,), 0.05)
+        w["ln_pre.bias"] = normalish(nxt(), (d,), 0.05)
+    for i in range(cfg.layers):
+        b = f"blocks.{i}."
+        w[b + "ln1.weight"] = 1.0 + normalish(nxt(), (d,), 0.05)
+        w[b + "ln1.bias"] = normalish(nxt(), (d,), 0.05)
+        qkv = normalish(nxt(), (3 * d, d), 0.03)
+        qkv[: 2 * d] *= 3.0
+        w[b + "qkv.weight"] = qkv
+        w[b + "qkv.bias"] = normalish(nxt(), (3 * d,), 0.05)
+        w[b + "proj.weight"] = normalish(nxt(), (d, d), 0.03)
+        w[b + "proj.bias"] = normalish(nxt(), (d,), 0.02)
+        w[b + "ln2.weight"] = 1.0 + normalish(nxt(), (d,), 0.05)
+        w[b + "ln2.bias"] = normalish(nxt(), (d,), 0.05)
+        w[b + "fc1.weight"] = normalish(nxt(), (m, d), 0.03)
+        w[b + "fc1.bias"] = normalish(nxt(), (m,), 0.05)
+        w[b + "fc2.weight"] = normalish(nxt(), (d, m), 0.02)
+        w[b + "fc2.bias"] = normalish(nxt(), (d,), 0.02)
+    w["ln_post.weight"] = 1.0 + normalish(nxt(), (d,), 0.05)
+    w["ln_post.bias"] = normalish(nxt(), (d,), 0.05)
+    if cfg.out_dim:
+        w["head.weight"] = normalish(nxt(), (cfg.out_dim, d), 0.05)
+        w["head.bias"] = normalish(nxt(), (cfg.out_dim,), 0.02)
+    return w
+
+
+def descriptor_bank(seed: int, n: int, dim: int = 512, l2: bool = True) -> np.ndarray:
+    """[n, dim] float32 bank; rows L2-normalised like emitted descriptors."""
+    x = normalish(seed, (n, dim))
+    if l2:
+        x = x / np.maximum(np.linalg.norm(x.astype(np.float64), axis=1, keepdims=True), 1e-30)
+    return np.ascontiguousarray(x, dtype=np.float32)
