@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the descriptor-track hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Primary workload (BASELINE.json configs[1]): ViT-B/16 224x224 bf16 encode, synthetic
+frames resident in HBM, random-init weights.  One step = one batch of --batch frames
+per GPU through vsc_encoder_forward (patchify .. L2-normalised 512-d descriptors).
+Frames shard across ranks with no data-path collective ("weak" scaling: per-GPU work
+fixed); value = frames of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel = the bf16 GEMM (gemm_bf16_kernel, all five call sites);
+                achieved = algorithmic FLOPs of those launches / their HIP-event time
+                measured inside the timed steps; peak = 2500 TFLOP/s dense bf16 MFMA.
+  cpu_baseline  the fp32 oracle (oracle/vit_oracle.py, a port) on the host cores, on a
+                bounded sample of the same frames.
+  search        secondary metric: exact 512-d inner-product top-100 sweep
+                (vsc_knn_ip_f32), Mpairs/s, with its own fp32-MFMA roofline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "vsc22-submission_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--preset", default="vit_b16_224")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-search", action="store_true")
+    ap.add_argument("--search-nq", type=int, default=16384)
+    ap.add_argument("--search-nr", type=int, default=1_000_000)
+    ap.add_argument("--search-k", type=int, default=100)
+    ap.add_argument("--search-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def gemm_flops_per_frame(cfg):
+    t, d, m = cfg.tokens, cfg.width, cfg.mlp_dim
+    return {
+        "gemm_patch": 2 * (t - 1) * cfg.patch_dim * d,
+        "gemm_qkv": cfg.layers * 2 * t * d * 3 * d,
+        "gemm_proj": cfg.layers * 2 * t * d * d,
+        "gemm_fc1": cfg.layers * 2 * t * d * m,
+        "gemm_fc2": cfg.layers * 2 * t * d * m,
+    }
+
+
+def cpu_baseline(cfg, weights, frames_np, budget_s=15.0):
+    from oracle import vit_oracle
+    torch.set_num_threads(os.cpu_count() or 1)
+    w = {k: torch.from_numpy(v) for k, v in weights.items()}
+    x = torch.from_numpy(frames_np)
+    with torch.no_grad():
+        vit_oracle.descriptors(w, cfg, x[:2])  # warm the thread pool / allocator
+        t0 = time.perf_counter()
+        vit_oracle.descriptors(w, cfg, x[:4])
+        per4 = time.perf_counter() - t0
+        n = int(max(4, min(len(x), 4 * (budget_s / max(per4, 1e-3)) // 4 * 4)))
+        t0 = time.perf_counter()
+        for i in range(0, n, 4):
+            vit_oracle.descriptors(w, cfg, x[i:i + 4])
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{n} of the bench frames, fp32 torch oracle, batches of 4"}
+
+
+def bench_search(dev, args):
+    from src import synth
+    from vsc_hip import ops
+    d = 512
+    nq, nr, k = args.search_nq, args.search_nr, args.search_k
+    g = torch.Generator(device="cpu").manual_seed(1)
+    r = torch.randn(nr, d, generator=g).to(dev)
+    q = torch.randn(nq, d, generator=g).to(dev)
+    ops.l2_normalize_(r)
+    ops.l2_normalize_(q)
+    ops.knn_ip(q[:256], r[:4096], k)  # allocate + warm
+    ops.knn_ip(q, r, k)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(args.search_steps):
+        D, I = ops.knn_ip(q, r, k)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / args.search_steps
+    pairs = nq * nr
+    tflops = 2.0 * pairs * d / (ms * 1e-3) / 1e12
+    return {"metric": "Mpairs/s (512-d exact inner-product top-k sweep)",
+            "value": round(pairs / (ms * 1e-3) / 1e6, 1), "unit": "Mpairs/s", "nq": nq, "nr": nr,
+            "k": k, "dtype": "f32", "ms_per_sweep": round(ms, 3),
+            "roofline": {"bound": "mfma", "kernel": "knn_kernel (v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(tflops, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(tflops / F32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None,
+                         "note": "event time covers pack + knn_kernel + merge of one call"}}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+
+    from src import synth
+    from vsc_hip import _lib
+    from vsc_hip.config import get_config
+    from vsc_hip.encoder import HipEncoder
+
+    _lib.require_device()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    cfg = get_config(args.preset)
+    weights = synth.encoder_weights(7, cfg)
+    enc = HipEncoder(cfg, weights, max_batch=args.batch, l2_normalize=True)
+    # every rank encodes its own shard of the (synthetic) frame set
+    base = synth.frames(1000 + rank, 32, cfg)
+    frames = torch.from_numpy(base).to(dev).repeat((args.batch + 31) // 32, 1, 1, 1)[: args.batch]
+    frames = (frames + 0.001 * torch.arange(args.batch, device=dev).view(-1, 1, 1, 1)).contiguous()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        enc(frames)
+    barrier()
+    enc.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = enc(frames)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = enc.get_profile()
+    enc.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        total_frames = args.steps * args.batch * world
+        fpf = gemm_flops_per_frame(cfg)
+        gemm_ms = sum(prof[k][0] for k in fpf)
+        gemm_flops = sum(fpf.values()) * args.steps * args.batch
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        per_class = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // args.steps,
+                         "avg_launch_us": round(1e3 * v[0] / max(v[1], 1), 2)}
+                     for k, v in prof.items() if v[1]}
+        for k in fpf:
+            per_class[k]["tflops"] = round(fpf[k] * args.batch * args.steps / (prof[k][0] * 1e-3) / 1e12, 1)
+        line = {
+            "metric": "frames/s (ViT-B/16 224x224 encode -> L2-normalised 512-d descriptors)",
+            "value": round(total_frames / dt, 1), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{cfg.name} bf16 encode, {args.batch} synthetic "
+                                   f"{cfg.image_size}x{cfg.image_size} frames per step per GPU "
+                                   "(BASELINE.json configs[1])",
+                       "frames_per_step_per_gpu": args.batch, "tokens": cfg.tokens,
+                       "gflop_per_frame": round(cfg.flops_per_frame() / 1e9, 2),
+                       "parallelism": f"frames sharded over {world} rank(s), no data-path collective"},
+            "model_tflops": round(cfg.flops_per_frame() * total_frames / dt / 1e12 / world, 1),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (patch/qkv/proj/fc1/fc2 launches)",
+                         "achieved": round(achieved, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "gemm_ms_per_step": round(gemm_ms / args.steps, 3)},
+            "kernels": per_class,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, weights, base)
+        if not args.no_search:
+            enc.close()
+            del frames
+            torch.cuda.empty_cache()
+            line["search"] = bench_search(dev, args)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/* vsc_hip.h -- C ABI of libvsc_hip.so, the MI355X (gfx950) hot path of the VSC22
+ * descriptor track.  Plain pointers and sizes only; every pointer named *_dev is
+ * device memory on the current HIP device, `stream` is a hipStream_t passed as
+ * void* (NULL = default stream).  Every entry point returns 0 on success and a
+ * negative vsc_status otherwise; vsc_last_error() gives the message of the last
+ * failure on the calling thread.  Nothing here falls back to the CPU.
+ *
+ * Each entry point names the reference interface it replaces
+ * (paths relative to /root/reference/VSC22-Descriptor-Track-1st).
+ */
+#ifndef VSC_HIP_H
+#define VSC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vsc_status {
+    VSC_OK = 0,
+    VSC_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+    VSC_ERR_HIP = -2,         /* a HIP runtime call failed */
+    VSC_ERR_NO_DEVICE = -3,   /* no gfx950 device visible */
+    VSC_ERR_STATE = -4,       /* call order (e.g. forward before finalize) */
+    VSC_ERR_NOMEM = -5
+} vsc_status;
+
+const char *vsc_last_error(void);
+/* Number of visible HIP devices whose arch is gfx950; <0 on runtime failure. */
+int vsc_device_count(void);
+const char *vsc_version(void);
+
+/* ------------------------------------------------------------------------ *
+ * Frame encoder: replaces `flat_features = model(flat_frames)` on the
+ * TorchScript backbones -- infer/src/extractor.py:23, infer/extract_query_feats.py:150
+ * (single_infer) and :171 (clip_model) -- for ViT-family backbones
+ * (train/train_v115/vsc/baseline/model_factory/backbones/vit.py:10-54,
+ *  train/train_vid_score/video/clip.py:82-161).
+ * ------------------------------------------------------------------------ */
+typedef struct vsc_encoder vsc_encoder;
+
+typedef struct vsc_encoder_config {
+    int32_t image_size;   /* square input, pixels */
+    int32_t patch_size;
+    int32_t channels;     /* 3 */
+    int32_t width;        /* multiple of 64; head_dim must be 64 */
+    int32_t layers;
+    int32_t heads;
+    int32_t mlp_dim;      /* multiple of 64 */
+    int32_t out_dim;      /* Linear head outputs; 0 = emit the pooled feature */
+    float ln_eps;
+    int32_t act;          /* 0 = exact GELU (HF/timm), 1 = QuickGELU (clip.py:22) */
+    int32_t pre_ln;       /* 1 = CLIP ln_pre after the position embedding */
+    int32_t patch_bias;   /* 0 = bias-free patch conv (CLIP) */
+    int32_t pool;         /* 0 = GeM over all tokens (vit.py:52), 1 = CLS token */
+    float gem_p;
+    int32_t max_batch;    /* frames per internal step; workspace is sized for it */
+    int32_t l2_normalize; /* 1 = emit sklearn-style L2-normalised descriptors */
+} vsc_encoder_config;
+
+int vsc_encoder_create(const vsc_encoder_config *cfg, vsc_encoder **out);
+void vsc_encoder_destroy(vsc_encoder *enc);
+
+/* Upload one weight tensor (float32, host memory, canonical names and layouts of
+ * vsc_hip/weights.py: "patch.weight", "blocks.3.qkv.bias", "head.weight" ...).
+ * `count` is the number of float32 elements and is checked against the config. */
+int vsc_encoder_set_weight(vsc_encoder *enc, const char *name, const float *host, size_t count);
+/* Check completeness, build the bf16 device copies.  Required before forward. */
+int vsc_encoder_finalize(vsc_encoder *enc);
+
+/* frames_dev: float32 [n, channels, image, image], already normalised as
+ * infer/src/transform.py does.  desc_dev: float32 [n, desc_dim] where desc_dim =
+ * out_dim ? out_dim : width.  Asynchronous on `stream`. */
+int vsc_encoder_forward(vsc_encoder *enc, const float *frames_dev, int64_t n, float *desc_dev,
+                        void *stream);
+/* Same, but also copies the last hidden state (after the final LayerNorm),
+ * float32 [n, tokens, width], for parity tests.  tokens_dev may be NULL. */
+int vsc_encoder_forward_debug(vsc_encoder *enc, const float *frames_dev, int64_t n,
+                              float *desc_dev, float *tokens_dev, void *stream);
+int64_t vsc_encoder_workspace_bytes(const vsc_encoder *enc);
+
+/* Per-kernel-class timing for bench.py's roofline: when on, every launch of
+ * vsc_encoder_forward is bracketed by HIP events on the caller's stream.
+ * vsc_encoder_get_profile synchronises the device, then returns the accumulated
+ * milliseconds and launch counts per class since profiling was switched on. */
+typedef enum vsc_prof_class {
+    VSC_PROF_PATCHIFY = 0, VSC_PROF_GEMM_PATCH = 1, VSC_PROF_LAYERNORM = 2, VSC_PROF_GEMM_QKV = 3,
+    VSC_PROF_ATTENTION = 4, VSC_PROF_GEMM_PROJ = 5, VSC_PROF_GEMM_FC1 = 6, VSC_PROF_GEMM_FC2 = 7,
+    VSC_PROF_POOL_HEAD = 8, VSC_PROF_MISC = 9, VSC_PROF_CLASSES = 10
+} vsc_prof_class;
+int vsc_encoder_set_profiling(vsc_encoder *enc, int32_t on);
+int vsc_encoder_get_profile(vsc_encoder *enc, double ms_out[VSC_PROF_CLASSES],
+                            int64_t launches_out[VSC_PROF_CLASSES]);
+
+/* ------------------------------------------------------------------------ *
+ * Flat inner-product search: replaces faiss.IndexFlat(d, METRIC_INNER_PRODUCT)
+ *   .search(x, k)        infer/vsc/index.py:167-175, infer/vsc/baseline/score_normalization.py:95,141,
+ *                        infer/vsc/exhaustive_search.py:66 (the k = 1024 probe of range_search_gpu)
+ * Scores are the ascending-k float32 fmaf chain (bit-identical to
+ * oracle/knn_oracle.c); ties rank the lower reference index first.
+ * ------------------------------------------------------------------------ */
+
+/* q_dev [nq,d], r_dev [nr,d] float32 row-major, 1 <= d <= 4096, 1 <= k <= 1024.  out_scores_dev [nq,k] float32 descending, out_ids_dev [nq,k]
+ * int64; slots beyond nr hold (-FLT_MAX, -1).  ref_id_offset is added to every
+ * reported id (a shard of a larger bank).  Workspace is allocated internally and
+ * cached on the calling thread's device. */
+int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d,
+                   int32_t k, int64_t ref_id_offset, float *out_scores_dev,
+                   int64_t *out_ids_dev, void *stream);
+
+/* sklearn.preprocessing.normalize(x) in place (l2, axis=1; zero rows untouched):
+ * infer/extract_query_feats.py:178, infer/vsc/baseline/score_normalization.py:84-88. */
+int vsc_l2_normalize_f32(float *x_dev, int64_t n, int32_t d, void *stream);
+
+/* ------------------------------------------------------------------------ *
+ * Building blocks, exported so the parity tests can check each kernel alone.
+ * bf16 tensors are raw uint16 bit patterns.
+ * ------------------------------------------------------------------------ */
+typedef enum vsc_epilogue {
+    VSC_EPI_BF16 = 0,        /* out bf16 = acc + bias */
+    VSC_EPI_GELU_BF16 = 1,   /* out bf16 = gelu(acc + bias) */
+    VSC_EPI_QGELU_BF16 = 2,  /* out bf16 = quick_gelu(acc + bias) */
+    VSC_EPI_RESADD_F32 = 3,  /* out f32  = residual + acc + bias (out may alias residual) */
+    VSC_EPI_PATCH_F32 = 4    /* out f32 row n*T+1+p = acc + bias + pos[1+p] (row = n*(T-1)+p) */
+} vsc_epilogue;
+
+/* out[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]);  A, W bf16 row-major, K % 64 == 0,
+ * N % 4 == 0.  bias may be NULL.  `aux_dev` = residual (RESADD) or pos (PATCH),
+ * `tokens` = T for PATCH. */
+int vsc_gemm_bf16(const uint16_t *a_dev, const uint16_t *w_dev, const float *bias_dev,
+                  const float *aux_dev, void *out_dev, int64_t m, int32_t n, int32_t k,
+                  int32_t epilogue, int32_t tokens, void *stream);
+
+/* qkv_dev bf16 [frames*tokens, 3*width] (q | k | v column blocks, head-major inside
+ * each) -> out_dev bf16 [frames*tokens, width]; softmax(q k^T / 8) v per head;
+ * head_dim 64. */
+int vsc_attention_bf16(const uint16_t *qkv_dev, uint16_t *out_dev, int32_t frames, int32_t tokens,
+                       int32_t heads, void *stream);
+
+/* Row LayerNorm over `width` of float32 x [rows,width]; out is bf16 (out_f32 = 0)
+ * or float32 (out_f32 = 1; may alias x). */
+int vsc_layernorm_f32(const float *x_dev, const float *gamma_dev, const float *beta_dev,
+                      void *out_dev, int64_t rows, int32_t width, float eps, int32_t out_f32,
+                      void *stream);
+
+/* frames float32 [n,C,H,W] -> patches bf16 [n*grid*grid, kpad], k = c*p*p + py*p + px,
+ * zero-filled up to kpad (kpad % 64 == 0). */
+int vsc_patchify_bf16(const float *frames_dev, uint16_t *patches_dev, int64_t n, int32_t channels,
+                      int32_t image, int32_t patch, int32_t kpad, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSC_HIP_H */

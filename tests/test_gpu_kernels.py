@@ -1,0 +1,173 @@
+"""Per-kernel parity on a real MI355X, through the C ABI (vsc_hip.ops -> libvsc_hip.so).
+
+Floating-point kernels are compared with a plain PyTorch fp32 statement of the same
+op on the same (bf16-rounded) inputs; tolerances are written next to each check.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from src import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from vsc_hip import _lib
+    _lib.require_device()  # fails loudly if the HIP path cannot run
+    return torch.device("cuda:0")
+
+
+def _rand(seed, shape, std=1.0):
+    return torch.from_numpy(synth.normalish(seed, shape, std))
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (200, 132, 128), (1000, 768, 768),
+                                   (5043, 2304, 768), (37, 512, 3072), (1, 4, 64)])
+def test_gemm_bf16_store(dev, m, n, k):
+    from vsc_hip import ops, _lib
+    a = _rand(1, (m, k)).to(torch.bfloat16)
+    w = _rand(2, (n, k), 0.05).to(torch.bfloat16)
+    b = _rand(3, (n,))
+    ref = a.float() @ w.float().t() + b
+    out = ops.gemm_bf16(a.to(dev), w.to(dev), b.to(dev), epilogue=_lib.EPI_BF16).float().cpu()
+    # fp32 accumulation, one bf16 rounding of the result: |err| <= 2^-8 |ref| + accumulation noise
+    torch.testing.assert_close(out, ref, rtol=2 ** -7, atol=2e-3)
+
+
+def test_gemm_is_not_transposed(dev):
+    """A = identity-like selector, asymmetric W: catches row/col swaps in the epilogue."""
+    from vsc_hip import ops, _lib
+    m = n = 192
+    k = 256
+    a = torch.zeros(m, k)
+    a[torch.arange(m), torch.arange(m)] = 1.0
+    w = (torch.arange(n).float()[:, None] * 0.5 + torch.arange(k).float()[None, :] * 0.001953125)
+    out = ops.gemm_bf16(a.to(dev), w.to(dev), None, epilogue=_lib.EPI_BF16).float().cpu()
+    ref = a.to(torch.bfloat16).float() @ w.to(torch.bfloat16).float().t()
+    torch.testing.assert_close(out, ref.to(torch.bfloat16).float(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("epi", ["gelu", "qgelu"])
+def test_gemm_activation_epilogues(dev, epi):
+    from vsc_hip import ops, _lib
+    m, n, k = 300, 512, 128
+    a = _rand(4, (m, k)).to(torch.bfloat16)
+    w = _rand(5, (n, k), 0.1).to(torch.bfloat16)
+    b = _rand(6, (n,), 0.1)
+    z = a.float() @ w.float().t() + b
+    if epi == "gelu":
+        ref, code = torch.nn.functional.gelu(z), _lib.EPI_GELU_BF16
+    else:
+        ref, code = z * torch.sigmoid(1.702 * z), _lib.EPI_QGELU_BF16
+    out = ops.gemm_bf16(a.to(dev), w.to(dev), b.to(dev), epilogue=code).float().cpu()
+    torch.testing.assert_close(out, ref, rtol=2 ** -7, atol=2e-3)
+
+
+def test_gemm_residual_epilogue_in_place(dev):
+    from vsc_hip import ops, _lib
+    m, n, k = 517, 768, 3072
+    a = _rand(7, (m, k)).to(torch.bfloat16)
+    w = _rand(8, (n, k), 0.02).to(torch.bfloat16)
+    b = _rand(9, (n,), 0.1)
+    res = _rand(10, (m, n))
+    ref = res + a.float() @ w.float().t() + b
+    x = res.clone().to(dev)
+    out = ops.gemm_bf16(a.to(dev), w.to(dev), b.to(dev), epilogue=_lib.EPI_RESADD_F32, aux=x, out=x)
+    assert out.data_ptr() == x.data_ptr()
+    # fp32 out; only the accumulation order differs
+    torch.testing.assert_close(x.cpu(), ref, rtol=1e-5, atol=2e-4)
+
+
+def test_gemm_patch_epilogue(dev):
+    from vsc_hip import ops, _lib
+    frames, tokens, n, k = 3, 17, 128, 768
+    a = _rand(11, (frames * (tokens - 1), k)).to(torch.bfloat16)
+    w = _rand(12, (n, k), 0.03).to(torch.bfloat16)
+    b = _rand(13, (n,), 0.1)
+    pos = _rand(14, (tokens, n), 0.3)
+    z = (a.float() @ w.float().t() + b).reshape(frames, tokens - 1, n) + pos[1:]
+    out = ops.gemm_bf16(a.to(dev), w.to(dev), b.to(dev), epilogue=_lib.EPI_PATCH_F32, aux=pos.to(dev),
+                        tokens=tokens).cpu().reshape(frames, tokens, n)
+    torch.testing.assert_close(out[:, 1:], z, rtol=1e-5, atol=2e-4)
+    assert torch.count_nonzero(out[:, 0]) == 0  # CLS rows are not this kernel's to write
+
+
+def test_gemm_rejects_bad_k(dev):
+    from vsc_hip import ops, _lib
+    with pytest.raises(_lib.VscHipError, match="multiple of 64"):
+        ops.gemm_bf16(torch.zeros(4, 100, device=dev), torch.zeros(8, 100, device=dev))
+
+
+@pytest.mark.parametrize("frames,tokens,heads", [(2, 17, 2), (3, 197, 12), (1, 145, 12), (2, 257, 16),
+                                                 (1, 1, 1), (2, 32, 3)])
+def test_attention(dev, frames, tokens, heads):
+    from vsc_hip import ops
+    d = heads * 64
+    qkv = _rand(20 + tokens, (frames * tokens, 3 * d))
+    qkv[:, : 2 * d] *= 2.0  # peaky-ish softmax
+    qkv = qkv.to(torch.bfloat16)
+    q, k, v = qkv.float().reshape(frames, tokens, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) / math.sqrt(64)
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(frames * tokens, d)
+    out = ops.attention_bf16(qkv.to(dev), frames, tokens, heads).float().cpu()
+    # P is rounded to bf16 before PV and the output is bf16: 2^-8 relative on O(1) values
+    torch.testing.assert_close(out, ref, rtol=2 ** -6, atol=1e-2)
+    assert (out - ref).abs().mean() < 2e-3
+
+
+def test_attention_spiked_key(dev):
+    """One key dominates one query (forces a large max); padded keys must stay masked."""
+    from vsc_hip import ops
+    frames, tokens, heads = 1, 197, 1
+    qkv = _rand(31, (tokens, 192), 0.3)
+    qkv[5, :64] = 6.0
+    qkv[100, 64:128] = 6.0  # q5 . k100 = 64*36/8 = 288 -> softmax one-hot on key 100
+    qkv = qkv.to(torch.bfloat16)
+    out = ops.attention_bf16(qkv.to(dev), frames, tokens, heads).float().cpu()
+    torch.testing.assert_close(out[5], qkv[100, 128:].float(), rtol=2 ** -7, atol=1e-3)
+    assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("rows,width", [(5, 128), (1000, 768), (3, 1024), (7, 2048)])
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_layernorm(dev, rows, width, out_f32):
+    from vsc_hip import ops
+    x = _rand(40, (rows, width), 2.0) + 0.5
+    g = 1.0 + _rand(41, (width,), 0.1)
+    b = _rand(42, (width,), 0.1)
+    for eps in (1e-12, 1e-6):
+        ref = torch.nn.functional.layer_norm(x, (width,), g, b, eps)
+        out = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), eps, out_f32).float().cpu()
+        if out_f32:
+            torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+        else:
+            torch.testing.assert_close(out, ref.to(torch.bfloat16).float(), rtol=2 ** -7, atol=1e-5)
+
+
+@pytest.mark.parametrize("preset", ["tiny", "vit_b16_224", "clip_vit_l14_224"])
+def test_patchify_bit_exact(dev, preset):
+    from oracle import vit_oracle
+    from vsc_hip import ops
+    from vsc_hip.config import get_config
+    cfg = get_config(preset)
+    x = torch.from_numpy(synth.frames(50, 2, cfg))
+    kpad = (cfg.patch_dim + 63) // 64 * 64
+    out = ops.patchify_bf16(x.to(dev), cfg.patch_size, kpad).cpu()
+    ref = vit_oracle.patchify(x, cfg.patch_size).reshape(-1, cfg.patch_dim).to(torch.bfloat16)
+    assert torch.equal(out[:, : cfg.patch_dim].view(torch.int16), ref.view(torch.int16))
+    assert torch.count_nonzero(out[:, cfg.patch_dim:].float()) == 0
+
+
+def test_l2_normalize(dev):
+    from oracle import knn_oracle
+    from vsc_hip import ops
+    x = synth.normalish(60, (1001, 512))
+    x[17] = 0.0
+    out = ops.l2_normalize_(torch.from_numpy(x).to(dev)).cpu().numpy()
+    ref = knn_oracle.l2_normalize(x)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-6)  # only the reduction order differs
+    assert not out[17].any()

@@ -1,0 +1,206 @@
+// Fused multi-head self-attention for ViT token counts (T <= 320), head_dim 64:
+//   out[f, t, h*64:(h+1)*64] = softmax(q k^T / 8) v          per frame f and head h
+// (the reference runs this inside the TorchScript backbone as HF ViTSelfAttention /
+//  nn.MultiheadAttention, train/train_vid_score/video/clip.py:31-47).
+//
+// CDNA4 mapping: one workgroup (4 waves) per (frame, head).
+//   * K [T,64] is staged row-major into LDS with the same 16-byte-chunk XOR swizzle as the
+//     GEMM tiles (conflict-free ds_read_b128 fragment reads); V is staged TRANSPOSED
+//     ([64][Tpad] bf16) so the PV contraction index (key) is contiguous per lane.
+//   * a wave owns 16 queries at a time.  Scores are computed "swapped":
+//     mfma(A = K fragment, B = Q fragment) gives D[key][query], so a lane holds scores of ONE
+//     query (lane & 15) for 4 keys per 16-key tile.  Row max / row sum are then in-lane
+//     reductions plus two xor-shuffles (16, 32) -- no LDS round trip, no online rescaling
+//     because a whole score row (<= 320 keys) lives in registers.
+//   * the same registers, packed to bf16, are directly the B operand of the PV MFMA
+//     (O^T[dh][query] = V^T[dh][key] . P^T[key][query]); the k-slot -> key assignment of
+//     that MFMA is permuted to match (slot (g,j<4) = key 32u+4g+j, slot (g,j>=4) = key
+//     32u+16+4g+j-4), which only changes WHICH V elements a lane loads.
+//   * O^T puts 4 consecutive head-dim columns of one query in a lane: 8-byte bf16 stores.
+//   * softmax runs in fp32 with exp2 and a folded scale (1/8 * log2 e); probabilities are
+//     rounded to bf16 for the PV MFMA, the row sum is kept in fp32 from the unrounded values.
+#include "common.h"
+
+namespace {
+
+constexpr int DH = 64;
+
+template <int KT>  // key tiles of 32 -> padded token count 32*KT
+__global__ __launch_bounds__(256, (KT <= 7 ? 2 : 1)) void attention_kernel(const uint16_t *__restrict__ qkv,
+                                                        uint16_t *__restrict__ out, int tokens,
+                                                        int heads) {
+    constexpr int TP = KT * 32;
+    constexpr int VSTRIDE = TP * 2 + 8;  // bytes per head-dim row of V^T (8-B aligned, odd multiple of 8)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *klds = smem;             // [TP][64] bf16, 128-B rows, chunk ^= (row >> 1) & 7
+    char *vt = smem + TP * 128;    // [64][VSTRIDE]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frame = blockIdx.x / heads, head = blockIdx.x - frame * heads;
+    const int width = heads * DH;
+    const int64_t ld = 3 * (int64_t)width;
+    const uint16_t *qptr = qkv + (int64_t)frame * tokens * ld + head * DH;
+    const uint16_t *kptr = qptr + width;
+    const uint16_t *vptr = qptr + 2 * width;
+
+    // ---- stage K (row-major, swizzled); pad rows are zero ----
+    for (int e = tid; e < TP * 8; e += 256) {
+        const int row = e >> 3, c = e & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < tokens) v = *(const uint4 *)(kptr + row * ld + c * 8);
+        *(uint4 *)(klds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+    }
+    // ---- stage V transposed: task = (4 keys) x (8 head-dim columns) ----
+    for (int e = tid; e < (TP / 4) * 8; e += 256) {
+        const int kg = e >> 3, c8 = e & 7;
+        bf16x8_t r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = kg * 4 + i;
+            if (row < tokens)
+                r[i] = *(const bf16x8_t *)(vptr + row * ld + c8 * 8);
+            else
+                r[i] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint2 pk;
+            pk.x = (uint32_t)(uint16_t)r[0][j] | ((uint32_t)(uint16_t)r[1][j] << 16);
+            pk.y = (uint32_t)(uint16_t)r[2][j] | ((uint32_t)(uint16_t)r[3][j] << 16);
+            *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + kg * 8) = pk;
+        }
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, g = lane >> 4;
+    const float scale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+    const int qtiles = (tokens + 15) >> 4;
+
+    for (int qt = wave; qt < qtiles; qt += 4) {
+        int qrow = qt * 16 + fr;
+        const bool qvalid = qrow < tokens;
+        if (!qvalid) qrow = tokens - 1;
+        bf16x8_t qf[2];
+        qf[0] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8);
+        qf[1] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8 + 32);
+
+        // scores: s[t][r] = <q[query = fr], k[key = 16 t + 4 g + r]>
+        f32x4_t s[2 * KT];
+#pragma unroll
+        for (int t = 0; t < 2 * KT; ++t) {
+            s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            const int krow = t * 16 + fr;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8_t kf =
+                    *(const bf16x8_t *)(klds + krow * 128 + (((g + 4 * kk) ^ ((krow >> 1) & 7)) << 4));
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+            }
+            // keep the scheduler from hoisting every tile's K fragments (register blow-up)
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        // mask padded keys, row max
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * KT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t * 16 + g * 4 + r;
+                s[t][r] = key < tokens ? s[t][r] * scale : -INFINITY;
+                mx = fmaxf(mx, s[t][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+        bf16x8_t pb[KT];
+#pragma unroll
+        for (int u = 0; u < KT; ++u) {
+            float e[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = exp2f(s[2 * u][r] - mx);
+                e[4 + r] = exp2f(s[2 * u + 1][r] - mx);
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sum += e[r];
+            union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pk.w[r] = pack_bf16x2(e[2 * r], e[2 * r + 1]);
+            pb[u] = pk.v;
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+
+        // O^T[dh][query] += V^T[dh][key] . P^T[key][query]
+        f32x4_t o[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) o[ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KT; ++u) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const char *vrow = vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 4 * g) * 2;
+                union { uint2 h[2]; bf16x8_t v; } vf;
+                vf.h[0] = *(const uint2 *)(vrow);
+                vf.h[1] = *(const uint2 *)(vrow + 32);
+                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
+            }
+            if (u & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (qvalid) {
+            uint16_t *orow = out + ((int64_t)frame * tokens + qrow) * width + head * DH + g * 4;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                uint2 pk;
+                pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
+                pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
+                *(uint2 *)(orow + ct * 16) = pk;
+            }
+        }
+    }
+}
+
+template <int KT>
+int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int heads,
+              hipStream_t stream) {
+    constexpr int TP = KT * 32;
+    constexpr int smem = TP * 128 + 64 * (TP * 2 + 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel<KT>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_kernel<KT>, dim3(frames * heads), dim3(256), smem, stream, qkv, out,
+                       tokens, heads);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+}  // namespace
+
+int launch_attention_bf16(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int heads,
+                          hipStream_t stream) {
+    VSC_REQUIRE(qkv && out, "attention: null operand");
+    VSC_REQUIRE(frames > 0 && tokens > 0 && heads > 0, "attention: empty problem");
+    VSC_REQUIRE((int64_t)frames * heads < (1ll << 31), "attention: grid too large");
+    const int kt = (tokens + 31) / 32;
+    switch (kt) {
+        case 1: return launch_kt<1>(qkv, out, frames, tokens, heads, stream);
+        case 2: return launch_kt<2>(qkv, out, frames, tokens, heads, stream);
+        case 3: return launch_kt<3>(qkv, out, frames, tokens, heads, stream);
+        case 4: return launch_kt<4>(qkv, out, frames, tokens, heads, stream);
+        case 5: return launch_kt<5>(qkv, out, frames, tokens, heads, stream);
+        case 6: return launch_kt<6>(qkv, out, frames, tokens, heads, stream);
+        case 7: return launch_kt<7>(qkv, out, frames, tokens, heads, stream);
+        case 8: return launch_kt<8>(qkv, out, frames, tokens, heads, stream);
+        case 9: return launch_kt<9>(qkv, out, frames, tokens, heads, stream);
+        case 10: return launch_kt<10>(qkv, out, frames, tokens, heads, stream);
+        default:
+            VSC_REQUIRE(false, "attention: %d tokens unsupported (max 320; windowed/long sequences are a later row)",
+                        tokens);
+    }
+    return VSC_OK;
+}

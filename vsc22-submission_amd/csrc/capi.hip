@@ -1,0 +1,58 @@
+// C-ABI glue: error state, device probe, and the per-kernel entry points of include/vsc_hip.h.
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void vsc_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *vsc_last_error(void) { return g_err; }
+
+extern "C" const char *vsc_version(void) { return "vsc_hip 0.1 (gfx950)"; }
+
+extern "C" int vsc_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        vsc_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return VSC_ERR_NO_DEVICE;
+    }
+    int ok = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && strstr(prop.gcnArchName, "gfx950")) ++ok;
+    }
+    return ok;
+}
+
+extern "C" int vsc_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux,
+                             void *out, int64_t m, int32_t n, int32_t k, int32_t epilogue,
+                             int32_t tokens, void *stream) {
+    return launch_gemm_bf16(a, w, bias, aux, out, m, n, k, epilogue, tokens, (hipStream_t)stream);
+}
+
+extern "C" int vsc_attention_bf16(const uint16_t *qkv, uint16_t *out, int32_t frames, int32_t tokens,
+                                  int32_t heads, void *stream) {
+    return launch_attention_bf16(qkv, out, frames, tokens, heads, (hipStream_t)stream);
+}
+
+extern "C" int vsc_layernorm_f32(const float *x, const float *g, const float *b, void *out,
+                                 int64_t rows, int32_t width, float eps, int32_t out_f32,
+                                 void *stream) {
+    return launch_layernorm(x, g, b, out, rows, width, eps, out_f32, (hipStream_t)stream);
+}
+
+extern "C" int vsc_patchify_bf16(const float *frames, uint16_t *patches, int64_t n, int32_t channels,
+                                 int32_t image, int32_t patch, int32_t kpad, void *stream) {
+    return launch_patchify(frames, patches, n, channels, image, patch, kpad, (hipStream_t)stream);
+}
+
+extern "C" int vsc_l2_normalize_f32(float *x, int64_t n, int32_t d, void *stream) {
+    return launch_l2_normalize(x, n, d, (hipStream_t)stream);
+}

@@ -1,0 +1,107 @@
+// Shared device/host helpers for libvsc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/vsc_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = 4 VGPRs (MFMA A/B operand)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;   // 8 bytes
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define VSC_WAVE 64
+
+// ---- error plumbing --------------------------------------------------------
+void vsc_set_error(const char *fmt, ...);
+
+#define VSC_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            vsc_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                          __LINE__);                                                     \
+            return VSC_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+#define VSC_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            vsc_set_error(__VA_ARGS__);   \
+            return VSC_ERR_INVALID;       \
+        }                                 \
+    } while (0)
+
+#define VSC_CHECK_LAUNCH() VSC_CHECK_HIP(hipGetLastError())
+
+// ---- bf16 <-> f32 ------------------------------------------------------------
+__device__ __host__ inline float bf16_to_f32(uint16_t h) {
+    union { uint32_t u; float f; } v;
+    v.u = ((uint32_t)h) << 16;
+    return v.f;
+}
+
+// round-to-nearest-even, NaN kept quiet
+__device__ __host__ inline uint16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } v;
+    v.f = f;
+    if ((v.u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((v.u >> 16) | 0x40);
+    uint32_t lsb = (v.u >> 16) & 1u;
+    v.u += 0x7fffu + lsb;
+    return (uint16_t)(v.u >> 16);
+}
+
+// device-side packing: one v_cvt_pk_bf16_f32 (RNE) per pair
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    hw_bf16x2_t b = __builtin_convertvector(v, hw_bf16x2_t);
+    return *(uint32_t *)&b;
+}
+
+// ---- wave reductions (64 lanes) --------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware block id remap (8 XCDs, block b runs on XCD b % 8): give every XCD a
+// contiguous range of logical tiles so neighbouring tiles share its L2.
+// Bijective for any grid size.
+__device__ inline int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+// ---- launchers implemented in the .hip files ----------------------------------------------------
+int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux,
+                     void *out, int64_t m, int n, int k, int epilogue, int tokens,
+                     hipStream_t stream);
+int launch_attention_bf16(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int heads,
+                          hipStream_t stream);
+int launch_layernorm(const float *x, const float *g, const float *b, void *out, int64_t rows,
+                     int width, float eps, int out_f32, hipStream_t stream);
+int launch_patchify(const float *frames, uint16_t *patches, int64_t n, int channels, int image,
+                    int patch, int kpad, hipStream_t stream);
+int launch_cls_rows(float *x, const float *cls, const float *pos, int64_t frames, int tokens,
+                    int width, hipStream_t stream);
+int launch_ln_pool(const float *x, const float *g, const float *b, float *pooled, float *tokens_out,
+                   int64_t frames, int tokens, int width, float eps, int pool, float gem_p,
+                   hipStream_t stream);
+int launch_head(const float *pooled, const float *w, const float *bias, float *desc, int64_t frames,
+                int width, int out_dim, int l2, hipStream_t stream);
+int launch_l2_normalize(float *x, int64_t n, int d, hipStream_t stream);
+int launch_f32_to_bf16(const float *src, uint16_t *dst, int64_t rows, int cols, int cols_pad,
+                       hipStream_t stream);

@@ -1,0 +1,360 @@
+// HBM-bound row kernels of the encoder: patch extraction, LayerNorm, CLS rows, the fused
+// final-LayerNorm + GeM/CLS pooling, the descriptor head and the L2 normalisation.
+// One wave (64 lanes) owns a row; rows are read as float4 per lane, reductions are
+// wave shuffles; nothing goes through LDS except the per-frame pooling combine.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXV = 8;  // float4 per lane -> width <= 2048
+
+// ------------------------------------------------------------------ patchify
+// frames f32 [n,C,H,W] -> patches bf16 [n*G*G, kpad], k = c*p*p + py*p + px.
+// One thread produces 8 consecutive k (one 16-byte store).  When p % 8 == 0 the 8 source
+// pixels are contiguous (two float4 loads); otherwise (p = 14) they are gathered.
+__global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ frames,
+                                                       uint16_t *__restrict__ patches,
+                                                       int64_t total_chunks, int channels,
+                                                       int image, int patch, int kpad) {
+    const int grid = image / patch;
+    const int kc = kpad >> 3;
+    const int pp = patch * patch;
+    const int kreal = channels * pp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total_chunks;
+         e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / kc;
+        const int k0 = (int)(e - row * kc) * 8;
+        const int64_t f = row / (grid * grid);
+        const int pidx = (int)(row - f * grid * grid);
+        const int gy = pidx / grid, gx = pidx - gy * grid;
+        const float *fb = frames + f * (int64_t)channels * image * image;
+        float v[8];
+        if ((patch & 7) == 0 && k0 + 8 <= kreal) {
+            const int c = k0 / pp, rem = k0 - c * pp;
+            const int py = rem / patch, px = rem - py * patch;
+            const float *src = fb + ((int64_t)c * image + gy * patch + py) * image + gx * patch + px;
+            const float4 a = *(const float4 *)src, b = *(const float4 *)(src + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                if (k < kreal) {
+                    const int c = k / pp, rem = k - c * pp;
+                    const int py = rem / patch, px = rem - py * patch;
+                    v[j] = fb[((int64_t)c * image + gy * patch + py) * image + gx * patch + px];
+                } else {
+                    v[j] = 0.f;
+                }
+            }
+        }
+        uint4 pk;
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
+        pk.z = pack_bf16x2(v[4], v[5]);
+        pk.w = pack_bf16x2(v[6], v[7]);
+        *(uint4 *)(patches + row * kpad + k0) = pk;
+    }
+}
+
+// ------------------------------------------------------------------ f32 -> bf16 (weights)
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restrict__ src,
+                                                          uint16_t *__restrict__ dst, int64_t rows,
+                                                          int cols, int cols_pad) {
+    const int64_t total = rows * cols_pad;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / cols_pad;
+        const int c = (int)(e - r * cols_pad);
+        dst[e] = c < cols ? f32_to_bf16(src[r * cols + c]) : (uint16_t)0;
+    }
+}
+
+// ------------------------------------------------------------------ cls rows
+// x[f*T + 0, :] = cls + pos[0, :]
+__global__ __launch_bounds__(256) void cls_rows_kernel(float *__restrict__ x,
+                                                       const float *__restrict__ cls,
+                                                       const float *__restrict__ pos, int64_t frames,
+                                                       int tokens, int width) {
+    const int64_t total = frames * (width >> 2);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * 256) {
+        const int64_t f = e / (width >> 2);
+        const int c = (int)(e - f * (width >> 2)) * 4;
+        const float4 a = *(const float4 *)(cls + c), b = *(const float4 *)(pos + c);
+        *(float4 *)(x + f * tokens * width + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm
+// A wave normalises one row held in registers (two-pass: mean, then centred variance).
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x,
+                                                        const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta,
+                                                        void *__restrict__ out, int64_t rows,
+                                                        int width, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = width >> 8;            // full float4 rounds of 256 columns
+    const int tail = width & 255;         // remaining columns (multiple of 4)
+    const float *xr = x + row * width;
+    float4 v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int col = i * 256 + lane * 4;
+        const bool on = i < nv || (i == nv && lane * 4 < tail);
+        v[i] = on ? *(const float4 *)(xr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) / (float)width;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const bool on = i < nv || (i == nv && lane * 4 < tail);
+        if (on) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)width + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int col = i * 256 + lane * 4;
+        const bool on = i < nv || (i == nv && lane * 4 < tail);
+        if (!on) continue;
+        const float4 g = *(const float4 *)(gamma + col), b = *(const float4 *)(beta + col);
+        const float y0 = (v[i].x - mean) * rstd * g.x + b.x;
+        const float y1 = (v[i].y - mean) * rstd * g.y + b.y;
+        const float y2 = (v[i].z - mean) * rstd * g.z + b.z;
+        const float y3 = (v[i].w - mean) * rstd * g.w + b.w;
+        if (OUT_F32) {
+            *(float4 *)((float *)out + row * width + col) = make_float4(y0, y1, y2, y3);
+        } else {
+            uint2 pk;
+            pk.x = pack_bf16x2(y0, y1);
+            pk.y = pack_bf16x2(y2, y3);
+            *(uint2 *)((uint16_t *)out + row * width + col) = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ final LN + pooling
+// One workgroup per frame.  Each wave normalises tokens w, w+4, ...; because a lane owns the
+// same columns for every token, GeM's per-column sum of clamp(y,1e-6)^p accumulates in
+// registers; the 4 waves combine through LDS.  pool = 1 (CLS): token 0 only.
+// tokens_out (optional) receives the normalised tokens (parity tests).
+__global__ __launch_bounds__(256) void ln_pool_kernel(const float *__restrict__ x,
+                                                      const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta,
+                                                      float *__restrict__ pooled,
+                                                      float *__restrict__ tokens_out, int tokens,
+                                                      int width, float eps, int pool, float gem_p) {
+    __shared__ float comb[4][2048];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t f = blockIdx.x;
+    const int nv = width >> 8, tail = width & 255;
+    float4 acc[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool cube = gem_p == 3.0f;
+    const int tend = (pool == 1 && tokens_out == nullptr) ? 1 : tokens;
+    for (int t = wave; t < tend; t += 4) {
+        const float *xr = x + (f * tokens + t) * width;
+        float4 v[MAXV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const bool on = i < nv || (i == nv && lane * 4 < tail);
+            v[i] = on ? *(const float4 *)(xr + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mean = wave_sum(sum) / (float)width;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const bool on = i < nv || (i == nv && lane * 4 < tail);
+            if (on) {
+                const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                sq += (a * a + b * b) + (c * c + d * d);
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)width + eps);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int col = i * 256 + lane * 4;
+            const bool on = i < nv || (i == nv && lane * 4 < tail);
+            if (!on) continue;
+            const float4 g = *(const float4 *)(gamma + col), b = *(const float4 *)(beta + col);
+            float y[4] = {(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                          (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w};
+            if (tokens_out)
+                *(float4 *)(tokens_out + (f * tokens + t) * width + col) = make_float4(y[0], y[1], y[2], y[3]);
+            if (pool == 1) {
+                if (t == 0) acc[i] = make_float4(y[0], y[1], y[2], y[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float c = fmaxf(y[j], 1e-6f);
+                    y[j] = cube ? c * c * c : __powf(c, gem_p);
+                }
+                acc[i].x += y[0]; acc[i].y += y[1]; acc[i].z += y[2]; acc[i].w += y[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int col = i * 256 + lane * 4;
+        if (col < width) *(float4 *)(&comb[wave][col]) = acc[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < width; c += 256) {
+        const float s = (comb[0][c] + comb[1][c]) + (comb[2][c] + comb[3][c]);
+        float r;
+        if (pool == 1) r = s;  // only wave 0 / token 0 contributed
+        else {
+            const float m = s / (float)tokens;
+            r = cube ? cbrtf(m) : __powf(m, 1.0f / gem_p);
+        }
+        pooled[f * width + c] = r;
+    }
+}
+
+// ------------------------------------------------------------------ descriptor head
+// desc[f,:] = pooled[f,:] . W^T + b (fp32), optionally L2-normalised (zero rows untouched).
+// One workgroup per frame; a wave computes outputs w, w+4, ... with coalesced weight rows.
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ pooled,
+                                                   const float *__restrict__ w,
+                                                   const float *__restrict__ bias,
+                                                   float *__restrict__ desc, int width, int out_dim,
+                                                   int l2) {
+    __shared__ float xs[2048];
+    __shared__ float ys[2048];
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t f = blockIdx.x;
+    for (int c = threadIdx.x; c < width; c += 256) xs[c] = pooled[f * width + c];
+    __syncthreads();
+    const int n_out = w ? out_dim : width;
+    if (w) {
+        for (int o = wave; o < out_dim; o += 4) {
+            const float *wr = w + (int64_t)o * width;
+            float a = 0.f;
+            for (int c = lane * 4; c < width; c += 256) {
+                const float4 wv = *(const float4 *)(wr + c);
+                a += (wv.x * xs[c] + wv.y * xs[c + 1]) + (wv.z * xs[c + 2] + wv.w * xs[c + 3]);
+            }
+            a = wave_sum(a);
+            if (lane == 0) ys[o] = a + (bias ? bias[o] : 0.f);
+        }
+    } else {
+        for (int c = threadIdx.x; c < width; c += 256) ys[c] = xs[c];
+    }
+    __syncthreads();
+    float scale = 1.f;
+    if (l2) {
+        float ss = 0.f;
+        for (int c = threadIdx.x; c < n_out; c += 256) ss += ys[c] * ys[c];
+        ss = wave_sum(ss);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        scale = nrm == 0.f ? 1.f : 1.0f / nrm;
+    }
+    for (int c = threadIdx.x; c < n_out; c += 256)
+        desc[f * n_out + c] = l2 ? ys[c] * scale : ys[c];
+}
+
+// ------------------------------------------------------------------ L2 normalise rows in place
+__global__ __launch_bounds__(256) void l2_normalize_kernel(float *__restrict__ x, int64_t n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float *xr = x + row * d;
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) ss += xr[c] * xr[c];
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    if (nrm == 0.f) return;
+    for (int c = lane; c < d; c += 64) xr[c] = xr[c] / nrm;
+}
+
+inline int grid_for(int64_t work_items) {
+    int64_t b = (work_items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+int launch_patchify(const float *frames, uint16_t *patches, int64_t n, int channels, int image,
+                    int patch, int kpad, hipStream_t stream) {
+    VSC_REQUIRE(frames && patches && n > 0, "patchify: null/empty");
+    VSC_REQUIRE(image % patch == 0, "patchify: image %d not a multiple of patch %d", image, patch);
+    VSC_REQUIRE(kpad % 64 == 0 && kpad >= channels * patch * patch, "patchify: bad kpad %d", kpad);
+    VSC_REQUIRE(image % 4 == 0, "patchify: image width must be a multiple of 4");
+    const int g = image / patch;
+    const int64_t chunks = n * g * g * (kpad / 8);
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(chunks)), dim3(256), 0, stream, frames, patches,
+                       chunks, channels, image, patch, kpad);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+int launch_f32_to_bf16(const float *src, uint16_t *dst, int64_t rows, int cols, int cols_pad,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(rows * cols_pad)), dim3(256), 0, stream, src,
+                       dst, rows, cols, cols_pad);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+int launch_cls_rows(float *x, const float *cls, const float *pos, int64_t frames, int tokens,
+                    int width, hipStream_t stream) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(grid_for(frames * (width / 4))), dim3(256), 0, stream, x,
+                       cls, pos, frames, tokens, width);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+int launch_layernorm(const float *x, const float *g, const float *b, void *out, int64_t rows,
+                     int width, float eps, int out_f32, hipStream_t stream) {
+    VSC_REQUIRE(x && g && b && out && rows > 0, "layernorm: null/empty");
+    VSC_REQUIRE(width % 4 == 0 && width <= MAXV * 256, "layernorm: width %d unsupported", width);
+    VSC_REQUIRE((rows + 3) / 4 < (1ll << 31), "layernorm: too many rows");
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (out_f32)
+        hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, stream, x, g, b, out, rows, width, eps);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<false>, grid, dim3(256), 0, stream, x, g, b, out, rows, width, eps);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+int launch_ln_pool(const float *x, const float *g, const float *b, float *pooled, float *tokens_out,
+                   int64_t frames, int tokens, int width, float eps, int pool, float gem_p,
+                   hipStream_t stream) {
+    VSC_REQUIRE(width % 4 == 0 && width <= 2048, "ln_pool: width %d unsupported", width);
+    hipLaunchKernelGGL(ln_pool_kernel, dim3((unsigned)frames), dim3(256), 0, stream, x, g, b, pooled,
+                       tokens_out, tokens, width, eps, pool, gem_p);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+int launch_head(const float *pooled, const float *w, const float *bias, float *desc, int64_t frames,
+                int width, int out_dim, int l2, hipStream_t stream) {
+    VSC_REQUIRE(width <= 2048 && out_dim <= 2048 && width % 4 == 0, "head: dims unsupported");
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)frames), dim3(256), 0, stream, pooled, w, bias, desc,
+                       width, out_dim, l2);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+int launch_l2_normalize(float *x, int64_t n, int d, hipStream_t stream) {
+    VSC_REQUIRE(x && n > 0 && d > 0, "l2_normalize: null/empty");
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, x, n, d);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}

@@ -1,0 +1,328 @@
+// vsc_encoder: weights, workspace and the launch sequence of one frame batch through the
+// ViT encoder + descriptor head.  Host-side C++; every numeric step is a HIP kernel from
+// gemm_bf16.hip / attention.hip / elementwise.hip.
+//
+// HBM layout for one step of B frames (T tokens, width D, M = B*T):
+//   patches bf16 [B*(T-1), Kpad]     x   f32 [M, D]   (residual stream, fp32 throughout)
+//   y       bf16 [M, D]  (LN output, then reused for the attention output)
+//   qkv     bf16 [M, 3D]             h   bf16 [M, mlp]
+//   pooled  f32  [B, D]
+// Weights: matrices as bf16 [out, in] (PyTorch Linear layout == the GEMM's W[N,K]),
+// biases / LayerNorm / cls / pos / head as f32.
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+struct LayerW {
+    uint16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    float *qkv_b, *proj_b, *fc1_b, *fc2_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
+
+struct vsc_encoder {
+    vsc_encoder_config cfg;
+    int tokens = 0, grid = 0, kpatch = 0, kpad = 0, desc_dim = 0;
+    bool finalized = false;
+    std::map<std::string, std::vector<float>> host_w;
+    std::map<std::string, size_t> expect;
+    std::vector<void *> allocs;
+    std::vector<LayerW> layers;
+    uint16_t *patch_w = nullptr;
+    float *patch_b = nullptr, *cls = nullptr, *pos = nullptr, *lnpre_g = nullptr, *lnpre_b = nullptr,
+          *lnpost_g = nullptr, *lnpost_b = nullptr, *head_w = nullptr, *head_b = nullptr;
+    uint16_t *patches = nullptr, *y = nullptr, *qkv = nullptr, *h = nullptr;
+    float *x = nullptr, *pooled = nullptr;
+    int64_t ws_bytes = 0;
+    // optional per-kernel-class timing (HIP events on the caller's stream)
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    struct Span { int cls; size_t e0, e1; };
+    std::vector<Span> spans;
+    double prof_ms[VSC_PROF_CLASSES] = {0};
+    int64_t prof_n[VSC_PROF_CLASSES] = {0};
+};
+
+namespace {
+
+int dev_alloc(vsc_encoder *e, size_t bytes, void **out) {
+    hipError_t err = hipMalloc(out, bytes);
+    if (err != hipSuccess) {
+        vsc_set_error("encoder: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+        return VSC_ERR_NOMEM;
+    }
+    e->allocs.push_back(*out);
+    return VSC_OK;
+}
+
+int upload_f32(vsc_encoder *e, const std::string &name, float **out) {
+    const std::vector<float> &v = e->host_w.at(name);
+    int rc = dev_alloc(e, v.size() * 4, (void **)out);
+    if (rc) return rc;
+    VSC_CHECK_HIP(hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    return VSC_OK;
+}
+
+// f32 host matrix [rows, cols] -> bf16 device [rows, cols_pad] (zero padded)
+int upload_bf16(vsc_encoder *e, const std::string &name, int64_t rows, int cols, int cols_pad,
+                uint16_t **out) {
+    const std::vector<float> &v = e->host_w.at(name);
+    float *tmp = nullptr;
+    VSC_CHECK_HIP(hipMalloc((void **)&tmp, v.size() * 4));
+    hipError_t err = hipMemcpy(tmp, v.data(), v.size() * 4, hipMemcpyHostToDevice);
+    int rc = err == hipSuccess ? dev_alloc(e, (size_t)rows * cols_pad * 2, (void **)out) : VSC_ERR_HIP;
+    if (!rc) rc = launch_f32_to_bf16(tmp, *out, rows, cols, cols_pad, nullptr);
+    hipError_t e2 = hipDeviceSynchronize();
+    (void)hipFree(tmp);
+    if (err != hipSuccess || e2 != hipSuccess) {
+        vsc_set_error("encoder: uploading %s failed", name.c_str());
+        return VSC_ERR_HIP;
+    }
+    return rc;
+}
+
+struct ProfScope {
+    vsc_encoder *e;
+    hipStream_t st;
+    size_t e0 = 0;
+    int cls;
+    ProfScope(vsc_encoder *enc, int c, hipStream_t s) : e(enc), st(s), cls(c) {
+        if (e->profile) e0 = rec();
+    }
+    ~ProfScope() {
+        if (e->profile) e->spans.push_back({cls, e0, rec()});
+    }
+    size_t rec() {
+        if (e->ev_used == e->ev_pool.size()) {
+            hipEvent_t ev;
+            (void)hipEventCreate(&ev);
+            e->ev_pool.push_back(ev);
+        }
+        (void)hipEventRecord(e->ev_pool[e->ev_used], st);
+        return e->ev_used++;
+    }
+};
+
+}  // namespace
+
+extern "C" int vsc_encoder_create(const vsc_encoder_config *cfg, vsc_encoder **out) {
+    VSC_REQUIRE(cfg && out, "encoder_create: null argument");
+    const vsc_encoder_config &c = *cfg;
+    VSC_REQUIRE(c.image_size > 0 && c.patch_size > 0 && c.image_size % c.patch_size == 0,
+                "encoder: image %d / patch %d", c.image_size, c.patch_size);
+    VSC_REQUIRE(c.image_size % 4 == 0, "encoder: image size must be a multiple of 4");
+    VSC_REQUIRE(c.channels >= 1, "encoder: channels");
+    VSC_REQUIRE(c.width % 64 == 0 && c.heads > 0 && c.width == c.heads * 64,
+                "encoder: width %d with %d heads -- only head_dim 64 is supported", c.width, c.heads);
+    VSC_REQUIRE(c.width <= 2048, "encoder: width %d > 2048", c.width);
+    VSC_REQUIRE(c.mlp_dim % 64 == 0 && c.mlp_dim > 0, "encoder: mlp_dim %d", c.mlp_dim);
+    VSC_REQUIRE(c.layers >= 1, "encoder: layers");
+    VSC_REQUIRE(c.out_dim >= 0 && c.out_dim <= 2048, "encoder: out_dim %d", c.out_dim);
+    VSC_REQUIRE(c.act == 0 || c.act == 1, "encoder: act %d", c.act);
+    VSC_REQUIRE(c.pool == 0 || c.pool == 1, "encoder: pool %d", c.pool);
+    VSC_REQUIRE(c.max_batch >= 1, "encoder: max_batch");
+    int g = c.image_size / c.patch_size;
+    int tokens = g * g + 1;
+    VSC_REQUIRE(tokens <= 320, "encoder: %d tokens > 320 (attention kernel limit)", tokens);
+
+    vsc_encoder *e = new vsc_encoder();
+    e->cfg = c;
+    e->grid = g;
+    e->tokens = tokens;
+    e->kpatch = c.channels * c.patch_size * c.patch_size;
+    e->kpad = (e->kpatch + 63) / 64 * 64;
+    e->desc_dim = c.out_dim ? c.out_dim : c.width;
+    const size_t D = c.width, Mlp = c.mlp_dim;
+    e->expect["patch.weight"] = D * e->kpatch;
+    if (c.patch_bias) e->expect["patch.bias"] = D;
+    e->expect["cls"] = D;
+    e->expect["pos"] = (size_t)tokens * D;
+    if (c.pre_ln) e->expect["ln_pre.weight"] = e->expect["ln_pre.bias"] = D;
+    for (int i = 0; i < c.layers; ++i) {
+        const std::string b = "blocks." + std::to_string(i) + ".";
+        e->expect[b + "ln1.weight"] = e->expect[b + "ln1.bias"] = D;
+        e->expect[b + "ln2.weight"] = e->expect[b + "ln2.bias"] = D;
+        e->expect[b + "qkv.weight"] = 3 * D * D;
+        e->expect[b + "qkv.bias"] = 3 * D;
+        e->expect[b + "proj.weight"] = D * D;
+        e->expect[b + "proj.bias"] = D;
+        e->expect[b + "fc1.weight"] = Mlp * D;
+        e->expect[b + "fc1.bias"] = Mlp;
+        e->expect[b + "fc2.weight"] = D * Mlp;
+        e->expect[b + "fc2.bias"] = D;
+    }
+    e->expect["ln_post.weight"] = e->expect["ln_post.bias"] = D;
+    if (c.out_dim) {
+        e->expect["head.weight"] = (size_t)c.out_dim * D;
+        e->expect["head.bias"] = c.out_dim;
+    }
+    *out = e;
+    return VSC_OK;
+}
+
+extern "C" void vsc_encoder_destroy(vsc_encoder *e) {
+    if (!e) return;
+    for (void *p : e->allocs) (void)hipFree(p);
+    for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+extern "C" int vsc_encoder_set_weight(vsc_encoder *e, const char *name, const float *host,
+                                      size_t count) {
+    VSC_REQUIRE(e && name && host, "set_weight: null argument");
+    if (e->finalized) {
+        vsc_set_error("set_weight(%s) after finalize", name);
+        return VSC_ERR_STATE;
+    }
+    auto it = e->expect.find(name);
+    VSC_REQUIRE(it != e->expect.end(), "set_weight: unknown tensor '%s' for this config", name);
+    VSC_REQUIRE(it->second == count, "set_weight: '%s' has %zu elements, expected %zu", name, count,
+                it->second);
+    e->host_w[name].assign(host, host + count);
+    return VSC_OK;
+}
+
+extern "C" int vsc_encoder_finalize(vsc_encoder *e) {
+    VSC_REQUIRE(e, "finalize: null encoder");
+    if (e->finalized) return VSC_OK;
+    for (auto &kv : e->expect)
+        if (!e->host_w.count(kv.first)) {
+            vsc_set_error("finalize: weight '%s' was never set", kv.first.c_str());
+            return VSC_ERR_STATE;
+        }
+    const vsc_encoder_config &c = e->cfg;
+    const int D = c.width;
+    int rc;
+#define TRY(x) do { if ((rc = (x))) return rc; } while (0)
+    TRY(upload_bf16(e, "patch.weight", D, e->kpatch, e->kpad, &e->patch_w));
+    if (c.patch_bias) TRY(upload_f32(e, "patch.bias", &e->patch_b));
+    TRY(upload_f32(e, "cls", &e->cls));
+    TRY(upload_f32(e, "pos", &e->pos));
+    if (c.pre_ln) {
+        TRY(upload_f32(e, "ln_pre.weight", &e->lnpre_g));
+        TRY(upload_f32(e, "ln_pre.bias", &e->lnpre_b));
+    }
+    e->layers.resize(c.layers);
+    for (int i = 0; i < c.layers; ++i) {
+        const std::string b = "blocks." + std::to_string(i) + ".";
+        LayerW &L = e->layers[i];
+        TRY(upload_f32(e, b + "ln1.weight", &L.ln1_g));
+        TRY(upload_f32(e, b + "ln1.bias", &L.ln1_b));
+        TRY(upload_f32(e, b + "ln2.weight", &L.ln2_g));
+        TRY(upload_f32(e, b + "ln2.bias", &L.ln2_b));
+        TRY(upload_bf16(e, b + "qkv.weight", 3 * D, D, D, &L.qkv_w));
+        TRY(upload_f32(e, b + "qkv.bias", &L.qkv_b));
+        TRY(upload_bf16(e, b + "proj.weight", D, D, D, &L.proj_w));
+        TRY(upload_f32(e, b + "proj.bias", &L.proj_b));
+        TRY(upload_bf16(e, b + "fc1.weight", c.mlp_dim, D, D, &L.fc1_w));
+        TRY(upload_f32(e, b + "fc1.bias", &L.fc1_b));
+        TRY(upload_bf16(e, b + "fc2.weight", D, c.mlp_dim, c.mlp_dim, &L.fc2_w));
+        TRY(upload_f32(e, b + "fc2.bias", &L.fc2_b));
+    }
+    TRY(upload_f32(e, "ln_post.weight", &e->lnpost_g));
+    TRY(upload_f32(e, "ln_post.bias", &e->lnpost_b));
+    if (c.out_dim) {
+        TRY(upload_f32(e, "head.weight", &e->head_w));
+        TRY(upload_f32(e, "head.bias", &e->head_b));
+    }
+    // workspace for max_batch frames
+    const size_t B = c.max_batch, M = B * e->tokens;
+    const size_t sz_patches = B * (e->tokens - 1) * e->kpad * 2, sz_x = M * D * 4, sz_y = M * D * 2,
+                 sz_qkv = M * 3 * D * 2, sz_h = M * (size_t)c.mlp_dim * 2, sz_pool = B * D * 4;
+    TRY(dev_alloc(e, sz_patches, (void **)&e->patches));
+    TRY(dev_alloc(e, sz_x, (void **)&e->x));
+    TRY(dev_alloc(e, sz_y, (void **)&e->y));
+    TRY(dev_alloc(e, sz_qkv, (void **)&e->qkv));
+    TRY(dev_alloc(e, sz_h, (void **)&e->h));
+    TRY(dev_alloc(e, sz_pool, (void **)&e->pooled));
+#undef TRY
+    e->ws_bytes = (int64_t)(sz_patches + sz_x + sz_y + sz_qkv + sz_h + sz_pool);
+    e->host_w.clear();
+    e->finalized = true;
+    return VSC_OK;
+}
+
+extern "C" int64_t vsc_encoder_workspace_bytes(const vsc_encoder *e) { return e ? e->ws_bytes : 0; }
+
+extern "C" int vsc_encoder_forward_debug(vsc_encoder *e, const float *frames, int64_t n, float *desc,
+                                         float *tokens_out, void *stream_) {
+    VSC_REQUIRE(e && frames && desc, "forward: null argument");
+    VSC_REQUIRE(n >= 0, "forward: negative frame count");
+    if (!e->finalized) {
+        vsc_set_error("forward before finalize");
+        return VSC_ERR_STATE;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    const vsc_encoder_config &c = e->cfg;
+    const int D = c.width, T = e->tokens;
+    const int act_epi = c.act == 0 ? VSC_EPI_GELU_BF16 : VSC_EPI_QGELU_BF16;
+    const int64_t frame_elems = (int64_t)c.channels * c.image_size * c.image_size;
+    int rc;
+#define TRY(x) do { if ((rc = (x))) return rc; } while (0)
+    for (int64_t off = 0; off < n; off += c.max_batch) {
+        const int64_t B = (n - off) < c.max_batch ? (n - off) : c.max_batch;
+        const int64_t M = B * T, Mp = B * (T - 1);
+        { ProfScope _ps(e, VSC_PROF_PATCHIFY, st); TRY(launch_patchify(frames + off * frame_elems, e->patches, B, c.channels, c.image_size,
+                            c.patch_size, e->kpad, st)); }
+        { ProfScope _ps(e, VSC_PROF_GEMM_PATCH, st); TRY(launch_gemm_bf16(e->patches, e->patch_w, e->patch_b, e->pos, e->x, Mp, D, e->kpad,
+                             VSC_EPI_PATCH_F32, T, st)); }
+        { ProfScope _ps(e, VSC_PROF_MISC, st); TRY(launch_cls_rows(e->x, e->cls, e->pos, B, T, D, st)); }
+        if (c.pre_ln) {
+            ProfScope _ps(e, VSC_PROF_LAYERNORM, st);
+            TRY(launch_layernorm(e->x, e->lnpre_g, e->lnpre_b, e->x, M, D, c.ln_eps, 1, st));
+        }
+        for (int l = 0; l < c.layers; ++l) {
+            const LayerW &L = e->layers[l];
+            { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_layernorm(e->x, L.ln1_g, L.ln1_b, e->y, M, D, c.ln_eps, 0, st)); }
+            { ProfScope _ps(e, VSC_PROF_GEMM_QKV, st); TRY(launch_gemm_bf16(e->y, L.qkv_w, L.qkv_b, nullptr, e->qkv, M, 3 * D, D, VSC_EPI_BF16, 0, st)); }
+            { ProfScope _ps(e, VSC_PROF_ATTENTION, st); TRY(launch_attention_bf16(e->qkv, e->y, (int)B, T, c.heads, st)); }
+            { ProfScope _ps(e, VSC_PROF_GEMM_PROJ, st); TRY(launch_gemm_bf16(e->y, L.proj_w, L.proj_b, e->x, e->x, M, D, D, VSC_EPI_RESADD_F32, 0, st)); }
+            { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_layernorm(e->x, L.ln2_g, L.ln2_b, e->y, M, D, c.ln_eps, 0, st)); }
+            { ProfScope _ps(e, VSC_PROF_GEMM_FC1, st); TRY(launch_gemm_bf16(e->y, L.fc1_w, L.fc1_b, nullptr, e->h, M, c.mlp_dim, D, act_epi, 0, st)); }
+            { ProfScope _ps(e, VSC_PROF_GEMM_FC2, st); TRY(launch_gemm_bf16(e->h, L.fc2_w, L.fc2_b, e->x, e->x, M, D, c.mlp_dim, VSC_EPI_RESADD_F32, 0, st)); }
+        }
+        { ProfScope _ps(e, VSC_PROF_POOL_HEAD, st); TRY(launch_ln_pool(e->x, e->lnpost_g, e->lnpost_b, e->pooled,
+                           tokens_out ? tokens_out + off * T * D : nullptr, B, T, D, c.ln_eps, c.pool,
+                           c.gem_p, st)); }
+        { ProfScope _ps(e, VSC_PROF_POOL_HEAD, st); TRY(launch_head(e->pooled, e->head_w, e->head_b, desc + off * e->desc_dim, B, D, c.out_dim,
+                        c.l2_normalize, st)); }
+    }
+#undef TRY
+    return VSC_OK;
+}
+
+extern "C" int vsc_encoder_forward(vsc_encoder *e, const float *frames, int64_t n, float *desc,
+                                   void *stream) {
+    return vsc_encoder_forward_debug(e, frames, n, desc, nullptr, stream);
+}
+
+extern "C" int vsc_encoder_set_profiling(vsc_encoder *e, int32_t on) {
+    VSC_REQUIRE(e, "set_profiling: null encoder");
+    e->profile = on != 0;
+    e->spans.clear();
+    e->ev_used = 0;
+    for (int i = 0; i < VSC_PROF_CLASSES; ++i) {
+        e->prof_ms[i] = 0;
+        e->prof_n[i] = 0;
+    }
+    return VSC_OK;
+}
+
+extern "C" int vsc_encoder_get_profile(vsc_encoder *e, double *ms_out, int64_t *launches_out) {
+    VSC_REQUIRE(e && ms_out && launches_out, "get_profile: null argument");
+    VSC_CHECK_HIP(hipDeviceSynchronize());
+    for (const vsc_encoder::Span &sp : e->spans) {
+        float ms = 0.f;
+        VSC_CHECK_HIP(hipEventElapsedTime(&ms, e->ev_pool[sp.e0], e->ev_pool[sp.e1]));
+        e->prof_ms[sp.cls] += ms;
+        e->prof_n[sp.cls] += 1;
+    }
+    e->spans.clear();
+    e->ev_used = 0;
+    for (int i = 0; i < VSC_PROF_CLASSES; ++i) {
+        ms_out[i] = e->prof_ms[i];
+        launches_out[i] = e->prof_n[i];
+    }
+    return VSC_OK;
+}

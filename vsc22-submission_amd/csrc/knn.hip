@@ -1,0 +1,411 @@
+// Exhaustive inner-product top-k over a flat float32 descriptor bank
+// (replaces faiss IndexFlatIP.search -- infer/vsc/index.py:167-175,
+//  infer/vsc/baseline/score_normalization.py:95).
+//
+// Exactness: scores are computed with v_mfma_f32_32x32x2_f32, which is bit-for-bit an
+// ascending-k fmaf chain (D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), one accumulator per
+// output over the whole dimension, no split-K), i.e. identical to oracle/knn_oracle.c.
+// Ranking is on a 64-bit key (order-preserving map of the score, then lower index first).
+//
+// CDNA4 mapping
+//   * operands are first re-laid out ("packed"): rows padded to a multiple of 32 floats and,
+//     inside every group of 8, stored as k = {0,2,4,6 | 1,3,5,7}.  A lane's ds_read_b128 then
+//     yields the operands of four consecutive MFMAs whose k pairs are (0,1),(2,3),(4,5),(6,7):
+//     wide LDS reads AND ascending chain order.
+//   * workgroup = 256 threads = 2x2 waves, tile 128 refs x 128 queries, wave tile 64x64 =
+//     2x2 accumulators of 32x32 (64 fp32 VGPRs).  Refs are the MFMA "A" (row) operand and
+//     queries the "B" (column) operand, so a lane owns ONE query per accumulator (col =
+//     lane & 31) and 16 refs of it: the running k-th-best threshold of that query sits in
+//     a register and the filter is one compare per score.
+//   * staging HBM/L2 -> LDS by global_load_lds_dwordx4 into double-buffered 128 x 32-float
+//     tiles with the same 16-byte-chunk XOR swizzle as the bf16 GEMM.
+//   * a workgroup is persistent over (query block, ref split) work items and walks its ref
+//     tiles in ascending order; every workgroup of a launch walks the same order, so a ref
+//     tile is pulled from HBM once per XCD and then served from L2.
+//   * survivors (score > threshold) are appended to a per-query candidate list in global
+//     memory (LDS atomic counter).  When a list could overflow, one wave rank-sorts it
+//     (O(n^2) on 64-bit keys, staged in LDS), keeps the best k and raises the threshold.
+//     With ascending refs a later equal score can never displace an earlier one, so the
+//     strict compare is exact.  Expected appends per query ~ k (1 + ln(n/k)).
+#include <float.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int TQ = 128, TR = 128, KS = 32;          // tile: queries, refs, floats per K-step
+constexpr int TILE_BYTES = 128 * KS * 4;            // 16 KiB per operand per stage
+constexpr int LDS_STAGE = 4 * TILE_BYTES;           // R0 Q0 R1 Q1
+constexpr int LDS_TOTAL = LDS_STAGE + 128 * 4 + 128 * 4 + 16;
+
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+struct KnnArgs {
+    const float *qp;   // packed queries [nq, dpad]
+    const float *rp;   // packed refs    [nr, dpad]
+    int64_t nq, nr;
+    int dpad, k, nqb, splits;
+    int64_t total_tiles, tiles_per_split;
+    unsigned long long *lists;  // [grid][128][CAP]
+    unsigned long long *part;   // [nq][splits][k] sorted keys, 0 = empty
+};
+
+// ---- key <-> (score, idx) ---------------------------------------------------------------
+__device__ __forceinline__ unsigned long long make_key(float s, unsigned idx) {
+    unsigned u = __float_as_uint(s);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;  // monotone: larger float -> larger uint
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+__device__ __forceinline__ float key_score(unsigned long long key) {
+    unsigned u = (unsigned)(key >> 32);
+    u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned key_index(unsigned long long key) {
+    return 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
+}
+
+// ---- layout pre-pass ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_pack_kernel(const float *__restrict__ src,
+                                                       float *__restrict__ dst, int64_t n, int d,
+                                                       int dpad) {
+    const int64_t total = n * (dpad >> 2);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / (dpad >> 2);
+        const int c4 = (int)(e - row * (dpad >> 2));  // 16-byte chunk within the row
+        const int base = (c4 >> 1) * 8, half = c4 & 1;
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = base + 2 * t + half;
+            v[t] = k < d ? src[row * d + k] : 0.f;
+        }
+        *(float4 *)(dst + row * dpad + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---- staging (128 rows x 32 floats, 128-byte rows, chunk ^= (row >> 1) & 7) -------------
+__device__ __forceinline__ void stage_tile(const float *src, int64_t ld, int64_t row0,
+                                           int64_t row_last, int k0, char *tile, int wave,
+                                           int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = j * 4 + wave;
+        const int r = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int64_t gr = row0 + r;
+        gr = gr > row_last ? row_last : gr;
+        const float *g = src + gr * ld + k0 + c * 4;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(tile + piece * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ f32x4_t lds_frag(const char *tile, int row, int chunk) {
+    return *(const f32x4_t *)(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+
+// Rank-sort one query's candidate list (n <= 64*EPL keys) with one wave, keep the best k.
+// `dst` is where the survivors go, in rank order (the list itself between ref tiles, the
+// per-split output at the end).
+template <int EPL>
+__device__ __forceinline__ void compact_list(const unsigned long long *list, int n, int k,
+                                             unsigned long long *scratch, unsigned long long *dst,
+                                             int *cnt_slot, float *tau_slot, int lane) {
+    unsigned long long e[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int idx = lane + 64 * i;
+        e[i] = idx < n ? list[idx] : 0ull;
+        if (idx < n) scratch[idx] = e[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int rank[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) rank[i] = 0;
+    for (int j = 0; j < n; ++j) {
+        const unsigned long long kj = scratch[j];
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) rank[i] += kj > e[i] ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < n && rank[i] < k) {
+            dst[rank[i]] = e[i];
+            if (rank[i] == k - 1) *tau_slot = key_score(e[i]);
+        }
+    }
+    if (lane == 0) *cnt_slot = n < k ? n : k;
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256, 2) void knn_kernel(KnnArgs p) {
+    constexpr int CAP = 64 * EPL;
+    // ONE shared array (a second __shared__ object de-pipelines the LDS-DMA loop).
+    __shared__ __attribute__((aligned(16))) char lds[LDS_TOTAL];
+    int *cnt_s = (int *)(lds + LDS_STAGE);
+    float *tau_s = (float *)(lds + LDS_STAGE + 512);
+    int *flag_s = (int *)(lds + LDS_STAGE + 1024);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    unsigned long long *mylists = p.lists + (size_t)blockIdx.x * 128 * CAP;
+    const int nks = p.dpad / KS;
+
+    for (int64_t work = blockIdx.x; work < (int64_t)p.nqb * p.splits; work += gridDim.x) {
+        const int qb = (int)(work / p.splits), sp = (int)(work - (int64_t)qb * p.splits);
+        const int64_t q0 = (int64_t)qb * TQ;
+        const int64_t t_begin = sp * p.tiles_per_split;
+        int64_t t_end = t_begin + p.tiles_per_split;
+        t_end = t_end > p.total_tiles ? p.total_tiles : t_end;
+
+        if (tid < 128) {
+            cnt_s[tid] = 0;
+            tau_s[tid] = -INFINITY;
+        }
+        if (tid == 0) *flag_s = 0;
+        __syncthreads();
+
+        for (int64_t rt = t_begin; rt < t_end; ++rt) {
+            const int64_t r0 = rt * TR;
+            f32x16_t acc[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+            stage_tile(p.rp, p.dpad, r0, p.nr - 1, 0, lds, wave, lane);
+            stage_tile(p.qp, p.dpad, q0, p.nq - 1, 0, lds + TILE_BYTES, wave, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int ks = 0; ks < nks; ++ks) {
+                const int cur = ks & 1;
+                if (ks + 1 < nks) {
+                    char *nxt = lds + (cur ^ 1) * 2 * TILE_BYTES;
+                    stage_tile(p.rp, p.dpad, r0, p.nr - 1, (ks + 1) * KS, nxt, wave, lane);
+                    stage_tile(p.qp, p.dpad, q0, p.nq - 1, (ks + 1) * KS, nxt + TILE_BYTES, wave, lane);
+                }
+                const char *rtile = lds + cur * 2 * TILE_BYTES;
+                const char *qtile = rtile + TILE_BYTES;
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {  // 8 k per chunk pair
+                    f32x4_t af[2], bf[2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) af[a] = lds_frag(rtile, wm * 64 + a * 32 + l31, 2 * pr + hi);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) bf[b] = lds_frag(qtile, wn * 64 + b * 32 + l31, 2 * pr + hi);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t],
+                                                                                acc[a][b], 0, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+
+            // ---- filter: acc[a][b][reg] = <ref r0 + wm*64 + a*32 + row(reg,hi), query q0 + wn*64 + b*32 + l31>
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ql = wn * 64 + b * 32 + l31;
+                const bool qok = q0 + ql < p.nq;
+                const float tau = tau_s[ql];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const float s = acc[a][b][reg];
+                        if (s > tau) {
+                            const int64_t ref = r0 + wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                            if (qok && ref < p.nr) {
+                                const int pos = atomicAdd(&cnt_s[ql], 1);
+                                mylists[(size_t)ql * CAP + pos] = make_key(s, (unsigned)ref);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < 128 && cnt_s[tid] + TR > CAP) *flag_s = 1;
+            __syncthreads();
+            if (*flag_s) {
+                unsigned long long *scratch = (unsigned long long *)(lds + wave * TILE_BYTES);
+                for (int ql = wave * 32; ql < wave * 32 + 32; ++ql) {
+                    const int n = cnt_s[ql];
+                    if (n + TR > CAP)
+                        compact_list<EPL>(mylists + (size_t)ql * CAP, n, p.k, scratch,
+                                          mylists + (size_t)ql * CAP, &cnt_s[ql], &tau_s[ql], lane);
+                }
+                __syncthreads();
+                if (tid == 0) *flag_s = 0;
+                __syncthreads();
+            }
+        }
+
+        // ---- final: sort every list, emit the best k keys of this (query block, split)
+        {
+            unsigned long long *scratch = (unsigned long long *)(lds + wave * TILE_BYTES);
+            for (int ql = wave * 32; ql < wave * 32 + 32; ++ql) {
+                if (q0 + ql >= p.nq) continue;
+                const int n = cnt_s[ql];
+                unsigned long long *dst = p.part + ((size_t)(q0 + ql) * p.splits + sp) * p.k;
+                compact_list<EPL>(mylists + (size_t)ql * CAP, n, p.k, scratch, dst, &cnt_s[ql],
+                                  &tau_s[ql], lane);
+                for (int i = (n < p.k ? n : p.k) + lane; i < p.k; i += 64) dst[i] = 0ull;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Merge the per-split sorted key lists of one query (one wave per query) and decode.
+__global__ __launch_bounds__(256) void knn_merge_kernel(const unsigned long long *__restrict__ part,
+                                                        int64_t nq, int splits, int k,
+                                                        int64_t id_offset, float *__restrict__ out_d,
+                                                        int64_t *__restrict__ out_i) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const unsigned long long *base = part + (size_t)q * splits * k;
+    // lane owns lists lane, lane+64, lane+128, lane+192 (splits <= 256)
+    int ptr[4] = {0, 0, 0, 0};
+    unsigned long long head[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int s = lane + 64 * j;
+        head[j] = s < splits ? base[(size_t)s * k] : 0ull;
+    }
+    for (int i = 0; i < k; ++i) {
+        unsigned long long best = head[0];
+        int bj = 0;
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (head[j] > best) { best = head[j]; bj = j; }
+        unsigned long long wbest = best;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = __shfl_xor((unsigned)(wbest & 0xFFFFFFFFu), o, 64);
+            const unsigned hi = __shfl_xor((unsigned)(wbest >> 32), o, 64);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            wbest = other > wbest ? other : wbest;
+        }
+        if (lane == 0) {
+            if (wbest == 0ull) {
+                out_d[q * k + i] = -FLT_MAX;
+                out_i[q * k + i] = -1;
+            } else {
+                out_d[q * k + i] = key_score(wbest);
+                out_i[q * k + i] = (int64_t)key_index(wbest) + id_offset;
+            }
+        }
+        if (wbest != 0ull && best == wbest) {  // keys are unique: exactly one lane advances
+            const int s = lane + 64 * bj;
+            const int np = ptr[bj] + 1;
+            const unsigned long long nh = np < k ? base[(size_t)s * k + np] : 0ull;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j == bj) { ptr[j] = np; head[j] = nh; }
+        }
+    }
+}
+
+// ---- grow-only device scratch, one per process (one process per GPU) ----------------------
+struct Scratch {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+Scratch g_scratch[4];
+
+int scratch_get(int slot, size_t bytes, void **out) {
+    Scratch &s = g_scratch[slot];
+    if (s.bytes < bytes) {
+        if (s.ptr) {
+            VSC_CHECK_HIP(hipDeviceSynchronize());
+            VSC_CHECK_HIP(hipFree(s.ptr));
+            s.ptr = nullptr;
+            s.bytes = 0;
+        }
+        hipError_t e = hipMalloc(&s.ptr, bytes);
+        if (e != hipSuccess) {
+            s.ptr = nullptr;
+            vsc_set_error("knn: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            return VSC_ERR_NOMEM;
+        }
+        s.bytes = bytes;
+    }
+    *out = s.ptr;
+    return VSC_OK;
+}
+
+inline int blocks_for(int64_t items) {
+    int64_t b = (items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace
+
+extern "C" int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr,
+                              int32_t d, int32_t k, int64_t ref_id_offset, float *out_scores_dev,
+                              int64_t *out_ids_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VSC_REQUIRE(q_dev && r_dev && out_scores_dev && out_ids_dev, "knn: null pointer");
+    VSC_REQUIRE(nq > 0 && nr > 0, "knn: empty query or reference set (nq=%lld nr=%lld)", (long long)nq,
+                (long long)nr);
+    VSC_REQUIRE(d > 0 && d <= 4096, "knn: dimension %d unsupported", d);
+    VSC_REQUIRE(k >= 1 && k <= 1024, "knn: k=%d out of range [1,1024]", k);
+    VSC_REQUIRE(nr < (1ll << 32) - 1, "knn: more than 2^32-2 references in one call");
+
+    const int dpad = (d + KS - 1) / KS * KS;
+    const int epl = k + TR <= 512 ? 8 : (k + TR <= 1024 ? 16 : 32);
+    const int cap = 64 * epl;
+    const int nqb = (int)((nq + TQ - 1) / TQ);
+    const int64_t total_tiles = (nr + TR - 1) / TR;
+    int64_t want = (512 + nqb - 1) / nqb;
+    if (want > 256) want = 256;
+    if (want > total_tiles) want = total_tiles;
+    if (want < 1) want = 1;
+    const int64_t tiles_per_split = (total_tiles + want - 1) / want;
+    const int splits = (int)((total_tiles + tiles_per_split - 1) / tiles_per_split);
+    const int64_t work = (int64_t)nqb * splits;
+    const int grid = (int)(work < 512 ? work : 512);
+
+    void *qp, *rp, *lists, *part;
+    int rc;
+    if ((rc = scratch_get(0, (size_t)nq * dpad * 4, &qp))) return rc;
+    if ((rc = scratch_get(1, (size_t)nr * dpad * 4, &rp))) return rc;
+    if ((rc = scratch_get(2, (size_t)grid * 128 * cap * 8, &lists))) return rc;
+    if ((rc = scratch_get(3, (size_t)nq * splits * k * 8, &part))) return rc;
+
+    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nq * (dpad / 4))), dim3(256), 0, stream, q_dev,
+                       (float *)qp, nq, d, dpad);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nr * (dpad / 4))), dim3(256), 0, stream, r_dev,
+                       (float *)rp, nr, d, dpad);
+    VSC_CHECK_LAUNCH();
+
+    KnnArgs a{(const float *)qp, (const float *)rp, nq, nr, dpad, k, nqb, splits, total_tiles,
+              tiles_per_split, (unsigned long long *)lists, (unsigned long long *)part};
+    if (epl == 8)
+        hipLaunchKernelGGL(knn_kernel<8>, dim3(grid), dim3(256), 0, stream, a);
+    else if (epl == 16)
+        hipLaunchKernelGGL(knn_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(knn_kernel<32>, dim3(grid), dim3(256), 0, stream, a);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream,
+                       (const unsigned long long *)part, nq, splits, k, ref_id_offset, out_scores_dev,
+                       out_ids_dev);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}

@@ -74,7 +74,7 @@ def encoder_weights(seed: int, cfg) -> dict:
         w[b + "ln1.weight"] = 1.0 + normalish(nxt(), (d,), 0.05)
         w[b + "ln1.bias"] = normalish(nxt(), (d,), 0.05)
         qkv = normalish(nxt(), (3 * d, d), 0.03)
-        qkv[: 2 * d] *= 3.0
+        qkv[: 2 * d] *= 1.5
         w[b + "qkv.weight"] = qkv
         w[b + "qkv.bias"] = normalish(nxt(), (3 * d,), 0.05)
         w[b + "proj.weight"] = normalish(nxt(), (d, d), 0.03)

@@ -1,0 +1,102 @@
+"""CSLS-style score normalisation of descriptors against a noise bank
+(reference: infer/vsc/baseline/score_normalization.py:34-192).
+
+    sim_sn(q, r) = <q, r> - beta * mean_k top-k <q, noise>
+
+encoded as one extra dimension: query' = [q, bias(q)], ref' = [r, 1].  The nearest-noise
+search (`index.search(query.feature, k)`, :95/:141) and the L2 normalisation (:84-88) run
+on the GPU through libvsc_hip.so; the bookkeeping stays numpy, as in the reference.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Callable, List, Tuple
+
+import numpy as np
+
+from vsc.index import FlatIPBank, VideoFeature
+
+
+def transform_features(features: List[VideoFeature], transform: Callable) -> List[VideoFeature]:
+    return [dataclasses.replace(f, feature=transform(f.feature)) for f in features]
+
+
+def normalize(x: np.ndarray) -> np.ndarray:
+    """sklearn.preprocessing.normalize (l2, axis=1) on the GPU."""
+    import torch
+    from vsc_hip import ops
+    t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+    return ops.l2_normalize_(t).cpu().numpy()
+
+
+def low_variance_dim(score_norm_refs: List[VideoFeature]) -> int:
+    """The dimension given up for the bias term (:74-76; infer/src/utils.py:2-5)."""
+    bank = np.concatenate([r.feature for r in score_norm_refs], axis=0)
+    return int(bank.var(axis=0).argmin())
+
+
+def _noise_bank(score_norm_refs: List[VideoFeature]) -> FlatIPBank:
+    bank = FlatIPBank(score_norm_refs[0].dimensions())
+    for r in score_norm_refs:
+        bank.add(r.feature)
+    return bank
+
+
+def _bias_terms(queries, bank: FlatIPBank, beta: float, nk: int):
+    """One batched search for all query videos (the reference loops per video; frames are
+    independent so batching changes nothing)."""
+    lens = [len(q) for q in queries]
+    sims, _ = bank.search(np.concatenate([q.feature for q in queries]), nk)
+    bias = -beta * sims[:, :nk].mean(axis=1, keepdims=True)
+    return np.split(bias, np.cumsum(lens)[:-1])
+
+
+def _check_disjoint(refs, score_norm_refs):
+    if {f.video_id for f in refs} & {f.video_id for f in score_norm_refs}:
+        raise Exception("Normalizing on the dataset we're evaluating on is against VSC rules. "
+                        "An independent dataset is needed.")
+
+
+def score_normalize(queries, refs, score_norm_refs, l2_normalize: bool = True, replace_dim: bool = True,
+                    beta: float = 1.0, nk: int = 1) -> Tuple[List[VideoFeature], List[VideoFeature]]:
+    _check_disjoint(refs, score_norm_refs)
+    if score_norm_refs is not None and replace_dim:
+        dim = low_variance_dim(score_norm_refs)
+        queries, refs, score_norm_refs = [
+            transform_features(x, lambda f: np.delete(f, dim, axis=1)) for x in (queries, refs, score_norm_refs)]
+    if l2_normalize:
+        queries, refs, score_norm_refs = [transform_features(x, normalize) for x in (queries, refs, score_norm_refs)]
+    bias = _bias_terms(queries, _noise_bank(score_norm_refs), beta, nk)
+    adapted_q = [dataclasses.replace(q, feature=np.concatenate([q.feature, b], axis=1)) for q, b in zip(queries, bias)]
+    adapted_r = [dataclasses.replace(r, feature=np.concatenate([r.feature, np.ones_like(r.feature[:, :1])], axis=1))
+                 for r in refs]
+    return adapted_q, adapted_r
+
+
+def query_score_normalize(queries, score_norm_refs, video_scores: dict, score_threshold: float = 0.001,
+                          low_var_dim: int = 0, l2_normalize: bool = True, replace_dim: bool = True,
+                          beta: float = 1.0, nk: int = 1) -> List[VideoFeature]:
+    if score_norm_refs is not None and replace_dim:
+        queries, score_norm_refs = [
+            transform_features(x, lambda f: np.delete(f, low_var_dim, axis=1)) for x in (queries, score_norm_refs)]
+    if l2_normalize:
+        queries, score_norm_refs = [transform_features(x, normalize) for x in (queries, score_norm_refs)]
+    bias = _bias_terms(queries, _noise_bank(score_norm_refs), beta, nk)
+    out = []
+    for q, b in zip(queries, bias):
+        if video_scores[q.metadata().video_id] < score_threshold:
+            b = -100.0 * np.ones_like(b)  # :143: videos judged "no copy" are pushed out of every ranking
+        out.append(dataclasses.replace(q, feature=np.concatenate([q.feature, b], axis=1)))
+    return out
+
+
+def ref_score_normalize(refs, score_norm_refs, l2_normalize: bool = True, replace_dim: bool = True,
+                        beta: float = 1.0, nk: int = 1) -> List[VideoFeature]:
+    _check_disjoint(refs, score_norm_refs)
+    if score_norm_refs is not None and replace_dim:
+        dim = low_variance_dim(score_norm_refs)
+        refs = transform_features(refs, lambda f: np.delete(f, dim, axis=1))
+    if l2_normalize:
+        refs = transform_features(refs, normalize)
+    return [dataclasses.replace(r, feature=np.concatenate([r.feature, np.ones_like(r.feature[:, :1])], axis=1))
+            for r in refs]

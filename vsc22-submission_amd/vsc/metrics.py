@@ -1,0 +1,73 @@
+"""The slice of the reference's vsc/metrics.py that the descriptor path touches:
+video-id formatting, candidate pairs, and the descriptor-track micro-AP
+(infer/vsc/metrics.py:21-95, 423-455).  The matching-track segment metric is out of
+scope of this path."""
+from __future__ import annotations
+
+import dataclasses
+import enum
+from typing import Collection, List, Optional, Union
+
+import numpy as np
+
+
+class Dataset(enum.Enum):
+    QUERIES = "Q"
+    REFS = "R"
+
+
+def format_video_id(video_id: Union[str, int], dataset: Optional[Dataset]) -> str:
+    """int ids become 'Q000123' / 'R000123'; str ids are checked against `dataset`."""
+    if isinstance(video_id, (int, np.integer)):
+        if dataset is None:
+            raise ValueError("Unable to convert integer video_id without a Dataset enum")
+        return f"{dataset.value}{int(video_id):06d}"
+    if not isinstance(video_id, str):
+        raise AssertionError(f"unexpected video_id: {video_id} of type {type(video_id)}")
+    if dataset is not None and video_id[0] != dataset.value:
+        raise AssertionError(f"dataset mismatch? got {video_id} for dataset {dataset}")
+    return video_id
+
+
+@dataclasses.dataclass
+class CandidatePair:
+    query_id: str
+    ref_id: str
+    score: float
+
+    @classmethod
+    def to_dataframe(cls, candidates: Collection["CandidatePair"]):
+        import pandas as pd
+        rows = [{"query_id": format_video_id(c.query_id, Dataset.QUERIES),
+                 "ref_id": format_video_id(c.ref_id, Dataset.REFS), "score": c.score}
+                for c in candidates]
+        return pd.DataFrame(rows, columns=["query_id", "ref_id", "score"])
+
+    @classmethod
+    def write_csv(cls, candidates, file):
+        cls.to_dataframe(candidates).to_csv(file, index=False)
+
+    @classmethod
+    def read_csv(cls, file) -> List["CandidatePair"]:
+        import pandas as pd
+        df = pd.read_csv(file)
+        return [CandidatePair(format_video_id(q, Dataset.QUERIES), format_video_id(r, Dataset.REFS), s)
+                for q, r, s in zip(df.query_id, df.ref_id, df.score)]
+
+
+def micro_average_precision(ground_truth: Collection[CandidatePair],
+                            predictions: Collection[CandidatePair]) -> float:
+    """uAP over (query, ref) pairs: sum_i P(i) * correct(i) / |gt| with predictions in
+    descending score order (metrics.py:439-451, the `simple_ap`)."""
+    gt = {(p.query_id, p.ref_id) for p in ground_truth}
+    if len(gt) != len(ground_truth):
+        raise AssertionError("Duplicates detected in ground truth")
+    seen = {(p.query_id, p.ref_id) for p in predictions}
+    if len(seen) != len(predictions):
+        raise AssertionError("Duplicates detected in predictions")
+    ranked = sorted(predictions, key=lambda p: p.score, reverse=True)
+    hit = np.array([(p.query_id, p.ref_id) in gt for p in ranked], dtype=np.float64)
+    if not len(hit) or not gt:
+        return 0.0
+    precision = np.cumsum(hit) / (np.arange(len(hit)) + 1)
+    return float(np.sum(precision * hit) / len(gt))

@@ -1,0 +1,109 @@
+"""ctypes binding of libvsc_hip.so (include/vsc_hip.h).
+
+There is no CPU implementation behind these calls: if the shared library is
+missing, or no gfx950 device is visible, they raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvsc_hip.so")
+
+EPI_BF16, EPI_GELU_BF16, EPI_QGELU_BF16, EPI_RESADD_F32, EPI_PATCH_F32 = range(5)
+PROF_CLASSES = ("patchify", "gemm_patch", "layernorm", "gemm_qkv", "attention", "gemm_proj",
+                "gemm_fc1", "gemm_fc2", "pool_head", "misc")
+
+
+class HipPathUnavailable(RuntimeError):
+    """The HIP hot path cannot run here (library not built or no MI355X)."""
+
+
+class VscHipError(RuntimeError):
+    pass
+
+
+class EncoderConfigC(ctypes.Structure):
+    _fields_ = [
+        ("image_size", c_int32), ("patch_size", c_int32), ("channels", c_int32),
+        ("width", c_int32), ("layers", c_int32), ("heads", c_int32), ("mlp_dim", c_int32),
+        ("out_dim", c_int32), ("ln_eps", c_float), ("act", c_int32), ("pre_ln", c_int32),
+        ("patch_bias", c_int32), ("pool", c_int32), ("gem_p", c_float),
+        ("max_batch", c_int32), ("l2_normalize", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); also the list the symbol test checks against the header
+SIGNATURES = {
+    "vsc_last_error": (c_char_p, []),
+    "vsc_device_count": (c_int32, []),
+    "vsc_version": (c_char_p, []),
+    "vsc_encoder_create": (c_int32, [POINTER(EncoderConfigC), POINTER(c_void_p)]),
+    "vsc_encoder_destroy": (None, [c_void_p]),
+    "vsc_encoder_set_weight": (c_int32, [c_void_p, c_char_p, c_void_p, c_size_t]),
+    "vsc_encoder_finalize": (c_int32, [c_void_p]),
+    "vsc_encoder_forward": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "vsc_encoder_forward_debug": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "vsc_encoder_workspace_bytes": (c_int64, [c_void_p]),
+    "vsc_encoder_set_profiling": (c_int32, [c_void_p, c_int32]),
+    "vsc_encoder_get_profile": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "vsc_knn_ip_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int64,
+                                 c_void_p, c_void_p, c_void_p]),
+    "vsc_l2_normalize_f32": (c_int32, [c_void_p, c_int64, c_int32, c_void_p]),
+    "vsc_gemm_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                c_int32, c_int32, c_int32, c_void_p]),
+    "vsc_attention_bf16": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "vsc_layernorm_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float,
+                                    c_int32, c_void_p]),
+    "vsc_patchify_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                    c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (no GPU needed for this step)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipPathUnavailable(
+                f"{LIB_PATH} is not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C vsc22-submission_amd/csrc`; there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def require_device() -> ctypes.CDLL:
+    lib = load()
+    n = lib.vsc_device_count()
+    if n < 1:
+        raise HipPathUnavailable(
+            "no gfx950 (MI355X) device visible to HIP "
+            f"(vsc_device_count() = {n}: {lib.vsc_last_error().decode()}); there is no CPU fallback")
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise VscHipError(f"libvsc_hip status {rc}: {load().vsc_last_error().decode()}")
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libvsc_hip takes contiguous device tensors"
+    return c_void_p(t.data_ptr())

@@ -1,0 +1,103 @@
+"""``HipEncoder``: the callable that stands where the reference puts its TorchScript
+backbone -- ``model = torch.jit.load(...)``, ``flat_features = model(flat_frames)``
+(infer/extract_ref_feats.py:24-27, infer/src/extractor.py:23,
+infer/extract_query_feats.py:145-155).  Same call shape: frames [n,3,H,W] float32
+on the GPU in, features [n, dim] float32 on the GPU out.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, weights as wnames
+from ._lib import EncoderConfigC, check, current_stream, ptr
+from .config import EncoderConfig, get_config
+
+
+class HipEncoder:
+    def __init__(self, cfg: EncoderConfig | str, weights: dict, *, max_batch: int = 128,
+                 l2_normalize: bool = False):
+        if isinstance(cfg, str):
+            cfg = get_config(cfg)
+        self.cfg = cfg
+        self.max_batch = max_batch
+        self.l2 = l2_normalize
+        self._lib = _lib.require_device()
+        wnames.check_complete(weights, cfg)
+        c = EncoderConfigC(
+            image_size=cfg.image_size, patch_size=cfg.patch_size, channels=cfg.channels,
+            width=cfg.width, layers=cfg.layers, heads=cfg.heads, mlp_dim=cfg.mlp_dim,
+            out_dim=cfg.out_dim, ln_eps=cfg.ln_eps, act={"gelu": 0, "quick_gelu": 1}[cfg.act],
+            pre_ln=int(cfg.pre_ln), patch_bias=int(cfg.patch_bias),
+            pool={"gem": 0, "cls": 1}[cfg.pool], gem_p=cfg.gem_p, max_batch=max_batch,
+            l2_normalize=int(l2_normalize))
+        handle = ctypes.c_void_p()
+        check(self._lib.vsc_encoder_create(ctypes.byref(c), ctypes.byref(handle)))
+        self._h = handle
+        try:
+            for name in wnames.canonical_names(cfg):
+                arr = np.ascontiguousarray(
+                    weights[name].detach().cpu().numpy() if isinstance(weights[name], torch.Tensor)
+                    else weights[name], dtype=np.float32)
+                check(self._lib.vsc_encoder_set_weight(
+                    self._h, name.encode(), arr.ctypes.data_as(ctypes.c_void_p), arr.size))
+            check(self._lib.vsc_encoder_finalize(self._h))
+        except Exception:
+            self.close()
+            raise
+
+    # nn.Module-ish surface the reference call sites use
+    def eval(self):
+        return self
+
+    def cuda(self, *_a, **_k):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self._lib.vsc_encoder_workspace_bytes(self._h))
+
+    def __call__(self, frames: torch.Tensor, return_tokens: bool = False):
+        assert self._h is not None, "encoder was closed"
+        cfg = self.cfg
+        if frames.dim() != 4 or tuple(frames.shape[1:]) != (cfg.channels, cfg.image_size, cfg.image_size):
+            raise ValueError(f"expected frames [n,{cfg.channels},{cfg.image_size},{cfg.image_size}], "
+                             f"got {tuple(frames.shape)}")
+        if not frames.is_cuda:
+            raise _lib.HipPathUnavailable("frames must be on the GPU; there is no CPU path")
+        frames = frames.to(torch.float32).contiguous()
+        n = frames.shape[0]
+        desc = torch.empty((n, cfg.desc_dim), dtype=torch.float32, device=frames.device)
+        tokens = None
+        if return_tokens:
+            tokens = torch.empty((n, cfg.tokens, cfg.width), dtype=torch.float32, device=frames.device)
+        if n:
+            check(self._lib.vsc_encoder_forward_debug(self._h, ptr(frames), n, ptr(desc), ptr(tokens),
+                                                      current_stream()))
+        return (desc, tokens) if return_tokens else desc
+
+    def set_profiling(self, on: bool) -> None:
+        check(self._lib.vsc_encoder_set_profiling(self._h, int(on)))
+
+    def get_profile(self) -> dict:
+        """{class: (total_ms, launches)} accumulated since set_profiling(True)."""
+        ms = (ctypes.c_double * len(_lib.PROF_CLASSES))()
+        cnt = (ctypes.c_int64 * len(_lib.PROF_CLASSES))()
+        check(self._lib.vsc_encoder_get_profile(self._h, ms, cnt))
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.PROF_CLASSES)}
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self._lib.vsc_encoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,96 @@
+"""Thin torch-tensor wrappers over the C ABI building blocks (used by the parity
+tests and by vsc/index.py).  torch here is device memory + streams only."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr
+
+
+def _dev(t: torch.Tensor, dtype) -> torch.Tensor:
+    assert t.is_cuda, "operand must live on the GPU"
+    return t.to(dtype).contiguous()
+
+
+def gemm_bf16(a, w, bias=None, *, epilogue=_lib.EPI_BF16, aux=None, tokens=0, out=None):
+    """out = epi(a @ w.T + bias); a [M,K] bf16, w [N,K] bf16."""
+    lib = _lib.require_device()
+    a, w = _dev(a, torch.bfloat16), _dev(w, torch.bfloat16)
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k
+    bias = None if bias is None else _dev(bias, torch.float32)
+    aux = None if aux is None else _dev(aux, torch.float32)
+    if out is None:
+        if epilogue in (_lib.EPI_BF16, _lib.EPI_GELU_BF16, _lib.EPI_QGELU_BF16):
+            out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+        elif epilogue == _lib.EPI_RESADD_F32:
+            out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        else:
+            frames = m // (tokens - 1)
+            out = torch.zeros((frames * tokens, n), dtype=torch.float32, device=a.device)
+    check(lib.vsc_gemm_bf16(ptr(a), ptr(w), ptr(bias), ptr(aux), ptr(out), m, n, k, epilogue, tokens,
+                            current_stream()))
+    return out
+
+
+def attention_bf16(qkv, frames: int, tokens: int, heads: int):
+    lib = _lib.require_device()
+    qkv = _dev(qkv, torch.bfloat16)
+    assert qkv.shape == (frames * tokens, 3 * heads * 64)
+    out = torch.empty((frames * tokens, heads * 64), dtype=torch.bfloat16, device=qkv.device)
+    check(lib.vsc_attention_bf16(ptr(qkv), ptr(out), frames, tokens, heads, current_stream()))
+    return out
+
+
+def layernorm(x, gamma, beta, eps: float, out_f32: bool = False):
+    lib = _lib.require_device()
+    x, gamma, beta = (_dev(t, torch.float32) for t in (x, gamma, beta))
+    rows, width = x.shape
+    out = torch.empty((rows, width), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    check(lib.vsc_layernorm_f32(ptr(x), ptr(gamma), ptr(beta), ptr(out), rows, width, eps,
+                                int(out_f32), current_stream()))
+    return out
+
+
+def patchify_bf16(frames, patch: int, kpad: int):
+    lib = _lib.require_device()
+    frames = _dev(frames, torch.float32)
+    n, c, h, w = frames.shape
+    assert h == w
+    g = h // patch
+    out = torch.empty((n * g * g, kpad), dtype=torch.bfloat16, device=frames.device)
+    check(lib.vsc_patchify_bf16(ptr(frames), ptr(out), n, c, h, patch, kpad, current_stream()))
+    return out
+
+
+def l2_normalize_(x):
+    """In place, sklearn.preprocessing.normalize semantics."""
+    lib = _lib.require_device()
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    if x.shape[0]:
+        check(lib.vsc_l2_normalize_f32(ptr(x), x.shape[0], x.shape[1], current_stream()))
+    return x
+
+
+def knn_ip(q, r, k: int, ref_id_offset: int = 0):
+    """Exact inner-product top-k.  q [nq,d], r [nr,d] float32 on the GPU ->
+    (scores [nq,k] float32 descending, ids [nq,k] int64).  Empty inputs follow
+    faiss: nq == 0 -> empty outputs; nr == 0 -> all (-FLT_MAX, -1)."""
+    lib = _lib.require_device()
+    q, r = _dev(q, torch.float32), _dev(r, torch.float32)
+    nq, d = q.shape
+    nr = r.shape[0]
+    assert r.shape[1] == d, "query / reference dimension mismatch"
+    scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+    ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+    if nq == 0:
+        return scores, ids
+    if nr == 0:
+        scores.fill_(torch.finfo(torch.float32).min)
+        ids.fill_(-1)
+        return scores, ids
+    check(lib.vsc_knn_ip_f32(ptr(q), nq, ptr(r), nr, d, k, ref_id_offset, ptr(scores), ptr(ids),
+                             current_stream()))
+    return scores, ids
