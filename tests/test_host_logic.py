@@ -1,0 +1,173 @@
+"""Host-side logic that needs no GPU: descriptor file format, video-id formatting, pair
+bookkeeping, weight-name translation -- and that the product path refuses to run without
+the HIP device instead of falling back to anything."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from vsc.index import VideoFeature, VideoIndex
+from vsc.metrics import CandidatePair, Dataset, format_video_id, micro_average_precision
+from vsc.storage import load_features, same_value_ranges, store_features
+
+no_gpu = pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+
+
+def _vf(video_id, n, dims=32, interval=False, fps=1.0, seed=0):
+    rs = np.random.RandomState(seed + n)
+    ts = np.arange(n) / fps
+    if interval:
+        ts = np.stack([ts, ts + fps], axis=1)
+    return VideoFeature(video_id=video_id, timestamps=ts, feature=rs.randn(n, dims))
+
+
+@pytest.mark.parametrize("interval", [False, True])
+def test_storage_round_trip(interval):
+    """Mirrors the reference's tests/test_storage.py (merged storage, int -> 'Q%06d' ids)."""
+    feats = [_vf(2, 10, interval=interval), _vf(3, 20, interval=interval, fps=3.0),
+             _vf(1, 30, interval=interval, fps=0.5)]
+    buf = io.BytesIO()
+    store_features(buf, feats, Dataset.QUERIES)
+    buf.seek(0)
+    back = load_features(buf)
+    assert [b.video_id for b in back] == ["Q000002", "Q000003", "Q000001"]
+    for a, b in zip(feats, back):
+        np.testing.assert_allclose(b.timestamps, a.timestamps)
+        np.testing.assert_allclose(b.feature, a.feature.astype(np.float32))
+        assert b.feature.dtype == np.float32
+    buf2 = io.BytesIO()
+    store_features(buf2, back)
+    buf2.seek(0)
+    for a, b in zip(back, load_features(buf2)):
+        assert a.video_id == b.video_id
+        np.testing.assert_array_equal(a.feature, b.feature)
+
+
+def test_npz_layout_is_the_reference_layout():
+    buf = io.BytesIO()
+    store_features(buf, [_vf("R000007", 3), _vf("R000009", 2)])
+    buf.seek(0)
+    data = np.load(buf)
+    assert sorted(data.files) == ["features", "timestamps", "video_ids"]
+    assert data["video_ids"].tolist() == ["R000007"] * 3 + ["R000009"] * 2
+    assert data["features"].shape == (5, 32) and data["features"].dtype == np.float32
+
+
+def test_same_value_ranges_and_id_format():
+    assert list(same_value_ranges(["a", "a", "b", "c", "c", "c"])) == [("a", 0, 2), ("b", 2, 3), ("c", 3, 6)]
+    assert format_video_id(12, Dataset.REFS) == "R000012"
+    assert format_video_id("Q000001", Dataset.QUERIES) == "Q000001"
+    with pytest.raises(AssertionError):
+        format_video_id("R000001", Dataset.QUERIES)
+    with pytest.raises(ValueError):
+        format_video_id(3, None)
+
+
+def test_load_rejects_bad_timestamps():
+    buf = io.BytesIO()
+    np.savez(buf, video_ids=np.array(["Q1"] * 3), features=np.zeros((3, 4), np.float32), timestamps=np.zeros(2))
+    buf.seek(0)
+    with pytest.raises(ValueError):
+        load_features(buf)
+
+
+def test_pair_matches_bookkeeping():
+    """The grouping the reference does after the search (index.py:129-143), fed with hits."""
+    refs = [VideoFeature("R1", np.array([2.0, 4.0, 6.0]), np.zeros((3, 4))),
+            VideoFeature("R2", np.array([[0.0, 5.0], [5.0, 10.0]]), np.zeros((2, 4)))]
+    idx = VideoIndex(4)
+    idx.add(refs)
+    assert idx.index.ntotal == 5 and idx.video_clip_idx == [0, 1, 2, 0, 1]
+    q = VideoFeature("Q1", np.array([0.0, 1.0]), np.zeros((2, 4)))
+    hits = [(0, 1, 0.9), (1, 4, 0.8), (1, 2, 0.7)]
+    pm = idx.pair_matches(hits, ["Q1", "Q1"], [0, 1], {"Q1": q.metadata()})
+    got = {(p.query_id, p.ref_id): p.matches for p in pm}
+    assert got[("Q1", "R1")][0].ref_timestamps == (4.0, 4.0) and got[("Q1", "R1")][1].score == 0.7
+    assert got[("Q1", "R2")][0].ref_timestamps == (5.0, 10.0) and got[("Q1", "R2")][0].query_timestamps == (1.0, 1.0)
+
+
+def test_micro_ap():
+    gt = [CandidatePair("Q1", "R2", 1.0)]
+    preds = [CandidatePair("Q2", "R2", 3.0), CandidatePair("Q1", "R1", 2.0), CandidatePair("Q1", "R2", 1.0)]
+    assert micro_average_precision(gt, preds) == pytest.approx(1 / 3)   # reference tests/test_metrics.py:124-135
+    assert micro_average_precision(gt, preds[2:]) == 1.0
+    with pytest.raises(AssertionError):
+        micro_average_precision(gt + gt, preds)
+
+
+def test_weight_name_translation_round_trip():
+    from src import synth
+    from vsc_hip import weights as W
+    from vsc_hip.config import get_config
+    cfg = get_config("tiny")
+    w = synth.encoder_weights(3, cfg)
+    d = cfg.width
+    hf_old = {"vit.embeddings.cls_token": w["cls"].reshape(1, 1, d),
+              "vit.embeddings.position_embeddings": w["pos"][None],
+              "vit.embeddings.patch_embeddings.projection.weight": w["patch.weight"],
+              "vit.embeddings.patch_embeddings.projection.bias": w["patch.bias"],
+              "vit.layernorm.weight": w["ln_post.weight"], "vit.layernorm.bias": w["ln_post.bias"],
+              "vit.pooler.dense.weight": np.zeros((d, d), np.float32),
+              "output_proj.weight": w["head.weight"], "output_proj.bias": w["head.bias"]}
+    for i in range(cfg.layers):
+        b, t = f"blocks.{i}.", f"vit.encoder.layer.{i}."
+        for j, nm in enumerate(("query", "key", "value")):
+            hf_old[t + f"attention.attention.{nm}.weight"] = w[b + "qkv.weight"][j * d:(j + 1) * d]
+            hf_old[t + f"attention.attention.{nm}.bias"] = w[b + "qkv.bias"][j * d:(j + 1) * d]
+        for src, dst in (("proj", "attention.output.dense"), ("ln1", "layernorm_before"), ("ln2", "layernorm_after"),
+                         ("fc1", "intermediate.dense"), ("fc2", "output.dense")):
+            hf_old[t + dst + ".weight"], hf_old[t + dst + ".bias"] = w[b + src + ".weight"], w[b + src + ".bias"]
+    got = W.from_hf_vit(hf_old, cfg)
+    W.check_complete(got, cfg)
+    for k in W.canonical_names(cfg):
+        np.testing.assert_array_equal(got[k].reshape(w[k].shape), w[k])
+
+    timm = {"cls_token": w["cls"].reshape(1, 1, d), "pos_embed": w["pos"][None],
+            "patch_embed.proj.weight": w["patch.weight"], "patch_embed.proj.bias": w["patch.bias"],
+            "norm.weight": w["ln_post.weight"], "norm.bias": w["ln_post.bias"]}
+    for i in range(cfg.layers):
+        for src, dst in (("ln1", "norm1"), ("qkv", "attn.qkv"), ("proj", "attn.proj"), ("ln2", "norm2"),
+                         ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
+            for kind in ("weight", "bias"):
+                timm[f"blocks.{i}.{dst}.{kind}"] = w[f"blocks.{i}.{src}.{kind}"]
+    got = W.from_timm_vit(timm, get_config("tiny", out_dim=0))
+    W.check_complete(got, get_config("tiny", out_dim=0))
+
+    ccfg = get_config("tiny_clip")
+    cw = synth.encoder_weights(3, ccfg)
+    clip = {"visual.conv1.weight": cw["patch.weight"], "visual.class_embedding": cw["cls"],
+            "visual.positional_embedding": cw["pos"]}
+    for nm in ("ln_pre", "ln_post"):
+        clip[f"visual.{nm}.weight"], clip[f"visual.{nm}.bias"] = cw[nm + ".weight"], cw[nm + ".bias"]
+    for i in range(ccfg.layers):
+        t, b = f"visual.transformer.resblocks.{i}.", f"blocks.{i}."
+        clip[t + "attn.in_proj_weight"], clip[t + "attn.in_proj_bias"] = cw[b + "qkv.weight"], cw[b + "qkv.bias"]
+        for src, dst in (("proj", "attn.out_proj"), ("ln1", "ln_1"), ("ln2", "ln_2"), ("fc1", "mlp.c_fc"), ("fc2", "mlp.c_proj")):
+            clip[t + dst + ".weight"], clip[t + dst + ".bias"] = cw[b + src + ".weight"], cw[b + src + ".bias"]
+    got = W.from_clip_visual(clip, ccfg)
+    W.check_complete(got, ccfg)
+
+
+@no_gpu
+def test_product_path_fails_loudly_without_gpu():
+    from src import synth
+    from vsc_hip import _lib, ops
+    from vsc_hip.config import get_config
+    from vsc_hip.encoder import HipEncoder
+    cfg = get_config("tiny")
+    with pytest.raises(_lib.HipPathUnavailable, match="no CPU fallback"):
+        HipEncoder(cfg, synth.encoder_weights(1, cfg))
+    with pytest.raises(_lib.HipPathUnavailable):
+        ops.l2_normalize_(torch.zeros(2, 4))
+    idx = VideoIndex(4)
+    idx.add([VideoFeature("R1", np.arange(3.0), np.ones((3, 4), np.float32))])
+    with pytest.raises(_lib.HipPathUnavailable):
+        idx.search([VideoFeature("Q1", np.arange(2.0), np.ones((2, 4), np.float32))], global_k=2)
+
+
+def test_config_flops():
+    from vsc_hip.config import get_config
+    cfg = get_config("vit_b16_224")
+    assert cfg.tokens == 197 and cfg.head_dim == 64 and cfg.patch_dim == 768
+    assert 34.5e9 < cfg.flops_per_frame() < 36e9   # ViT-B/16: ~17.5 GMAC
