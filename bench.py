@@ -66,7 +66,15 @@ def gemm_flops_per_frame(cfg):
 
 def cpu_baseline(cfg, weights, frames_np, budget_s=15.0):
     from oracle import vit_oracle
-    torch.set_num_threads(os.cpu_count() or 1)
+    # threads this process may really use: affinity mask, capped by the cgroup CPU quota
+    ncpu = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncpu = max(1, min(ncpu, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    torch.set_num_threads(ncpu)
     w = {k: torch.from_numpy(v) for k, v in weights.items()}
     x = torch.from_numpy(frames_np)
     with torch.no_grad():
@@ -88,9 +96,9 @@ def bench_search(dev, args):
     from vsc_hip import ops
     d = 512
     nq, nr, k = args.search_nq, args.search_nr, args.search_k
-    g = torch.Generator(device="cpu").manual_seed(1)
-    r = torch.randn(nr, d, generator=g).to(dev)
-    q = torch.randn(nq, d, generator=g).to(dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    r = torch.randn(nr, d, generator=g, device=dev)
+    q = torch.randn(nq, d, generator=g, device=dev)
     ops.l2_normalize_(r)
     ops.l2_normalize_(q)
     ops.knn_ip(q[:256], r[:4096], k)  # allocate + warm
