@@ -20,6 +20,8 @@
 //     stores 8 B (bf16) / 16 B (fp32) per lane instead of four scalars.
 //   * block id -> tile is XCD-aware (common.h xcd_remap): each XCD walks a contiguous
 //     range of tiles, N fastest, so an A row-panel is fetched into one L2 only.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -37,7 +39,8 @@ struct GemmArgs {
     const float *aux;
     void *out;
     int64_t m;
-    int n, k, tokens, tiles_n;
+    int n, k, tokens, tiles_n, tiles_m, group_n;
+    int abl;  // diagnostic ablation bits (VSC_GEMM_ABL): 1 no loop DMA, 2 no MFMA, 4 no epilogue stores, 8 no frag reads
 };
 
 // Stage rows [row0, row0+128) x k in [k0, k0+64) of a row-major bf16 matrix into one
@@ -61,11 +64,24 @@ __device__ __forceinline__ bf16x8_t lds_frag(const char *tile, int row, int chun
     return *(const bf16x8_t *)(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
+// exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16
+// rounding of the stored result): one v_rcp_f32 + one v_exp_f32 instead of libm's erff.
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);  // v_rcp_f32 (1 ulp), not the IEEE divide sequence
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    // exp(-z^2) = exp2(-(x^2/2) * log2 e): one multiply feeding v_exp_f32
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
+    const float half_erfc = 0.5f * poly * t * e;      // 0.5 * (1 - erf(z)), z >= 0
+    // Phi(x) = 0.5 (1 + erf(x / sqrt 2)) = 1 - half_erfc (x > 0) | half_erfc (x <= 0)
+    return x * (x > 0.f ? 1.0f - half_erfc : half_erfc);
 }
 __device__ __forceinline__ float quick_gelu(float x) {
-    return x / (1.0f + __expf(-1.702f * x));
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.45546696f));  // 1.702 * log2 e
 }
 
 template <int EPI>
@@ -163,6 +179,325 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v2: 256-row tiles, 8 waves, BK = 32, STAGES-deep LDS-DMA ring with counted vmcnt.
+//   * tile 256 x BN (BN = 256: waves 2x4, wave tile 128x64; BN = 128: waves 4x2, wave tile 64x64)
+//     -> 128 / 85 FLOP per byte of LDS-DMA traffic instead of 64: the v1 tile was bound by
+//     L2->LDS bandwidth, not by the matrix pipe.
+//   * BK = 32 = one v_mfma_f32_16x16x32_bf16 k-slice; LDS rows are 64 B, 16-B chunk c of row r is
+//     stored at c ^ ((-(r >> 2)) & 3): conflict-free for ds_read_b128's real lane groups
+//     ({0-3,12-15,20-27}, ...) where four rows share one 256-B bank row.
+//   * ring of STAGES stages; tile kt+STAGES-1 is issued right after the barrier of step kt, and
+//     the wait before that barrier is `s_waitcnt vmcnt(L * (STAGES-2))` -- the newest STAGES-2
+//     tiles stay in flight ACROSS the barrier (raw s_barrier: __syncthreads would drain them).
+//     RAW: a wave waits for its own pieces of tile kt, the barrier covers the other waves'
+//     pieces.  WAR: the stage refilled after barrier kt was last read in step kt-1, which every
+//     wave finished before arriving at barrier kt.
+template <int ROWS, int NW>  // rows of a 64-byte-row tile region, staged by NW waves
+__device__ __forceinline__ void stage_rows32(const uint16_t *src, int64_t ld, int64_t row0,
+                                             int64_t row_last, int k0, char *region, int wave,
+                                             int lane) {
+    constexpr int PIECES = ROWS / 16;  // 1 KiB pieces of 16 rows
+#pragma unroll
+    for (int j = 0; j < PIECES / NW; ++j) {
+        const int piece = j * NW + wave;
+        const int r = piece * 16 + (lane >> 2);
+        const int c = (lane & 3) ^ ((-(r >> 2)) & 3);
+        int64_t gr = row0 + r;
+        gr = gr > row_last ? row_last : gr;
+        const uint16_t *g = src + gr * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(region + piece * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8_t lds_frag32(const char *region, int row, int g) {
+    return *(const bf16x8_t *)(region + row * 64 + ((g ^ ((-(row >> 2)) & 3)) << 4));
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wait until at most `tiles` whole tiles (L LDS-DMA instructions each) of this wave are in flight
+template <int L, int STAGES>
+__device__ __forceinline__ void wait_tiles(int tiles) {
+    if (STAGES >= 5 && tiles >= 3) wait_vmcnt<3 * L>();
+    else if (STAGES >= 4 && tiles >= 2) wait_vmcnt<2 * L>();
+    else if (tiles >= 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+}
+
+// one lane's 4 consecutive columns of one output row
+template <int EPI>
+__device__ __forceinline__ void epilogue_frag(const GemmArgs &p, f32x4_t v, int64_t orow,
+                                              const float *auxrow, int n) {
+    if (p.bias) v += *(const f32x4_t *)(p.bias + n);
+    if (EPI == VSC_EPI_BF16 || EPI == VSC_EPI_GELU_BF16 || EPI == VSC_EPI_QGELU_BF16) {
+        if (EPI == VSC_EPI_GELU_BF16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        } else if (EPI == VSC_EPI_QGELU_BF16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
+        *(uint2 *)((uint16_t *)p.out + orow * p.n + n) = pk;
+    } else {
+        v += *(const f32x4_t *)(auxrow + n);
+        *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
+    }
+}
+
+template <int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int STAGES>
+__global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(GemmArgs p) {
+    constexpr int NW = WAVES_M * WAVES_N;  // 8: one block per CU, two staggered wave groups;
+                                           // 4: two independent blocks per CU (their phases
+                                           //    drift apart, so one block's write-out overlaps
+                                           //    the other's K loop)
+    constexpr int BM2 = WAVES_M * TM * 16, BN2 = WAVES_N * TN * 16, BK2 = 32;
+    constexpr int A_BYTES = BM2 * 64, W_BYTES = BN2 * 64, STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int L = (BM2 + BN2) / (16 * NW);  // LDS-DMA instructions per thread per tile
+    static_assert(NW == 8 || NW == 4, "4 or 8 waves");
+    static_assert(L * (STAGES - 2) < 64, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) char lds2[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    // group-of-G ordering along N inside the XCD's range keeps a W panel L2-resident
+    int tm, tn;
+    {
+        const int G = p.group_n;
+        const int per_group = G * p.tiles_m;
+        const int grp = t / per_group;
+        const int first = grp * G;
+        const int width = (p.tiles_n - first) < G ? (p.tiles_n - first) : G;
+        const int rem = t - grp * per_group;
+        tm = rem / width;
+        tn = first + (rem - tm * width);
+    }
+    const int64_t m0 = (int64_t)tm * BM2;
+    const int n0 = tn * BN2;
+    const int64_t a_last = p.m - 1, w_last = p.n - 1;
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // Two-phase, two-group schedule.  Every K-step is an L phase (issue the LDS-DMA of tile
+    // kt+STAGES-1, read the fragments of tile kt into registers) and a C phase (32 MFMAs), each
+    // closed by a workgroup barrier.  Waves 4-7 (the second wave of every SIMD) run one phase
+    // behind waves 0-3, so on each SIMD one wave is in C while the other is in L: the matrix
+    // pipe is fed while DMA issue / LDS reads proceed.
+    //   RAW: a wave waits for ITS pieces of tile kt+1 at the end of L(kt); the barrier closing
+    //        that phase precedes every read of tile kt+1 by either group.
+    //   WAR: the stage refilled in L(kt) was last read in L(kt-1) of both groups, whose
+    //        ds_reads were drained (lgkmcnt(0)) before the barrier that precedes L(kt).
+    const int nk = p.k / BK2;
+    const int group = NW == 8 ? wave >> 2 : 0;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) {
+        if (s < nk) {
+            char *st = lds2 + s * STAGE_BYTES;
+            stage_rows32<BM2, NW>(p.a, p.k, m0, a_last, s * BK2, st, wave, lane);
+            stage_rows32<BN2, NW>(p.w, p.k, n0, w_last, s * BK2, st + A_BYTES, wave, lane);
+        }
+    }
+    {
+        const int issued = nk < STAGES - 1 ? nk : STAGES - 1;
+        wait_tiles<L, STAGES>(issued - 1);  // tile 0 landed
+    }
+    __builtin_amdgcn_s_barrier();
+    if (NW == 8 && group == 1) __builtin_amdgcn_s_barrier();  // stagger
+    const int fr = lane & 15, fq = lane >> 4;
+    int cur = 0;  // stage of tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---- L phase
+        if (kt + STAGES - 1 < nk && !(p.abl & 1)) {
+            int ns = cur + STAGES - 1;
+            ns = ns >= STAGES ? ns - STAGES : ns;
+            char *st = lds2 + ns * STAGE_BYTES;
+            stage_rows32<BM2, NW>(p.a, p.k, m0, a_last, (kt + STAGES - 1) * BK2, st, wave, lane);
+            stage_rows32<BN2, NW>(p.w, p.k, n0, w_last, (kt + STAGES - 1) * BK2, st + A_BYTES, wave, lane);
+        }
+        const char *at = lds2 + cur * STAGE_BYTES;
+        const char *wt = at + A_BYTES;
+        bf16x8_t wf[TN], af[TM];
+        if (!(p.abl & 8)) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = lds_frag32(wt, wn * TN * 16 + j * 16 + fr, fq);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = lds_frag32(at, wm * TM * 16 + i * 16 + fr, fq);
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = (bf16x8_t){1, 2, 3, 4, 5, 6, 7, (short)kt};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = (bf16x8_t){1, 2, 3, 4, 5, 6, 7, (short)i};
+        }
+        {
+            int allowed = nk - 2 - kt;  // tiles issued after tile kt+1
+            allowed = allowed > STAGES - 2 ? STAGES - 2 : (allowed < 0 ? 0 : allowed);
+            wait_tiles<L, STAGES>(allowed);
+        }
+        // pin: every fragment is live (and its ds_read retired) before the phase barrier
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wf[j]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[i]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- C phase
+        __builtin_amdgcn_s_setprio(1);
+        if (!(p.abl & 2)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (NW == 8) __builtin_amdgcn_s_barrier();  // single group: the L-phase barrier alone orders RAW and WAR
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+    }
+    if (NW == 8 && group == 0) __builtin_amdgcn_s_barrier();
+    if (NW == 4) __builtin_amdgcn_s_barrier();  // every wave is past its last fragment read
+
+    // ---- epilogue through LDS.  A lane's accumulators are 4 columns of 16 different rows
+    // per fragment: stored directly that is 32-byte pieces of 16 rows per instruction, and the
+    // partial-line writes cost 30-40 % of the kernel.  The ring is idle now (every wave is
+    // past its last fragment read and every DMA has landed), so each wave transposes its
+    // 64-column tile through a private 16 KiB region and writes whole 128-B (bf16) / 256-B
+    // (fp32) row segments with 16-byte stores; the residual / position rows are read the
+    // same way.  16-B chunks are XOR-swizzled by the row so both the fragment-layout
+    // writes and the row-layout reads are conflict-free (<= 2-way for the 8-B bf16 writes).
+    static_assert(TN == 4, "wave tile is 64 columns wide");
+    char *reg = lds2 + wave * 16384;  // NW x 16 KiB <= the ring (checked in launch_v2)
+    const int ncol0 = n0 + wn * 64;
+    if (EPI == VSC_EPI_BF16 || EPI == VSC_EPI_GELU_BF16 || EPI == VSC_EPI_QGELU_BF16) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = ncol0 + j * 16 + fq * 4;
+            f32x4_t bz = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.n) bz = *(const f32x4_t *)(p.bias + n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                f32x4_t v = acc[i][j] + bz;
+                if (EPI == VSC_EPI_GELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                } else if (EPI == VSC_EPI_QGELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                const int row = i * 16 + fr, chunk = 2 * j + (fq >> 1);
+                *(uint2 *)(reg + row * 128 + ((chunk ^ (row & 7)) << 4) + (fq & 1) * 8) = pk;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int c = lane & 7;
+        const int n = ncol0 + c * 8;
+#pragma unroll
+        for (int it = 0; it < TM * 2; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const uint4 d = *(const uint4 *)(reg + row * 128 + ((c ^ (row & 7)) << 4));
+            const int64_t m = m0 + wm * TM * 16 + row;
+            if (m < p.m && n < p.n && !((p.abl & 4) && d.x != 0x12345678u))
+                *(uint4 *)((uint16_t *)p.out + m * p.n + n) = d;
+        }
+    } else {
+        const int c = lane & 15;
+        const int n = ncol0 + c * 4;
+#pragma unroll
+        for (int pass = 0; pass < TM / 4; ++pass) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nb = ncol0 + j * 16 + fq * 4;
+                f32x4_t bz = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                if (p.bias && nb < p.n) bz = *(const f32x4_t *)(p.bias + nb);
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int row = ii * 16 + fr, chunk = 4 * j + fq;
+                    *(f32x4_t *)(reg + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[pass * 4 + ii][j] + bz;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ (row & 15)) << 4));
+                const int64_t m = m0 + wm * TM * 16 + pass * 64 + row;
+                if (m < p.m && n < p.n) {
+                    int64_t orow = m;
+                    const float *auxrow;
+                    if (EPI == VSC_EPI_PATCH_F32) {
+                        const int pt = p.tokens - 1;
+                        const int64_t f = m / pt;
+                        const int tok = (int)(m - f * pt) + 1;
+                        orow = f * p.tokens + tok;
+                        auxrow = p.aux + (int64_t)tok * p.n;
+                    } else {
+                        auxrow = p.aux + m * p.n;
+                    }
+                    v += *(const f32x4_t *)(auxrow + n);
+                    if (!((p.abl & 4) && v[0] != 12345.678f)) *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int STAGES>
+int launch_v2(GemmArgs p, hipStream_t stream) {
+    constexpr int BM2 = WAVES_M * TM * 16, BN2 = WAVES_N * TN * 16;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int ring = STAGES * (BM2 + BN2) * 64;
+    constexpr int smem = ring > NW * 16384 ? ring : NW * 16384;
+    auto kern = gemm_bf16_v2_kernel<EPI, WAVES_M, WAVES_N, TM, TN, STAGES>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    p.tiles_m = (int)((p.m + BM2 - 1) / BM2);
+    p.tiles_n = (p.n + BN2 - 1) / BN2;
+    // W panel of one N-group (G tiles x K) should sit in a 4 MiB XCD L2 next to the A panels
+    int g = (int)((int64_t)(3 << 19) / ((int64_t)BN2 * p.k * 2));
+    if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
+    p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), smem, stream, p);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+template <int EPI>
+int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
+    // wide N: 256x256 tile; N <= 1024 (proj / fc2 / patch): 256x128 so the grid still fills 256 CUs
+    // A: 8 waves 256x256 (1 block/CU)   B: 8 waves 256x128
+    // C: 4 waves 128x256 (2 blocks/CU)  D: 4 waves 256x128 (2 blocks/CU)
+    static const char *force = getenv("VSC_GEMM_CFG");
+    const char cfg = force ? force[0] : (p.n > 128 ? 'A' : 'B');  // measured: A wins on every encoder shape
+    switch (cfg) {
+        case 'A': return launch_v2<EPI, 2, 4, 8, 4, 4>(p, stream);
+        case 'B': return launch_v2<EPI, 4, 2, 4, 4, 4>(p, stream);
+        case 'C': return launch_v2<EPI, 1, 4, 8, 4, 3>(p, stream);
+        default: return launch_v2<EPI, 2, 2, 8, 4, 3>(p, stream);
+    }
+}
+
 template <int EPI>
 int launch_t(const GemmArgs &p, int tiles_m, hipStream_t stream) {
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles_m * p.tiles_n), dim3(256), 0, stream, p);
@@ -182,7 +517,26 @@ int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, co
     const int64_t tiles_m = (m + BM - 1) / BM;
     const int tiles_n = (n + BN - 1) / BN;
     VSC_REQUIRE(tiles_m * tiles_n < (1ll << 31), "gemm: grid too large");
-    GemmArgs p{a, w, bias, aux, out, m, n, k, tokens, tiles_n};
+    GemmArgs p{a, w, bias, aux, out, m, n, k, tokens, tiles_n, (int)tiles_m, 1, 0};
+    if (const char *e = getenv("VSC_GEMM_ABL")) p.abl = atoi(e);
+    static const bool force_v1 = getenv("VSC_GEMM_V1") != nullptr;
+    const bool v2 = !force_v1 && m >= 1024 && k % 32 == 0 && n % 8 == 0;
+    if (epilogue == VSC_EPI_RESADD_F32) VSC_REQUIRE(aux, "gemm: RESADD needs the residual pointer");
+    if (epilogue == VSC_EPI_PATCH_F32) {
+        VSC_REQUIRE(aux && tokens > 1, "gemm: PATCH needs pos and tokens");
+        VSC_REQUIRE(m % (tokens - 1) == 0, "gemm: PATCH rows %lld not a multiple of %d patches",
+                    (long long)m, tokens - 1);
+    }
+    if (v2) {
+        switch (epilogue) {
+            case VSC_EPI_BF16: return launch_v2_pick<VSC_EPI_BF16>(p, stream);
+            case VSC_EPI_GELU_BF16: return launch_v2_pick<VSC_EPI_GELU_BF16>(p, stream);
+            case VSC_EPI_QGELU_BF16: return launch_v2_pick<VSC_EPI_QGELU_BF16>(p, stream);
+            case VSC_EPI_RESADD_F32: return launch_v2_pick<VSC_EPI_RESADD_F32>(p, stream);
+            case VSC_EPI_PATCH_F32: return launch_v2_pick<VSC_EPI_PATCH_F32>(p, stream);
+            default: VSC_REQUIRE(false, "gemm: unknown epilogue %d", epilogue);
+        }
+    }
     switch (epilogue) {
         case VSC_EPI_BF16: return launch_t<VSC_EPI_BF16>(p, (int)tiles_m, stream);
         case VSC_EPI_GELU_BF16: return launch_t<VSC_EPI_GELU_BF16>(p, (int)tiles_m, stream);
