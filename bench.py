@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=332,
+                    help="frames per step per GPU (332 x 197 tokens = 255.5 -> 256 GEMM row tiles: every "
+                         "GEMM grid is then a whole number of 256-CU rounds)")
     ap.add_argument("--preset", default="vit_b16_224")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true")
@@ -201,7 +203,7 @@ def main():
                        "gflop_per_frame": round(cfg.flops_per_frame() / 1e9, 2),
                        "parallelism": f"frames sharded over {world} rank(s), no data-path collective"},
             "model_tflops": round(cfg.flops_per_frame() * total_frames / dt / 1e12 / world, 1),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (patch/qkv/proj/fc1/fc2 launches)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_v2_kernel (patch/qkv/proj/fc1/fc2 launches)",
                          "achieved": round(achieved, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_PEAK_TFLOPS, 4), "traffic": None,
                          "gemm_ms_per_step": round(gemm_ms / args.steps, 3)},

@@ -40,6 +40,7 @@ struct GemmArgs {
     void *out;
     int64_t m;
     int n, k, tokens, tiles_n, tiles_m, group_n;
+    int skew;  // first-round start skew in shader cycles (see phase_skew)
     int abl;  // diagnostic ablation bits (VSC_GEMM_ABL): 1 no loop DMA, 2 no MFMA, 4 no epilogue stores, 8 no frag reads
 };
 
@@ -215,6 +216,19 @@ __device__ __forceinline__ bf16x8_t lds_frag32(const char *region, int row, int 
     return *(const bf16x8_t *)(region + row * 64 + ((g ^ ((-(row >> 2)) & 3)) << 4));
 }
 
+// All 256 CUs start their first tile together and every tile takes the same time, so the
+// chip runs in lockstep rounds: compute, then 256 workgroups write 32 MiB at once while no
+// MFMA issues.  Delaying first-round workgroup b by (b / 256) of a tile time spreads the CUs'
+// phases for the rest of the launch, so one CU's write-out overlaps the others' K loops.
+// Speed only: results never depend on it.
+__device__ __forceinline__ void phase_skew(int skew_cycles) {
+    if (skew_cycles > 0 && blockIdx.x < 256 && gridDim.x > 256) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = ((unsigned long long)skew_cycles * blockIdx.x) >> 8;
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -252,6 +266,104 @@ __device__ __forceinline__ void epilogue_frag(const GemmArgs &p, f32x4_t v, int6
     }
 }
 
+// Shared LDS-staged write-out of a wave's TM x 4 fragment tile (64 columns wide); see the
+// comment inside.  `lds2` must be free (no reader, no DMA in flight) and hold NW x 16 KiB.
+template <int EPI, int TM, int TN>
+__device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&acc)[TM][TN], char *lds2,
+                                                 int wave, int lane, int wm, int wn, int64_t m0,
+                                                 int n0) {
+    const int fr = lane & 15, fq = lane >> 4;
+    // ---- epilogue through LDS.  A lane's accumulators are 4 columns of 16 different rows
+    // per fragment: stored directly that is 32-byte pieces of 16 rows per instruction, and the
+    // partial-line writes cost 30-40 % of the kernel.  The ring is idle now (every wave is
+    // past its last fragment read and every DMA has landed), so each wave transposes its
+    // 64-column tile through a private 16 KiB region and writes whole 128-B (bf16) / 256-B
+    // (fp32) row segments with 16-byte stores; the residual / position rows are read the
+    // same way.  16-B chunks are XOR-swizzled by the row so both the fragment-layout
+    // writes and the row-layout reads are conflict-free (<= 2-way for the 8-B bf16 writes).
+    static_assert(TN == 4, "wave tile is 64 columns wide");
+    char *reg = lds2 + wave * 16384;  // NW x 16 KiB <= the ring (checked in launch_v2)
+    const int ncol0 = n0 + wn * 64;
+    if (EPI == VSC_EPI_BF16 || EPI == VSC_EPI_GELU_BF16 || EPI == VSC_EPI_QGELU_BF16) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = ncol0 + j * 16 + fq * 4;
+            f32x4_t bz = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.n) bz = *(const f32x4_t *)(p.bias + n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                f32x4_t v = acc[i][j] + bz;
+                if (EPI == VSC_EPI_GELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                } else if (EPI == VSC_EPI_QGELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+                }
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                const int row = i * 16 + fr, chunk = 2 * j + (fq >> 1);
+                *(uint2 *)(reg + row * 128 + ((chunk ^ (row & 7)) << 4) + (fq & 1) * 8) = pk;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int c = lane & 7;
+        const int n = ncol0 + c * 8;
+#pragma unroll
+        for (int it = 0; it < TM * 2; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const uint4 d = *(const uint4 *)(reg + row * 128 + ((c ^ (row & 7)) << 4));
+            const int64_t m = m0 + wm * TM * 16 + row;
+            if (m < p.m && n < p.n && !((p.abl & 4) && d.x != 0x12345678u))
+                *(uint4 *)((uint16_t *)p.out + m * p.n + n) = d;
+        }
+    } else {
+        const int c = lane & 15;
+        const int n = ncol0 + c * 4;
+#pragma unroll
+        for (int pass = 0; pass < TM / 4; ++pass) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nb = ncol0 + j * 16 + fq * 4;
+                f32x4_t bz = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                if (p.bias && nb < p.n) bz = *(const f32x4_t *)(p.bias + nb);
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int row = ii * 16 + fr, chunk = 4 * j + fq;
+                    *(f32x4_t *)(reg + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[pass * 4 + ii][j] + bz;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ (row & 15)) << 4));
+                const int64_t m = m0 + wm * TM * 16 + pass * 64 + row;
+                if (m < p.m && n < p.n) {
+                    int64_t orow = m;
+                    const float *auxrow;
+                    if (EPI == VSC_EPI_PATCH_F32) {
+                        const int pt = p.tokens - 1;
+                        const int64_t f = m / pt;
+                        const int tok = (int)(m - f * pt) + 1;
+                        orow = f * p.tokens + tok;
+                        auxrow = p.aux + (int64_t)tok * p.n;
+                    } else {
+                        auxrow = p.aux + m * p.n;
+                    }
+                    v += *(const f32x4_t *)(auxrow + n);
+                    if (!((p.abl & 4) && v[0] != 12345.678f)) *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 template <int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int STAGES>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(GemmArgs p) {
     constexpr int NW = WAVES_M * WAVES_N;  // 8: one block per CU, two staggered wave groups;
@@ -264,6 +376,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
     static_assert(NW == 8 || NW == 4, "4 or 8 waves");
     static_assert(L * (STAGES - 2) < 64, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) char lds2[];
+    phase_skew(p.skew);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -369,95 +482,13 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
     if (NW == 8 && group == 0) __builtin_amdgcn_s_barrier();
     if (NW == 4) __builtin_amdgcn_s_barrier();  // every wave is past its last fragment read
 
-    // ---- epilogue through LDS.  A lane's accumulators are 4 columns of 16 different rows
-    // per fragment: stored directly that is 32-byte pieces of 16 rows per instruction, and the
-    // partial-line writes cost 30-40 % of the kernel.  The ring is idle now (every wave is
-    // past its last fragment read and every DMA has landed), so each wave transposes its
-    // 64-column tile through a private 16 KiB region and writes whole 128-B (bf16) / 256-B
-    // (fp32) row segments with 16-byte stores; the residual / position rows are read the
-    // same way.  16-B chunks are XOR-swizzled by the row so both the fragment-layout
-    // writes and the row-layout reads are conflict-free (<= 2-way for the 8-B bf16 writes).
-    static_assert(TN == 4, "wave tile is 64 columns wide");
-    char *reg = lds2 + wave * 16384;  // NW x 16 KiB <= the ring (checked in launch_v2)
-    const int ncol0 = n0 + wn * 64;
-    if (EPI == VSC_EPI_BF16 || EPI == VSC_EPI_GELU_BF16 || EPI == VSC_EPI_QGELU_BF16) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = ncol0 + j * 16 + fq * 4;
-            f32x4_t bz = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n < p.n) bz = *(const f32x4_t *)(p.bias + n);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                f32x4_t v = acc[i][j] + bz;
-                if (EPI == VSC_EPI_GELU_BF16) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                } else if (EPI == VSC_EPI_QGELU_BF16) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
-                }
-                uint2 pk;
-                pk.x = pack_bf16x2(v[0], v[1]);
-                pk.y = pack_bf16x2(v[2], v[3]);
-                const int row = i * 16 + fr, chunk = 2 * j + (fq >> 1);
-                *(uint2 *)(reg + row * 128 + ((chunk ^ (row & 7)) << 4) + (fq & 1) * 8) = pk;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int c = lane & 7;
-        const int n = ncol0 + c * 8;
-#pragma unroll
-        for (int it = 0; it < TM * 2; ++it) {
-            const int row = it * 8 + (lane >> 3);
-            const uint4 d = *(const uint4 *)(reg + row * 128 + ((c ^ (row & 7)) << 4));
-            const int64_t m = m0 + wm * TM * 16 + row;
-            if (m < p.m && n < p.n && !((p.abl & 4) && d.x != 0x12345678u))
-                *(uint4 *)((uint16_t *)p.out + m * p.n + n) = d;
-        }
-    } else {
-        const int c = lane & 15;
-        const int n = ncol0 + c * 4;
-#pragma unroll
-        for (int pass = 0; pass < TM / 4; ++pass) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nb = ncol0 + j * 16 + fq * 4;
-                f32x4_t bz = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                if (p.bias && nb < p.n) bz = *(const f32x4_t *)(p.bias + nb);
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) {
-                    const int row = ii * 16 + fr, chunk = 4 * j + fq;
-                    *(f32x4_t *)(reg + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[pass * 4 + ii][j] + bz;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int row = it * 4 + (lane >> 4);
-                f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ (row & 15)) << 4));
-                const int64_t m = m0 + wm * TM * 16 + pass * 64 + row;
-                if (m < p.m && n < p.n) {
-                    int64_t orow = m;
-                    const float *auxrow;
-                    if (EPI == VSC_EPI_PATCH_F32) {
-                        const int pt = p.tokens - 1;
-                        const int64_t f = m / pt;
-                        const int tok = (int)(m - f * pt) + 1;
-                        orow = f * p.tokens + tok;
-                        auxrow = p.aux + (int64_t)tok * p.n;
-                    } else {
-                        auxrow = p.aux + m * p.n;
-                    }
-                    v += *(const f32x4_t *)(auxrow + n);
-                    if (!((p.abl & 4) && v[0] != 12345.678f)) *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
+    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0);
+}
+
+// one tile time in s_memtime ticks (100 MHz): VSC_GEMM_SKEW_NS_PER_K nanoseconds per unit of K
+inline int skew_cycles(int k) {
+    static const int ns_per_k = [] { const char *e = getenv("VSC_GEMM_SKEW_NS_PER_K"); return e ? atoi(e) : 20; }();  // measured: +7 % on qkv, neutral elsewhere
+    return (int)((int64_t)ns_per_k * k / 10);
 }
 
 template <int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int STAGES>
@@ -478,7 +509,133 @@ int launch_v2(GemmArgs p, hipStream_t stream) {
     int g = (int)((int64_t)(3 << 19) / ((int64_t)BN2 * p.k * 2));
     if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
     p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
+    p.skew = skew_cycles(p.k);
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), smem, stream, p);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// v3: as v2 (256x256, 8 waves, staggered L/C phases, LDS write-out) but a stage holds 64 k
+// (128-byte rows): the 32-k stages of v2 fetch every 128-B line as two 64-B L2 requests, and
+// PMC showed the L2 request rate (not bytes) capping operand delivery at ~7 TB/s.  Two stages
+// of 64 KiB; each stage feeds two L/C sub-steps; the DMA of stage kt+1 is issued in the first
+// L phase of stage kt and waited for in the second.
+template <int ROWS>
+__device__ __forceinline__ void stage_rows64(const uint16_t *src, int64_t ld, int64_t row0,
+                                             int64_t row_last, int k0, char *region, int wave,
+                                             int lane) {
+    constexpr int PIECES = ROWS / 8;  // 1 KiB pieces of 8 rows x 128 B
+#pragma unroll
+    for (int j = 0; j < PIECES / 8; ++j) {
+        const int piece = j * 8 + wave;
+        const int r = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int64_t gr = row0 + r;
+        gr = gr > row_last ? row_last : gr;
+        const uint16_t *g = src + gr * ld + k0 + c * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(region + piece * 1024), 16, 0, 0);
+    }
+}
+
+template <int EPI, int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs p) {
+    constexpr int BM2 = WAVES_M * TM * 16, BN2 = WAVES_N * TN * 16, BK3 = 64;
+    constexpr int A_BYTES = BM2 * 128, W_BYTES = BN2 * 128, STAGE_BYTES = A_BYTES + W_BYTES;
+    static_assert(WAVES_M * WAVES_N == 8, "8 waves");
+    extern __shared__ __attribute__((aligned(16))) char lds2[];
+    phase_skew(p.skew);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    {
+        const int G = p.group_n;
+        const int per_group = G * p.tiles_m;
+        const int grp = t / per_group;
+        const int first = grp * G;
+        const int width = (p.tiles_n - first) < G ? (p.tiles_n - first) : G;
+        const int rem = t - grp * per_group;
+        tm = rem / width;
+        tn = first + (rem - tm * width);
+    }
+    const int64_t m0 = (int64_t)tm * BM2;
+    const int n0 = tn * BN2;
+    const int64_t a_last = p.m - 1, w_last = p.n - 1;
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.k / BK3;
+    const int group = wave >> 2;
+    stage_rows64<BM2>(p.a, p.k, m0, a_last, 0, lds2, wave, lane);
+    stage_rows64<BN2>(p.w, p.k, n0, w_last, 0, lds2 + A_BYTES, wave, lane);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (group == 1) __builtin_amdgcn_s_barrier();  // stagger: waves 4-7 run one phase behind
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char *at = lds2 + (kt & 1) * STAGE_BYTES;
+        const char *wt = at + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            // ---- L phase
+            if (kk == 0 && kt + 1 < nk && !(p.abl & 1)) {
+                char *st = lds2 + ((kt + 1) & 1) * STAGE_BYTES;
+                stage_rows64<BM2>(p.a, p.k, m0, a_last, (kt + 1) * BK3, st, wave, lane);
+                stage_rows64<BN2>(p.w, p.k, n0, w_last, (kt + 1) * BK3, st + A_BYTES, wave, lane);
+            }
+            bf16x8_t wf[TN], af[TM];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = lds_frag(wt, wn * TN * 16 + j * 16 + fr, fq + 4 * kk);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = lds_frag(at, wm * TM * 16 + i * 16 + fr, fq + 4 * kk);
+            if (kk == 1) wait_vmcnt<0>();  // this wave's pieces of stage kt+1 have landed
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wf[j]));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[i]));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- C phase
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (group == 0) __builtin_amdgcn_s_barrier();
+    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0);
+}
+
+template <int EPI, int WAVES_M, int WAVES_N, int TM, int TN>
+int launch_v3(GemmArgs p, hipStream_t stream) {
+    constexpr int BM2 = WAVES_M * TM * 16, BN2 = WAVES_N * TN * 16;
+    constexpr int smem = 2 * (BM2 + BN2) * 128;  // >= 8 x 16 KiB for the write-out
+    static_assert(smem >= 8 * 16384, "epilogue region");
+    auto kern = gemm_bf16_v3_kernel<EPI, WAVES_M, WAVES_N, TM, TN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    p.tiles_m = (int)((p.m + BM2 - 1) / BM2);
+    p.tiles_n = (p.n + BN2 - 1) / BN2;
+    int g = (int)((int64_t)(3 << 19) / ((int64_t)BN2 * p.k * 2));
+    if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
+    p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
+    p.skew = skew_cycles(p.k);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, stream, p);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }
@@ -494,6 +651,8 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
         case 'A': return launch_v2<EPI, 2, 4, 8, 4, 4>(p, stream);
         case 'B': return launch_v2<EPI, 4, 2, 4, 4, 4>(p, stream);
         case 'C': return launch_v2<EPI, 1, 4, 8, 4, 3>(p, stream);
+        case 'E': return launch_v2<EPI, 2, 4, 8, 4, 5>(p, stream);  // A with a 5-deep ring (all 160 KiB)
+        case 'F': if (p.k % 64 == 0) return launch_v3<EPI, 2, 4, 8, 4>(p, stream); return launch_v2<EPI, 2, 4, 8, 4, 4>(p, stream);
         default: return launch_v2<EPI, 2, 2, 8, 4, 3>(p, stream);
     }
 }
@@ -517,7 +676,7 @@ int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, co
     const int64_t tiles_m = (m + BM - 1) / BM;
     const int tiles_n = (n + BN - 1) / BN;
     VSC_REQUIRE(tiles_m * tiles_n < (1ll << 31), "gemm: grid too large");
-    GemmArgs p{a, w, bias, aux, out, m, n, k, tokens, tiles_n, (int)tiles_m, 1, 0};
+    GemmArgs p{a, w, bias, aux, out, m, n, k, tokens, tiles_n, (int)tiles_m, 1, 0, 0};
     if (const char *e = getenv("VSC_GEMM_ABL")) p.abl = atoi(e);
     static const bool force_v1 = getenv("VSC_GEMM_V1") != nullptr;
     const bool v2 = !force_v1 && m >= 1024 && k % 32 == 0 && n % 8 == 0;
