@@ -98,6 +98,7 @@ int vsc_encoder_get_profile(vsc_encoder *enc, double ms_out[VSC_PROF_CLASSES],
  * Flat inner-product search: replaces faiss.IndexFlat(d, METRIC_INNER_PRODUCT)
  *   .search(x, k)        infer/vsc/index.py:167-175, infer/vsc/baseline/score_normalization.py:95,141,
  *                        infer/vsc/exhaustive_search.py:66 (the k = 1024 probe of range_search_gpu)
+ *   .range_search(x, r)  infer/vsc/exhaustive_search.py:78,250
  * Scores are the ascending-k float32 fmaf chain (bit-identical to
  * oracle/knn_oracle.c); ties rank the lower reference index first.
  * ------------------------------------------------------------------------ */
@@ -109,6 +110,18 @@ int vsc_encoder_get_profile(vsc_encoder *enc, double ms_out[VSC_PROF_CLASSES],
 int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d,
                    int32_t k, int64_t ref_id_offset, float *out_scores_dev,
                    int64_t *out_ids_dev, void *stream);
+
+/* Range search: every pair with <q,r> > radius -- faiss IndexFlat.range_search
+ * (infer/vsc/exhaustive_search.py:78,250; the radius sweep behind
+ * infer/vsc/index.py:145-165).  lims_dev [nq+1] int64 receives the CSR offsets, *total_out
+ * (host) the number of hits.  Hits of query i go to [lims[i], lims[i+1]) of out_scores_dev /
+ * out_ids_dev in ascending reference id, but only if total <= capacity; otherwise nothing is
+ * written and the caller calls again with capacity >= *total_out (capacity 0 = count only).
+ * Synchronises `stream` once (to read the total). */
+int vsc_range_search_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr,
+                            int32_t d, float radius, int64_t ref_id_offset, int64_t *lims_dev,
+                            float *out_scores_dev, int64_t *out_ids_dev, int64_t capacity,
+                            int64_t *total_out, void *stream);
 
 /* sklearn.preprocessing.normalize(x) in place (l2, axis=1; zero rows untouched):
  * infer/extract_query_feats.py:178, infer/vsc/baseline/score_normalization.py:84-88. */

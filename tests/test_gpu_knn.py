@@ -93,3 +93,73 @@ def test_knn_linearity_property_full_width(dev):
     D2, I2 = ops.knn_ip(torch.from_numpy(q).to(dev), rt[torch.from_numpy(perm).to(dev)], 4)
     assert torch.equal(D, D2)
     assert (perm[I2.cpu().numpy()] == I.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("nq,nr,d,radius", [(9, 200, 64, 0.1), (130, 5000, 511, 0.08), (1, 70000, 512, 0.12),
+                                            (300, 3000, 32, -2.0), (64, 1000, 512, 0.9)])
+def test_range_search_bit_exact(dev, nq, nr, d, radius):
+    """Every pair above the radius, CSR layout, ascending ref id: identical to the oracle."""
+    from oracle import knn_oracle
+    from vsc_hip import ops
+    q, r = synth.descriptor_bank(300 + nq, nq, d), synth.descriptor_bank(400 + nr, nr, d)
+    lims, D, I = ops.range_search_ip(torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev), radius, capacity=16)
+    lr, Dr, Ir = knn_oracle.range_search_ip(q, r, radius)
+    assert np.array_equal(lims.cpu().numpy(), lr)
+    assert np.array_equal(I.cpu().numpy(), Ir)
+    assert np.array_equal(D.cpu().numpy().view(np.uint32), Dr.view(np.uint32))
+    if radius < -1.5:
+        assert lr[-1] == nq * nr     # everything matches: the dense limit
+
+
+def test_video_index_reference_vectors(dev):
+    """The reference's own unit tests, run through VideoIndex / CandidateGeneration on the HIP path:
+    tests/test_candidates.py (expected candidate list) and tests/test_index.py (self match)."""
+    from vsc.candidates import CandidateGeneration, MaxScoreAggregation
+    from vsc.index import VideoFeature, VideoIndex
+    from vsc.metrics import CandidatePair
+    queries = [VideoFeature(video_id=1, feature=np.eye(3, dtype=np.float32), timestamps=np.array([0.0, 1.0, 2.0]))]
+    refs = [VideoFeature(video_id=5, feature=np.array([[0, 0, 0], [0, 0, 0], [0, 1, 0], [0, 2, 0], [0, 0, 0]], np.float32),
+                         timestamps=np.array([2.0, 4.0, 6.0, 8.0, 10.0])),
+            VideoFeature(video_id=8, feature=np.array([[0, 0, 0], [1, 0, 0], [1, 0, 0]], np.float32),
+                         timestamps=np.array([[0.0, 5.0], [5.0, 10.0], [10.0, 15.0]])),
+            VideoFeature(video_id=10, feature=np.array([[0, 0, 0], [0, 0, 0.25], [0, 0, 0]], np.float32),
+                         timestamps=np.array([0.0, 0.1, 0.2]))]
+    cands = CandidateGeneration(refs, MaxScoreAggregation()).query(queries, 2 * 3)
+    assert cands == [CandidatePair(query_id=1, ref_id=5, score=2.0), CandidatePair(query_id=1, ref_id=8, score=1.0),
+                     CandidatePair(query_id=1, ref_id=10, score=0.25)]
+
+    from oracle import knn_oracle
+    feats = np.array([[[1, 2, 3], [4, 5, 6], [7, 8, 9]], [[11, 12, 13], [14, 15, 16], [17, 18, 19]],
+                      [[111, 112, 113], [114, 115, 116], [117, 118, 119]]], np.float32)
+    feats = knn_oracle.l2_normalize(feats.reshape(9, 3)).reshape(3, 3, 3)
+    mk = lambda pre: [VideoFeature(video_id=f"{pre}{i:06d}", feature=f, timestamps=np.arange(3, dtype=np.float32))
+                      for i, f in enumerate(feats)]
+    for gk in (1, -1):
+        idx = VideoIndex(3)
+        idx.add(mk("R"))
+        for res in idx.search(mk("Q"), gk):
+            assert res.query_id[1:] == res.ref_id[1:]
+
+
+def test_global_threshold_search_is_the_global_top_k(dev):
+    """_global_threshold_knn_search == the global_k best pairs of the full score matrix, including
+    the case where one query row owns more winners than the per-row probe (range-sweep path)."""
+    from oracle import knn_oracle
+    from vsc.index import VideoFeature, VideoIndex
+    import vsc.index as vi
+    r = synth.descriptor_bank(5, 4000, 32)
+    q = synth.descriptor_bank(6, 40, 32)
+    r[100:1400] = q[3] + 0.01 * synth.normalish(7, (1300, 32))   # 1300 refs glued to query row 3
+    idx = VideoIndex(32)
+    idx.add([VideoFeature("R1", np.arange(4000.0), r)])
+    S = knn_oracle.ip_matrix(q, r)
+    for gk, probe in ((50, 1024), (1200, 64)):
+        old, vi.MAX_K = vi.MAX_K, probe
+        try:
+            hits = idx._global_threshold_knn_search(q, gk)
+        finally:
+            vi.MAX_K = old
+        flat = np.argsort(-S.ravel().astype(np.float64), kind="stable")[:gk]
+        want = sorted(((int(f // 4000), int(f % 4000)) for f in flat))
+        assert sorted((i, j) for i, j, _ in hits) == want
+        assert all(s == S[i, j] for i, j, s in hits)

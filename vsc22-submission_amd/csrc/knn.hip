@@ -106,6 +106,55 @@ __device__ __forceinline__ f32x4_t lds_frag(const char *tile, int row, int chunk
     return *(const f32x4_t *)(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
+// acc[a][b][reg] = <ref r0 + wm*64 + a*32 + row(reg, lane>>5), query q0 + wn*64 + b*32 + (lane&31)>
+// for one 128 x 128 tile: double-buffered LDS-DMA staging + 32x32x2 f32 MFMA, ascending k.
+// Ends with a workgroup barrier (the staging buffers are free on return).
+__device__ __forceinline__ void score_tile(f32x16_t (&acc)[2][2], const float *rp, const float *qp,
+                                           int64_t nr, int64_t nq, int dpad, int64_t r0, int64_t q0,
+                                           char *lds, int wave, int lane) {
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nks = dpad / KS;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    stage_tile(rp, dpad, r0, nr - 1, 0, lds, wave, lane);
+    stage_tile(qp, dpad, q0, nq - 1, 0, lds + TILE_BYTES, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ks = 0; ks < nks; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nks) {
+            char *nxt = lds + (cur ^ 1) * 2 * TILE_BYTES;
+            stage_tile(rp, dpad, r0, nr - 1, (ks + 1) * KS, nxt, wave, lane);
+            stage_tile(qp, dpad, q0, nq - 1, (ks + 1) * KS, nxt + TILE_BYTES, wave, lane);
+        }
+        const char *rtile = lds + cur * 2 * TILE_BYTES;
+        const char *qtile = rtile + TILE_BYTES;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {  // 8 k per chunk pair
+            f32x4_t af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = lds_frag(rtile, wm * 64 + a * 32 + l31, 2 * pr + hi);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = lds_frag(qtile, wn * 64 + b * 32 + l31, 2 * pr + hi);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+}
+
 // Rank-sort one query's candidate list (n <= 64*EPL keys) with one wave, keep the best k.
 // `dst` is where the survivors go, in rank order (the list itself between ref tiles, the
 // per-split output at the end).
@@ -156,7 +205,6 @@ __global__ __launch_bounds__(256, 2) void knn_kernel(KnnArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     unsigned long long *mylists = p.lists + (size_t)blockIdx.x * 128 * CAP;
-    const int nks = p.dpad / KS;
 
     for (int64_t work = blockIdx.x; work < (int64_t)p.nqb * p.splits; work += gridDim.x) {
         const int qb = (int)(work / p.splits), sp = (int)(work - (int64_t)qb * p.splits);
@@ -175,45 +223,7 @@ __global__ __launch_bounds__(256, 2) void knn_kernel(KnnArgs p) {
         for (int64_t rt = t_begin; rt < t_end; ++rt) {
             const int64_t r0 = rt * TR;
             f32x16_t acc[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-            stage_tile(p.rp, p.dpad, r0, p.nr - 1, 0, lds, wave, lane);
-            stage_tile(p.qp, p.dpad, q0, p.nq - 1, 0, lds + TILE_BYTES, wave, lane);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            for (int ks = 0; ks < nks; ++ks) {
-                const int cur = ks & 1;
-                if (ks + 1 < nks) {
-                    char *nxt = lds + (cur ^ 1) * 2 * TILE_BYTES;
-                    stage_tile(p.rp, p.dpad, r0, p.nr - 1, (ks + 1) * KS, nxt, wave, lane);
-                    stage_tile(p.qp, p.dpad, q0, p.nq - 1, (ks + 1) * KS, nxt + TILE_BYTES, wave, lane);
-                }
-                const char *rtile = lds + cur * 2 * TILE_BYTES;
-                const char *qtile = rtile + TILE_BYTES;
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr) {  // 8 k per chunk pair
-                    f32x4_t af[2], bf[2];
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) af[a] = lds_frag(rtile, wm * 64 + a * 32 + l31, 2 * pr + hi);
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) bf[b] = lds_frag(qtile, wn * 64 + b * 32 + l31, 2 * pr + hi);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int b = 0; b < 2; ++b)
-                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t],
-                                                                                acc[a][b], 0, 0, 0);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
+            score_tile(acc, p.rp, p.qp, p.nr, p.nq, p.dpad, r0, q0, lds, wave, lane);
 
             // ---- filter: acc[a][b][reg] = <ref r0 + wm*64 + a*32 + row(reg,hi), query q0 + wn*64 + b*32 + l31>
 #pragma unroll
@@ -320,12 +330,166 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const unsigned long long
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Range search: every pair with <q, r> > radius (faiss IndexFlat.range_search,
+// infer/vsc/exhaustive_search.py:78,250).  Same score tiles as the top-k sweep.
+//   pass 1  range_count_kernel : hits per (query, ref split)
+//   scan    range_scan_kernel  : exclusive prefix -> write bases, lims
+//   pass 2  range_fill_kernel  : hits written at base + cursor + rank-inside-tile; ranks come
+//           from a per-tile LDS hit bitmap (128 refs = 4 words per query), so the output order
+//           is ascending reference id whatever the order waves reach the epilogue in.
+struct RangeArgs {
+    const float *qp;
+    const float *rp;
+    int64_t nq, nr;
+    int dpad, nqb, splits;
+    int64_t total_tiles, tiles_per_split;
+    float radius;
+    long long *counts;       // [nq][splits] (pass 1 out; then exclusive bases)
+    float *out_d;
+    int64_t *out_i;
+    int64_t id_offset;
+};
+
+constexpr int RLDS_TOTAL = LDS_STAGE + 128 * 4 /*cnt*/ + 128 * 16 /*bitmap*/ + 16;
+
+template <bool FILL>
+__global__ __launch_bounds__(256, 2) void range_kernel(RangeArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[RLDS_TOTAL];
+    int *cnt_s = (int *)(lds + LDS_STAGE);                    // hits so far of this (query, split)
+    unsigned *bits_s = (unsigned *)(lds + LDS_STAGE + 512);   // [128 queries][4 words]
+    int *flag_s = (int *)(lds + LDS_STAGE + 512 + 2048);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    for (int64_t work = blockIdx.x; work < (int64_t)p.nqb * p.splits; work += gridDim.x) {
+        const int qb = (int)(work / p.splits), sp = (int)(work - (int64_t)qb * p.splits);
+        const int64_t q0 = (int64_t)qb * TQ;
+        const int64_t t_begin = sp * p.tiles_per_split;
+        int64_t t_end = t_begin + p.tiles_per_split;
+        t_end = t_end > p.total_tiles ? p.total_tiles : t_end;
+        if (tid < 128) cnt_s[tid] = 0;
+        for (int i = tid; i < 512; i += 256) bits_s[i] = 0;
+        if (tid == 0) *flag_s = 0;
+        __syncthreads();
+
+        for (int64_t rt = t_begin; rt < t_end; ++rt) {
+            const int64_t r0 = rt * TR;
+            f32x16_t acc[2][2];
+            score_tile(acc, p.rp, p.qp, p.nr, p.nq, p.dpad, r0, q0, lds, wave, lane);
+            // hit masks: bit (8*(reg>>2) + 4*hi + (reg&3)) of word (wm*2 + a) of query ql
+            unsigned mask[2][2];
+            bool any = false;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const bool qok = q0 + wn * 64 + b * 32 + l31 < p.nq;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    unsigned m = 0;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int pos = 8 * (reg >> 2) + 4 * hi + (reg & 3);
+                        const int64_t ref = r0 + wm * 64 + a * 32 + pos;
+                        if (acc[a][b][reg] > p.radius && qok && ref < p.nr) m |= 1u << pos;
+                    }
+                    mask[a][b] = m;
+                    any |= m != 0;
+                }
+            }
+            if (__any(any)) {
+                if (lane == 0) *flag_s = 1;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        if (mask[a][b]) atomicOr(&bits_s[(wn * 64 + b * 32 + l31) * 4 + wm * 2 + a], mask[a][b]);
+            }
+            __syncthreads();
+            const int tile_has_hits = *flag_s;
+            __syncthreads();  // every wave has read the flag before thread 0 clears it
+            if (tile_has_hits) {
+                if (FILL) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int ql = wn * 64 + b * 32 + l31;
+                        const uint4 w = *(const uint4 *)(bits_s + ql * 4);
+                        const unsigned words[4] = {w.x, w.y, w.z, w.w};
+                        const long long base = p.counts[(q0 + ql < p.nq ? q0 + ql : 0) * p.splits + sp] + cnt_s[ql];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            unsigned m = mask[a][b];
+                            if (!m) continue;
+                            const int word = wm * 2 + a;
+                            int before = 0;
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) before += x < word ? __popc(words[x]) : 0;
+#pragma unroll
+                            for (int reg = 0; reg < 16; ++reg) {
+                                const int pos = 8 * (reg >> 2) + 4 * hi + (reg & 3);
+                                if (m & (1u << pos)) {
+                                    const int rank = before + __popc(words[word] & ((1u << pos) - 1u));
+                                    p.out_d[base + rank] = acc[a][b][reg];
+                                    p.out_i[base + rank] = r0 + wm * 64 + a * 32 + pos + p.id_offset;
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (tid < 128) {
+                    const uint4 w = *(const uint4 *)(bits_s + tid * 4);
+                    cnt_s[tid] += __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+                    *(uint4 *)(bits_s + tid * 4) = make_uint4(0, 0, 0, 0);
+                }
+                if (tid == 0) *flag_s = 0;
+                __syncthreads();
+            }
+        }
+        if (!FILL && tid < 128 && q0 + tid < p.nq) p.counts[(q0 + tid) * p.splits + sp] = cnt_s[tid];
+        __syncthreads();
+    }
+}
+
+// counts[nq*splits] -> exclusive prefix in place; lims[q] = base of (q, split 0); lims[nq] = total
+__global__ __launch_bounds__(1024) void range_scan_kernel(long long *counts, int64_t n, int splits,
+                                                          int64_t nq, int64_t *lims) {
+    __shared__ long long part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = tid * per, hi = lo + per < n ? lo + per : n;
+    long long sum = 0;
+    for (int64_t i = lo; i < hi; ++i) sum += counts[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const long long v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        lims[nq] = run;
+    }
+    __syncthreads();
+    long long run = part[tid];
+    for (int64_t i = lo; i < hi; ++i) {
+        const long long v = counts[i];
+        counts[i] = run;
+        if (i % splits == 0) lims[i / splits] = run;
+        run += v;
+    }
+}
+
 // ---- grow-only device scratch, one per process (one process per GPU) ----------------------
 struct Scratch {
     void *ptr = nullptr;
     size_t bytes = 0;
 };
-Scratch g_scratch[4];
+Scratch g_scratch[5];
 
 int scratch_get(int slot, size_t bytes, void **out) {
     Scratch &s = g_scratch[slot];
@@ -407,5 +571,57 @@ extern "C" int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev
                        (const unsigned long long *)part, nq, splits, k, ref_id_offset, out_scores_dev,
                        out_ids_dev);
     VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+extern "C" int vsc_range_search_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr,
+                                       int32_t d, float radius, int64_t ref_id_offset,
+                                       int64_t *lims_dev, float *out_scores_dev, int64_t *out_ids_dev,
+                                       int64_t capacity, int64_t *total_out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VSC_REQUIRE(q_dev && r_dev && lims_dev && total_out, "range_search: null pointer");
+    VSC_REQUIRE(nq > 0 && nr > 0, "range_search: empty query or reference set");
+    VSC_REQUIRE(d > 0 && d <= 4096, "range_search: dimension %d unsupported", d);
+    VSC_REQUIRE(capacity >= 0 && (capacity == 0 || (out_scores_dev && out_ids_dev)),
+                "range_search: capacity %lld without output buffers", (long long)capacity);
+    const int dpad = (d + KS - 1) / KS * KS;
+    const int nqb = (int)((nq + TQ - 1) / TQ);
+    const int64_t total_tiles = (nr + TR - 1) / TR;
+    int64_t want = (512 + nqb - 1) / nqb;
+    if (want > 256) want = 256;
+    if (want > total_tiles) want = total_tiles;
+    if (want < 1) want = 1;
+    const int64_t tiles_per_split = (total_tiles + want - 1) / want;
+    const int splits = (int)((total_tiles + tiles_per_split - 1) / tiles_per_split);
+    const int64_t work = (int64_t)nqb * splits;
+    const int grid = (int)(work < 512 ? work : 512);
+
+    void *qp, *rp, *counts;
+    int rc;
+    if ((rc = scratch_get(0, (size_t)nq * dpad * 4, &qp))) return rc;
+    if ((rc = scratch_get(1, (size_t)nr * dpad * 4, &rp))) return rc;
+    if ((rc = scratch_get(4, (size_t)nq * splits * 8, &counts))) return rc;
+    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nq * (dpad / 4))), dim3(256), 0, stream, q_dev,
+                       (float *)qp, nq, d, dpad);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nr * (dpad / 4))), dim3(256), 0, stream, r_dev,
+                       (float *)rp, nr, d, dpad);
+    VSC_CHECK_LAUNCH();
+    RangeArgs a{(const float *)qp, (const float *)rp, nq, nr, dpad, nqb, splits, total_tiles,
+                tiles_per_split, radius, (long long *)counts, out_scores_dev, out_ids_dev, ref_id_offset};
+    hipLaunchKernelGGL(range_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(range_scan_kernel, dim3(1), dim3(1024), 0, stream, (long long *)counts,
+                       (int64_t)nq * splits, splits, nq, lims_dev);
+    VSC_CHECK_LAUNCH();
+    int64_t total = 0;
+    VSC_CHECK_HIP(hipMemcpyAsync(&total, lims_dev + nq, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    VSC_CHECK_HIP(hipStreamSynchronize(stream));
+    *total_out = total;
+    if (total > capacity) return VSC_OK;  // caller re-calls with capacity >= total
+    if (total > 0) {
+        hipLaunchKernelGGL(range_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
+        VSC_CHECK_LAUNCH();
+    }
     return VSC_OK;
 }

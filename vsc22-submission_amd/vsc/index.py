@@ -101,6 +101,18 @@ class FlatIPBank:
             self._bank = torch.from_numpy(host).cuda()
         return self._bank
 
+    def range_search(self, x: np.ndarray, radius: float):
+        """All (query row, ref row, score) with score > radius -> three flat arrays, query-major,
+        ascending ref row inside a query (faiss.Index.range_search, flattened)."""
+        import torch
+        from vsc_hip import ops
+        bank = self.device_bank()
+        q = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+        lims, D, I = ops.range_search_ip(q, bank, float(radius))
+        lims = lims.cpu().numpy()
+        rows = np.repeat(np.arange(len(lims) - 1), np.diff(lims))
+        return rows, I.cpu().numpy(), D.cpu().numpy()
+
     def search(self, x: np.ndarray, k: int):
         """-> (D [nq,k] float32 descending, I [nq,k] int64), faiss.Index.search semantics."""
         import torch
@@ -165,8 +177,9 @@ class VideoIndex:
         """The reference keeps every pair above an adaptively tightened radius, sorts all of
         them by score and truncates to global_k (index.py:145-165): the result is the
         global_k best (query row, ref row) pairs over ALL pairs.  Here: per-row exact
-        top-k', then the same sort/truncate on the host.  Exact as long as no query row
-        owns more than k' of the global_k winners, which is checked."""
+        top-k', then the same sort/truncate on the host; if a query row could own
+        more than k' of the winners, the exact range sweep at the provisional threshold
+        replaces the candidate set (always exact)."""
         nr = self.index.ntotal
         kk = int(min(global_k, nr, MAX_K))
         if kk <= 0 or feats.shape[0] == 0:
@@ -179,7 +192,8 @@ class VideoIndex:
         if len(order) == global_k and kk < min(global_k, nr):
             threshold = scores[order[-1]]
             if (D[:, kk - 1] > threshold).any():
-                raise NotImplementedError(
-                    f"a query row has more than {kk} pairs above the global threshold; the exact "
-                    "range sweep (faiss range_search) is not on the HIP path yet")
+                # some query row owns more than kk of the winners: sweep every pair scoring
+                # >= threshold (the reference's radius search) and redo the sort/truncate
+                rows, refs, scores = self.index.range_search(feats, np.nextafter(threshold, -np.inf))
+                order = np.lexsort((refs, rows, -scores.astype(np.float64)))[:global_k]
         return [(int(rows[o]), int(refs[o]), float(scores[o])) for o in order]

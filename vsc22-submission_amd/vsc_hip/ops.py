@@ -94,3 +94,29 @@ def knn_ip(q, r, k: int, ref_id_offset: int = 0):
     check(lib.vsc_knn_ip_f32(ptr(q), nq, ptr(r), nr, d, k, ref_id_offset, ptr(scores), ptr(ids),
                              current_stream()))
     return scores, ids
+
+
+def range_search_ip(q, r, radius: float, ref_id_offset: int = 0, capacity: int = 1 << 20):
+    """All pairs with <q, r> > radius.  -> (lims [nq+1] int64, scores, ids), hits of query i in
+    lims[i]:lims[i+1], ascending reference id (faiss range_search layout)."""
+    import ctypes
+    lib = _lib.require_device()
+    q, r = _dev(q, torch.float32), _dev(r, torch.float32)
+    nq, d = q.shape
+    nr = r.shape[0]
+    assert r.shape[1] == d, "query / reference dimension mismatch"
+    lims = torch.zeros(nq + 1, dtype=torch.int64, device=q.device)
+    empty = (lims, torch.empty(0, dtype=torch.float32, device=q.device),
+             torch.empty(0, dtype=torch.int64, device=q.device))
+    if nq == 0 or nr == 0:
+        return empty
+    total = ctypes.c_int64(0)
+    while True:
+        scores = torch.empty(capacity, dtype=torch.float32, device=q.device)
+        ids = torch.empty(capacity, dtype=torch.int64, device=q.device)
+        check(lib.vsc_range_search_ip_f32(ptr(q), nq, ptr(r), nr, d, float(radius), ref_id_offset, ptr(lims),
+                                          ptr(scores), ptr(ids), capacity, ctypes.byref(total),
+                                          current_stream()))
+        if total.value <= capacity:
+            return lims, scores[: total.value], ids[: total.value]
+        capacity = int(total.value)
