@@ -1,0 +1,75 @@
+"""Reference-descriptor extraction, one process per GPU (reference: infer/extract_ref_feats.py).
+
+    python -m torch.distributed.run --nproc-per-node N extract_ref_feats.py \
+        --checkpoint_path vit.pth --arch vit_b16_224 --zip_prefix ../data/jpg_zips \
+        --input_file ../data/meta/train/train_ref_vids.txt --save_file outputs/train_refs
+
+Same outputs: <save_file>.npz in the reference layout, videos sorted by id.  Videos shard over
+ranks; each rank writes <save_file>_<rank>.npz, rank 0 merges (as the reference does)."""
+from __future__ import annotations
+
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from src.dataset import ZipFrames, collate_fn, vit_transform
+from src.extractor import extract_vsc_feat
+from vsc.storage import load_features, store_features
+from vsc_hip import distributed as vdist
+from vsc_hip import weights as W
+from vsc_hip.config import get_config
+from vsc_hip.encoder import HipEncoder
+
+LOADERS = {"hf_vit": W.from_hf_vit, "timm_vit": W.from_timm_vit, "clip": W.from_clip_visual}
+
+
+def load_encoder(args) -> HipEncoder:
+    cfg = get_config(args.arch)
+    state = torch.load(args.checkpoint_path, map_location="cpu")
+    state = state.get("state_dict", state) if isinstance(state, dict) else state.state_dict()
+    return HipEncoder(cfg, LOADERS[args.weights_format](state, cfg), max_batch=args.max_batch)
+
+
+def main(args):
+    import torch.distributed as dist
+    distributed = "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+    rank, world_size = vdist.world()
+    model = load_encoder(args)
+    with open(args.input_file, encoding="utf-8") as f:
+        vids = [x.strip() for x in f if x.strip()]
+    lo, hi = vdist.shard_bounds(len(vids), rank, world_size)
+    cfg = model.cfg
+    data = ZipFrames(vids[lo:hi], args.zip_prefix, vit_transform(cfg.image_size, cfg.image_size))
+    loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, num_workers=4, collate_fn=collate_fn)
+    ids, feats, stamps = extract_vsc_feat(model, loader, device)
+    np.savez(f"{args.save_file}_{rank}.npz", video_ids=ids, features=feats, timestamps=stamps)
+    if distributed:
+        dist.barrier()
+    if rank == 0:
+        parts = [np.load(f"{args.save_file}_{i}.npz") for i in range(world_size)]
+        np.savez(args.save_file + ".npz", video_ids=np.concatenate([p["video_ids"] for p in parts]),
+                 features=np.concatenate([p["features"] for p in parts]),
+                 timestamps=np.concatenate([p["timestamps"] for p in parts]))
+        for i in range(world_size):
+            os.remove(f"{args.save_file}_{i}.npz")
+        store_features(args.save_file + ".npz", sorted(load_features(args.save_file + ".npz"), key=lambda v: v.video_id))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--save_file", default="test_refs")
+    ap.add_argument("--zip_prefix", default="")
+    ap.add_argument("--input_file", default="test/test_reference.txt")
+    ap.add_argument("--checkpoint_path", required=True)
+    ap.add_argument("--arch", default="vit_b16_224")
+    ap.add_argument("--weights_format", default="hf_vit", choices=sorted(LOADERS))
+    ap.add_argument("--batch_size", type=int, default=2, help="videos per loader batch")
+    ap.add_argument("--max_batch", type=int, default=332, help="frames per encoder step")
+    main(ap.parse_args())

@@ -1,0 +1,65 @@
+"""Frame sources for the extractor (reference: infer/src/dataset.py:101-153 D_vsc, and
+infer/src/transform.py:37-42 vit_transform).  torchvision is not needed: Resize on a PIL image
+is PIL's own bicubic resize, ToTensor is /255 and Normalize(0.5, 0.5) is 2x-1."""
+from __future__ import annotations
+
+import io
+import os
+from typing import List, Sequence
+from zipfile import ZipFile
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import pad_sequence
+
+
+def vit_transform(width: int, height: int):
+    from PIL import Image
+
+    def apply(img) -> torch.Tensor:
+        img = img.convert("RGB").resize((height, width), Image.BICUBIC)   # Resize([w, h]) = (rows, cols)
+        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
+        return (x - 0.5) / 0.5
+    return apply
+
+
+class ZipFrames(torch.utils.data.Dataset):
+    """One item = all frames of one video, read from <prefix>/<vid[-2:]>/<vid>.zip of jpgs."""
+
+    def __init__(self, video_ids: Sequence[str], zip_prefix: str, transform):
+        self.zip_prefix, self.transform = zip_prefix, transform
+        self.video_ids = [v for v in video_ids if os.path.exists(self._path(v))]
+
+    def _path(self, vid):
+        return "%s/%s/%s.zip" % (self.zip_prefix, vid[-2:], vid)
+
+    def __len__(self):
+        return len(self.video_ids)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        vid = self.video_ids[i]
+        with ZipFile(self._path(vid), "r") as z:
+            frames = [self.transform(Image.open(io.BytesIO(z.read(n)))) for n in sorted(z.namelist())]
+        return torch.stack(frames), vid
+
+
+class TensorFrames(torch.utils.data.Dataset):
+    """Already decoded videos: a list of (frames [S,3,H,W] float32, video_id)."""
+
+    def __init__(self, videos: List):
+        self.videos = videos
+
+    def __len__(self):
+        return len(self.videos)
+
+    def __getitem__(self, i):
+        return self.videos[i]
+
+
+def collate_fn(batch):
+    frames, vids = zip(*batch)
+    lengths = torch.tensor([f.shape[0] for f in frames])
+    frames = pad_sequence(frames, batch_first=True, padding_value=0.0)
+    mask = (torch.arange(frames.shape[1])[None, :] < lengths[:, None]).long()
+    return frames, mask, vids
