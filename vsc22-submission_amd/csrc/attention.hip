@@ -3,7 +3,7 @@
 // (the reference runs this inside the TorchScript backbone as HF ViTSelfAttention /
 //  nn.MultiheadAttention, train/train_vid_score/video/clip.py:31-47).
 //
-// CDNA4 mapping: one workgroup (4 waves) per (frame, head).
+// CDNA4 mapping: one workgroup (8 waves) per (frame, head).
 //   * K [T,64] is staged row-major into LDS with the same 16-byte-chunk XOR swizzle as the
 //     GEMM tiles (conflict-free ds_read_b128 fragment reads); V is staged TRANSPOSED
 //     ([64][Tpad] bf16) so the PV contraction index (key) is contiguous per lane.
@@ -26,11 +26,12 @@ namespace {
 constexpr int DH = 64;
 
 template <int KT>  // key tiles of 32 -> padded token count 32*KT
-__global__ __launch_bounds__(256, (KT <= 7 ? 2 : 1)) void attention_kernel(const uint16_t *__restrict__ qkv,
-                                                        uint16_t *__restrict__ out, int tokens,
-                                                        int heads) {
+__global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__restrict__ qkv,
+                                                           uint16_t *__restrict__ out, int tokens,
+                                                           int heads) {
     constexpr int TP = KT * 32;
     constexpr int VSTRIDE = TP * 2 + 8;  // bytes per head-dim row of V^T (8-B aligned, odd multiple of 8)
+    constexpr int QT_MAX = (2 * KT + 7) / 8;  // 16-query tiles per wave (8 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *klds = smem;             // [TP][64] bf16, 128-B rows, chunk ^= (row >> 1) & 7
     char *vt = smem + TP * 128;    // [64][VSTRIDE]
@@ -43,17 +44,32 @@ __global__ __launch_bounds__(256, (KT <= 7 ? 2 : 1)) void attention_kernel(const
     const uint16_t *qptr = qkv + (int64_t)frame * tokens * ld + head * DH;
     const uint16_t *kptr = qptr + width;
     const uint16_t *vptr = qptr + 2 * width;
+    const int fr = lane & 15, g = lane >> 4;
+    const int qtiles = (tokens + 15) >> 4;
 
+    // ---- Q fragments of every query tile this wave owns, issued first: their HBM latency
+    //      hides behind the K/V staging instead of stalling each tile.
+    bf16x8_t qf[QT_MAX][2];
+#pragma unroll
+    for (int i = 0; i < QT_MAX; ++i) {
+        int qrow = (wave + 8 * i) * 16 + fr;
+        qrow = qrow < tokens ? qrow : tokens - 1;
+        qf[i][0] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8);
+        qf[i][1] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8 + 32);
+    }
     // ---- stage K (row-major, swizzled); pad rows are zero ----
-    for (int e = tid; e < TP * 8; e += 256) {
+    for (int e = tid; e < TP * 8; e += 512) {
         const int row = e >> 3, c = e & 7;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row < tokens) v = *(const uint4 *)(kptr + row * ld + c * 8);
         *(uint4 *)(klds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
     }
-    // ---- stage V transposed: task = (4 keys) x (8 head-dim columns) ----
-    for (int e = tid; e < (TP / 4) * 8; e += 256) {
-        const int kg = e >> 3, c8 = e & 7;
+    // ---- stage V transposed: task = (4 keys) x (8 head-dim columns).  16 consecutive lanes
+    //      take 16 consecutive key groups of one column block, so every ds_write_b64 of a
+    //      16-lane group lands on 128 contiguous bytes (conflict-free).
+    for (int e = tid; e < ((TP / 4 + 15) / 16) * 128; e += 512) {  // 16 key groups x 8 column blocks per 128 tasks
+        const int blk = e >> 7, c8 = (e >> 4) & 7, kg = blk * 16 + (e & 15);
+        if (kg >= TP / 4) continue;
         bf16x8_t r[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -73,17 +89,15 @@ __global__ __launch_bounds__(256, (KT <= 7 ? 2 : 1)) void attention_kernel(const
     }
     __syncthreads();
 
-    const int fr = lane & 15, g = lane >> 4;
     const float scale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
-    const int qtiles = (tokens + 15) >> 4;
+    const int full_tiles = tokens >> 4;                    // 16-key tiles without padding
 
-    for (int qt = wave; qt < qtiles; qt += 4) {
-        int qrow = qt * 16 + fr;
+#pragma unroll
+    for (int qi = 0; qi < QT_MAX; ++qi) {
+        const int qt = wave + 8 * qi;
+        if (qt >= qtiles) break;
+        const int qrow = qt * 16 + fr;
         const bool qvalid = qrow < tokens;
-        if (!qvalid) qrow = tokens - 1;
-        bf16x8_t qf[2];
-        qf[0] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8);
-        qf[1] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8 + 32);
 
         // scores: s[t][r] = <q[query = fr], k[key = 16 t + 4 g + r]>
         f32x4_t s[2 * KT];
@@ -95,23 +109,25 @@ __global__ __launch_bounds__(256, (KT <= 7 ? 2 : 1)) void attention_kernel(const
             for (int kk = 0; kk < 2; ++kk) {
                 const bf16x8_t kf =
                     *(const bf16x8_t *)(klds + krow * 128 + (((g + 4 * kk) ^ ((krow >> 1) & 7)) << 4));
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][kk], s[t], 0, 0, 0);
             }
             // keep the scheduler from hoisting every tile's K fragments (register blow-up)
             if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        // mask padded keys, row max
+        // row max on the raw scores (scale > 0); only the ragged tail tile needs masking
         float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < 2 * KT; ++t)
+        for (int t = 0; t < 2 * KT; ++t) {
+            if (t >= full_tiles) {  // wave-uniform
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = t * 16 + g * 4 + r;
-                s[t][r] = key < tokens ? s[t][r] * scale : -INFINITY;
-                mx = fmaxf(mx, s[t][r]);
+                for (int r = 0; r < 4; ++r)
+                    if (t * 16 + g * 4 + r >= tokens) s[t][r] = -INFINITY;
             }
+            mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mxs = mx * scale;
         float sum = 0.f;
         bf16x8_t pb[KT];
 #pragma unroll
@@ -119,11 +135,10 @@ __global__ __launch_bounds__(256, (KT <= 7 ? 2 : 1)) void attention_kernel(const
             float e[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                e[r] = exp2f(s[2 * u][r] - mx);
-                e[4 + r] = exp2f(s[2 * u + 1][r] - mx);
+                e[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * u][r], scale, -mxs));
+                e[4 + r] = __builtin_amdgcn_exp2f(fmaf(s[2 * u + 1][r], scale, -mxs));
             }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) sum += e[r];
+            sum += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
             union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
             for (int r = 0; r < 4; ++r) pk.w[r] = pack_bf16x2(e[2 * r], e[2 * r + 1]);
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(256, (KT <= 7 ? 2 : 1)) void attention_kernel(const
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
 
         // O^T[dh][query] += V^T[dh][key] . P^T[key][query]
         f32x4_t o[4];
@@ -173,7 +188,7 @@ int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int he
                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_kernel<KT>, dim3(frames * heads), dim3(256), smem, stream, qkv, out,
+    hipLaunchKernelGGL(attention_kernel<KT>, dim3(frames * heads), dim3(512), smem, stream, qkv, out,
                        tokens, heads);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
