@@ -516,143 +516,19 @@ int launch_v2(GemmArgs p, hipStream_t stream) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// v3: as v2 (256x256, 8 waves, staggered L/C phases, LDS write-out) but a stage holds 64 k
-// (128-byte rows): the 32-k stages of v2 fetch every 128-B line as two 64-B L2 requests, and
-// PMC showed the L2 request rate (not bytes) capping operand delivery at ~7 TB/s.  Two stages
-// of 64 KiB; each stage feeds two L/C sub-steps; the DMA of stage kt+1 is issued in the first
-// L phase of stage kt and waited for in the second.
-template <int ROWS>
-__device__ __forceinline__ void stage_rows64(const uint16_t *src, int64_t ld, int64_t row0,
-                                             int64_t row_last, int k0, char *region, int wave,
-                                             int lane) {
-    constexpr int PIECES = ROWS / 8;  // 1 KiB pieces of 8 rows x 128 B
-#pragma unroll
-    for (int j = 0; j < PIECES / 8; ++j) {
-        const int piece = j * 8 + wave;
-        const int r = piece * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        int64_t gr = row0 + r;
-        gr = gr > row_last ? row_last : gr;
-        const uint16_t *g = src + gr * ld + k0 + c * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(region + piece * 1024), 16, 0, 0);
-    }
-}
-
-template <int EPI, int WAVES_M, int WAVES_N, int TM, int TN>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs p) {
-    constexpr int BM2 = WAVES_M * TM * 16, BN2 = WAVES_N * TN * 16, BK3 = 64;
-    constexpr int A_BYTES = BM2 * 128, W_BYTES = BN2 * 128, STAGE_BYTES = A_BYTES + W_BYTES;
-    static_assert(WAVES_M * WAVES_N == 8, "8 waves");
-    extern __shared__ __attribute__((aligned(16))) char lds2[];
-    phase_skew(p.skew);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int t = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    {
-        const int G = p.group_n;
-        const int per_group = G * p.tiles_m;
-        const int grp = t / per_group;
-        const int first = grp * G;
-        const int width = (p.tiles_n - first) < G ? (p.tiles_n - first) : G;
-        const int rem = t - grp * per_group;
-        tm = rem / width;
-        tn = first + (rem - tm * width);
-    }
-    const int64_t m0 = (int64_t)tm * BM2;
-    const int n0 = tn * BN2;
-    const int64_t a_last = p.m - 1, w_last = p.n - 1;
-
-    f32x4_t acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.k / BK3;
-    const int group = wave >> 2;
-    stage_rows64<BM2>(p.a, p.k, m0, a_last, 0, lds2, wave, lane);
-    stage_rows64<BN2>(p.w, p.k, n0, w_last, 0, lds2 + A_BYTES, wave, lane);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (group == 1) __builtin_amdgcn_s_barrier();  // stagger: waves 4-7 run one phase behind
-    const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const char *at = lds2 + (kt & 1) * STAGE_BYTES;
-        const char *wt = at + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            // ---- L phase
-            if (kk == 0 && kt + 1 < nk && !(p.abl & 1)) {
-                char *st = lds2 + ((kt + 1) & 1) * STAGE_BYTES;
-                stage_rows64<BM2>(p.a, p.k, m0, a_last, (kt + 1) * BK3, st, wave, lane);
-                stage_rows64<BN2>(p.w, p.k, n0, w_last, (kt + 1) * BK3, st + A_BYTES, wave, lane);
-            }
-            bf16x8_t wf[TN], af[TM];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j] = lds_frag(wt, wn * TN * 16 + j * 16 + fr, fq + 4 * kk);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = lds_frag(at, wm * TM * 16 + i * 16 + fr, fq + 4 * kk);
-            if (kk == 1) wait_vmcnt<0>();  // this wave's pieces of stage kt+1 have landed
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wf[j]));
-#pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[i]));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // ---- C phase
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_s_barrier();
-        }
-    }
-    if (group == 0) __builtin_amdgcn_s_barrier();
-    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0);
-}
-
-template <int EPI, int WAVES_M, int WAVES_N, int TM, int TN>
-int launch_v3(GemmArgs p, hipStream_t stream) {
-    constexpr int BM2 = WAVES_M * TM * 16, BN2 = WAVES_N * TN * 16;
-    constexpr int smem = 2 * (BM2 + BN2) * 128;  // >= 8 x 16 KiB for the write-out
-    static_assert(smem >= 8 * 16384, "epilogue region");
-    auto kern = gemm_bf16_v3_kernel<EPI, WAVES_M, WAVES_N, TM, TN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
-    p.tiles_m = (int)((p.m + BM2 - 1) / BM2);
-    p.tiles_n = (p.n + BN2 - 1) / BN2;
-    int g = (int)((int64_t)(3 << 19) / ((int64_t)BN2 * p.k * 2));
-    if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
-    p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
-    p.skew = skew_cycles(p.k);
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, stream, p);
-    VSC_CHECK_LAUNCH();
-    return VSC_OK;
-}
-
 template <int EPI>
 int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
     // wide N: 256x256 tile; N <= 1024 (proj / fc2 / patch): 256x128 so the grid still fills 256 CUs
     // A: 8 waves 256x256 (1 block/CU)   B: 8 waves 256x128
     // C: 4 waves 128x256 (2 blocks/CU)  D: 4 waves 256x128 (2 blocks/CU)
+    // Tried and dropped: 64-k stages with full 128-B line fetches (+0.6 %),
+    // a 5-deep ring (+0.4 %), register staging instead of LDS-DMA (0.47x, spills).
     static const char *force = getenv("VSC_GEMM_CFG");
     const char cfg = force ? force[0] : (p.n > 128 ? 'A' : 'B');  // measured: A wins on every encoder shape
     switch (cfg) {
         case 'A': return launch_v2<EPI, 2, 4, 8, 4, 4>(p, stream);
         case 'B': return launch_v2<EPI, 4, 2, 4, 4, 4>(p, stream);
         case 'C': return launch_v2<EPI, 1, 4, 8, 4, 3>(p, stream);
-        case 'E': return launch_v2<EPI, 2, 4, 8, 4, 5>(p, stream);  // A with a 5-deep ring (all 160 KiB)
-        case 'F': if (p.k % 64 == 0) return launch_v3<EPI, 2, 4, 8, 4>(p, stream); return launch_v2<EPI, 2, 4, 8, 4, 4>(p, stream);
         default: return launch_v2<EPI, 2, 2, 8, 4, 3>(p, stream);
     }
 }
