@@ -90,3 +90,19 @@ def test_encoder_rejects_wrong_input(dev):
     from vsc_hip.encoder import HipEncoder
     with pytest.raises(KeyError):
         HipEncoder(cfg, w2)
+
+
+@pytest.mark.parametrize("preset,n", [("vit_b32_384", 3), ("clip_vit_l14_224", 2)])
+def test_other_reference_backbones_full_size(dev, preset, n):
+    """The reference's other ViT towers at full size against the fp32 oracle: timm ViT-B/32-384
+    (vit_v68 backbone: 145 tokens, eps 1e-6, pooled feature) and the CLIP ViT-L/14 video-score tower
+    (257 tokens, patch 14 -> K padded 588->640, ln_pre, QuickGELU, CLS readout)."""
+    from oracle import vit_oracle
+    cfg, w, enc = _encoder(preset, 31, max_batch=2, l2_normalize=True)
+    x = torch.from_numpy(synth.frames(32, n, cfg))
+    with torch.no_grad():
+        ref = vit_oracle.descriptors({k: torch.from_numpy(v) for k, v in w.items()}, cfg, x).numpy()
+    out = enc(x.to(dev)).cpu().numpy()
+    assert out.shape == (n, cfg.width)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=DESC_L2_ATOL)
+    assert ((out * ref).sum(1) > 0.9999).all()

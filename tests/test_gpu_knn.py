@@ -163,3 +163,54 @@ def test_global_threshold_search_is_the_global_top_k(dev):
         want = sorted(((int(f // 4000), int(f % 4000)) for f in flat))
         assert sorted((i, j) for i, j, _ in hits) == want
         assert all(s == S[i, j] for i, j, s in hits)
+
+
+def test_eval_entry_point_end_to_end(dev, tmp_path):
+    """`python -m vsc.baseline.sscd_baseline` (what infer/eval.sh runs): .npz in, candidates.csv out;
+    planted copies are the top candidates and uAP is 1.0; score-normalised run agrees with the
+    oracle's statement of score_normalize."""
+    import vsc.baseline.sscd_baseline as entry
+    from oracle import knn_oracle
+    from vsc.baseline import score_normalization as sn
+    from vsc.index import VideoFeature
+    from vsc.metrics import CandidatePair
+    from vsc.storage import load_features, store_features
+    rs = np.random.RandomState(3)
+    dim = 64
+    refs = [VideoFeature(f"R{i:06d}", np.arange(12.0), synth.descriptor_bank(500 + i, 12, dim)) for i in range(40)]
+    noise = [VideoFeature(f"R{i:06d}", np.arange(10.0), synth.descriptor_bank(900 + i, 10, dim)) for i in range(100, 130)]
+    queries = []
+    for i in range(10):
+        f = synth.descriptor_bank(700 + i, 8, dim)
+        if i < 4:   # queries 0..3 copy frames of refs 5, 6, 7, 8
+            f[2:6] = refs[5 + i].feature[3:7] + 0.01 * rs.randn(4, dim).astype(np.float32)
+        queries.append(VideoFeature(f"Q{i:06d}", np.arange(8.0), f))
+    store_features(tmp_path / "q.npz", queries)
+    store_features(tmp_path / "r.npz", refs)
+    store_features(tmp_path / "n.npz", noise)
+    gt = tmp_path / "gt.csv"
+    gt.write_text("query_id,ref_id,query_start,query_end,ref_start,ref_end\n" +
+                  "".join(f"Q{i:06d},R{5 + i:06d},2,6,3,7\n" for i in range(4)))
+    args = entry.build_parser().parse_args(["--query_features", str(tmp_path / "q.npz"), "--ref_features",
+                                            str(tmp_path / "r.npz"), "--output_path", str(tmp_path / "out"),
+                                            "--ground_truth", str(gt), "--overwrite"])
+    entry.main(args)
+    cands = CandidatePair.read_csv(tmp_path / "out" / "candidates.csv")
+    assert {(c.query_id, c.ref_id) for c in cands[:4]} == {(f"Q{i:06d}", f"R{5 + i:06d}") for i in range(4)}
+    assert all(a.score >= b.score for a, b in zip(cands, cands[1:]))
+    assert entry.micro_average_precision(entry.read_ground_truth_pairs(str(gt)), cands) == 1.0
+
+    # score normalisation: compare with a numpy/oracle restatement of score_normalization.py:34-110
+    q2, r2 = sn.score_normalize(queries, refs, noise, beta=1.2)
+    bank = np.concatenate([n.feature for n in noise])
+    dim_drop = int(bank.var(axis=0).argmin())
+    drop = lambda x: knn_oracle.l2_normalize(np.delete(x, dim_drop, axis=1))
+    nb = drop(bank)
+    for q, qn in zip(queries, q2):
+        f = drop(q.feature)
+        D, _ = knn_oracle.knn_ip(f, nb, 1)
+        want = np.concatenate([f, -1.2 * D[:, :1]], axis=1)
+        np.testing.assert_allclose(qn.feature, want, rtol=0, atol=2e-6)
+    assert all(r.feature.shape[1] == dim and (r.feature[:, -1] == 1).all() for r in r2)
+    with pytest.raises(Exception, match="against VSC rules"):
+        sn.score_normalize(queries, refs, refs)

@@ -304,7 +304,9 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
                 pk.x = pack_bf16x2(v[0], v[1]);
                 pk.y = pack_bf16x2(v[2], v[3]);
                 const int row = i * 16 + fr, chunk = 2 * j + (fq >> 1);
-                *(uint2 *)(reg + row * 128 + ((chunk ^ (row & 7)) << 4) + (fq & 1) * 8) = pk;
+                // rows r and r+8 share (r & 7): give them opposite 8-byte halves of the chunk so
+                // the 16 lanes of a ds_write_b64 group hit 16 different bank pairs
+                *(uint2 *)(reg + row * 128 + ((chunk ^ (row & 7)) << 4) + ((fq ^ (row >> 3)) & 1) * 8) = pk;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -314,7 +316,8 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
 #pragma unroll
         for (int it = 0; it < TM * 2; ++it) {
             const int row = it * 8 + (lane >> 3);
-            const uint4 d = *(const uint4 *)(reg + row * 128 + ((c ^ (row & 7)) << 4));
+            uint4 d = *(const uint4 *)(reg + row * 128 + ((c ^ (row & 7)) << 4));
+            if (it & 1) d = make_uint4(d.z, d.w, d.x, d.y);  // (row >> 3) & 1 == it & 1: halves were swapped
             const int64_t m = m0 + wm * TM * 16 + row;
             if (m < p.m && n < p.n && !((p.abl & 4) && d.x != 0x12345678u))
                 *(uint4 *)((uint16_t *)p.out + m * p.n + n) = d;
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
             for (int i = 0; i < TM; ++i) af[i] = (bf16x8_t){1, 2, 3, 4, 5, 6, 7, (short)i};
         }
         {
-            int allowed = nk - 2 - kt;  // tiles issued after tile kt+1
+            int allowed = nk - 2 - kt;  // tiles issued after tile kt+1: may stay in flight across the barrier
             allowed = allowed > STAGES - 2 ? STAGES - 2 : (allowed < 0 ? 0 : allowed);
             wait_tiles<L, STAGES>(allowed);
         }
@@ -522,7 +525,8 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
     // A: 8 waves 256x256 (1 block/CU)   B: 8 waves 256x128
     // C: 4 waves 128x256 (2 blocks/CU)  D: 4 waves 256x128 (2 blocks/CU)
     // Tried and dropped: 64-k stages with full 128-B line fetches (+0.6 %),
-    // a 5-deep ring (+0.4 %), register staging instead of LDS-DMA (0.47x, spills).
+    // a 5-deep ring (+0.4 %), register staging instead of LDS-DMA (0.47x, spills), issuing the
+    // LDS-DMA between the MFMA rows of the C phase (-1 %).
     static const char *force = getenv("VSC_GEMM_CFG");
     const char cfg = force ? force[0] : (p.n > 128 ? 'A' : 'B');  // measured: A wins on every encoder shape
     switch (cfg) {
