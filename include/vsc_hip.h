@@ -58,6 +58,8 @@ typedef struct vsc_encoder_config {
     float gem_p;
     int32_t max_batch;    /* frames per internal step; workspace is sized for it */
     int32_t l2_normalize; /* 1 = emit sklearn-style L2-normalised descriptors */
+    int32_t head_conv_dim; /* >0: SSCD head (sscd.py:25-42): tokens -> Conv1d(width, head_conv_dim, 1)
+                              -> GeM over tokens -> Linear(head_conv_dim, out_dim); needs pool = 0 */
 } vsc_encoder_config;
 
 int vsc_encoder_create(const vsc_encoder_config *cfg, vsc_encoder **out);

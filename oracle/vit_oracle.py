@@ -96,6 +96,10 @@ def gem(tokens: torch.Tensor, p: float, eps: float = 1e-6) -> torch.Tensor:
 def descriptors(params: dict, cfg, frames: torch.Tensor, l2: bool = True) -> torch.Tensor:
     """frames [N,C,H,W] -> descriptors [N, out_dim]."""
     tok = encode_tokens(params, cfg, frames)
+    if getattr(cfg, "head_conv_dim", 0):
+        # SSCD head, train/train_v68/vsc/baseline/model_factory/backbones/sscd.py:33-42:
+        # x.transpose(1,2) -> Conv1d(D, 2048, 1) -> clamp(1e-6).pow(p).mean(tokens).pow(1/p)
+        tok = tok @ params["head_conv.weight"].float().t() + params["head_conv.bias"].float()
     if cfg.pool == "gem":
         pooled = gem(tok, cfg.gem_p)
     elif cfg.pool == "cls":  # extract_query_feats.py:171 ``clip_model(...)[:, 0]``

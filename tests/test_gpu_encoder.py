@@ -106,3 +106,18 @@ def test_other_reference_backbones_full_size(dev, preset, n):
     assert out.shape == (n, cfg.width)
     np.testing.assert_allclose(out, ref, rtol=0, atol=DESC_L2_ATOL)
     assert ((out * ref).sum(1) > 0.9999).all()
+
+
+@pytest.mark.parametrize("preset,n", [("tiny_sscd", 5), ("vit_v68", 3)])
+def test_sscd_head_model(dev, preset, n):
+    """vit_v68 = timm ViT-B/32-384 + the SSCD head (Conv1d 768->2048 over tokens, GeM, Linear
+    2048->512; train/train_v68/vsc/baseline/model_factory/backbones/sscd.py:25-42,88-94), the model
+    infer/infer_ref.sh actually runs.  The conv output is rounded to bf16 before the cube."""
+    from oracle import vit_oracle
+    cfg, w, enc = _encoder(preset, 41, max_batch=2, l2_normalize=True)
+    x = torch.from_numpy(synth.frames(42, n, cfg))
+    with torch.no_grad():
+        ref = vit_oracle.descriptors({k: torch.from_numpy(v) for k, v in w.items()}, cfg, x).numpy()
+    out = enc(x.to(dev)).cpu().numpy()
+    assert out.shape == (n, cfg.out_dim)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=DESC_L2_ATOL)

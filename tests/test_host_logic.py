@@ -133,6 +133,17 @@ def test_weight_name_translation_round_trip():
                 timm[f"blocks.{i}.{dst}.{kind}"] = w[f"blocks.{i}.{src}.{kind}"]
     got = W.from_timm_vit(timm, get_config("tiny", out_dim=0))
     W.check_complete(got, get_config("tiny", out_dim=0))
+    # the vit_v68 checkpoint layout (train/train_v68/torch2scripts.py:17-23): model.backbone.* + model.embeddings.*
+    scfg = get_config("tiny_sscd")
+    sw = synth.encoder_weights(3, scfg)
+    v68 = {"model.backbone." + k: v for k, v in timm.items()}
+    v68.update({"model.embeddings.0.conv.weight": sw["head_conv.weight"][:, :, None],
+                "model.embeddings.0.conv.bias": sw["head_conv.bias"],
+                "model.embeddings.1.weight": sw["head.weight"], "model.embeddings.1.bias": sw["head.bias"]})
+    got = W.from_timm_vit(v68, scfg)
+    W.check_complete(got, scfg)
+    np.testing.assert_array_equal(got["head_conv.weight"], sw["head_conv.weight"])
+    np.testing.assert_array_equal(got["head.weight"], sw["head.weight"])
 
     ccfg = get_config("tiny_clip")
     cw = synth.encoder_weights(3, ccfg)

@@ -100,6 +100,8 @@ int launch_cls_rows(float *x, const float *cls, const float *pos, int64_t frames
 int launch_ln_pool(const float *x, const float *g, const float *b, float *pooled, float *tokens_out,
                    int64_t frames, int tokens, int width, float eps, int pool, float gem_p,
                    hipStream_t stream);
+int launch_gem_pool_bf16(const uint16_t *x, float *pooled, int64_t frames, int tokens, int channels, float gem_p,
+                         hipStream_t stream);
 int launch_head(const float *pooled, const float *w, const float *bias, float *desc, int64_t frames,
                 int width, int out_dim, int l2, hipStream_t stream);
 int launch_l2_normalize(float *x, int64_t n, int d, hipStream_t stream);

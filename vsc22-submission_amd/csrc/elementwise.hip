@@ -223,6 +223,33 @@ __global__ __launch_bounds__(256) void ln_pool_kernel(const float *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------ GeM over tokens, bf16 input
+// pooled[f, c] = (mean_t clamp(x[f, t, c], 1e-6)^p)^(1/p)   (sscd.py:40-42).  A thread owns 8
+// consecutive channels (one 16-byte load per token); a block covers 2048 channels of one frame.
+__global__ __launch_bounds__(256) void gem_pool_bf16_kernel(const uint16_t *__restrict__ x,
+                                                            float *__restrict__ pooled, int tokens,
+                                                            int channels, float gem_p) {
+    const int64_t f = blockIdx.x;
+    const int c0 = (blockIdx.y * 256 + threadIdx.x) * 8;
+    if (c0 >= channels) return;
+    const bool cube = gem_p == 3.0f;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint16_t *base = x + f * tokens * (int64_t)channels + c0;
+    for (int t = 0; t < tokens; ++t) {
+        const bf16x8_t v = *(const bf16x8_t *)(base + (int64_t)t * channels);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float c = fmaxf(bf16_to_f32((uint16_t)v[j]), 1e-6f);
+            acc[j] += cube ? c * c * c : __powf(c, gem_p);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float m = acc[j] / (float)tokens;
+        pooled[f * channels + c0 + j] = cube ? cbrtf(m) : __powf(m, 1.0f / gem_p);
+    }
+}
+
 // ------------------------------------------------------------------ descriptor head
 // desc[f,:] = pooled[f,:] . W^T + b (fp32), optionally L2-normalised (zero rows untouched).
 // One workgroup per frame; a wave computes outputs w, w+4, ... with coalesced weight rows.
@@ -339,6 +366,15 @@ int launch_ln_pool(const float *x, const float *g, const float *b, float *pooled
     VSC_REQUIRE(width % 4 == 0 && width <= 2048, "ln_pool: width %d unsupported", width);
     hipLaunchKernelGGL(ln_pool_kernel, dim3((unsigned)frames), dim3(256), 0, stream, x, g, b, pooled,
                        tokens_out, tokens, width, eps, pool, gem_p);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+int launch_gem_pool_bf16(const uint16_t *x, float *pooled, int64_t frames, int tokens, int channels, float gem_p,
+                         hipStream_t stream) {
+    VSC_REQUIRE(channels % 8 == 0, "gem_pool: channels %d not a multiple of 8", channels);
+    hipLaunchKernelGGL(gem_pool_bf16_kernel, dim3((unsigned)frames, (channels + 2047) / 2048), dim3(256), 0, stream,
+                       x, pooled, tokens, channels, gem_p);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }

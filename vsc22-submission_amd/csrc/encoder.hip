@@ -30,7 +30,8 @@ struct vsc_encoder {
     std::vector<LayerW> layers;
     uint16_t *patch_w = nullptr;
     float *patch_b = nullptr, *cls = nullptr, *pos = nullptr, *lnpre_g = nullptr, *lnpre_b = nullptr,
-          *lnpost_g = nullptr, *lnpost_b = nullptr, *head_w = nullptr, *head_b = nullptr;
+          *lnpost_g = nullptr, *lnpost_b = nullptr, *head_w = nullptr, *head_b = nullptr, *hconv_b = nullptr;
+    uint16_t *hconv_w = nullptr, *hconv_out = nullptr;  // SSCD head conv weight, its [M, C] bf16 output
     uint16_t *patches = nullptr, *y = nullptr, *qkv = nullptr, *h = nullptr;
     float *x = nullptr, *pooled = nullptr;
     int64_t ws_bytes = 0;
@@ -122,6 +123,10 @@ extern "C" int vsc_encoder_create(const vsc_encoder_config *cfg, vsc_encoder **o
     VSC_REQUIRE(c.act == 0 || c.act == 1, "encoder: act %d", c.act);
     VSC_REQUIRE(c.pool == 0 || c.pool == 1, "encoder: pool %d", c.pool);
     VSC_REQUIRE(c.max_batch >= 1, "encoder: max_batch");
+    VSC_REQUIRE(c.head_conv_dim >= 0 && c.head_conv_dim <= 2048 && c.head_conv_dim % 8 == 0,
+                "encoder: head_conv_dim %d", c.head_conv_dim);
+    VSC_REQUIRE(!c.head_conv_dim || (c.pool == 0 && c.out_dim > 0),
+                "encoder: the SSCD head needs GeM pooling and a Linear output");
     int g = c.image_size / c.patch_size;
     int tokens = g * g + 1;
     VSC_REQUIRE(tokens <= 320, "encoder: %d tokens > 320 (attention kernel limit)", tokens);
@@ -153,8 +158,12 @@ extern "C" int vsc_encoder_create(const vsc_encoder_config *cfg, vsc_encoder **o
         e->expect[b + "fc2.bias"] = D;
     }
     e->expect["ln_post.weight"] = e->expect["ln_post.bias"] = D;
+    if (c.head_conv_dim) {
+        e->expect["head_conv.weight"] = (size_t)c.head_conv_dim * D;
+        e->expect["head_conv.bias"] = c.head_conv_dim;
+    }
     if (c.out_dim) {
-        e->expect["head.weight"] = (size_t)c.out_dim * D;
+        e->expect["head.weight"] = (size_t)c.out_dim * (c.head_conv_dim ? c.head_conv_dim : D);
         e->expect["head.bias"] = c.out_dim;
     }
     *out = e;
@@ -222,6 +231,10 @@ extern "C" int vsc_encoder_finalize(vsc_encoder *e) {
     }
     TRY(upload_f32(e, "ln_post.weight", &e->lnpost_g));
     TRY(upload_f32(e, "ln_post.bias", &e->lnpost_b));
+    if (c.head_conv_dim) {
+        TRY(upload_bf16(e, "head_conv.weight", c.head_conv_dim, D, D, &e->hconv_w));
+        TRY(upload_f32(e, "head_conv.bias", &e->hconv_b));
+    }
     if (c.out_dim) {
         TRY(upload_f32(e, "head.weight", &e->head_w));
         TRY(upload_f32(e, "head.bias", &e->head_b));
@@ -229,13 +242,16 @@ extern "C" int vsc_encoder_finalize(vsc_encoder *e) {
     // workspace for max_batch frames
     const size_t B = c.max_batch, M = B * e->tokens;
     const size_t sz_patches = B * (e->tokens - 1) * e->kpad * 2, sz_x = M * D * 4, sz_y = M * D * 2,
-                 sz_qkv = M * 3 * D * 2, sz_h = M * (size_t)c.mlp_dim * 2, sz_pool = B * D * 4;
+                 sz_qkv = M * 3 * D * 2, sz_h = M * (size_t)c.mlp_dim * 2,
+                 sz_pool = B * (size_t)(c.head_conv_dim ? c.head_conv_dim : D) * 4;
     TRY(dev_alloc(e, sz_patches, (void **)&e->patches));
     TRY(dev_alloc(e, sz_x, (void **)&e->x));
     TRY(dev_alloc(e, sz_y, (void **)&e->y));
     TRY(dev_alloc(e, sz_qkv, (void **)&e->qkv));
     TRY(dev_alloc(e, sz_h, (void **)&e->h));
     TRY(dev_alloc(e, sz_pool, (void **)&e->pooled));
+    e->hconv_out = e->h;  // [M, head_conv_dim] bf16 fits in the (idle) MLP buffer: head_conv_dim <= mlp_dim
+    VSC_REQUIRE(c.head_conv_dim <= c.mlp_dim, "encoder: head_conv_dim %d > mlp_dim %d", c.head_conv_dim, c.mlp_dim);
 #undef TRY
     e->ws_bytes = (int64_t)(sz_patches + sz_x + sz_y + sz_qkv + sz_h + sz_pool);
     e->host_w.clear();
@@ -282,11 +298,24 @@ extern "C" int vsc_encoder_forward_debug(vsc_encoder *e, const float *frames, in
             { ProfScope _ps(e, VSC_PROF_GEMM_FC1, st); TRY(launch_gemm_bf16(e->y, L.fc1_w, L.fc1_b, nullptr, e->h, M, c.mlp_dim, D, act_epi, 0, st)); }
             { ProfScope _ps(e, VSC_PROF_GEMM_FC2, st); TRY(launch_gemm_bf16(e->h, L.fc2_w, L.fc2_b, e->x, e->x, M, D, c.mlp_dim, VSC_EPI_RESADD_F32, 0, st)); }
         }
+        if (c.head_conv_dim) {
+            // SSCD head: final LN -> bf16 tokens -> Conv1d(D, C, 1) as a GEMM -> GeM over tokens
+            ProfScope _ps(e, VSC_PROF_POOL_HEAD, st);
+            if (tokens_out)
+                TRY(launch_layernorm(e->x, e->lnpost_g, e->lnpost_b, tokens_out + off * T * D, M, D, c.ln_eps, 1, st));
+            TRY(launch_layernorm(e->x, e->lnpost_g, e->lnpost_b, e->y, M, D, c.ln_eps, 0, st));
+            TRY(launch_gemm_bf16(e->y, e->hconv_w, e->hconv_b, nullptr, e->hconv_out, M, c.head_conv_dim, D,
+                                 VSC_EPI_BF16, 0, st));
+            TRY(launch_gem_pool_bf16(e->hconv_out, e->pooled, B, T, c.head_conv_dim, c.gem_p, st));
+            TRY(launch_head(e->pooled, e->head_w, e->head_b, desc + off * e->desc_dim, B, c.head_conv_dim,
+                            c.out_dim, c.l2_normalize, st));
+        } else {
         { ProfScope _ps(e, VSC_PROF_POOL_HEAD, st); TRY(launch_ln_pool(e->x, e->lnpost_g, e->lnpost_b, e->pooled,
                            tokens_out ? tokens_out + off * T * D : nullptr, B, T, D, c.ln_eps, c.pool,
                            c.gem_p, st)); }
-        { ProfScope _ps(e, VSC_PROF_POOL_HEAD, st); TRY(launch_head(e->pooled, e->head_w, e->head_b, desc + off * e->desc_dim, B, D, c.out_dim,
+            { ProfScope _ps(e, VSC_PROF_POOL_HEAD, st); TRY(launch_head(e->pooled, e->head_w, e->head_b, desc + off * e->desc_dim, B, D, c.out_dim,
                         c.l2_normalize, st)); }
+        }
     }
 #undef TRY
     return VSC_OK;

@@ -87,8 +87,11 @@ def encoder_weights(seed: int, cfg) -> dict:
         w[b + "fc2.bias"] = normalish(nxt(), (d,), 0.02)
     w["ln_post.weight"] = 1.0 + normalish(nxt(), (d,), 0.05)
     w["ln_post.bias"] = normalish(nxt(), (d,), 0.05)
+    if cfg.head_conv_dim:
+        w["head_conv.weight"] = normalish(nxt(), (cfg.head_conv_dim, d), 0.05)
+        w["head_conv.bias"] = normalish(nxt(), (cfg.head_conv_dim,), 0.3)
     if cfg.out_dim:
-        w["head.weight"] = normalish(nxt(), (cfg.out_dim, d), 0.05)
+        w["head.weight"] = normalish(nxt(), (cfg.out_dim, cfg.head_conv_dim or d), 0.05)
         w["head.bias"] = normalish(nxt(), (cfg.out_dim,), 0.02)
     return w
 

@@ -6,9 +6,9 @@ Each preset names the reference backbone it stands for:
   config + GeM(p=3) + ``output_proj``
   (train/train_v115/vsc/baseline/model_factory/backbones/vit.py:10-54); 512-d
   descriptors as emitted by every model of infer/infer_ref.sh.
-* ``vit_b32_384``  -- ``vit_v68`` = timm ``vit_base_patch32_384``
-  (train/train_v68/torch2scripts.py:10-15); backbone only, the 768->2048 conv +
-  GeM + Linear head of sscd.py:25-42 is a "next" row.
+* ``vit_b32_384``  -- timm ``vit_base_patch32_384`` backbone of ``vit_v68``
+  (train/train_v68/torch2scripts.py:10-15); ``vit_v68`` adds its SSCD head
+  (768->2048 Conv1d over tokens, GeM, Linear 2048->512: sscd.py:25-42,88-94).
 * ``clip_vit_l14_224`` -- the video-score CLIP tower
   (train/train_vid_score/video/clip.py:82-161, torch2scripts.py:7-9), CLS readout.
 """
@@ -34,6 +34,7 @@ class EncoderConfig:
     patch_bias: bool = True
     pool: str = "gem"           # "gem" | "cls"
     gem_p: float = 3.0
+    head_conv_dim: int = 0      # SSCD head: Conv1d(width, head_conv_dim, 1) before GeM (sscd.py:25-42)
 
     @property
     def grid(self) -> int:
@@ -61,7 +62,9 @@ class EncoderConfig:
         f = 2 * (t - 1) * self.patch_dim * d
         per_layer = 2 * t * d * 3 * d + 2 * 2 * t * t * d + 2 * t * d * d + 2 * 2 * t * d * m
         f += self.layers * per_layer
-        if self.out_dim:
+        if self.head_conv_dim:
+            f += 2 * t * d * self.head_conv_dim + 2 * self.head_conv_dim * self.out_dim
+        elif self.out_dim:
             f += 2 * d * self.out_dim
         return f
 
@@ -70,6 +73,12 @@ PRESETS = {
     "vit_b16_224": EncoderConfig(),
     "vit_b32_384": EncoderConfig(name="vit_b32_384", image_size=384, patch_size=32,
                                  ln_eps=1e-6, out_dim=0),
+    # the full vit_v68 model: backbone + SSCD head (train/train_v68/torch2scripts.py:14,
+    # SSCDModel(pool="gem", pool_param=3., dims=(768, 512), add_head=True))
+    "vit_v68": EncoderConfig(name="vit_v68", image_size=384, patch_size=32, ln_eps=1e-6, out_dim=512,
+                             head_conv_dim=2048),
+    "tiny_sscd": EncoderConfig(name="tiny_sscd", image_size=64, patch_size=16, width=128, layers=2, heads=2,
+                               mlp_dim=512, out_dim=64, ln_eps=1e-6, head_conv_dim=256),
     "clip_vit_l14_224": EncoderConfig(name="clip_vit_l14_224", patch_size=14, width=1024,
                                       layers=24, heads=16, mlp_dim=4096, out_dim=0,
                                       ln_eps=1e-5, act="quick_gelu", pre_ln=True,

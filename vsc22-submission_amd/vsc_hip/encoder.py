@@ -32,7 +32,7 @@ class HipEncoder:
             out_dim=cfg.out_dim, ln_eps=cfg.ln_eps, act={"gelu": 0, "quick_gelu": 1}[cfg.act],
             pre_ln=int(cfg.pre_ln), patch_bias=int(cfg.patch_bias),
             pool={"gem": 0, "cls": 1}[cfg.pool], gem_p=cfg.gem_p, max_batch=max_batch,
-            l2_normalize=int(l2_normalize))
+            l2_normalize=int(l2_normalize), head_conv_dim=cfg.head_conv_dim)
         handle = ctypes.c_void_p()
         check(self._lib.vsc_encoder_create(ctypes.byref(c), ctypes.byref(handle)))
         self._h = handle

@@ -8,6 +8,7 @@ Canonical names (all float32, PyTorch ``Linear`` layout ``[out, in]``):
     blocks.{i}.proj.{weight,bias} blocks.{i}.ln2.{weight,bias}
     blocks.{i}.fc1.{weight,bias}  blocks.{i}.fc2.{weight,bias}
     ln_post.{weight,bias}   head.{weight [out,D],bias}
+    head_conv.{weight [C,D],bias}             (SSCD head only; then head.weight is [out,C])
 
 Sources understood (model loading is host-side Python, as in the reference):
   * HF ``ViTModel`` state dicts, both the transformers 4.27 naming the reference
@@ -39,6 +40,8 @@ def canonical_names(cfg) -> list:
         for part in ("ln1", "qkv", "proj", "ln2", "fc1", "fc2"):
             names += [f"blocks.{i}.{part}.weight", f"blocks.{i}.{part}.bias"]
     names += ["ln_post.weight", "ln_post.bias"]
+    if cfg.head_conv_dim:
+        names += ["head_conv.weight", "head_conv.bias"]
     if cfg.out_dim:
         names += ["head.weight", "head.bias"]
     return names
@@ -112,6 +115,10 @@ def from_timm_vit(state: dict, cfg) -> dict:
             out["patch." + name.rsplit(".", 1)[1]] = v
         elif name.startswith("norm."):
             out["ln_post." + name.rsplit(".", 1)[1]] = v
+        elif re.match(r"(model\.)?embeddings\.0\.conv\.(weight|bias)$", name):   # sscd.py:31 Conv1d(D, 2048, 1)
+            out["head_conv." + name.rsplit(".", 1)[1]] = v.reshape(v.shape[0], -1) if v.ndim == 3 else v
+        elif re.match(r"(model\.)?embeddings\.1\.(weight|bias)$", name):          # sscd.py:91 Linear(2048, out)
+            out["head." + name.rsplit(".", 1)[1]] = v
         else:
             m = re.match(r"blocks\.(\d+)\.(norm1|attn\.qkv|attn\.proj|norm2|mlp\.fc1|mlp\.fc2)\.(weight|bias)$", name)
             if m:
