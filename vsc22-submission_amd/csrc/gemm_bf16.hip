@@ -519,6 +519,7 @@ int launch_v2(GemmArgs p, hipStream_t stream) {
 }
 
 
+
 template <int EPI>
 int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
     // wide N: 256x256 tile; N <= 1024 (proj / fc2 / patch): 256x128 so the grid still fills 256 CUs
@@ -526,7 +527,8 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
     // C: 4 waves 128x256 (2 blocks/CU)  D: 4 waves 256x128 (2 blocks/CU)
     // Tried and dropped: 64-k stages with full 128-B line fetches (+0.6 %),
     // a 5-deep ring (+0.4 %), register staging instead of LDS-DMA (0.47x, spills), issuing the
-    // LDS-DMA between the MFMA rows of the C phase (-1 %).
+    // LDS-DMA between the MFMA rows of the C phase (-1 %), hybrid staging with A by LDS-DMA and W
+    // through registers (-3 %).  Operand delivery sits at ~30 GB/s per CU whatever the path.
     static const char *force = getenv("VSC_GEMM_CFG");
     const char cfg = force ? force[0] : (p.n > 128 ? 'A' : 'B');  // measured: A wins on every encoder shape
     switch (cfg) {
