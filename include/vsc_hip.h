@@ -60,6 +60,9 @@ typedef struct vsc_encoder_config {
     int32_t l2_normalize; /* 1 = emit sklearn-style L2-normalised descriptors */
     int32_t head_conv_dim; /* >0: SSCD head (sscd.py:25-42): tokens -> Conv1d(width, head_conv_dim, 1)
                               -> GeM over tokens -> Linear(head_conv_dim, out_dim); needs pool = 0 */
+    int32_t lanes;        /* 2: a forward call of more than max_batch frames alternates its chunks over
+                             two internal streams (two workspaces) so memory-bound kernels of one
+                             chunk overlap the GEMMs of the other; anything else = 1 */
 } vsc_encoder_config;
 
 int vsc_encoder_create(const vsc_encoder_config *cfg, vsc_encoder **out);

@@ -56,7 +56,7 @@ def test_encoder_matches_golden(dev, preset, golden_dir):
 def test_encoder_batching_is_invisible(dev):
     """Ragged batch (n not a multiple of max_batch) and different max_batch give
     bit-identical descriptors: frames are independent."""
-    cfg, w, enc3 = _encoder("tiny", 3, max_batch=3, l2_normalize=True)
+    cfg, w, enc3 = _encoder("tiny", 3, max_batch=3, l2_normalize=True, lanes=2)   # 4 chunks over 2 streams
     from vsc_hip.encoder import HipEncoder
     enc7 = HipEncoder(cfg, w, max_batch=7, l2_normalize=True)
     x = torch.from_numpy(synth.frames(5, 11, cfg)).to(dev)

@@ -31,9 +31,17 @@ struct vsc_encoder {
     uint16_t *patch_w = nullptr;
     float *patch_b = nullptr, *cls = nullptr, *pos = nullptr, *lnpre_g = nullptr, *lnpre_b = nullptr,
           *lnpost_g = nullptr, *lnpost_b = nullptr, *head_w = nullptr, *head_b = nullptr, *hconv_b = nullptr;
-    uint16_t *hconv_w = nullptr, *hconv_out = nullptr;  // SSCD head conv weight, its [M, C] bf16 output
-    uint16_t *patches = nullptr, *y = nullptr, *qkv = nullptr, *h = nullptr;
-    float *x = nullptr, *pooled = nullptr;
+    uint16_t *hconv_w = nullptr;  // SSCD head conv weight
+    // One workspace per lane.  With two lanes, consecutive max_batch chunks of a forward call run
+    // on two internal streams: the HBM-bound kernels of one chunk (LayerNorm, residual write-out)
+    // co-run with the MFMA-bound GEMMs of the other instead of leaving the matrix pipes idle.
+    struct Workspace {
+        uint16_t *patches = nullptr, *y = nullptr, *qkv = nullptr, *h = nullptr, *hconv_out = nullptr;
+        float *x = nullptr, *pooled = nullptr;
+    } ws[2];
+    int lanes = 1;
+    hipStream_t lane_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     int64_t ws_bytes = 0;
     // optional per-kernel-class timing (HIP events on the caller's stream)
     bool profile = false;
@@ -174,6 +182,11 @@ extern "C" void vsc_encoder_destroy(vsc_encoder *e) {
     if (!e) return;
     for (void *p : e->allocs) (void)hipFree(p);
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (int l = 0; l < 2; ++l) {
+        if (e->lane_stream[l]) (void)hipStreamDestroy(e->lane_stream[l]);
+        if (e->ev_join[l]) (void)hipEventDestroy(e->ev_join[l]);
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     delete e;
 }
 
@@ -244,16 +257,25 @@ extern "C" int vsc_encoder_finalize(vsc_encoder *e) {
     const size_t sz_patches = B * (e->tokens - 1) * e->kpad * 2, sz_x = M * D * 4, sz_y = M * D * 2,
                  sz_qkv = M * 3 * D * 2, sz_h = M * (size_t)c.mlp_dim * 2,
                  sz_pool = B * (size_t)(c.head_conv_dim ? c.head_conv_dim : D) * 4;
-    TRY(dev_alloc(e, sz_patches, (void **)&e->patches));
-    TRY(dev_alloc(e, sz_x, (void **)&e->x));
-    TRY(dev_alloc(e, sz_y, (void **)&e->y));
-    TRY(dev_alloc(e, sz_qkv, (void **)&e->qkv));
-    TRY(dev_alloc(e, sz_h, (void **)&e->h));
-    TRY(dev_alloc(e, sz_pool, (void **)&e->pooled));
-    e->hconv_out = e->h;  // [M, head_conv_dim] bf16 fits in the (idle) MLP buffer: head_conv_dim <= mlp_dim
     VSC_REQUIRE(c.head_conv_dim <= c.mlp_dim, "encoder: head_conv_dim %d > mlp_dim %d", c.head_conv_dim, c.mlp_dim);
+    e->lanes = c.lanes == 2 ? 2 : 1;
+    for (int l = 0; l < e->lanes; ++l) {
+        vsc_encoder::Workspace &w = e->ws[l];
+        TRY(dev_alloc(e, sz_patches, (void **)&w.patches));
+        TRY(dev_alloc(e, sz_x, (void **)&w.x));
+        TRY(dev_alloc(e, sz_y, (void **)&w.y));
+        TRY(dev_alloc(e, sz_qkv, (void **)&w.qkv));
+        TRY(dev_alloc(e, sz_h, (void **)&w.h));
+        TRY(dev_alloc(e, sz_pool, (void **)&w.pooled));
+        w.hconv_out = w.h;  // [M, head_conv_dim] bf16 fits in the (idle) MLP buffer: head_conv_dim <= mlp_dim
+        if (e->lanes == 2) {
+            VSC_CHECK_HIP(hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking));
+            VSC_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join[l], hipEventDisableTiming));
+        }
+    }
+    if (e->lanes == 2) VSC_CHECK_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
 #undef TRY
-    e->ws_bytes = (int64_t)(sz_patches + sz_x + sz_y + sz_qkv + sz_h + sz_pool);
+    e->ws_bytes = (int64_t)(sz_patches + sz_x + sz_y + sz_qkv + sz_h + sz_pool) * e->lanes;
     e->host_w.clear();
     e->finalized = true;
     return VSC_OK;
@@ -269,52 +291,67 @@ extern "C" int vsc_encoder_forward_debug(vsc_encoder *e, const float *frames, in
         vsc_set_error("forward before finalize");
         return VSC_ERR_STATE;
     }
-    hipStream_t st = (hipStream_t)stream_;
+    hipStream_t user = (hipStream_t)stream_;
     const vsc_encoder_config &c = e->cfg;
+    const bool fork = e->lanes == 2 && n > c.max_batch;  // >= 2 chunks: alternate them over the two lanes
+    if (fork) {
+        VSC_CHECK_HIP(hipEventRecord(e->ev_fork, user));
+        for (int l = 0; l < 2; ++l) VSC_CHECK_HIP(hipStreamWaitEvent(e->lane_stream[l], e->ev_fork, 0));
+    }
     const int D = c.width, T = e->tokens;
     const int act_epi = c.act == 0 ? VSC_EPI_GELU_BF16 : VSC_EPI_QGELU_BF16;
     const int64_t frame_elems = (int64_t)c.channels * c.image_size * c.image_size;
     int rc;
 #define TRY(x) do { if ((rc = (x))) return rc; } while (0)
-    for (int64_t off = 0; off < n; off += c.max_batch) {
+    int chunk = 0;
+    for (int64_t off = 0; off < n; off += c.max_batch, ++chunk) {
+        const int lane = fork ? (chunk & 1) : 0;
+        hipStream_t st = fork ? e->lane_stream[lane] : user;
+        vsc_encoder::Workspace &w = e->ws[lane];
         const int64_t B = (n - off) < c.max_batch ? (n - off) : c.max_batch;
         const int64_t M = B * T, Mp = B * (T - 1);
-        { ProfScope _ps(e, VSC_PROF_PATCHIFY, st); TRY(launch_patchify(frames + off * frame_elems, e->patches, B, c.channels, c.image_size,
+        { ProfScope _ps(e, VSC_PROF_PATCHIFY, st); TRY(launch_patchify(frames + off * frame_elems, w.patches, B, c.channels, c.image_size,
                             c.patch_size, e->kpad, st)); }
-        { ProfScope _ps(e, VSC_PROF_GEMM_PATCH, st); TRY(launch_gemm_bf16(e->patches, e->patch_w, e->patch_b, e->pos, e->x, Mp, D, e->kpad,
+        { ProfScope _ps(e, VSC_PROF_GEMM_PATCH, st); TRY(launch_gemm_bf16(w.patches, e->patch_w, e->patch_b, e->pos, w.x, Mp, D, e->kpad,
                              VSC_EPI_PATCH_F32, T, st)); }
-        { ProfScope _ps(e, VSC_PROF_MISC, st); TRY(launch_cls_rows(e->x, e->cls, e->pos, B, T, D, st)); }
+        { ProfScope _ps(e, VSC_PROF_MISC, st); TRY(launch_cls_rows(w.x, e->cls, e->pos, B, T, D, st)); }
         if (c.pre_ln) {
             ProfScope _ps(e, VSC_PROF_LAYERNORM, st);
-            TRY(launch_layernorm(e->x, e->lnpre_g, e->lnpre_b, e->x, M, D, c.ln_eps, 1, st));
+            TRY(launch_layernorm(w.x, e->lnpre_g, e->lnpre_b, w.x, M, D, c.ln_eps, 1, st));
         }
         for (int l = 0; l < c.layers; ++l) {
             const LayerW &L = e->layers[l];
-            { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_layernorm(e->x, L.ln1_g, L.ln1_b, e->y, M, D, c.ln_eps, 0, st)); }
-            { ProfScope _ps(e, VSC_PROF_GEMM_QKV, st); TRY(launch_gemm_bf16(e->y, L.qkv_w, L.qkv_b, nullptr, e->qkv, M, 3 * D, D, VSC_EPI_BF16, 0, st)); }
-            { ProfScope _ps(e, VSC_PROF_ATTENTION, st); TRY(launch_attention_bf16(e->qkv, e->y, (int)B, T, c.heads, st)); }
-            { ProfScope _ps(e, VSC_PROF_GEMM_PROJ, st); TRY(launch_gemm_bf16(e->y, L.proj_w, L.proj_b, e->x, e->x, M, D, D, VSC_EPI_RESADD_F32, 0, st)); }
-            { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_layernorm(e->x, L.ln2_g, L.ln2_b, e->y, M, D, c.ln_eps, 0, st)); }
-            { ProfScope _ps(e, VSC_PROF_GEMM_FC1, st); TRY(launch_gemm_bf16(e->y, L.fc1_w, L.fc1_b, nullptr, e->h, M, c.mlp_dim, D, act_epi, 0, st)); }
-            { ProfScope _ps(e, VSC_PROF_GEMM_FC2, st); TRY(launch_gemm_bf16(e->h, L.fc2_w, L.fc2_b, e->x, e->x, M, D, c.mlp_dim, VSC_EPI_RESADD_F32, 0, st)); }
+            { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_layernorm(w.x, L.ln1_g, L.ln1_b, w.y, M, D, c.ln_eps, 0, st)); }
+            { ProfScope _ps(e, VSC_PROF_GEMM_QKV, st); TRY(launch_gemm_bf16(w.y, L.qkv_w, L.qkv_b, nullptr, w.qkv, M, 3 * D, D, VSC_EPI_BF16, 0, st)); }
+            { ProfScope _ps(e, VSC_PROF_ATTENTION, st); TRY(launch_attention_bf16(w.qkv, w.y, (int)B, T, c.heads, st)); }
+            { ProfScope _ps(e, VSC_PROF_GEMM_PROJ, st); TRY(launch_gemm_bf16(w.y, L.proj_w, L.proj_b, w.x, w.x, M, D, D, VSC_EPI_RESADD_F32, 0, st)); }
+            { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_layernorm(w.x, L.ln2_g, L.ln2_b, w.y, M, D, c.ln_eps, 0, st)); }
+            { ProfScope _ps(e, VSC_PROF_GEMM_FC1, st); TRY(launch_gemm_bf16(w.y, L.fc1_w, L.fc1_b, nullptr, w.h, M, c.mlp_dim, D, act_epi, 0, st)); }
+            { ProfScope _ps(e, VSC_PROF_GEMM_FC2, st); TRY(launch_gemm_bf16(w.h, L.fc2_w, L.fc2_b, w.x, w.x, M, D, c.mlp_dim, VSC_EPI_RESADD_F32, 0, st)); }
         }
         if (c.head_conv_dim) {
             // SSCD head: final LN -> bf16 tokens -> Conv1d(D, C, 1) as a GEMM -> GeM over tokens
             ProfScope _ps(e, VSC_PROF_POOL_HEAD, st);
             if (tokens_out)
-                TRY(launch_layernorm(e->x, e->lnpost_g, e->lnpost_b, tokens_out + off * T * D, M, D, c.ln_eps, 1, st));
-            TRY(launch_layernorm(e->x, e->lnpost_g, e->lnpost_b, e->y, M, D, c.ln_eps, 0, st));
-            TRY(launch_gemm_bf16(e->y, e->hconv_w, e->hconv_b, nullptr, e->hconv_out, M, c.head_conv_dim, D,
+                TRY(launch_layernorm(w.x, e->lnpost_g, e->lnpost_b, tokens_out + off * T * D, M, D, c.ln_eps, 1, st));
+            TRY(launch_layernorm(w.x, e->lnpost_g, e->lnpost_b, w.y, M, D, c.ln_eps, 0, st));
+            TRY(launch_gemm_bf16(w.y, e->hconv_w, e->hconv_b, nullptr, w.hconv_out, M, c.head_conv_dim, D,
                                  VSC_EPI_BF16, 0, st));
-            TRY(launch_gem_pool_bf16(e->hconv_out, e->pooled, B, T, c.head_conv_dim, c.gem_p, st));
-            TRY(launch_head(e->pooled, e->head_w, e->head_b, desc + off * e->desc_dim, B, c.head_conv_dim,
+            TRY(launch_gem_pool_bf16(w.hconv_out, w.pooled, B, T, c.head_conv_dim, c.gem_p, st));
+            TRY(launch_head(w.pooled, e->head_w, e->head_b, desc + off * e->desc_dim, B, c.head_conv_dim,
                             c.out_dim, c.l2_normalize, st));
         } else {
-        { ProfScope _ps(e, VSC_PROF_POOL_HEAD, st); TRY(launch_ln_pool(e->x, e->lnpost_g, e->lnpost_b, e->pooled,
+        { ProfScope _ps(e, VSC_PROF_POOL_HEAD, st); TRY(launch_ln_pool(w.x, e->lnpost_g, e->lnpost_b, w.pooled,
                            tokens_out ? tokens_out + off * T * D : nullptr, B, T, D, c.ln_eps, c.pool,
                            c.gem_p, st)); }
-            { ProfScope _ps(e, VSC_PROF_POOL_HEAD, st); TRY(launch_head(e->pooled, e->head_w, e->head_b, desc + off * e->desc_dim, B, D, c.out_dim,
+            { ProfScope _ps(e, VSC_PROF_POOL_HEAD, st); TRY(launch_head(w.pooled, e->head_w, e->head_b, desc + off * e->desc_dim, B, D, c.out_dim,
                         c.l2_normalize, st)); }
+        }
+    }
+    if (fork) {
+        for (int l = 0; l < 2; ++l) {
+            VSC_CHECK_HIP(hipEventRecord(e->ev_join[l], e->lane_stream[l]));
+            VSC_CHECK_HIP(hipStreamWaitEvent(user, e->ev_join[l], 0));
         }
     }
 #undef TRY
