@@ -102,3 +102,59 @@ def descriptor_bank(seed: int, n: int, dim: int = 512, l2: bool = True) -> np.nd
     if l2:
         x = x / np.maximum(np.linalg.norm(x.astype(np.float64), axis=1, keepdims=True), 1e-30)
     return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def swin_weights(seed: int, cfg) -> dict:
+    """Random-init Swin-V2 weights in the reference's own state-dict naming
+    (train/train_v115/torch2scripts.py: patch_embed.proj, layers.S.blocks.B.attn.qkv, ...)."""
+    s = seed * 100000
+    w = {}
+
+    def nxt():
+        nonlocal s
+        s += 1
+        return s
+
+    c0 = cfg.embed_dim
+    w["patch_embed.proj.weight"] = normalish(nxt(), (c0, cfg.channels, cfg.patch_size, cfg.patch_size), 0.15)
+    w["patch_embed.proj.bias"] = normalish(nxt(), (c0,), 0.05)
+    w["patch_embed.norm.weight"] = 1.0 + normalish(nxt(), (c0,), 0.05)
+    w["patch_embed.norm.bias"] = normalish(nxt(), (c0,), 0.05)
+    for st in range(cfg.stages):
+        c, h = cfg.dim(st), cfg.heads[st]
+        for b in range(cfg.depths[st]):
+            p = f"layers.{st}.blocks.{b}."
+            w[p + "attn.qkv.weight"] = normalish(nxt(), (3 * c, c), 1.0 / np.sqrt(c))
+            w[p + "attn.q_bias"] = normalish(nxt(), (c,), 0.1)
+            w[p + "attn.v_bias"] = normalish(nxt(), (c,), 0.1)
+            w[p + "attn.logit_scale"] = (np.log(10.0) + normalish(nxt(), (h, 1, 1), 0.3)).astype(np.float32)
+            w[p + "attn.cpb_mlp.0.weight"] = normalish(nxt(), (512, 2), 0.5)
+            w[p + "attn.cpb_mlp.0.bias"] = normalish(nxt(), (512,), 0.3)
+            w[p + "attn.cpb_mlp.2.weight"] = normalish(nxt(), (h, 512), 0.08)
+            w[p + "attn.proj.weight"] = normalish(nxt(), (c, c), 1.0 / np.sqrt(c))
+            w[p + "attn.proj.bias"] = normalish(nxt(), (c,), 0.05)
+            # res-post-norm: the LayerNorm gains scale each residual update (the reference
+            # initialises them to 0; trained values are small)
+            w[p + "norm1.weight"] = 0.3 + normalish(nxt(), (c,), 0.05)
+            w[p + "norm1.bias"] = normalish(nxt(), (c,), 0.05)
+            w[p + "mlp.fc1.weight"] = normalish(nxt(), (cfg.mlp_ratio * c, c), 1.0 / np.sqrt(c))
+            w[p + "mlp.fc1.bias"] = normalish(nxt(), (cfg.mlp_ratio * c,), 0.1)
+            w[p + "mlp.fc2.weight"] = normalish(nxt(), (c, cfg.mlp_ratio * c), 0.5 / np.sqrt(c))
+            w[p + "mlp.fc2.bias"] = normalish(nxt(), (c,), 0.05)
+            w[p + "norm2.weight"] = 0.3 + normalish(nxt(), (c,), 0.05)
+            w[p + "norm2.bias"] = normalish(nxt(), (c,), 0.05)
+        if st + 1 < cfg.stages:
+            p = f"layers.{st}.downsample."
+            w[p + "reduction.weight"] = normalish(nxt(), (2 * c, 4 * c), 0.5 / np.sqrt(c))
+            w[p + "norm.weight"] = 1.0 + normalish(nxt(), (2 * c,), 0.05)
+            w[p + "norm.bias"] = normalish(nxt(), (2 * c,), 0.05)
+    cl = cfg.dim(cfg.stages - 1)
+    w["norm.weight"] = 1.0 + normalish(nxt(), (cl,), 0.05)
+    w["norm.bias"] = normalish(nxt(), (cl,), 0.05)
+    w["output_proj.weight"] = normalish(nxt(), (cfg.out_dim, cl), 0.05)
+    w["output_proj.bias"] = normalish(nxt(), (cfg.out_dim,), 0.02)
+    return w
+
+
+def swin_frames(seed: int, n: int, cfg) -> np.ndarray:
+    return uniform(seed, (n, cfg.channels, cfg.image_size, cfg.image_size))
