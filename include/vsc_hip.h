@@ -100,6 +100,37 @@ int vsc_encoder_get_profile(vsc_encoder *enc, double ms_out[VSC_PROF_CLASSES],
                             int64_t launches_out[VSC_PROF_CLASSES]);
 
 /* ------------------------------------------------------------------------ *
+ * Swin-Transformer-V2 frame encoder: replaces `model(flat_frames)` for the swinv2_v106/v107/v115
+ * TorchScript backbones (infer/infer_ref.sh; model = train/train_v115/torch2scripts.py:480-657:
+ * patch embed + norm, stages of res-post-norm blocks with windowed cosine attention and continuous
+ * relative position bias, patch merging, final norm, GeM(p) over tokens, output_proj).
+ * Weight names are the reference's state-dict names ("layers.2.blocks.5.attn.qkv.weight" ...).
+ * Supported: head_dim 32, window 16 or 8 (after clipping to the feature map), mlp_ratio 4.
+ * ------------------------------------------------------------------------ */
+typedef struct vsc_swin vsc_swin;
+
+typedef struct vsc_swin_config {
+    int32_t image_size, patch_size, channels, embed_dim, stages;
+    int32_t depths[4], heads[4];
+    int32_t window_size;
+    int32_t pretrained_window_sizes[4];
+    int32_t mlp_ratio, out_dim;
+    float ln_eps, gem_p;
+    int32_t max_batch, l2_normalize;
+} vsc_swin_config;
+
+int vsc_swin_create(const vsc_swin_config *cfg, vsc_swin **out);
+void vsc_swin_destroy(vsc_swin *enc);
+int vsc_swin_set_weight(vsc_swin *enc, const char *name, const float *host, size_t count);
+int vsc_swin_finalize(vsc_swin *enc);
+/* frames_dev f32 [n, channels, image, image] -> desc_dev f32 [n, out_dim]; asynchronous on `stream`. */
+int vsc_swin_forward(vsc_swin *enc, const float *frames_dev, int64_t n, float *desc_dev, void *stream);
+/* also returns the last-stage tokens after the final LayerNorm, f32 [n, tokens_last, width_last] */
+int vsc_swin_forward_debug(vsc_swin *enc, const float *frames_dev, int64_t n, float *desc_dev,
+                           float *tokens_dev, void *stream);
+int64_t vsc_swin_workspace_bytes(const vsc_swin *enc);
+
+/* ------------------------------------------------------------------------ *
  * Flat inner-product search: replaces faiss.IndexFlat(d, METRIC_INNER_PRODUCT)
  *   .search(x, k)        infer/vsc/index.py:167-175, infer/vsc/baseline/score_normalization.py:95,141,
  *                        infer/vsc/exhaustive_search.py:66 (the k = 1024 probe of range_search_gpu)
@@ -141,7 +172,8 @@ typedef enum vsc_epilogue {
     VSC_EPI_GELU_BF16 = 1,   /* out bf16 = gelu(acc + bias) */
     VSC_EPI_QGELU_BF16 = 2,  /* out bf16 = quick_gelu(acc + bias) */
     VSC_EPI_RESADD_F32 = 3,  /* out f32  = residual + acc + bias (out may alias residual) */
-    VSC_EPI_PATCH_F32 = 4    /* out f32 row n*T+1+p = acc + bias + pos[1+p] (row = n*(T-1)+p) */
+    VSC_EPI_PATCH_F32 = 4,   /* out f32 row n*T+1+p = acc + bias + pos[1+p] (row = n*(T-1)+p) */
+    VSC_EPI_F32 = 5          /* out f32  = acc + bias */
 } vsc_epilogue;
 
 /* out[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]);  A, W bf16 row-major, K % 64 == 0,
@@ -167,6 +199,20 @@ int vsc_layernorm_f32(const float *x_dev, const float *gamma_dev, const float *b
  * zero-filled up to kpad (kpad % 64 == 0). */
 int vsc_patchify_bf16(const float *frames_dev, uint16_t *patches_dev, int64_t n, int32_t channels,
                       int32_t image, int32_t patch, int32_t kpad, void *stream);
+
+/* Swin-V2 windowed cosine attention, head_dim 32.  qkv_dev bf16 [frames*res*res, 3*heads*32] in
+ * image token order; the cyclic shift and window partition are index math.  bias_dev f32
+ * [heads, N, N] (N = window^2), scale_dev f32 [heads] = exp(min(logit_scale, ln 100)). */
+int vsc_window_attention_bf16(const uint16_t *qkv_dev, uint16_t *out_dev, const float *bias_dev,
+                              const float *scale_dev, int32_t frames, int32_t res, int32_t window,
+                              int32_t shift, int32_t heads, void *stream);
+/* x_out = (x_in ? x_in : 0) + LayerNorm(t) ; xb = bf16(x_out).  x_in may be NULL or alias x_out. */
+int vsc_ln_residual_f32(const float *t_dev, const float *gamma_dev, const float *beta_dev,
+                        const float *x_in_dev, float *x_out_dev, uint16_t *xb_dev, int64_t rows,
+                        int32_t width, float eps, void *stream);
+/* PatchMerging gather on bf16 tokens [frames, res, res, c] -> [frames*(res/2)^2, 4c] */
+int vsc_merge_gather_bf16(const uint16_t *xb_dev, uint16_t *out_dev, int64_t frames, int32_t res,
+                          int32_t c, void *stream);
 
 #ifdef __cplusplus
 }

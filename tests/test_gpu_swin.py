@@ -1,0 +1,115 @@
+"""Swin-V2 on the HIP path: kernels alone against plain torch fp32 statements of the same op, and the
+whole encoder against the golden vectors (transformers.Swinv2Model) and the fp32 oracle.
+Tolerance on L2-normalised descriptors: 1e-3 absolute (north_star)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import swin_oracle
+from src import synth
+from vsc_hip.swin_config import get_swin_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from vsc_hip import _lib
+    _lib.require_device()
+    return torch.device("cuda:0")
+
+
+def _rand(seed, shape, std=1.0):
+    return torch.from_numpy(synth.normalish(seed, shape, std))
+
+
+@pytest.mark.parametrize("frames,res,window,shift,heads", [(2, 32, 16, 0, 2), (2, 32, 16, 8, 2), (1, 16, 16, 0, 4),
+                                                           (3, 16, 8, 4, 2), (2, 8, 8, 0, 4), (1, 64, 16, 8, 4)])
+def test_window_attention(dev, frames, res, window, shift, heads):
+    from vsc_hip import ops
+    c, n = heads * 32, window * window
+    qkv = _rand(res + shift, (frames * res * res, 3 * c)).to(torch.bfloat16)
+    bias = 16 * torch.sigmoid(_rand(7, (heads, n, n)))
+    scale = torch.exp(torch.clamp(math.log(10.0) + _rand(8, (heads,), 0.4), max=math.log(100.0)))
+    out = ops.window_attention_bf16(qkv.to(dev), bias.to(dev), scale.to(dev), frames, res, window, shift, heads)
+    # torch statement of torch2scripts.py:147-187 + :272-296 on the same bf16 qkv
+    x = qkv.float().reshape(frames, res, res, 3 * c)
+    if shift:
+        x = torch.roll(x, (-shift, -shift), (1, 2))
+    xw = swin_oracle._windows(x, res, window)
+    q, k, v = xw.reshape(-1, n, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    attn = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1) * scale.reshape(1, heads, 1, 1) + bias[None]
+    if shift:
+        m = swin_oracle.shift_mask(res, window, shift)
+        attn = (attn.reshape(frames, -1, heads, n, n) + m[None, :, None]).reshape(-1, heads, n, n)
+    o = (torch.softmax(attn, -1) @ v).transpose(1, 2).reshape(-1, n, c)
+    o = swin_oracle._unwindows(o, res, window, frames)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    ref = o.reshape(frames * res * res, c)
+    got = out.float().cpu()
+    # q-hat / k-hat / P rounded to bf16, bf16 output
+    torch.testing.assert_close(got, ref, rtol=2 ** -6, atol=2e-2)
+    assert (got - ref).abs().mean() < 4e-3
+
+
+@pytest.mark.parametrize("rows,width", [(7, 64), (1000, 128), (33, 1024)])
+def test_ln_residual(dev, rows, width):
+    from vsc_hip import ops
+    t, x0 = _rand(1, (rows, width), 2.0) + 0.3, _rand(2, (rows, width))
+    g, b = 0.3 + _rand(3, (width,), 0.05), _rand(4, (width,), 0.05)
+    ref = x0 + F.layer_norm(t, (width,), g, b, 1e-5)
+    x, xb = ops.ln_residual(t.to(dev), g.to(dev), b.to(dev), 1e-5, x_in=x0.to(dev))
+    torch.testing.assert_close(x.cpu(), ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(xb.cpu(), x.cpu().to(torch.bfloat16))
+    x2, _ = ops.ln_residual(t.to(dev), g.to(dev), b.to(dev), 1e-5)
+    torch.testing.assert_close(x2.cpu(), F.layer_norm(t, (width,), g, b, 1e-5), rtol=1e-5, atol=1e-5)
+
+
+def test_merge_gather_bit_exact(dev):
+    from vsc_hip import ops
+    frames, res, c = 3, 8, 64
+    xb = _rand(5, (frames * res * res, c)).to(torch.bfloat16)
+    g = xb.reshape(frames, res, res, c)
+    ref = torch.cat([g[:, 0::2, 0::2], g[:, 1::2, 0::2], g[:, 0::2, 1::2], g[:, 1::2, 1::2]], -1).reshape(-1, 4 * c)
+    out = ops.merge_gather_bf16(xb.to(dev), frames, res).cpu()
+    assert torch.equal(out.view(torch.int16), ref.contiguous().view(torch.int16))
+
+
+@pytest.mark.parametrize("preset", ["tiny_swin", "tiny_swin_w8", "swinv2_base_256"])
+def test_swin_encoder_matches_golden(dev, preset, golden_dir):
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    g = np.load(os.path.join(golden_dir, f"swin_{preset}.npz"))
+    cfg = get_swin_config(preset)
+    w = synth.swin_weights(int(g["weights_seed"]), cfg)
+    x = torch.from_numpy(synth.swin_frames(int(g["frames_seed"]), int(g["n_frames"]), cfg)).to(dev)
+    enc = SwinHipEncoder(cfg, w, max_batch=2)
+    desc, tok = enc(x, return_tokens=True)
+    desc, tok = desc.cpu().numpy(), tok.cpu().numpy()
+    assert np.abs(tok[:, :4] - g["tokens_head"]).max() < 0.1
+    assert np.abs(tok[:, :4] - g["tokens_head"]).mean() < 0.012
+    assert np.abs(desc - g["desc"]).max() < 0.02 * np.abs(g["desc"]).max()
+    d2 = SwinHipEncoder(cfg, w, max_batch=3, l2_normalize=True)(x).cpu().numpy()
+    np.testing.assert_allclose(d2, g["desc_l2"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(np.linalg.norm(d2, axis=1), 1.0, atol=1e-5)
+
+
+def test_swin_encoder_vs_oracle_and_batching(dev):
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    cfg = get_swin_config("tiny_swin")
+    w = synth.swin_weights(9, cfg)
+    x = torch.from_numpy(synth.swin_frames(10, 7, cfg))
+    with torch.no_grad():
+        ref = swin_oracle.descriptors({k: torch.from_numpy(v) for k, v in w.items()}, cfg, x).numpy()
+    a = SwinHipEncoder(cfg, w, max_batch=3, l2_normalize=True)(x.to(dev))
+    b = SwinHipEncoder(cfg, w, max_batch=7, l2_normalize=True)(x.to(dev))
+    np.testing.assert_allclose(a.cpu().numpy(), ref, rtol=0, atol=1e-3)
+    assert torch.equal(a, b)
+    w2 = dict(w)
+    del w2["layers.1.blocks.0.attn.logit_scale"]
+    with pytest.raises(KeyError):
+        SwinHipEncoder(cfg, w2)

@@ -56,3 +56,19 @@ extern "C" int vsc_patchify_bf16(const float *frames, uint16_t *patches, int64_t
 extern "C" int vsc_l2_normalize_f32(float *x, int64_t n, int32_t d, void *stream) {
     return launch_l2_normalize(x, n, d, (hipStream_t)stream);
 }
+
+extern "C" int vsc_window_attention_bf16(const uint16_t *qkv, uint16_t *out, const float *bias, const float *scale,
+                                         int32_t frames, int32_t res, int32_t window, int32_t shift,
+                                         int32_t heads, void *stream) {
+    return launch_window_attention(qkv, out, bias, scale, frames, res, window, shift, heads, (hipStream_t)stream);
+}
+
+extern "C" int vsc_ln_residual_f32(const float *t, const float *g, const float *b, const float *x_in, float *x_out,
+                                   uint16_t *xb, int64_t rows, int32_t width, float eps, void *stream) {
+    return launch_ln_residual(t, g, b, x_in, x_out, xb, rows, width, eps, (hipStream_t)stream);
+}
+
+extern "C" int vsc_merge_gather_bf16(const uint16_t *xb, uint16_t *out, int64_t frames, int32_t res, int32_t c,
+                                     void *stream) {
+    return launch_merge_gather(xb, out, frames, res, c, (hipStream_t)stream);
+}

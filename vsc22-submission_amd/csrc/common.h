@@ -104,6 +104,11 @@ int launch_gem_pool_bf16(const uint16_t *x, float *pooled, int64_t frames, int t
                          hipStream_t stream);
 int launch_head(const float *pooled, const float *w, const float *bias, float *desc, int64_t frames,
                 int width, int out_dim, int l2, hipStream_t stream);
+int launch_window_attention(const uint16_t *qkv, uint16_t *out, const float *bias, const float *scale,
+                            int frames, int res, int ws, int shift, int heads, hipStream_t stream);
+int launch_ln_residual(const float *t, const float *gamma, const float *beta, const float *x_in, float *x_out,
+                       uint16_t *xb, int64_t rows, int width, float eps, hipStream_t stream);
+int launch_merge_gather(const uint16_t *xb, uint16_t *out, int64_t frames, int res, int c, hipStream_t stream);
 int launch_l2_normalize(float *x, int64_t n, int d, hipStream_t stream);
 int launch_f32_to_bf16(const float *src, uint16_t *dst, int64_t rows, int cols, int cols_pad,
                        hipStream_t stream);

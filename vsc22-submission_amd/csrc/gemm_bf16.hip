@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                 pk.y = pack_bf16x2(v[2], v[3]);
                 *(uint2 *)((uint16_t *)p.out + orow * p.n + n) = pk;
             } else {
-                v += *(const f32x4_t *)(auxrow + n);
+                if (EPI != VSC_EPI_F32) v += *(const f32x4_t *)(auxrow + n);
                 *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
             }
         }
@@ -261,7 +261,7 @@ __device__ __forceinline__ void epilogue_frag(const GemmArgs &p, f32x4_t v, int6
         pk.y = pack_bf16x2(v[2], v[3]);
         *(uint2 *)((uint16_t *)p.out + orow * p.n + n) = pk;
     } else {
-        v += *(const f32x4_t *)(auxrow + n);
+        if (EPI != VSC_EPI_F32) v += *(const f32x4_t *)(auxrow + n);
         *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
     }
 }
@@ -347,8 +347,9 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
                 const int64_t m = m0 + wm * TM * 16 + pass * 64 + row;
                 if (m < p.m && n < p.n) {
                     int64_t orow = m;
-                    const float *auxrow;
-                    if (EPI == VSC_EPI_PATCH_F32) {
+                    const float *auxrow = nullptr;
+                    if (EPI == VSC_EPI_F32) {
+                    } else if (EPI == VSC_EPI_PATCH_F32) {
                         const int pt = p.tokens - 1;
                         const int64_t f = m / pt;
                         const int tok = (int)(m - f * pt) + 1;
@@ -357,7 +358,7 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
                     } else {
                         auxrow = p.aux + m * p.n;
                     }
-                    v += *(const f32x4_t *)(auxrow + n);
+                    if (EPI != VSC_EPI_F32) v += *(const f32x4_t *)(auxrow + n);
                     if (!((p.abl & 4) && v[0] != 12345.678f)) *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
                 }
             }
@@ -575,6 +576,7 @@ int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, co
             case VSC_EPI_QGELU_BF16: return launch_v2_pick<VSC_EPI_QGELU_BF16>(p, stream);
             case VSC_EPI_RESADD_F32: return launch_v2_pick<VSC_EPI_RESADD_F32>(p, stream);
             case VSC_EPI_PATCH_F32: return launch_v2_pick<VSC_EPI_PATCH_F32>(p, stream);
+            case VSC_EPI_F32: return launch_v2_pick<VSC_EPI_F32>(p, stream);
             default: VSC_REQUIRE(false, "gemm: unknown epilogue %d", epilogue);
         }
     }
@@ -590,6 +592,7 @@ int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, co
             VSC_REQUIRE(m % (tokens - 1) == 0, "gemm: PATCH rows %lld not a multiple of %d patches",
                         (long long)m, tokens - 1);
             return launch_t<VSC_EPI_PATCH_F32>(p, (int)tiles_m, stream);
+        case VSC_EPI_F32: return launch_t<VSC_EPI_F32>(p, (int)tiles_m, stream);
         default: VSC_REQUIRE(false, "gemm: unknown epilogue %d", epilogue);
     }
     return VSC_OK;

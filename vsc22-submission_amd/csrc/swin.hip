@@ -1,0 +1,306 @@
+// Swin-Transformer-V2 kernels (reference model: train/train_v115/torch2scripts.py:70-366).
+//   window_attention_kernel  windowed cosine multi-head attention, head_dim 32
+//   ln_residual_kernel       x (+)= LayerNorm(t) (res-post-norm) + bf16 shadow of x for the next GEMM
+//   merge_gather_kernel      PatchMerging's 2x2 gather (x0|x1|x2|x3) on the bf16 shadow
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 32;  // head dim of every Swin-V2 stage (C / heads)
+
+// ------------------------------------------------------------------------------------------
+// One workgroup per (frame, window, head).  The cyclic shift, the window partition and their
+// inverses (torch.roll + window_partition / window_reverse, torch2scripts.py:37-67,275-296) are
+// pure index math here: window token i sits at shifted coords (sy, sx) and is read from / written
+// to image position ((sy + shift) % res, (sx + shift) % res); nothing is materialised.
+//   * K rows are L2-normalised in fp32 while staged (F.normalize(k), :159) and stored bf16 with
+//     the 64-byte-row swizzle; V is staged transposed; Q is normalised in registers (the four
+//     lanes holding a query's 32 dims reduce with two xor-shuffles).
+//   * scores use the swapped MFMA (A = K-hat, B = Q-hat) so a lane owns one query: logits =
+//     cos * exp(min(logit_scale, ln 100)) + 16*sigmoid(cpb) bias (+ -100 where the shift mask
+//     separates the two tokens' regions, :236-254), whole row in registers, exp2 softmax.
+//   * P (bf16) is directly the B operand of the PV MFMA (k-slot permutation as attention.hip).
+template <int NT>  // 16-key tiles per window: 4 (8x8 window) or 16 (16x16 window)
+__global__ __launch_bounds__(NT * 32, 2) void window_attention_kernel(
+    const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, const float *__restrict__ bias,
+    const float *__restrict__ scale, int res, int ws, int shift, int heads) {
+    constexpr int N = NT * 16, NWAVES = NT / 2, NTHREADS = NWAVES * 64;
+    constexpr int VSTRIDE = N * 2 + 8;
+    __shared__ __attribute__((aligned(16))) char smem[N * 64 + HD * VSTRIDE + N * 4 + N];
+    char *klds = smem;                                   // [N][32] bf16, 64-B rows, chunk ^= (-(row>>2)) & 3
+    char *vt = smem + N * 64;                            // [32][VSTRIDE]
+    int *rowmap = (int *)(smem + N * 64 + HD * VSTRIDE);  // image token index of window token i
+    unsigned char *region = (unsigned char *)(rowmap + N);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwx = res / ws, nw = nwx * nwx;
+    int b = blockIdx.x;
+    const int head = b % heads; b /= heads;
+    const int win = b % nw;
+    const int frame = b / nw;
+    const int wh = win / nwx, wwx = win - wh * nwx;
+    const int C = heads * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const uint16_t *base = qkv + (int64_t)frame * res * res * ld + head * HD;
+
+    for (int i = tid; i < N; i += NTHREADS) {
+        const int wy = i / ws, wx = i - wy * ws;
+        const int sy = wh * ws + wy, sx = wwx * ws + wx;
+        int y = sy + shift, x = sx + shift;
+        y = y >= res ? y - res : y;
+        x = x >= res ? x - res : x;
+        rowmap[i] = y * res + x;
+        const int hr = sy < res - ws ? 0 : (sy < res - shift ? 1 : 2);
+        const int wr = sx < res - ws ? 0 : (sx < res - shift ? 1 : 2);
+        region[i] = (unsigned char)(3 * hr + wr);
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, g = lane >> 4;
+    // ---- Q fragments (normalised) of this wave's two query tiles, issued before the staging
+    bf16x8_t qf[2];
+    int qrow[2];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        const int q = (wave * 2 + qi) * 16 + fr;
+        qrow[qi] = rowmap[q];
+        const bf16x8_t raw = *(const bf16x8_t *)(base + qrow[qi] * ld + g * 8);
+        float v[8], ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = bf16_to_f32((uint16_t)raw[j]);
+            ss += v[j] * v[j];
+        }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk.w[j] = pack_bf16x2(v[2 * j] * inv, v[2 * j + 1] * inv);
+        qf[qi] = pk.v;
+    }
+    // ---- stage K-hat: 4 threads per key row (16 B each), norm over the row by two shuffles
+    for (int e = tid; e < N * 4; e += NTHREADS) {
+        const int i = e >> 2, c = e & 3;
+        const bf16x8_t raw = *(const bf16x8_t *)(base + C + rowmap[i] * ld + c * 8);
+        float v[8], ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = bf16_to_f32((uint16_t)raw[j]);
+            ss += v[j] * v[j];
+        }
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        uint4 pk;
+        pk.x = pack_bf16x2(v[0] * inv, v[1] * inv);
+        pk.y = pack_bf16x2(v[2] * inv, v[3] * inv);
+        pk.z = pack_bf16x2(v[4] * inv, v[5] * inv);
+        pk.w = pack_bf16x2(v[6] * inv, v[7] * inv);
+        *(uint4 *)(klds + i * 64 + ((c ^ ((-(i >> 2)) & 3)) << 4)) = pk;
+    }
+    // ---- stage V transposed: task = (4 keys) x (8 dims); 16 consecutive lanes = 16 key groups
+    for (int e = tid; e < (N / 4) * 4; e += NTHREADS) {
+        const int blk = e >> 6, c8 = (e >> 4) & 3, kg = blk * 16 + (e & 15);
+        bf16x8_t r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *(const bf16x8_t *)(base + 2 * C + rowmap[kg * 4 + i] * ld + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint2 pk;
+            pk.x = (uint32_t)(uint16_t)r[0][j] | ((uint32_t)(uint16_t)r[1][j] << 16);
+            pk.y = (uint32_t)(uint16_t)r[2][j] | ((uint32_t)(uint16_t)r[3][j] << 16);
+            *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + kg * 8) = pk;
+        }
+    }
+    __syncthreads();
+
+    const float LOG2E = 1.44269504088896340736f;
+    const float sc = scale[head] * LOG2E;
+    const float *hb = bias + (int64_t)head * N * N;
+
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        const int q = (wave * 2 + qi) * 16 + fr;
+        const int rq = region[q];
+        f32x4_t s[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int krow = t * 16 + fr;
+            const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
+            f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi], z, 0, 0, 0);
+            const f32x4_t bz = *(const f32x4_t *)(hb + (int64_t)q * N + t * 16 + g * 4);
+            const uint32_t rk = *(const uint32_t *)(region + t * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float l = fmaf(z[r], sc, bz[r] * LOG2E);
+                if (shift > 0 && (int)((rk >> (8 * r)) & 0xff) != rq) l -= 100.0f * LOG2E;
+                s[t][r] = l;
+                mx = fmaxf(mx, l);
+            }
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+        bf16x8_t pb[NT / 2];
+#pragma unroll
+        for (int u = 0; u < NT / 2; ++u) {
+            float e[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = __builtin_amdgcn_exp2f(s[2 * u][r] - mx);
+                e[4 + r] = __builtin_amdgcn_exp2f(s[2 * u + 1][r] - mx);
+            }
+            sum += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+            union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pk.w[r] = pack_bf16x2(e[2 * r], e[2 * r + 1]);
+            pb[u] = pk.v;
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+
+        f32x4_t o[2];
+        o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NT / 2; ++u) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const char *vrow = vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 4 * g) * 2;
+                union { uint2 h[2]; bf16x8_t v; } vf;
+                vf.h[0] = *(const uint2 *)(vrow);
+                vf.h[1] = *(const uint2 *)(vrow + 32);
+                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
+            }
+            if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        uint16_t *orow = out + ((int64_t)frame * res * res + qrow[qi]) * C + head * HD + g * 4;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            uint2 pk;
+            pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
+            pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
+            *(uint2 *)(orow + ct * 16) = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// y = LayerNorm(t) * gamma + beta;  x = (x_in ? x_in : 0) + y;  writes x (fp32) and its bf16
+// shadow.  One wave per row, row in registers (two-pass statistics).
+constexpr int MAXV = 8;
+__global__ __launch_bounds__(256) void ln_residual_kernel(const float *__restrict__ t,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta,
+                                                          const float *x_in, float *x_out,
+                                                          uint16_t *__restrict__ xb, int64_t rows,
+                                                          int width, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = width >> 8, tail = width & 255;
+    const float *tr = t + row * width;
+    float4 v[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const bool on = i < nv || (i == nv && lane * 4 < tail);
+        v[i] = on ? *(const float4 *)(tr + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) / (float)width;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const bool on = i < nv || (i == nv && lane * 4 < tail);
+        if (on) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            sq += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)width + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int col = i * 256 + lane * 4;
+        const bool on = i < nv || (i == nv && lane * 4 < tail);
+        if (!on) continue;
+        const float4 gm = *(const float4 *)(gamma + col), bt = *(const float4 *)(beta + col);
+        float4 y = make_float4((v[i].x - mean) * rstd * gm.x + bt.x, (v[i].y - mean) * rstd * gm.y + bt.y,
+                               (v[i].z - mean) * rstd * gm.z + bt.z, (v[i].w - mean) * rstd * gm.w + bt.w);
+        if (x_in) {
+            const float4 r = *(const float4 *)(x_in + row * width + col);
+            y = make_float4(r.x + y.x, r.y + y.y, r.z + y.z, r.w + y.w);
+        }
+        *(float4 *)(x_out + row * width + col) = y;
+        uint2 pk;
+        pk.x = pack_bf16x2(y.x, y.y);
+        pk.y = pack_bf16x2(y.z, y.w);
+        *(uint2 *)(xb + row * width + col) = pk;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// PatchMerging gather (torch2scripts.py:353-358): out[b, (Y, X), :] = xb[b, 2Y+dy, 2X+dx, :] for
+// (dy, dx) = (0,0), (1,0), (0,1), (1,1) concatenated.  16-byte chunks.
+__global__ __launch_bounds__(256) void merge_gather_kernel(const uint16_t *__restrict__ xb,
+                                                           uint16_t *__restrict__ out, int64_t total,
+                                                           int res, int c) {
+    const int c8 = c >> 3, half = res >> 1;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int chunk = (int)(e % (4 * c8));
+        const int64_t tok = e / (4 * c8);
+        const int part = chunk / c8, cc = chunk - part * c8;
+        const int X = (int)(tok % half), Y = (int)((tok / half) % half);
+        const int64_t b = tok / ((int64_t)half * half);
+        const int dy = part & 1, dx = part >> 1;
+        const int64_t src = ((b * res + 2 * Y + dy) * res + 2 * X + dx) * c + cc * 8;
+        *(uint4 *)(out + e * 8) = *(const uint4 *)(xb + src);
+    }
+}
+
+}  // namespace
+
+int launch_window_attention(const uint16_t *qkv, uint16_t *out, const float *bias, const float *scale,
+                            int frames, int res, int ws, int shift, int heads, hipStream_t stream) {
+    VSC_REQUIRE(qkv && out && bias && scale, "window_attention: null operand");
+    VSC_REQUIRE(res % ws == 0 && shift >= 0 && shift < ws, "window_attention: res %d window %d shift %d", res, ws,
+                shift);
+    const int nw = (res / ws) * (res / ws);
+    const int64_t grid = (int64_t)frames * nw * heads;
+    VSC_REQUIRE(grid > 0 && grid < (1ll << 31), "window_attention: grid");
+    if (ws == 16)
+        hipLaunchKernelGGL(window_attention_kernel<16>, dim3((unsigned)grid), dim3(512), 0, stream, qkv, out, bias,
+                           scale, res, ws, shift, heads);
+    else if (ws == 8)
+        hipLaunchKernelGGL(window_attention_kernel<4>, dim3((unsigned)grid), dim3(128), 0, stream, qkv, out, bias,
+                           scale, res, ws, shift, heads);
+    else
+        VSC_REQUIRE(false, "window_attention: window %d unsupported (8 or 16)", ws);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+int launch_ln_residual(const float *t, const float *gamma, const float *beta, const float *x_in, float *x_out,
+                       uint16_t *xb, int64_t rows, int width, float eps, hipStream_t stream) {
+    VSC_REQUIRE(t && gamma && beta && x_out && xb && rows > 0, "ln_residual: null/empty");
+    VSC_REQUIRE(width % 4 == 0 && width <= MAXV * 256, "ln_residual: width %d unsupported", width);
+    hipLaunchKernelGGL(ln_residual_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, t, gamma, beta,
+                       x_in, x_out, xb, rows, width, eps);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+int launch_merge_gather(const uint16_t *xb, uint16_t *out, int64_t frames, int res, int c, hipStream_t stream) {
+    VSC_REQUIRE(xb && out && res % 2 == 0 && c % 8 == 0, "merge_gather: res %d c %d", res, c);
+    const int64_t total = frames * (res / 2) * (res / 2) * 4 * (c / 8);
+    int64_t blocks = (total + 255) / 256;
+    blocks = blocks > 16384 ? 16384 : blocks;
+    hipLaunchKernelGGL(merge_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, xb, out, total, res, c);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}

@@ -1,0 +1,343 @@
+// vsc_swin: weights, workspace and launch sequence of the Swin-Transformer-V2 frame encoder
+// (reference model: train/train_v115/torch2scripts.py, SwinTransformerV2 :480-657).
+//
+// HBM layout for one step of B frames; stage s has res_s x res_s tokens of width C_s (M = B res^2,
+// M*C halves from stage to stage, so stage-0 sizes bound every buffer):
+//   patches bf16 [B L0, 64]     x  f32 [M, C]  residual stream       xb bf16 [M, C]  its shadow
+//   t       f32  [M, C]   fp32 GEMM outputs awaiting their post-LayerNorm (proj, fc2, reduction)
+//   qkv     bf16 [M, 3C]        att bf16 [M, C]      h bf16 [M, 4C]   merged bf16 [M/4, 4C]
+// Per block (res-post-norm):  qkv = xb Wqkv^T + (q_bias|0|v_bias);  att = window attention;
+//   t = att Wproj^T + b;  x += LN1(t);  h = gelu(xb W1^T + b1);  t = h W2^T + b2;  x += LN2(t).
+// The continuous-position-bias tables 16*sigmoid(cpb_mlp(coords))[index] depend only on the
+// weights: they are evaluated once on the host in finalize (model loading) and kept as
+// fp32 [heads, N, N] per block.
+#include <math.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+struct SwinBlockW {
+    uint16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    float *qkv_b, *proj_b, *fc1_b, *fc2_b, *n1_g, *n1_b, *n2_g, *n2_b, *bias, *scale;
+};
+struct SwinStageW {
+    std::vector<SwinBlockW> blocks;
+    uint16_t *red_w = nullptr;
+    float *dn_g = nullptr, *dn_b = nullptr;
+};
+
+struct vsc_swin {
+    vsc_swin_config cfg;
+    bool finalized = false;
+    std::map<std::string, std::vector<float>> host_w;
+    std::map<std::string, size_t> expect;
+    std::vector<void *> allocs;
+    std::vector<SwinStageW> stages;
+    uint16_t *pe_w = nullptr;
+    float *pe_b = nullptr, *pe_g = nullptr, *pe_beta = nullptr, *norm_g = nullptr, *norm_b = nullptr,
+          *out_w = nullptr, *out_b = nullptr;
+    int kpad = 0;
+    uint16_t *patches = nullptr, *xb = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr, *merged = nullptr;
+    float *x = nullptr, *t = nullptr, *pooled = nullptr;
+    int64_t ws_bytes = 0;
+
+    int res(int s) const { return cfg.image_size / cfg.patch_size >> s; }
+    int dim(int s) const { return cfg.embed_dim << s; }
+    int window(int s) const { return cfg.window_size < res(s) ? cfg.window_size : res(s); }
+    int shift(int s, int b) const { return res(s) <= cfg.window_size ? 0 : ((b & 1) ? cfg.window_size / 2 : 0); }
+};
+
+namespace {
+
+int sw_alloc(vsc_swin *e, size_t bytes, void **out) {
+    hipError_t err = hipMalloc(out, bytes);
+    if (err != hipSuccess) {
+        vsc_set_error("swin: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+        return VSC_ERR_NOMEM;
+    }
+    e->allocs.push_back(*out);
+    return VSC_OK;
+}
+
+int sw_upload_f32v(vsc_swin *e, const std::vector<float> &v, float **out) {
+    int rc = sw_alloc(e, v.size() * 4, (void **)out);
+    if (rc) return rc;
+    VSC_CHECK_HIP(hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    return VSC_OK;
+}
+int sw_upload_f32(vsc_swin *e, const std::string &name, float **out) { return sw_upload_f32v(e, e->host_w.at(name), out); }
+
+int sw_upload_bf16(vsc_swin *e, const std::string &name, int64_t rows, int cols, int cols_pad, uint16_t **out) {
+    const std::vector<float> &v = e->host_w.at(name);
+    float *tmp = nullptr;
+    VSC_CHECK_HIP(hipMalloc((void **)&tmp, v.size() * 4));
+    hipError_t err = hipMemcpy(tmp, v.data(), v.size() * 4, hipMemcpyHostToDevice);
+    int rc = err == hipSuccess ? sw_alloc(e, (size_t)rows * cols_pad * 2, (void **)out) : VSC_ERR_HIP;
+    if (!rc) rc = launch_f32_to_bf16(tmp, *out, rows, cols, cols_pad, nullptr);
+    hipError_t e2 = hipDeviceSynchronize();
+    (void)hipFree(tmp);
+    if (err != hipSuccess || e2 != hipSuccess) {
+        vsc_set_error("swin: uploading %s failed", name.c_str());
+        return VSC_ERR_HIP;
+    }
+    return rc;
+}
+
+// 16 * sigmoid(cpb_mlp(log-spaced relative coords))[relative_position_index] -> [heads, N, N]
+// (torch2scripts.py:100-128, 166-171).
+std::vector<float> position_bias(const std::vector<float> &w0, const std::vector<float> &b0,
+                                 const std::vector<float> &w2, int window, int pretrained, int heads) {
+    const int side = 2 * window - 1, n = window * window;
+    const float denom = (float)((pretrained > 0 ? pretrained : window) - 1);
+    std::vector<float> table((size_t)side * side * heads);
+    std::vector<float> hid(512);
+    for (int a = 0; a < side; ++a)
+        for (int b = 0; b < side; ++b) {
+            float c[2] = {(float)(a - (window - 1)) / denom * 8.f, (float)(b - (window - 1)) / denom * 8.f};
+            for (int k = 0; k < 2; ++k) {
+                const float s = c[k] > 0.f ? 1.f : (c[k] < 0.f ? -1.f : 0.f);
+                c[k] = s * log2f(fabsf(c[k]) + 1.0f) / 3.0f;  // log2(8) = 3
+            }
+            for (int j = 0; j < 512; ++j) {
+                const float v = c[0] * w0[j * 2] + c[1] * w0[j * 2 + 1] + b0[j];
+                hid[j] = v > 0.f ? v : 0.f;
+            }
+            for (int hh = 0; hh < heads; ++hh) {
+                float acc = 0.f;
+                for (int j = 0; j < 512; ++j) acc += hid[j] * w2[(size_t)hh * 512 + j];
+                table[((size_t)a * side + b) * heads + hh] = acc;
+            }
+        }
+    std::vector<float> bias((size_t)heads * n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const int dy = i / window - j / window + window - 1, dx = i % window - j % window + window - 1;
+            const size_t idx = (size_t)dy * side + dx;
+            for (int hh = 0; hh < heads; ++hh)
+                bias[((size_t)hh * n + i) * n + j] = 16.0f / (1.0f + expf(-table[idx * heads + hh]));
+        }
+    return bias;
+}
+
+}  // namespace
+
+extern "C" int vsc_swin_create(const vsc_swin_config *cfg, vsc_swin **out) {
+    VSC_REQUIRE(cfg && out, "swin_create: null argument");
+    const vsc_swin_config &c = *cfg;
+    VSC_REQUIRE(c.stages >= 1 && c.stages <= 4, "swin: stages %d", c.stages);
+    VSC_REQUIRE(c.image_size % (c.patch_size << (c.stages - 1)) == 0, "swin: image %d / patch %d over %d stages",
+                c.image_size, c.patch_size, c.stages);
+    VSC_REQUIRE(c.image_size % 4 == 0, "swin: image size must be a multiple of 4");
+    VSC_REQUIRE(c.embed_dim % 64 == 0, "swin: embed_dim %d must be a multiple of 64", c.embed_dim);
+    VSC_REQUIRE(c.mlp_ratio == 4, "swin: mlp_ratio %d (only 4)", c.mlp_ratio);
+    VSC_REQUIRE(c.max_batch >= 1 && c.out_dim >= 1 && c.out_dim <= 2048, "swin: max_batch / out_dim");
+    vsc_swin *e = new vsc_swin();
+    e->cfg = c;
+    for (int s = 0; s < c.stages; ++s) {
+        if (e->dim(s) != c.heads[s] * 32) {
+            vsc_set_error("swin: stage %d width %d with %d heads -- only head_dim 32 is supported", s, e->dim(s),
+                          c.heads[s]);
+            delete e;
+            return VSC_ERR_INVALID;
+        }
+        const int w = e->window(s);
+        if (!((w == 8 || w == 16) && e->res(s) % w == 0) || c.depths[s] < 1) {
+            vsc_set_error("swin: stage %d window %d on a %d x %d map unsupported (8 or 16)", s, w, e->res(s), e->res(s));
+            delete e;
+            return VSC_ERR_INVALID;
+        }
+    }
+    if (e->dim(c.stages - 1) > 2048) {
+        vsc_set_error("swin: last-stage width %d > 2048", e->dim(c.stages - 1));
+        delete e;
+        return VSC_ERR_INVALID;
+    }
+    const int kp = c.channels * c.patch_size * c.patch_size;
+    e->kpad = (kp + 63) / 64 * 64;
+    const size_t C0 = c.embed_dim;
+    e->expect["patch_embed.proj.weight"] = C0 * kp;
+    e->expect["patch_embed.proj.bias"] = e->expect["patch_embed.norm.weight"] = e->expect["patch_embed.norm.bias"] = C0;
+    for (int s = 0; s < c.stages; ++s) {
+        const size_t C = e->dim(s), H = c.heads[s];
+        for (int b = 0; b < c.depths[s]; ++b) {
+            const std::string p = "layers." + std::to_string(s) + ".blocks." + std::to_string(b) + ".";
+            e->expect[p + "attn.qkv.weight"] = 3 * C * C;
+            e->expect[p + "attn.q_bias"] = e->expect[p + "attn.v_bias"] = C;
+            e->expect[p + "attn.logit_scale"] = H;
+            e->expect[p + "attn.cpb_mlp.0.weight"] = 1024;
+            e->expect[p + "attn.cpb_mlp.0.bias"] = 512;
+            e->expect[p + "attn.cpb_mlp.2.weight"] = H * 512;
+            e->expect[p + "attn.proj.weight"] = C * C;
+            e->expect[p + "attn.proj.bias"] = C;
+            e->expect[p + "norm1.weight"] = e->expect[p + "norm1.bias"] = C;
+            e->expect[p + "norm2.weight"] = e->expect[p + "norm2.bias"] = C;
+            e->expect[p + "mlp.fc1.weight"] = 4 * C * C;
+            e->expect[p + "mlp.fc1.bias"] = 4 * C;
+            e->expect[p + "mlp.fc2.weight"] = 4 * C * C;
+            e->expect[p + "mlp.fc2.bias"] = C;
+        }
+        if (s + 1 < c.stages) {
+            const std::string p = "layers." + std::to_string(s) + ".downsample.";
+            e->expect[p + "reduction.weight"] = 8 * C * C;
+            e->expect[p + "norm.weight"] = e->expect[p + "norm.bias"] = 2 * C;
+        }
+    }
+    const size_t CL = e->dim(c.stages - 1);
+    e->expect["norm.weight"] = e->expect["norm.bias"] = CL;
+    e->expect["output_proj.weight"] = (size_t)c.out_dim * CL;
+    e->expect["output_proj.bias"] = c.out_dim;
+    *out = e;
+    return VSC_OK;
+}
+
+extern "C" void vsc_swin_destroy(vsc_swin *e) {
+    if (!e) return;
+    for (void *p : e->allocs) (void)hipFree(p);
+    delete e;
+}
+
+extern "C" int vsc_swin_set_weight(vsc_swin *e, const char *name, const float *host, size_t count) {
+    VSC_REQUIRE(e && name && host, "swin set_weight: null argument");
+    if (e->finalized) {
+        vsc_set_error("swin set_weight(%s) after finalize", name);
+        return VSC_ERR_STATE;
+    }
+    auto it = e->expect.find(name);
+    VSC_REQUIRE(it != e->expect.end(), "swin set_weight: unknown tensor '%s' for this config", name);
+    VSC_REQUIRE(it->second == count, "swin set_weight: '%s' has %zu elements, expected %zu", name, count, it->second);
+    e->host_w[name].assign(host, host + count);
+    return VSC_OK;
+}
+
+extern "C" int vsc_swin_finalize(vsc_swin *e) {
+    VSC_REQUIRE(e, "swin finalize: null");
+    if (e->finalized) return VSC_OK;
+    for (auto &kv : e->expect)
+        if (!e->host_w.count(kv.first)) {
+            vsc_set_error("swin finalize: weight '%s' was never set", kv.first.c_str());
+            return VSC_ERR_STATE;
+        }
+    const vsc_swin_config &c = e->cfg;
+    int rc;
+#define TRY(x) do { if ((rc = (x))) return rc; } while (0)
+    const int kp = c.channels * c.patch_size * c.patch_size;
+    TRY(sw_upload_bf16(e, "patch_embed.proj.weight", c.embed_dim, kp, e->kpad, &e->pe_w));
+    TRY(sw_upload_f32(e, "patch_embed.proj.bias", &e->pe_b));
+    TRY(sw_upload_f32(e, "patch_embed.norm.weight", &e->pe_g));
+    TRY(sw_upload_f32(e, "patch_embed.norm.bias", &e->pe_beta));
+    e->stages.resize(c.stages);
+    for (int s = 0; s < c.stages; ++s) {
+        const int C = e->dim(s), H = c.heads[s], W = e->window(s);
+        e->stages[s].blocks.resize(c.depths[s]);
+        for (int b = 0; b < c.depths[s]; ++b) {
+            const std::string p = "layers." + std::to_string(s) + ".blocks." + std::to_string(b) + ".";
+            SwinBlockW &B = e->stages[s].blocks[b];
+            TRY(sw_upload_bf16(e, p + "attn.qkv.weight", 3 * C, C, C, &B.qkv_w));
+            std::vector<float> qb(3 * (size_t)C, 0.f);  // (q_bias | 0 | v_bias), :151-153
+            const std::vector<float> &q = e->host_w.at(p + "attn.q_bias"), &v = e->host_w.at(p + "attn.v_bias");
+            for (int i = 0; i < C; ++i) {
+                qb[i] = q[i];
+                qb[2 * C + i] = v[i];
+            }
+            TRY(sw_upload_f32v(e, qb, &B.qkv_b));
+            std::vector<float> sc(H);
+            const std::vector<float> &ls = e->host_w.at(p + "attn.logit_scale");
+            for (int i = 0; i < H; ++i) sc[i] = expf(fminf(ls[i], logf(100.0f)));  // clamp(max = ln(1/0.01)).exp(), :161
+            TRY(sw_upload_f32v(e, sc, &B.scale));
+            TRY(sw_upload_f32v(e, position_bias(e->host_w.at(p + "attn.cpb_mlp.0.weight"), e->host_w.at(p + "attn.cpb_mlp.0.bias"),
+                                                e->host_w.at(p + "attn.cpb_mlp.2.weight"), W,
+                                                c.pretrained_window_sizes[s], H), &B.bias));
+            TRY(sw_upload_bf16(e, p + "attn.proj.weight", C, C, C, &B.proj_w));
+            TRY(sw_upload_f32(e, p + "attn.proj.bias", &B.proj_b));
+            TRY(sw_upload_f32(e, p + "norm1.weight", &B.n1_g));
+            TRY(sw_upload_f32(e, p + "norm1.bias", &B.n1_b));
+            TRY(sw_upload_bf16(e, p + "mlp.fc1.weight", 4 * C, C, C, &B.fc1_w));
+            TRY(sw_upload_f32(e, p + "mlp.fc1.bias", &B.fc1_b));
+            TRY(sw_upload_bf16(e, p + "mlp.fc2.weight", C, 4 * C, 4 * C, &B.fc2_w));
+            TRY(sw_upload_f32(e, p + "mlp.fc2.bias", &B.fc2_b));
+            TRY(sw_upload_f32(e, p + "norm2.weight", &B.n2_g));
+            TRY(sw_upload_f32(e, p + "norm2.bias", &B.n2_b));
+        }
+        if (s + 1 < c.stages) {
+            const std::string p = "layers." + std::to_string(s) + ".downsample.";
+            TRY(sw_upload_bf16(e, p + "reduction.weight", 2 * C, 4 * C, 4 * C, &e->stages[s].red_w));
+            TRY(sw_upload_f32(e, p + "norm.weight", &e->stages[s].dn_g));
+            TRY(sw_upload_f32(e, p + "norm.bias", &e->stages[s].dn_b));
+        }
+    }
+    TRY(sw_upload_f32(e, "norm.weight", &e->norm_g));
+    TRY(sw_upload_f32(e, "norm.bias", &e->norm_b));
+    TRY(sw_upload_f32(e, "output_proj.weight", &e->out_w));
+    TRY(sw_upload_f32(e, "output_proj.bias", &e->out_b));
+    const size_t B = c.max_batch, M0 = B * e->res(0) * e->res(0), MC = M0 * c.embed_dim;
+    const size_t sz[] = {M0 * (size_t)e->kpad * 2, MC * 4, MC * 2, MC * 4, MC * 3 * 2, MC * 2, MC * 4 * 2, MC * 2,
+                         B * (size_t)e->dim(c.stages - 1) * 4};
+    void **dst[] = {(void **)&e->patches, (void **)&e->x, (void **)&e->xb, (void **)&e->t, (void **)&e->qkv,
+                    (void **)&e->att, (void **)&e->h, (void **)&e->merged, (void **)&e->pooled};
+    for (int i = 0; i < 9; ++i) {
+        TRY(sw_alloc(e, sz[i], dst[i]));
+        e->ws_bytes += (int64_t)sz[i];
+    }
+#undef TRY
+    e->host_w.clear();
+    e->finalized = true;
+    return VSC_OK;
+}
+
+extern "C" int64_t vsc_swin_workspace_bytes(const vsc_swin *e) { return e ? e->ws_bytes : 0; }
+
+extern "C" int vsc_swin_forward_debug(vsc_swin *e, const float *frames, int64_t n, float *desc, float *tokens_out,
+                                      void *stream_) {
+    VSC_REQUIRE(e && frames && desc && n >= 0, "swin forward: bad argument");
+    if (!e->finalized) {
+        vsc_set_error("swin forward before finalize");
+        return VSC_ERR_STATE;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    const vsc_swin_config &c = e->cfg;
+    const int64_t frame_elems = (int64_t)c.channels * c.image_size * c.image_size;
+    const int SL = c.stages - 1, TL = e->res(SL) * e->res(SL), CL = e->dim(SL);
+    int rc;
+#define TRY(x) do { if ((rc = (x))) return rc; } while (0)
+    for (int64_t off = 0; off < n; off += c.max_batch) {
+        const int64_t B = (n - off) < c.max_batch ? (n - off) : c.max_batch;
+        int64_t M = B * e->res(0) * e->res(0);
+        TRY(launch_patchify(frames + off * frame_elems, e->patches, B, c.channels, c.image_size, c.patch_size,
+                            e->kpad, st));
+        TRY(launch_gemm_bf16(e->patches, e->pe_w, e->pe_b, nullptr, e->t, M, c.embed_dim, e->kpad, VSC_EPI_F32, 0, st));
+        TRY(launch_ln_residual(e->t, e->pe_g, e->pe_beta, nullptr, e->x, e->xb, M, c.embed_dim, c.ln_eps, st));
+        for (int s = 0; s < c.stages; ++s) {
+            const int C = e->dim(s), R = e->res(s), W = e->window(s), H = c.heads[s];
+            M = B * R * R;
+            for (int b = 0; b < c.depths[s]; ++b) {
+                const SwinBlockW &K = e->stages[s].blocks[b];
+                TRY(launch_gemm_bf16(e->xb, K.qkv_w, K.qkv_b, nullptr, e->qkv, M, 3 * C, C, VSC_EPI_BF16, 0, st));
+                TRY(launch_window_attention(e->qkv, e->att, K.bias, K.scale, (int)B, R, W, e->shift(s, b), H, st));
+                TRY(launch_gemm_bf16(e->att, K.proj_w, K.proj_b, nullptr, e->t, M, C, C, VSC_EPI_F32, 0, st));
+                TRY(launch_ln_residual(e->t, K.n1_g, K.n1_b, e->x, e->x, e->xb, M, C, c.ln_eps, st));
+                TRY(launch_gemm_bf16(e->xb, K.fc1_w, K.fc1_b, nullptr, e->h, M, 4 * C, C, VSC_EPI_GELU_BF16, 0, st));
+                TRY(launch_gemm_bf16(e->h, K.fc2_w, K.fc2_b, nullptr, e->t, M, C, 4 * C, VSC_EPI_F32, 0, st));
+                TRY(launch_ln_residual(e->t, K.n2_g, K.n2_b, e->x, e->x, e->xb, M, C, c.ln_eps, st));
+            }
+            if (s + 1 < c.stages) {
+                TRY(launch_merge_gather(e->xb, e->merged, B, R, C, st));
+                TRY(launch_gemm_bf16(e->merged, e->stages[s].red_w, nullptr, nullptr, e->t, M / 4, 2 * C, 4 * C,
+                                     VSC_EPI_F32, 0, st));
+                TRY(launch_ln_residual(e->t, e->stages[s].dn_g, e->stages[s].dn_b, nullptr, e->x, e->xb, M / 4, 2 * C,
+                                       c.ln_eps, st));
+            }
+        }
+        TRY(launch_ln_pool(e->x, e->norm_g, e->norm_b, e->pooled, tokens_out ? tokens_out + off * TL * CL : nullptr, B,
+                           TL, CL, c.ln_eps, 0, c.gem_p, st));
+        TRY(launch_head(e->pooled, e->out_w, e->out_b, desc + off * c.out_dim, B, CL, c.out_dim, c.l2_normalize, st));
+    }
+#undef TRY
+    return VSC_OK;
+}
+
+extern "C" int vsc_swin_forward(vsc_swin *e, const float *frames, int64_t n, float *desc, void *stream) {
+    return vsc_swin_forward_debug(e, frames, n, desc, nullptr, stream);
+}

@@ -35,6 +35,15 @@ class EncoderConfigC(ctypes.Structure):
     ]
 
 
+class SwinConfigC(ctypes.Structure):
+    _fields_ = [
+        ("image_size", c_int32), ("patch_size", c_int32), ("channels", c_int32), ("embed_dim", c_int32),
+        ("stages", c_int32), ("depths", c_int32 * 4), ("heads", c_int32 * 4), ("window_size", c_int32),
+        ("pretrained_window_sizes", c_int32 * 4), ("mlp_ratio", c_int32), ("out_dim", c_int32),
+        ("ln_eps", c_float), ("gem_p", c_float), ("max_batch", c_int32), ("l2_normalize", c_int32),
+    ]
+
+
 # name -> (restype, argtypes); also the list the symbol test checks against the header
 SIGNATURES = {
     "vsc_last_error": (c_char_p, []),
@@ -49,6 +58,18 @@ SIGNATURES = {
     "vsc_encoder_workspace_bytes": (c_int64, [c_void_p]),
     "vsc_encoder_set_profiling": (c_int32, [c_void_p, c_int32]),
     "vsc_encoder_get_profile": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "vsc_swin_create": (c_int32, [POINTER(SwinConfigC), POINTER(c_void_p)]),
+    "vsc_swin_destroy": (None, [c_void_p]),
+    "vsc_swin_set_weight": (c_int32, [c_void_p, c_char_p, c_void_p, c_size_t]),
+    "vsc_swin_finalize": (c_int32, [c_void_p]),
+    "vsc_swin_forward": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "vsc_swin_forward_debug": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "vsc_swin_workspace_bytes": (c_int64, [c_void_p]),
+    "vsc_window_attention_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                            c_int32, c_int32, c_void_p]),
+    "vsc_ln_residual_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                      c_float, c_void_p]),
+    "vsc_merge_gather_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "vsc_knn_ip_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int64,
                                  c_void_p, c_void_p, c_void_p]),
     "vsc_range_search_ip_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_float, c_int64,

@@ -120,3 +120,39 @@ def range_search_ip(q, r, radius: float, ref_id_offset: int = 0, capacity: int =
         if total.value <= capacity:
             return lims, scores[: total.value], ids[: total.value]
         capacity = int(total.value)
+
+
+def window_attention_bf16(qkv, bias, scale, frames: int, res: int, window: int, shift: int, heads: int):
+    """Swin-V2 windowed cosine attention (head_dim 32) on image-ordered tokens."""
+    lib = _lib.require_device()
+    qkv = _dev(qkv, torch.bfloat16)
+    bias, scale = _dev(bias, torch.float32), _dev(scale, torch.float32)
+    assert qkv.shape == (frames * res * res, 3 * heads * 32)
+    assert bias.shape == (heads, window * window, window * window) and scale.shape == (heads,)
+    out = torch.empty((frames * res * res, heads * 32), dtype=torch.bfloat16, device=qkv.device)
+    check(lib.vsc_window_attention_bf16(ptr(qkv), ptr(out), ptr(bias), ptr(scale), frames, res, window, shift, heads,
+                                        current_stream()))
+    return out
+
+
+def ln_residual(t, gamma, beta, eps: float, x_in=None):
+    """-> (x fp32, xb bf16) with x = (x_in or 0) + LayerNorm(t)."""
+    lib = _lib.require_device()
+    t, gamma, beta = (_dev(a, torch.float32) for a in (t, gamma, beta))
+    x_in = None if x_in is None else _dev(x_in, torch.float32)
+    rows, width = t.shape
+    x = torch.empty_like(t)
+    xb = torch.empty((rows, width), dtype=torch.bfloat16, device=t.device)
+    check(lib.vsc_ln_residual_f32(ptr(t), ptr(gamma), ptr(beta), ptr(x_in), ptr(x), ptr(xb), rows, width, eps,
+                                  current_stream()))
+    return x, xb
+
+
+def merge_gather_bf16(xb, frames: int, res: int):
+    lib = _lib.require_device()
+    xb = _dev(xb, torch.bfloat16)
+    c = xb.shape[1]
+    assert xb.shape[0] == frames * res * res
+    out = torch.empty((frames * (res // 2) ** 2, 4 * c), dtype=torch.bfloat16, device=xb.device)
+    check(lib.vsc_merge_gather_bf16(ptr(xb), ptr(out), frames, res, c, current_stream()))
+    return out

@@ -1,0 +1,112 @@
+"""``SwinHipEncoder``: stands where the reference puts the swinv2_v1xx TorchScript backbones
+(``torch.jit.load(...)`` / ``model(flat_frames)``: infer/extract_ref_feats.py:24-27,
+infer/src/extractor.py:23).  Weights are given under the reference's own state-dict names
+(train/train_v115/torch2scripts.py:677-684: ``module.backbone.`` prefix stripped)."""
+from __future__ import annotations
+
+import ctypes
+import re
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SwinConfigC, check, current_stream, ptr
+from .swin_config import SwinConfig, get_swin_config
+
+
+def swin_weight_names(cfg: SwinConfig) -> list:
+    names = ["patch_embed.proj.weight", "patch_embed.proj.bias", "patch_embed.norm.weight", "patch_embed.norm.bias"]
+    for s in range(cfg.stages):
+        for b in range(cfg.depths[s]):
+            p = f"layers.{s}.blocks.{b}."
+            names += [p + n for n in (
+                "attn.qkv.weight", "attn.q_bias", "attn.v_bias", "attn.logit_scale", "attn.cpb_mlp.0.weight",
+                "attn.cpb_mlp.0.bias", "attn.cpb_mlp.2.weight", "attn.proj.weight", "attn.proj.bias",
+                "norm1.weight", "norm1.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias",
+                "norm2.weight", "norm2.bias")]
+        if s + 1 < cfg.stages:
+            p = f"layers.{s}.downsample."
+            names += [p + "reduction.weight", p + "norm.weight", p + "norm.bias"]
+    return names + ["norm.weight", "norm.bias", "output_proj.weight", "output_proj.bias"]
+
+
+def from_reference_state(state: dict) -> dict:
+    """Strip ``module.`` / ``backbone.`` prefixes (torch2scripts.py:679-683); buffers are ignored."""
+    out = {}
+    for k, v in state.items():
+        k = re.sub(r"^(module\.)?(backbone\.)?", "", k)
+        out[k] = v.detach().cpu().float().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, np.float32)
+    return out
+
+
+class SwinHipEncoder:
+    def __init__(self, cfg: SwinConfig | str, weights: dict, *, max_batch: int = 32, l2_normalize: bool = False):
+        if isinstance(cfg, str):
+            cfg = get_swin_config(cfg)
+        self.cfg, self.max_batch = cfg, max_batch
+        self._lib = _lib.require_device()
+        names = swin_weight_names(cfg)
+        missing = [n for n in names if n not in weights]
+        if missing:
+            raise KeyError(f"swin weights missing {len(missing)} tensors, e.g. {missing[:4]}")
+        pad4 = lambda t: (ctypes.c_int32 * 4)(*(list(t) + [0] * (4 - len(t))))
+        c = SwinConfigC(image_size=cfg.image_size, patch_size=cfg.patch_size, channels=cfg.channels,
+                        embed_dim=cfg.embed_dim, stages=cfg.stages, depths=pad4(cfg.depths), heads=pad4(cfg.heads),
+                        window_size=cfg.window_size, pretrained_window_sizes=pad4(cfg.pretrained_window_sizes),
+                        mlp_ratio=cfg.mlp_ratio, out_dim=cfg.out_dim, ln_eps=cfg.ln_eps, gem_p=cfg.gem_p,
+                        max_batch=max_batch, l2_normalize=int(l2_normalize))
+        handle = ctypes.c_void_p()
+        check(self._lib.vsc_swin_create(ctypes.byref(c), ctypes.byref(handle)))
+        self._h = handle
+        try:
+            for name in names:
+                arr = weights[name]
+                arr = arr.detach().cpu().numpy() if isinstance(arr, torch.Tensor) else arr
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+                check(self._lib.vsc_swin_set_weight(self._h, name.encode(), arr.ctypes.data_as(ctypes.c_void_p), arr.size))
+            check(self._lib.vsc_swin_finalize(self._h))
+        except Exception:
+            self.close()
+            raise
+
+    def eval(self):
+        return self
+
+    def cuda(self, *_a, **_k):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self._lib.vsc_swin_workspace_bytes(self._h))
+
+    def __call__(self, frames: torch.Tensor, return_tokens: bool = False):
+        cfg = self.cfg
+        if frames.dim() != 4 or tuple(frames.shape[1:]) != (cfg.channels, cfg.image_size, cfg.image_size):
+            raise ValueError(f"expected frames [n,{cfg.channels},{cfg.image_size},{cfg.image_size}], got {tuple(frames.shape)}")
+        if not frames.is_cuda:
+            raise _lib.HipPathUnavailable("frames must be on the GPU; there is no CPU path")
+        frames = frames.to(torch.float32).contiguous()
+        n = frames.shape[0]
+        desc = torch.empty((n, cfg.out_dim), dtype=torch.float32, device=frames.device)
+        tokens = None
+        if return_tokens:
+            last = cfg.stages - 1
+            tokens = torch.empty((n, cfg.resolution(last) ** 2, cfg.dim(last)), dtype=torch.float32, device=frames.device)
+        if n:
+            check(self._lib.vsc_swin_forward_debug(self._h, ptr(frames), n, ptr(desc), ptr(tokens), current_stream()))
+        return (desc, tokens) if return_tokens else desc
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            self._lib.vsc_swin_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
