@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ poo
                                                    const float *__restrict__ bias,
                                                    float *__restrict__ desc, int width, int out_dim,
                                                    int l2) {
-    __shared__ float xs[2048];
+    __shared__ __attribute__((aligned(16))) float xs[2048];
     __shared__ float ys[2048];
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -267,15 +267,24 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ poo
     __syncthreads();
     const int n_out = w ? out_dim : width;
     if (w) {
-        for (int o = wave; o < out_dim; o += 4) {
-            const float *wr = w + (int64_t)o * width;
-            float a = 0.f;
+        // 8 outputs per wave iteration: 8 independent load streams / accumulators, so the weight
+        // rows' latency overlaps instead of serialising one dot product after another
+        for (int o0 = wave * 8; o0 < out_dim; o0 += 32) {
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             for (int c = lane * 4; c < width; c += 256) {
-                const float4 wv = *(const float4 *)(wr + c);
-                a += (wv.x * xs[c] + wv.y * xs[c + 1]) + (wv.z * xs[c + 2] + wv.w * xs[c + 3]);
+                const float4 xv = *(const float4 *)(xs + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int o = o0 + j < out_dim ? o0 + j : out_dim - 1;
+                    const float4 wv = *(const float4 *)(w + (int64_t)o * width + c);
+                    a[j] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
+                }
             }
-            a = wave_sum(a);
-            if (lane == 0) ys[o] = a + (bias ? bias[o] : 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float r = wave_sum(a[j]);
+                if (lane == 0 && o0 + j < out_dim) ys[o0 + j] = r + (bias ? bias[o0 + j] : 0.f);
+            }
         }
     } else {
         for (int c = threadIdx.x; c < width; c += 256) ys[c] = xs[c];
