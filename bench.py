@@ -70,6 +70,34 @@ def gemm_flops_per_frame(cfg):
     }
 
 
+def gemm_traffic(cfg, chunk):
+    """(measured HBM bytes per GEMM launch from the committed PMC profile, algorithmic bytes per launch).
+
+    PMC counters need rocprofv3, so they are not collected live: profiles/r01_pmc_per_launch.json holds
+    FETCH_SIZE / WRITE_SIZE per launch of this same configuration.  Calibration on a known byte count in
+    this access pattern (64-byte row pieces by LDS-DMA): the residual GEMMs read 431 MB algorithmically and
+    FETCH_SIZE says 425 MB, so the guide's x2 correction for wide coalesced streams is NOT applied."""
+    t, d, m = cfg.tokens, cfg.width, cfg.mlp_dim
+    rows = chunk * t
+    launches = {"0": cfg.layers, "1": cfg.layers, "3": 2 * cfg.layers, "4": 1}   # EPI class -> launches per chunk
+    algo = {"0": rows * d * 2 + 3 * d * d * 2 + rows * 3 * d * 2,
+            "1": rows * d * 2 + m * d * 2 + rows * m * 2,
+            "3": ((rows * d * 2 + d * d * 2 + 2 * rows * d * 4) + (rows * m * 2 + m * d * 2 + 2 * rows * d * 4)) / 2,
+            "4": chunk * (t - 1) * cfg.patch_dim * 2 + cfg.patch_dim * d * 2 + chunk * (t - 1) * d * 4}
+    n = sum(launches.values())
+    algorithmic = sum(launches[k] * algo[k] for k in launches) / n
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")))["per_launch"]
+        meas = 0.0
+        for key, v in prof.items():
+            if "gemm_bf16_v2_kernel<" in key:
+                epi = key.split("<")[1].split(",")[0]
+                meas += launches.get(epi, 0) * (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+        return meas / n, algorithmic
+    except (OSError, KeyError, ValueError):
+        return None, algorithmic
+
+
 def cpu_baseline(cfg, weights, frames_np, budget_s=15.0):
     from oracle import vit_oracle
     # threads this process may really use: affinity mask, capped by the cgroup CPU quota
@@ -194,6 +222,7 @@ def main():
                      for k, v in prof.items() if v[1]}
         for k in fpf:
             per_class[k]["tflops"] = round(fpf[k] * args.batch * args.steps / (prof[k][0] * 1e-3) / 1e12, 1)
+        traffic, algo_bytes = gemm_traffic(cfg, min(args.max_batch, args.batch))
         line = {
             "metric": "frames/s (ViT-B/16 224x224 encode -> L2-normalised 512-d descriptors)",
             "value": round(total_frames / dt, 1), "unit": "frames/s", "n_gpus": world,
@@ -210,7 +239,11 @@ def main():
             "model_tflops": round(cfg.flops_per_frame() * total_frames / dt / 1e12 / world, 1),
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_v2_kernel (patch/qkv/proj/fc1/fc2 launches)",
                          "achieved": round(achieved, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / BF16_PEAK_TFLOPS, 4),
+                         "traffic": None if traffic is None else round(traffic),
+                         "traffic_unit": "HBM bytes per GEMM launch (mean over the 49 launches of one 332-frame chunk; "
+                                         "PMC FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_per_launch.json, calibrated on the residual GEMMs)",
+                         "algorithmic_bytes_per_launch": round(algo_bytes),
                          "gemm_ms_per_step": round(gemm_ms / args.steps, 3),
                          "note": "per-launch HIP-event time; with lanes=2 launches of the two chunks "
                                  "overlap, so the sum of kernel times exceeds ms_per_step"},
