@@ -214,3 +214,16 @@ def test_eval_entry_point_end_to_end(dev, tmp_path):
     assert all(r.feature.shape[1] == dim and (r.feature[:, -1] == 1).all() for r in r2)
     with pytest.raises(Exception, match="against VSC rules"):
         sn.score_normalize(queries, refs, refs)
+
+
+def test_query_postprocess_on_device(dev):
+    """Frame de-duplication with the similarity matrix and normalisation computed by the HIP ops."""
+    from src.query_postprocess import HipOps, select_frames
+    base = synth.normalish(3, (40, 64))
+    frames = np.concatenate([base, base[:10] * 1.5, base[20:25] + 1e-4])   # scaled copies are duplicates in cosine
+    keep = select_frames(frames, HipOps)
+    S = HipOps.self_similarity(HipOps.normalize(frames))
+    from oracle import knn_oracle
+    assert np.array_equal(S.view(np.uint32), knn_oracle.ip_matrix(knn_oracle.l2_normalize(frames), knn_oracle.l2_normalize(frames)).view(np.uint32)) or \
+        np.allclose(S, knn_oracle.ip_matrix(knn_oracle.l2_normalize(frames), knn_oracle.l2_normalize(frames)), atol=2e-6)
+    assert len(keep) == 40 and len(set(keep)) == 40

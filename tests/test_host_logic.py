@@ -182,3 +182,52 @@ def test_config_flops():
     cfg = get_config("vit_b16_224")
     assert cfg.tokens == 197 and cfg.head_dim == 64 and cfg.patch_dim == 768
     assert 34.5e9 < cfg.flops_per_frame() < 36e9   # ViT-B/16: ~17.5 GMAC
+
+
+class _NumpyOps:
+    """CPU stand-in for the two device ops, only to exercise the host bookkeeping here."""
+
+    @staticmethod
+    def normalize(x):
+        from sklearn.preprocessing import normalize
+        return normalize(np.asarray(x, np.float32))
+
+    @staticmethod
+    def self_similarity(x):
+        return np.matmul(x, x.T)
+
+
+def test_query_postprocess_matches_reference_statement():
+    """src/query_postprocess.py against a literal numpy restatement of extract_query_feats.py:176-228."""
+    from sklearn.preprocessing import normalize
+    from src.query_postprocess import process_query_video
+    rs = np.random.RandomState(0)
+    base = rs.randn(6, 16).astype(np.float32)
+    frames = np.concatenate([base, base[:3] + 1e-3 * rs.randn(3, 16).astype(np.float32)])   # 3 near-duplicates
+    subs = [frames[:, :8].copy(), frames[:, 8:].copy()]
+    stamps = np.stack([np.arange(9.0), np.arange(9.0) + 1], axis=1)
+    proj = rs.randn(16, 5).astype(np.float32)
+    pca = lambda x: x @ proj
+
+    feat, per_model, idx = process_query_video("Q000001", subs, stamps, 0.9, pca, rnd_idx=0, ops=_NumpyOps)
+    # reference statement
+    sub_n = [normalize(s) for s in subs]
+    f = np.concatenate(sub_n, axis=1)
+    fn = f / np.linalg.norm(f, axis=1, keepdims=True)
+    sim = np.matmul(fn, fn.T) - np.eye(len(fn))
+    to_remove = []
+    for i in sim.mean(0).argsort()[::-1]:
+        if i in to_remove:
+            continue
+        for j in np.where(sim[i] > 0.975)[0]:
+            to_remove.append(j)
+    keep = [i for i in range(len(sim)) if i not in to_remove]
+    assert len(keep) == 6 and idx == 0
+    np.testing.assert_allclose(feat.feature, pca(f[keep]), rtol=1e-6)
+    np.testing.assert_array_equal(feat.timestamps, stamps[keep])
+    assert len(per_model) == 2 and per_model[1].feature.shape == (9, 8)
+
+    low, _, idx = process_query_video("Q000002", subs, stamps, 0.0001, pca, rnd_idx=4, ops=_NumpyOps)
+    np.random.seed(5)
+    assert idx == 5 and low.feature.shape == (1, 512)
+    np.testing.assert_array_equal(low.feature[0], np.random.uniform(-1e-5, 1e-5, size=512).astype(np.float32))

@@ -1,0 +1,77 @@
+"""Query-side descriptor post-processing (reference: infer/extract_query_feats.py:163-216,
+``Main.process`` after the backbones have run).
+
+Per query video: the per-model frame features are L2-normalised and concatenated (:176-181); if
+the video-score model says "may contain a copy" (score >= SCORE_THRESHOLD), near-duplicate frames
+are dropped greedily (cosine > FRAME_THRESHOLD against a kept frame, frames visited by descending
+mean similarity, :197-207) and the survivors go through the fitted PCA (:210); otherwise the video
+gets one tiny random descriptor (:218-228) so it can never match.  The result feeds
+``query_score_normalize``.
+
+Host bookkeeping stays numpy as in the reference; the row normalisation and the frame x frame
+similarity matrix go through libvsc_hip.so when ``device_ops`` is left at its default.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from vsc.index import VideoFeature
+
+SCORE_THRESHOLD = 0.001   # extract_query_feats.py:53
+FRAME_THRESHOLD = 0.975   # :55
+
+
+class HipOps:
+    """normalize / similarity on the GPU (no CPU fallback: raises without a device)."""
+
+    @staticmethod
+    def normalize(x: np.ndarray) -> np.ndarray:
+        import torch
+        from vsc_hip import ops
+        return ops.l2_normalize_(torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda()).cpu().numpy()
+
+    @staticmethod
+    def self_similarity(x: np.ndarray) -> np.ndarray:
+        """x x^T in the fp32 fmaf-chain order of the search kernel (n <= 1024 frames per video)."""
+        import torch
+        from vsc_hip import ops
+        t = torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda()
+        n = t.shape[0]
+        D, I = ops.knn_ip(t, t, n)
+        out = torch.empty((n, n), dtype=torch.float32, device=t.device)
+        out.scatter_(1, I, D)
+        return out.cpu().numpy()
+
+
+def select_frames(features: np.ndarray, ops=HipOps, frame_threshold: float = FRAME_THRESHOLD) -> List[int]:
+    """Indices kept by the greedy near-duplicate filter (:197-207)."""
+    feat = ops.normalize(features)
+    sim = ops.self_similarity(feat) - np.eye(len(feat), dtype=np.float32)
+    removed = set()
+    for i in sim.mean(0).argsort()[::-1]:
+        if i in removed:
+            continue
+        removed.update(np.where(sim[i] > frame_threshold)[0].tolist())
+    return [i for i in range(len(sim)) if i not in removed]
+
+
+def process_query_video(video_id: str, sub_features: Sequence[np.ndarray], timestamps: np.ndarray, score: float,
+                        pca_transform: Callable[[np.ndarray], np.ndarray], rnd_idx: int, ops=HipOps,
+                        score_threshold: float = SCORE_THRESHOLD) -> Tuple[VideoFeature, List[VideoFeature], int]:
+    """-> (descriptor for the video, per-model VideoFeatures, updated rnd_idx)."""
+    subs = [ops.normalize(f) for f in sub_features]
+    features = np.concatenate(subs, axis=1)
+    ratio = len(features) // len(timestamps)
+    stamps = np.asarray(list(timestamps) * ratio) if ratio != 1 else np.asarray(timestamps)
+    assert len(stamps) == len(features)
+    per_model = [VideoFeature(video_id=video_id, timestamps=stamps, feature=s) for s in subs]
+    if score >= score_threshold:
+        keep = select_frames(features, ops)
+        return VideoFeature(video_id=video_id, timestamps=stamps[keep],
+                            feature=pca_transform(features[keep])), per_model, rnd_idx
+    rnd_idx += 1
+    np.random.seed(rnd_idx)
+    rnd = np.random.uniform(-1e-5, 1e-5, size=512).astype(np.float32)
+    return VideoFeature(video_id=video_id, timestamps=np.array([0, 1])[None, ...], feature=rnd[None, ...]), per_model, rnd_idx
