@@ -202,7 +202,9 @@ int vsc_patchify_bf16(const float *frames_dev, uint16_t *patches_dev, int64_t n,
 
 /* Swin-V2 windowed cosine attention, head_dim 32.  qkv_dev bf16 [frames*res*res, 3*heads*32] in
  * image token order; the cyclic shift and window partition are index math.  bias_dev f32
- * [heads, N, N] (N = window^2), scale_dev f32 [heads] = exp(min(logit_scale, ln 100)). */
+ * [heads, (2*window-1)^2]: the compact relative-position table 16*sigmoid(cpb_mlp(coords)),
+ * bias(i, j) = table[(yi-yj+window-1)*(2*window-1) + xi-xj+window-1]; scale_dev f32 [heads] =
+ * exp(min(logit_scale, ln 100)). */
 int vsc_window_attention_bf16(const uint16_t *qkv_dev, uint16_t *out_dev, const float *bias_dev,
                               const float *scale_dev, int32_t frames, int32_t res, int32_t window,
                               int32_t shift, int32_t heads, void *stream);

@@ -33,9 +33,10 @@ def test_window_attention(dev, frames, res, window, shift, heads):
     from vsc_hip import ops
     c, n = heads * 32, window * window
     qkv = _rand(res + shift, (frames * res * res, 3 * c)).to(torch.bfloat16)
-    bias = 16 * torch.sigmoid(_rand(7, (heads, n, n)))
+    table = 16 * torch.sigmoid(_rand(7, (heads, (2 * window - 1) ** 2)))            # compact table the kernel takes
+    bias = table[:, swin_oracle.relative_position_index(window).reshape(-1)].reshape(heads, n, n)
     scale = torch.exp(torch.clamp(math.log(10.0) + _rand(8, (heads,), 0.4), max=math.log(100.0)))
-    out = ops.window_attention_bf16(qkv.to(dev), bias.to(dev), scale.to(dev), frames, res, window, shift, heads)
+    out = ops.window_attention_bf16(qkv.to(dev), table.to(dev), scale.to(dev), frames, res, window, shift, heads)
     # torch statement of torch2scripts.py:147-187 + :272-296 on the same bf16 qkv
     x = qkv.float().reshape(frames, res, res, 3 * c)
     if shift:

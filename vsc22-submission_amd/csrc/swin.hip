@@ -19,6 +19,9 @@ constexpr int HD = 32;  // head dim of every Swin-V2 stage (C / heads)
 //   * scores use the swapped MFMA (A = K-hat, B = Q-hat) so a lane owns one query: logits =
 //     cos * exp(min(logit_scale, ln 100)) + 16*sigmoid(cpb) bias (+ -100 where the shift mask
 //     separates the two tokens' regions, :236-254), whole row in registers, exp2 softmax.
+//   * the position bias is NOT the expanded [N, N] matrix of the reference (256 KiB per head, 16
+//     dependent global loads per query tile): bias[i][j] = table[(yi - yj + w-1) * (2w-1) + (xi - xj + w-1)],
+//     so the head's compact (2w-1)^2 table (3.8 KiB) sits in LDS and is gathered with ds_read_b32.
 //   * P (bf16) is directly the B operand of the PV MFMA (k-slot permutation as attention.hip).
 template <int NT>  // 16-key tiles per window: 4 (8x8 window) or 16 (16x16 window)
 __global__ __launch_bounds__(NT * 32, 2) void window_attention_kernel(
@@ -26,11 +29,13 @@ __global__ __launch_bounds__(NT * 32, 2) void window_attention_kernel(
     const float *__restrict__ scale, int res, int ws, int shift, int heads) {
     constexpr int N = NT * 16, NWAVES = NT / 2, NTHREADS = NWAVES * 64;
     constexpr int VSTRIDE = N * 2 + 8;
-    __shared__ __attribute__((aligned(16))) char smem[N * 64 + HD * VSTRIDE + N * 4 + N];
+    constexpr int WS = NT == 16 ? 16 : 8, SIDE = 2 * WS - 1;
+    __shared__ __attribute__((aligned(16))) char smem[N * 64 + HD * VSTRIDE + N * 4 + N + SIDE * SIDE * 4];
     char *klds = smem;                                   // [N][32] bf16, 64-B rows, chunk ^= (-(row>>2)) & 3
     char *vt = smem + N * 64;                            // [32][VSTRIDE]
     int *rowmap = (int *)(smem + N * 64 + HD * VSTRIDE);  // image token index of window token i
     unsigned char *region = (unsigned char *)(rowmap + N);
+    float *tbl = (float *)(smem + N * 64 + HD * VSTRIDE + N * 4 + N);  // this head's bias table, * log2(e)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,6 +60,8 @@ __global__ __launch_bounds__(NT * 32, 2) void window_attention_kernel(
         const int wr = sx < res - ws ? 0 : (sx < res - shift ? 1 : 2);
         region[i] = (unsigned char)(3 * hr + wr);
     }
+    for (int i = tid; i < SIDE * SIDE; i += NTHREADS)
+        tbl[i] = bias[(int64_t)head * SIDE * SIDE + i] * 1.44269504088896340736f;
     __syncthreads();
 
     const int fr = lane & 15, g = lane >> 4;
@@ -118,12 +125,13 @@ __global__ __launch_bounds__(NT * 32, 2) void window_attention_kernel(
 
     const float LOG2E = 1.44269504088896340736f;
     const float sc = scale[head] * LOG2E;
-    const float *hb = bias + (int64_t)head * N * N;
 
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         const int q = (wave * 2 + qi) * 16 + fr;
         const int rq = region[q];
+        // table index of (query q, key j) = tq - (yj * SIDE + xj),  tq = (yq + WS-1) * SIDE + xq + WS-1
+        const int tq = (q / WS + WS - 1) * SIDE + (q % WS) + WS - 1;
         f32x4_t s[NT];
         float mx = -INFINITY;
 #pragma unroll
@@ -132,11 +140,11 @@ __global__ __launch_bounds__(NT * 32, 2) void window_attention_kernel(
             const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
             f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi], z, 0, 0, 0);
-            const f32x4_t bz = *(const f32x4_t *)(hb + (int64_t)q * N + t * 16 + g * 4);
             const uint32_t rk = *(const uint32_t *)(region + t * 16 + g * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float l = fmaf(z[r], sc, bz[r] * LOG2E);
+                const int j = t * 16 + g * 4 + r;
+                float l = fmaf(z[r], sc, tbl[tq - ((j / WS) * SIDE + (j % WS))]);
                 if (shift > 0 && (int)((rk >> (8 * r)) & 0xff) != rq) l -= 100.0f * LOG2E;
                 s[t][r] = l;
                 mx = fmaxf(mx, l);
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(256) void merge_gather_kernel(const uint16_t *__res
 
 int launch_window_attention(const uint16_t *qkv, uint16_t *out, const float *bias, const float *scale,
                             int frames, int res, int ws, int shift, int heads, hipStream_t stream) {
-    VSC_REQUIRE(qkv && out && bias && scale, "window_attention: null operand");
+    VSC_REQUIRE(qkv && out && bias && scale, "window_attention: null operand");  // bias: [heads, (2w-1)^2] compact table
     VSC_REQUIRE(res % ws == 0 && shift >= 0 && shift < ws, "window_attention: res %d window %d shift %d", res, ws,
                 shift);
     const int nw = (res / ws) * (res / ws);

@@ -10,7 +10,7 @@
 //   t = att Wproj^T + b;  x += LN1(t);  h = gelu(xb W1^T + b1);  t = h W2^T + b2;  x += LN2(t).
 // The continuous-position-bias tables 16*sigmoid(cpb_mlp(coords))[index] depend only on the
 // weights: they are evaluated once on the host in finalize (model loading) and kept as
-// fp32 [heads, N, N] per block.
+// fp32 [heads, (2w-1)^2] per block (the kernel applies the relative_position_index map itself).
 #include <math.h>
 
 #include <map>
@@ -86,11 +86,11 @@ int sw_upload_bf16(vsc_swin *e, const std::string &name, int64_t rows, int cols,
     return rc;
 }
 
-// 16 * sigmoid(cpb_mlp(log-spaced relative coords))[relative_position_index] -> [heads, N, N]
+// 16 * sigmoid(cpb_mlp(log-spaced relative coords)) -> compact table [heads, (2w-1)^2]
 // (torch2scripts.py:100-128, 166-171).
 std::vector<float> position_bias(const std::vector<float> &w0, const std::vector<float> &b0,
                                  const std::vector<float> &w2, int window, int pretrained, int heads) {
-    const int side = 2 * window - 1, n = window * window;
+    const int side = 2 * window - 1;
     const float denom = (float)((pretrained > 0 ? pretrained : window) - 1);
     std::vector<float> table((size_t)side * side * heads);
     std::vector<float> hid(512);
@@ -111,14 +111,11 @@ std::vector<float> position_bias(const std::vector<float> &w0, const std::vector
                 table[((size_t)a * side + b) * heads + hh] = acc;
             }
         }
-    std::vector<float> bias((size_t)heads * n * n);
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            const int dy = i / window - j / window + window - 1, dx = i % window - j % window + window - 1;
-            const size_t idx = (size_t)dy * side + dx;
-            for (int hh = 0; hh < heads; ++hh)
-                bias[((size_t)hh * n + i) * n + j] = 16.0f / (1.0f + expf(-table[idx * heads + hh]));
-        }
+    // compact [heads, side*side]: the kernel gathers bias[i][j] = table[(yi-yj+w-1)*side + xi-xj+w-1]
+    std::vector<float> bias((size_t)heads * side * side);
+    for (size_t idx = 0; idx < (size_t)side * side; ++idx)
+        for (int hh = 0; hh < heads; ++hh)
+            bias[(size_t)hh * side * side + idx] = 16.0f / (1.0f + expf(-table[idx * heads + hh]));
     return bias;
 }
 

@@ -128,7 +128,7 @@ def window_attention_bf16(qkv, bias, scale, frames: int, res: int, window: int, 
     qkv = _dev(qkv, torch.bfloat16)
     bias, scale = _dev(bias, torch.float32), _dev(scale, torch.float32)
     assert qkv.shape == (frames * res * res, 3 * heads * 32)
-    assert bias.shape == (heads, window * window, window * window) and scale.shape == (heads,)
+    assert bias.shape == (heads, (2 * window - 1) ** 2) and scale.shape == (heads,)   # compact table
     out = torch.empty((frames * res * res, heads * 32), dtype=torch.bfloat16, device=qkv.device)
     check(lib.vsc_window_attention_bf16(ptr(qkv), ptr(out), ptr(bias), ptr(scale), frames, res, window, shift, heads,
                                         current_stream()))
