@@ -108,10 +108,14 @@ __device__ __forceinline__ f32x4_t lds_frag(const char *tile, int row, int chunk
 
 // acc[a][b][reg] = <ref r0 + wm*64 + a*32 + row(reg, lane>>5), query q0 + wn*64 + b*32 + (lane&31)>
 // for one 128 x 128 tile: double-buffered LDS-DMA staging + 32x32x2 f32 MFMA, ascending k.
-// Ends with a workgroup barrier (the staging buffers are free on return).
+// The stream of K-slabs is continuous ACROSS ref tiles: during the last K-step of this tile the
+// first slab of the next one (next_r0 >= 0) is already in flight, so a tile does not start with
+// an exposed HBM round trip.  `cur` is the LDS buffer holding this tile's first slab; `primed`
+// says whether it is already there.  Ends with a workgroup barrier.
 __device__ __forceinline__ void score_tile(f32x16_t (&acc)[2][2], const float *rp, const float *qp,
-                                           int64_t nr, int64_t nq, int dpad, int64_t r0, int64_t q0,
-                                           char *lds, int wave, int lane) {
+                                           int64_t nr, int64_t nq, int dpad, int64_t r0, int64_t next_r0,
+                                           int64_t q0, char *lds, int wave, int lane, int &cur,
+                                           bool primed) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     const int nks = dpad / KS;
@@ -122,16 +126,20 @@ __device__ __forceinline__ void score_tile(f32x16_t (&acc)[2][2], const float *r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    stage_tile(rp, dpad, r0, nr - 1, 0, lds, wave, lane);
-    stage_tile(qp, dpad, q0, nq - 1, 0, lds + TILE_BYTES, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!primed) {
+        stage_tile(rp, dpad, r0, nr - 1, 0, lds + cur * 2 * TILE_BYTES, wave, lane);
+        stage_tile(qp, dpad, q0, nq - 1, 0, lds + cur * 2 * TILE_BYTES + TILE_BYTES, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     for (int ks = 0; ks < nks; ++ks) {
-        const int cur = ks & 1;
+        char *nxt = lds + (cur ^ 1) * 2 * TILE_BYTES;
         if (ks + 1 < nks) {
-            char *nxt = lds + (cur ^ 1) * 2 * TILE_BYTES;
             stage_tile(rp, dpad, r0, nr - 1, (ks + 1) * KS, nxt, wave, lane);
             stage_tile(qp, dpad, q0, nq - 1, (ks + 1) * KS, nxt + TILE_BYTES, wave, lane);
+        } else if (next_r0 >= 0) {
+            stage_tile(rp, dpad, next_r0, nr - 1, 0, nxt, wave, lane);
+            stage_tile(qp, dpad, q0, nq - 1, 0, nxt + TILE_BYTES, wave, lane);
         }
         const char *rtile = lds + cur * 2 * TILE_BYTES;
         const char *qtile = rtile + TILE_BYTES;
@@ -152,6 +160,7 @@ __device__ __forceinline__ void score_tile(f32x16_t (&acc)[2][2], const float *r
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        cur ^= 1;
     }
 }
 
@@ -220,10 +229,14 @@ __global__ __launch_bounds__(256, 2) void knn_kernel(KnnArgs p) {
         if (tid == 0) *flag_s = 0;
         __syncthreads();
 
+        int cur = 0;
+        bool primed = false;
         for (int64_t rt = t_begin; rt < t_end; ++rt) {
             const int64_t r0 = rt * TR;
             f32x16_t acc[2][2];
-            score_tile(acc, p.rp, p.qp, p.nr, p.nq, p.dpad, r0, q0, lds, wave, lane);
+            score_tile(acc, p.rp, p.qp, p.nr, p.nq, p.dpad, r0, rt + 1 < t_end ? r0 + TR : -1, q0, lds, wave, lane,
+                       cur, primed);
+            primed = rt + 1 < t_end;
 
             // ---- filter: acc[a][b][reg] = <ref r0 + wm*64 + a*32 + row(reg,hi), query q0 + wn*64 + b*32 + l31>
 #pragma unroll
@@ -260,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void knn_kernel(KnnArgs p) {
                 __syncthreads();
                 if (tid == 0) *flag_s = 0;
                 __syncthreads();
+                primed = false;  // the compaction scratch overwrote the prefetched slab
             }
         }
 
@@ -377,10 +391,14 @@ __global__ __launch_bounds__(256, 2) void range_kernel(RangeArgs p) {
         if (tid == 0) *flag_s = 0;
         __syncthreads();
 
+        int cur = 0;
+        bool primed = false;
         for (int64_t rt = t_begin; rt < t_end; ++rt) {
             const int64_t r0 = rt * TR;
             f32x16_t acc[2][2];
-            score_tile(acc, p.rp, p.qp, p.nr, p.nq, p.dpad, r0, q0, lds, wave, lane);
+            score_tile(acc, p.rp, p.qp, p.nr, p.nq, p.dpad, r0, rt + 1 < t_end ? r0 + TR : -1, q0, lds, wave, lane,
+                       cur, primed);
+            primed = rt + 1 < t_end;
             // hit masks: bit (8*(reg>>2) + 4*hi + (reg&3)) of word (wm*2 + a) of query ql
             unsigned mask[2][2];
             bool any = false;
