@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 bounded sample of the same frames.
   search        secondary metric: exact 512-d inner-product top-100 sweep
                 (vsc_knn_ip_f32), Mpairs/s, with its own fp32-MFMA roofline.
+  swin          secondary metric: Swin-V2-B 256 encode (vsc_swin_forward), frames/s.
 """
 import argparse
 import json
@@ -52,10 +53,12 @@ def parse():
     ap.add_argument("--preset", default="vit_b16_224")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true")
-    ap.add_argument("--search-nq", type=int, default=16384)
+    ap.add_argument("--search-nq", type=int, default=65536)
     ap.add_argument("--search-nr", type=int, default=1_000_000)
     ap.add_argument("--search-k", type=int, default=100)
     ap.add_argument("--search-steps", type=int, default=3)
+    ap.add_argument("--no-swin", action="store_true")
+    ap.add_argument("--swin-batch", type=int, default=256)
     return ap.parse_args()
 
 
@@ -158,6 +161,32 @@ def bench_search(dev, args):
                          "note": "event time covers pack + knn_kernel + merge of one call"}}
 
 
+def bench_swin(dev, args):
+    """Secondary: the reference's other backbone family (swinv2_v1xx), same contract as the ViT step."""
+    from src import synth
+    from vsc_hip.swin_config import get_swin_config
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    cfg = get_swin_config("swinv2_base_256")
+    enc = SwinHipEncoder(cfg, synth.swin_weights(5, cfg), max_batch=args.swin_batch, l2_normalize=True)
+    b = args.swin_batch
+    x = torch.from_numpy(synth.swin_frames(1, 8, cfg)).to(dev).repeat((b + 7) // 8, 1, 1, 1)[:b].contiguous()
+    for _ in range(2):
+        enc(x)
+    torch.cuda.synchronize()
+    steps = 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = enc(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(out).all()
+    enc.close()
+    return {"metric": "frames/s (Swin-V2-B 256x256 window-16 encode -> L2-normalised 512-d descriptors)",
+            "value": round(b / dt, 1), "unit": "frames/s", "frames_per_step": b, "ms_per_step": round(dt * 1e3, 3),
+            "dtype": "bf16", "gflop_per_frame": round(cfg.flops_per_frame() / 1e9, 2),
+            "model_tflops": round(cfg.flops_per_frame() * b / dt / 1e12, 1)}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -251,10 +280,13 @@ def main():
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, weights, base)
-        if not args.no_search:
-            enc.close()
-            del frames
+        enc.close()
+        del frames
+        torch.cuda.empty_cache()
+        if not args.no_swin:
+            line["swin"] = bench_swin(dev, args)
             torch.cuda.empty_cache()
+        if not args.no_search:
             line["search"] = bench_search(dev, args)
         print(json.dumps(line), flush=True)
     if dist is not None:
