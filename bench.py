@@ -278,15 +278,16 @@ def main():
                                  "overlap, so the sum of kernel times exceeds ms_per_step"},
             "kernels": per_class,
         }
-        if not args.no_cpu_baseline:
+        secondary = world == 1   # cpu baseline and the secondary metrics are rank-0, N = 1 only
+        if not args.no_cpu_baseline and secondary:
             line["cpu_baseline"] = cpu_baseline(cfg, weights, base)
         enc.close()
         del frames
         torch.cuda.empty_cache()
-        if not args.no_swin:
+        if not args.no_swin and secondary:
             line["swin"] = bench_swin(dev, args)
             torch.cuda.empty_cache()
-        if not args.no_search:
+        if not args.no_search and secondary:
             line["search"] = bench_search(dev, args)
         print(json.dumps(line), flush=True)
     if dist is not None:
