@@ -212,6 +212,13 @@ int vsc_window_attention_bf16(const uint16_t *qkv_dev, uint16_t *out_dev, const 
 int vsc_ln_residual_f32(const float *t_dev, const float *gamma_dev, const float *beta_dev,
                         const float *x_in_dev, float *x_out_dev, uint16_t *xb_dev, int64_t rows,
                         int32_t width, float eps, void *stream);
+/* The same update with the LayerNorm input produced in place by a GEMM whose tile owns whole rows:
+ * x_out = (x_in ? x_in : 0) + LayerNorm(A[m,k] W[n,k]^T + bias) ; xb = bf16(x_out).  n in {128, 256, 512},
+ * k % 32 == 0 (torch2scripts.py:297-300, 361-362: Swin-V2 res-post-norm and the PatchMerging norm). */
+int vsc_gemm_ln_bf16(const uint16_t *a_dev, const uint16_t *w_dev, const float *bias_dev,
+                     const float *gamma_dev, const float *beta_dev, const float *x_in_dev,
+                     float *x_out_dev, uint16_t *xb_dev, int64_t m, int32_t n, int32_t k, float eps,
+                     void *stream);
 /* PatchMerging gather on bf16 tokens [frames, res, res, c] -> [frames*(res/2)^2, 4c] */
 int vsc_merge_gather_bf16(const uint16_t *xb_dev, uint16_t *out_dev, int64_t frames, int32_t res,
                           int32_t c, void *stream);

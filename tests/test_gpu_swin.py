@@ -71,6 +71,34 @@ def test_ln_residual(dev, rows, width):
     torch.testing.assert_close(x2.cpu(), F.layer_norm(t, (width,), g, b, 1e-5), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("m,n,k", [(5, 128, 64), (1000, 128, 128), (777, 256, 256), (300, 256, 1024), (129, 512, 512),
+                                   (2048, 512, 2048)])
+def test_gemm_ln_matches_torch(dev, m, n, k):
+    """Row-owning GEMM with the res-post-norm epilogue vs fp32 torch on the same bf16 operands."""
+    from vsc_hip import ops
+    a = _rand(11, (m, k)).to(torch.bfloat16)
+    w = _rand(12, (n, k), k ** -0.5).to(torch.bfloat16)
+    bias, x0 = _rand(13, (n,), 0.2), _rand(14, (m, n))
+    g, b = 0.3 + _rand(15, (n,), 0.05), _rand(16, (n,), 0.05)
+    t = a.float() @ w.float().T + bias
+    ref = x0 + F.layer_norm(t, (n,), g, b, 1e-5)
+    x, xb = ops.gemm_ln_bf16(a.to(dev), w.to(dev), bias.to(dev), g.to(dev), b.to(dev), 1e-5, x_in=x0.to(dev))
+    torch.testing.assert_close(x.cpu(), ref, rtol=1e-4, atol=1e-4)
+    assert torch.equal(xb.cpu(), x.cpu().to(torch.bfloat16))
+    # no bias, no residual (the PatchMerging form), in place on x is also what the encoder does
+    x2, _ = ops.gemm_ln_bf16(a.to(dev), w.to(dev), None, g.to(dev), b.to(dev), 1e-5)
+    torch.testing.assert_close(x2.cpu(), F.layer_norm(a.float() @ w.float().T, (n,), g, b, 1e-5), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_ln_rejects_other_widths(dev):
+    from vsc_hip import ops
+    from vsc_hip._lib import VscHipError
+    a, w = torch.zeros(4, 64, dtype=torch.bfloat16, device=dev), torch.zeros(96, 64, dtype=torch.bfloat16, device=dev)
+    g = torch.ones(96, device=dev)
+    with pytest.raises(VscHipError, match="unsupported"):
+        ops.gemm_ln_bf16(a, w, None, g, g, 1e-5)
+
+
 def test_merge_gather_bit_exact(dev):
     from vsc_hip import ops
     frames, res, c = 3, 8, 64

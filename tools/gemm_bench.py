@@ -9,7 +9,8 @@ import torch
 
 from vsc_hip import _lib, ops
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+SWIN = len(sys.argv) > 1 and sys.argv[1] == "swin"
+B = int(sys.argv[2 if SWIN else 1]) if len(sys.argv) > (2 if SWIN else 1) else 256
 M = B * 197
 dev = torch.device("cuda:0")
 shapes = [("qkv", M, 2304, 768, _lib.EPI_BF16), ("proj", M, 768, 768, _lib.EPI_RESADD_F32),
@@ -17,6 +18,10 @@ shapes = [("qkv", M, 2304, 768, _lib.EPI_BF16), ("proj", M, 768, 768, _lib.EPI_R
           ("patch", B * 196, 768, 768, _lib.EPI_BF16),
           ("fc1ng", M, 3072, 768, _lib.EPI_BF16), ("fc2nr", M, 768, 3072, _lib.EPI_BF16),
           ("sq4k", 4096, 4096, 4096, _lib.EPI_BF16), ("sq8k", 8192, 8192, 8192, _lib.EPI_BF16)]
+if SWIN:  # Swin-V2-B/256 stages 1-3 at batch B: (tokens, width) = (B*4096, 128), (B*1024, 256), (B*256, 512)
+    shapes = []
+    for st, (t, c) in enumerate([(4096, 128), (1024, 256), (256, 512)], 1):
+        shapes += [(f"s{st}qkv", B * t, 3 * c, c, _lib.EPI_BF16), (f"s{st}fc1", B * t, 4 * c, c, _lib.EPI_GELU_BF16)]
 tot_f = tot_t = 0.0
 for name, m, n, k, epi in shapes:
     a = torch.randn(m, k, device=dev).to(torch.bfloat16)

@@ -68,6 +68,12 @@ extern "C" int vsc_ln_residual_f32(const float *t, const float *g, const float *
     return launch_ln_residual(t, g, b, x_in, x_out, xb, rows, width, eps, (hipStream_t)stream);
 }
 
+extern "C" int vsc_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *g, const float *b,
+                                const float *x_in, float *x_out, uint16_t *xb, int64_t m, int32_t n, int32_t k,
+                                float eps, void *stream) {
+    return launch_gemm_ln_bf16(a, w, bias, g, b, x_in, x_out, xb, m, n, k, eps, (hipStream_t)stream);
+}
+
 extern "C" int vsc_merge_gather_bf16(const uint16_t *xb, uint16_t *out, int64_t frames, int32_t res, int32_t c,
                                      void *stream) {
     return launch_merge_gather(xb, out, frames, res, c, (hipStream_t)stream);

@@ -89,6 +89,10 @@ __device__ inline int xcd_remap(int bid, int nblk) {
 int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux,
                      void *out, int64_t m, int n, int k, int epilogue, int tokens,
                      hipStream_t stream);
+int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *gamma,
+                        const float *beta, const float *x_in, float *x_out, uint16_t *xb_out, int64_t m, int n,
+                        int k, float eps, hipStream_t stream);
+bool gemm_ln_supported(int n, int k);
 int launch_attention_bf16(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int heads,
                           hipStream_t stream);
 int launch_layernorm(const float *x, const float *g, const float *b, void *out, int64_t rows,

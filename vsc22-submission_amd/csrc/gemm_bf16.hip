@@ -531,7 +531,12 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
     // LDS-DMA between the MFMA rows of the C phase (-1 %), hybrid staging with A by LDS-DMA and W
     // through registers (-3 %).  Operand delivery sits at ~30 GB/s per CU whatever the path.
     static const char *force = getenv("VSC_GEMM_CFG");
-    const char cfg = force ? force[0] : (p.n > 128 ? 'A' : 'B');  // measured: A wins on every encoder shape
+    // measured: A wins on every ViT shape (K >= 768).  With K <= 512 (Swin) the K loop is only 4-16 stages long and
+    // the epilogue is a large share of a tile: the 4-wave tiles run two workgroups per CU, so one's write-out
+    // overlaps the other's K loop (stage-3 qkv 765 -> 875 TF/s); D when N is a multiple of 128 but not of 256.
+    char cfg = p.n > 128 ? 'A' : 'B';
+    if (p.k <= 512 && p.n > 128) cfg = (p.n % 256 != 0 && p.n % 128 == 0) ? 'D' : 'C';
+    if (force) cfg = force[0];
     switch (cfg) {
         case 'A': return launch_v2<EPI, 2, 4, 8, 4, 4>(p, stream);
         case 'B': return launch_v2<EPI, 4, 2, 4, 4, 4>(p, stream);
@@ -543,6 +548,213 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
 template <int EPI>
 int launch_t(const GemmArgs &p, int tiles_m, hipStream_t stream) {
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// gemm_ln: out rows are OWNED by one workgroup (BN == N), so the res-post-norm update of Swin-V2
+//   x_out = (x_in ? x_in : 0) + LayerNorm(A W^T + bias) * gamma + beta,   xb_out = bf16(x_out)
+// happens in the epilogue: no fp32 round trip of the GEMM result and no separate LayerNorm pass
+// (torch2scripts.py:297-300 `shortcut + norm1(attn)`, `x + norm2(mlp(x))`; :361-362 reduction+norm).
+// Same ring / two-phase two-group schedule as v2; wave tile 64 x 128 (4 x 8 fragments), block
+// WAVES_M*64 x WAVES_N*128: 512x128 (N=128), 256x256 (N=256), 128x512 (N=512).
+// Row statistics: per-lane partial sums -> xor-shuffles over the 4 lanes of a row -> per-wave
+// partials in LDS -> combined across the WAVES_N waves; two passes (mean, centred squares).
+struct GemmLnArgs {
+    const uint16_t *a, *w;
+    const float *bias, *gamma, *beta, *x_in;
+    float *x_out;
+    uint16_t *xb_out;
+    int64_t m;
+    int n, k;
+    float eps;
+};
+
+template <int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
+    constexpr int TM = 4, TN = 8, NW = 8, BK2 = 32;
+    constexpr int BM2 = WAVES_M * 64, BN2 = WAVES_N * 128;
+    constexpr int A_BYTES = BM2 * 64, W_BYTES = BN2 * 64, STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr int L = (BM2 + BN2) / (16 * NW);
+    constexpr int OUT_BYTES = 8 * 16384;  // write-out regions; the row-statistic partials sit behind them
+    static_assert(WAVES_M * WAVES_N == 8, "8 waves");
+    static_assert(STAGES * STAGE_BYTES <= OUT_BYTES + 8192, "ring fits the allocation");
+    extern __shared__ __attribute__((aligned(16))) char lds2[];
+    float *part = (float *)(lds2 + OUT_BYTES);             // [WAVES_N][BM2] row sums
+    float *part2 = part + WAVES_N * BM2;                   // [WAVES_N][BM2] centred squares
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int64_t m0 = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * BM2;
+    const int64_t a_last = p.m - 1, w_last = p.n - 1;
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.k / BK2;
+    const int group = wave >> 2;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) {
+        if (s < nk) {
+            char *st = lds2 + s * STAGE_BYTES;
+            stage_rows32<BM2, NW>(p.a, p.k, m0, a_last, s * BK2, st, wave, lane);
+            stage_rows32<BN2, NW>(p.w, p.k, 0, w_last, s * BK2, st + A_BYTES, wave, lane);
+        }
+    }
+    {
+        const int issued = nk < STAGES - 1 ? nk : STAGES - 1;
+        wait_tiles<L, STAGES>(issued - 1);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (group == 1) __builtin_amdgcn_s_barrier();  // stagger
+    const int fr = lane & 15, fq = lane >> 4;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + STAGES - 1 < nk) {
+            int ns = cur + STAGES - 1;
+            ns = ns >= STAGES ? ns - STAGES : ns;
+            char *st = lds2 + ns * STAGE_BYTES;
+            stage_rows32<BM2, NW>(p.a, p.k, m0, a_last, (kt + STAGES - 1) * BK2, st, wave, lane);
+            stage_rows32<BN2, NW>(p.w, p.k, 0, w_last, (kt + STAGES - 1) * BK2, st + A_BYTES, wave, lane);
+        }
+        const char *at = lds2 + cur * STAGE_BYTES;
+        const char *wt = at + A_BYTES;
+        bf16x8_t wf[TN], af[TM];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[j] = lds_frag32(wt, wn * 128 + j * 16 + fr, fq);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = lds_frag32(at, wm * 64 + i * 16 + fr, fq);
+        {
+            int allowed = nk - 2 - kt;
+            allowed = allowed > STAGES - 2 ? STAGES - 2 : (allowed < 0 ? 0 : allowed);
+            wait_tiles<L, STAGES>(allowed);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wf[j]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[i]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+    }
+    if (group == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- bias, then row statistics over the full N = BN2 columns
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = wn * 128 + j * 16 + fq * 4;
+        if (p.bias) {
+            const f32x4_t bz = *(const f32x4_t *)(p.bias + n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] += bz;
+        }
+    }
+    float mean[TM], rstd[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        if (fq == 0) part[wn * BM2 + wm * 64 + i * 16 + fr] = sm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float sm = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_N; ++w) sm += part[w * BM2 + wm * 64 + i * 16 + fr];
+        mean[i] = sm / (float)BN2;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[i][j][r] - mean[i];
+                sq += d * d;
+            }
+        sq += __shfl_xor(sq, 16, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (fq == 0) part2[wn * BM2 + wm * 64 + i * 16 + fr] = sq;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float sq = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES_N; ++w) sq += part2[w * BM2 + wm * 64 + i * 16 + fr];
+        rstd[i] = rsqrtf(sq / (float)BN2 + p.eps);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = wn * 128 + j * 16 + fq * 4;
+        const f32x4_t gm = *(const f32x4_t *)(p.gamma + n), bt = *(const f32x4_t *)(p.beta + n);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] - mean[i]) * rstd[i] * gm[r] + bt[r];
+    }
+    // ---- write-out through LDS, one 64-column half at a time (64 rows x 64 cols fp32 = 16 KiB per wave)
+    char *reg = lds2 + wave * 16384;
+    const int c = lane & 15;
+#pragma unroll
+    for (int hj = 0; hj < 2; ++hj) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = i * 16 + fr, chunk = 4 * jj + fq;
+                *(f32x4_t *)(reg + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][hj * 4 + jj];
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int n = wn * 128 + hj * 64 + c * 4;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + (lane >> 4);
+            f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ (row & 15)) << 4));
+            const int64_t m = m0 + wm * 64 + row;
+            if (m < p.m) {
+                if (p.x_in) v += *(const f32x4_t *)(p.x_in + m * p.n + n);
+                *(f32x4_t *)(p.x_out + m * p.n + n) = v;
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                *(uint2 *)(p.xb_out + m * p.n + n) = pk;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int WAVES_M, int WAVES_N, int STAGES>
+int launch_ln_t(const GemmLnArgs &p, hipStream_t stream) {
+    constexpr int smem = 8 * 16384 + 8192;
+    auto kern = gemm_ln_kernel<WAVES_M, WAVES_N, STAGES>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int64_t blocks = (p.m + WAVES_M * 64 - 1) / (WAVES_M * 64);
+    VSC_REQUIRE(blocks < (1ll << 31), "gemm_ln: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), smem, stream, p);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }
@@ -597,3 +809,20 @@ int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, co
     }
     return VSC_OK;
 }
+
+int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *gamma,
+                        const float *beta, const float *x_in, float *x_out, uint16_t *xb_out, int64_t m, int n,
+                        int k, float eps, hipStream_t stream) {
+    VSC_REQUIRE(a && w && gamma && beta && x_out && xb_out, "gemm_ln: null operand");
+    VSC_REQUIRE(m > 0 && k > 0 && k % 32 == 0, "gemm_ln: m=%lld k=%d (k must be a multiple of 32)", (long long)m, k);
+    GemmLnArgs p{a, w, bias, gamma, beta, x_in, x_out, xb_out, m, n, k, eps};
+    switch (n) {
+        case 128: return launch_ln_t<8, 1, 3>(p, stream);
+        case 256: return launch_ln_t<4, 2, 4>(p, stream);
+        case 512: return launch_ln_t<2, 4, 3>(p, stream);
+        default: VSC_REQUIRE(false, "gemm_ln: N=%d unsupported (row-owning tiles exist for 128, 256, 512)", n);
+    }
+    return VSC_OK;
+}
+
+bool gemm_ln_supported(int n, int k) { return (n == 128 || n == 256 || n == 512) && k % 32 == 0; }

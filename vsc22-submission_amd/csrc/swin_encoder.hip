@@ -286,6 +286,18 @@ extern "C" int vsc_swin_finalize(vsc_swin *e) {
 
 extern "C" int64_t vsc_swin_workspace_bytes(const vsc_swin *e) { return e ? e->ws_bytes : 0; }
 
+// x_out = (x_in ? x_in : 0) + LayerNorm(A W^T + bias): one row-owning GEMM when a tile can hold the whole row
+// (widths 128/256/512), otherwise GEMM to fp32 scratch + the row kernel (width 1024: the last stage).
+static int gemm_ln(vsc_swin *e, const uint16_t *a, const uint16_t *w, const float *bias, const float *g, const float *b,
+                   const float *x_in, int64_t m, int n, int k, hipStream_t st) {
+    static const bool split = getenv("VSC_SWIN_SPLIT_LN") != nullptr;
+    if (!split && gemm_ln_supported(n, k))
+        return launch_gemm_ln_bf16(a, w, bias, g, b, x_in, e->x, e->xb, m, n, k, e->cfg.ln_eps, st);
+    int rc = launch_gemm_bf16(a, w, bias, nullptr, e->t, m, n, k, VSC_EPI_F32, 0, st);
+    if (rc) return rc;
+    return launch_ln_residual(e->t, g, b, x_in, e->x, e->xb, m, n, e->cfg.ln_eps, st);
+}
+
 extern "C" int vsc_swin_forward_debug(vsc_swin *e, const float *frames, int64_t n, float *desc, float *tokens_out,
                                       void *stream_) {
     VSC_REQUIRE(e && frames && desc && n >= 0, "swin forward: bad argument");
@@ -304,8 +316,7 @@ extern "C" int vsc_swin_forward_debug(vsc_swin *e, const float *frames, int64_t 
         int64_t M = B * e->res(0) * e->res(0);
         TRY(launch_patchify(frames + off * frame_elems, e->patches, B, c.channels, c.image_size, c.patch_size,
                             e->kpad, st));
-        TRY(launch_gemm_bf16(e->patches, e->pe_w, e->pe_b, nullptr, e->t, M, c.embed_dim, e->kpad, VSC_EPI_F32, 0, st));
-        TRY(launch_ln_residual(e->t, e->pe_g, e->pe_beta, nullptr, e->x, e->xb, M, c.embed_dim, c.ln_eps, st));
+        TRY(gemm_ln(e, e->patches, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, nullptr, M, c.embed_dim, e->kpad, st));
         for (int s = 0; s < c.stages; ++s) {
             const int C = e->dim(s), R = e->res(s), W = e->window(s), H = c.heads[s];
             M = B * R * R;
@@ -313,18 +324,14 @@ extern "C" int vsc_swin_forward_debug(vsc_swin *e, const float *frames, int64_t 
                 const SwinBlockW &K = e->stages[s].blocks[b];
                 TRY(launch_gemm_bf16(e->xb, K.qkv_w, K.qkv_b, nullptr, e->qkv, M, 3 * C, C, VSC_EPI_BF16, 0, st));
                 TRY(launch_window_attention(e->qkv, e->att, K.bias, K.scale, (int)B, R, W, e->shift(s, b), H, st));
-                TRY(launch_gemm_bf16(e->att, K.proj_w, K.proj_b, nullptr, e->t, M, C, C, VSC_EPI_F32, 0, st));
-                TRY(launch_ln_residual(e->t, K.n1_g, K.n1_b, e->x, e->x, e->xb, M, C, c.ln_eps, st));
+                TRY(gemm_ln(e, e->att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, e->x, M, C, C, st));
                 TRY(launch_gemm_bf16(e->xb, K.fc1_w, K.fc1_b, nullptr, e->h, M, 4 * C, C, VSC_EPI_GELU_BF16, 0, st));
-                TRY(launch_gemm_bf16(e->h, K.fc2_w, K.fc2_b, nullptr, e->t, M, C, 4 * C, VSC_EPI_F32, 0, st));
-                TRY(launch_ln_residual(e->t, K.n2_g, K.n2_b, e->x, e->x, e->xb, M, C, c.ln_eps, st));
+                TRY(gemm_ln(e, e->h, K.fc2_w, K.fc2_b, K.n2_g, K.n2_b, e->x, M, C, 4 * C, st));
             }
             if (s + 1 < c.stages) {
                 TRY(launch_merge_gather(e->xb, e->merged, B, R, C, st));
-                TRY(launch_gemm_bf16(e->merged, e->stages[s].red_w, nullptr, nullptr, e->t, M / 4, 2 * C, 4 * C,
-                                     VSC_EPI_F32, 0, st));
-                TRY(launch_ln_residual(e->t, e->stages[s].dn_g, e->stages[s].dn_b, nullptr, e->x, e->xb, M / 4, 2 * C,
-                                       c.ln_eps, st));
+                TRY(gemm_ln(e, e->merged, e->stages[s].red_w, nullptr, e->stages[s].dn_g, e->stages[s].dn_b, nullptr,
+                            M / 4, 2 * C, 4 * C, st));
             }
         }
         TRY(launch_ln_pool(e->x, e->norm_g, e->norm_b, e->pooled, tokens_out ? tokens_out + off * TL * CL : nullptr, B,

@@ -69,6 +69,8 @@ SIGNATURES = {
                                             c_int32, c_int32, c_void_p]),
     "vsc_ln_residual_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                       c_float, c_void_p]),
+    "vsc_gemm_ln_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int64, c_int32, c_int32, c_float, c_void_p]),
     "vsc_merge_gather_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "vsc_knn_ip_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int64,
                                  c_void_p, c_void_p, c_void_p]),

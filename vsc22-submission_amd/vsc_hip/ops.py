@@ -148,6 +148,23 @@ def ln_residual(t, gamma, beta, eps: float, x_in=None):
     return x, xb
 
 
+def gemm_ln_bf16(a, w, bias, gamma, beta, eps: float, x_in=None):
+    """-> (x fp32, xb bf16) with x = (x_in or 0) + LayerNorm(a @ w.T + bias); w is [n, k], n in {128, 256, 512}."""
+    lib = _lib.require_device()
+    a, w = _dev(a, torch.bfloat16), _dev(w, torch.bfloat16)
+    gamma, beta = _dev(gamma, torch.float32), _dev(beta, torch.float32)
+    bias = None if bias is None else _dev(bias, torch.float32)
+    x_in = None if x_in is None else _dev(x_in, torch.float32)
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k
+    x = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    xb = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    check(lib.vsc_gemm_ln_bf16(ptr(a), ptr(w), ptr(bias), ptr(gamma), ptr(beta), ptr(x_in), ptr(x), ptr(xb), m, n, k,
+                               eps, current_stream()))
+    return x, xb
+
+
 def merge_gather_bf16(xb, frames: int, res: int):
     lib = _lib.require_device()
     xb = _dev(xb, torch.bfloat16)
