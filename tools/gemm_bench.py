@@ -10,7 +10,8 @@ import torch
 from vsc_hip import _lib, ops
 
 SWIN = len(sys.argv) > 1 and sys.argv[1] == "swin"
-B = int(sys.argv[2 if SWIN else 1]) if len(sys.argv) > (2 if SWIN else 1) else 256
+CUSTOM = len(sys.argv) > 4 and sys.argv[1] == "shape"
+B = 256 if CUSTOM else (int(sys.argv[2 if SWIN else 1]) if len(sys.argv) > (2 if SWIN else 1) else 256)
 M = B * 197
 dev = torch.device("cuda:0")
 shapes = [("qkv", M, 2304, 768, _lib.EPI_BF16), ("proj", M, 768, 768, _lib.EPI_RESADD_F32),
@@ -18,6 +19,9 @@ shapes = [("qkv", M, 2304, 768, _lib.EPI_BF16), ("proj", M, 768, 768, _lib.EPI_R
           ("patch", B * 196, 768, 768, _lib.EPI_BF16),
           ("fc1ng", M, 3072, 768, _lib.EPI_BF16), ("fc2nr", M, 768, 3072, _lib.EPI_BF16),
           ("sq4k", 4096, 4096, 4096, _lib.EPI_BF16), ("sq8k", 8192, 8192, 8192, _lib.EPI_BF16)]
+if len(sys.argv) > 4 and sys.argv[1] == "shape":  # python tools/gemm_bench.py shape M N K
+    shapes = [("custom", int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), _lib.EPI_BF16)]
+    SWIN = False
 if SWIN:  # Swin-V2-B/256 stages 1-3 at batch B: (tokens, width) = (B*4096, 128), (B*1024, 256), (B*256, 512)
     shapes = []
     for st, (t, c) in enumerate([(4096, 128), (1024, 256), (256, 512)], 1):

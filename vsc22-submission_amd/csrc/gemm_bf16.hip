@@ -22,6 +22,8 @@
 //     range of tiles, N fastest, so an A row-panel is fetched into one L2 only.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -68,18 +70,18 @@ __device__ __forceinline__ bf16x8_t lds_frag(const char *tile, int row, int chun
 // exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16
 // rounding of the stored result): one v_rcp_f32 + one v_exp_f32 instead of libm's erff.
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);  // v_rcp_f32 (1 ulp), not the IEEE divide sequence
-    float poly = 1.061405429f;
-    poly = poly * t - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));  // v_rcp_f32 (1 ulp)
+    float poly = 0.5f * 1.061405429f;  // 0.5 folded into the A&S coefficients
+    poly = fmaf(poly, t, 0.5f * -1.453152027f);
+    poly = fmaf(poly, t, 0.5f * 1.421413741f);
+    poly = fmaf(poly, t, 0.5f * -0.284496736f);
+    poly = fmaf(poly, t, 0.5f * 0.254829592f);
     // exp(-z^2) = exp2(-(x^2/2) * log2 e): one multiply feeding v_exp_f32
     const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
-    const float half_erfc = 0.5f * poly * t * e;      // 0.5 * (1 - erf(z)), z >= 0
-    // Phi(x) = 0.5 (1 + erf(x / sqrt 2)) = 1 - half_erfc (x > 0) | half_erfc (x <= 0)
-    return x * (x > 0.f ? 1.0f - half_erfc : half_erfc);
+    const float half_erfc = poly * t * e;  // 0.5 * (1 - erf(|x| / sqrt 2))
+    // x * Phi(x) with Phi = 1 - half_erfc (x > 0) | half_erfc (x <= 0)  ==  max(x, 0) - |x| * half_erfc
+    return fmaf(-ax, half_erfc, fmaxf(x, 0.f));
 }
 __device__ __forceinline__ float quick_gelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.45546696f));  // 1.702 * log2 e

@@ -2,10 +2,13 @@
 //   window_attention_kernel  windowed cosine multi-head attention, head_dim 32
 //   ln_residual_kernel       x (+)= LayerNorm(t) (res-post-norm) + bf16 shadow of x for the next GEMM
 //   merge_gather_kernel      PatchMerging's 2x2 gather (x0|x1|x2|x3) on the bf16 shadow
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int HD = 32;  // head dim of every Swin-V2 stage (C / heads)
 
 // ------------------------------------------------------------------------------------------
@@ -24,7 +27,7 @@ constexpr int HD = 32;  // head dim of every Swin-V2 stage (C / heads)
 //     so the head's compact (2w-1)^2 table (3.8 KiB) sits in LDS and is gathered with ds_read_b32.
 //   * P (bf16) is directly the B operand of the PV MFMA (k-slot permutation as attention.hip).
 template <int NT>  // 16-key tiles per window: 4 (8x8 window) or 16 (16x16 window)
-__global__ __launch_bounds__(NT * 32, 2) void window_attention_kernel(
+__global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
     const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, const float *__restrict__ bias,
     const float *__restrict__ scale, int res, int ws, int shift, int heads) {
     constexpr int N = NT * 16, NWAVES = NT / 2, NTHREADS = NWAVES * 64;
@@ -126,76 +129,97 @@ __global__ __launch_bounds__(NT * 32, 2) void window_attention_kernel(
     const float LOG2E = 1.44269504088896340736f;
     const float sc = scale[head] * LOG2E;
 
+    // Only windows in the last window row / column of a shifted layer hold more than one mask region
+    // (torch2scripts.py:236-254): every other workgroup runs the body without the mask compares/selects
+    // (3 of the ~15 VALU instructions per score; the kernel is VALU-bound).
+    const bool need_mask = shift > 0 && (wh == nwx - 1 || wwx == nwx - 1);
+    auto rows = [&](auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        const int q = (wave * 2 + qi) * 16 + fr;
-        const int rq = region[q];
-        // table index of (query q, key j) = tq - (yj * SIDE + xj),  tq = (yq + WS-1) * SIDE + xq + WS-1
-        const int tq = (q / WS + WS - 1) * SIDE + (q % WS) + WS - 1;
-        f32x4_t s[NT];
-        float mx = -INFINITY;
+        for (int qi = 0; qi < 2; ++qi) {
+            const int q = (wave * 2 + qi) * 16 + fr;
+            const int rq = region[q];
+            // table index of (query q, key j) = tq - (yj * SIDE + xj),  tq = (yq + WS-1) * SIDE + xq + WS-1
+            const int tq = (q / WS + WS - 1) * SIDE + (q % WS) + WS - 1;
+            f32x2_t s[NT][2];
+            float mx = -INFINITY;
+            const f32x2_t sc2 = (f32x2_t){sc, sc};
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int krow = t * 16 + fr;
-            const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
-            f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi], z, 0, 0, 0);
-            const uint32_t rk = *(const uint32_t *)(region + t * 16 + g * 4);
+            for (int t = 0; t < NT; ++t) {
+                const int krow = t * 16 + fr;
+                const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
+                f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi], z, 0, 0, 0);
+                float tb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = t * 16 + g * 4 + r;
-                float l = fmaf(z[r], sc, tbl[tq - ((j / WS) * SIDE + (j % WS))]);
-                if (shift > 0 && (int)((rk >> (8 * r)) & 0xff) != rq) l -= 100.0f * LOG2E;
-                s[t][r] = l;
-                mx = fmaxf(mx, l);
+                for (int r = 0; r < 4; ++r) {
+                    const int j = t * 16 + g * 4 + r;
+                    tb[r] = tbl[tq - ((j / WS) * SIDE + (j % WS))];
+                }
+                if (MASKED) {
+                    const uint32_t rk = *(const uint32_t *)(region + t * 16 + g * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if ((int)((rk >> (8 * r)) & 0xff) != rq) tb[r] -= 100.0f * LOG2E;
+                }
+                s[t][0] = (f32x2_t){z[0], z[1]} * sc2 + (f32x2_t){tb[0], tb[1]};  // v_pk_fma_f32
+                s[t][1] = (f32x2_t){z[2], z[3]} * sc2 + (f32x2_t){tb[2], tb[3]};
+                mx = fmaxf(fmaxf(mx, s[t][0][0]), s[t][0][1]);                    // v_max3_f32
+                mx = fmaxf(fmaxf(mx, s[t][1][0]), s[t][1][1]);
+                if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-        bf16x8_t pb[NT / 2];
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const f32x2_t nmx = (f32x2_t){-mx, -mx};
+            f32x2_t sum2 = (f32x2_t){0.f, 0.f};
+            bf16x8_t pb[NT / 2];
 #pragma unroll
-        for (int u = 0; u < NT / 2; ++u) {
-            float e[8];
+            for (int u = 0; u < NT / 2; ++u) {
+                f32x2_t e[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                e[r] = __builtin_amdgcn_exp2f(s[2 * u][r] - mx);
-                e[4 + r] = __builtin_amdgcn_exp2f(s[2 * u + 1][r] - mx);
+                for (int h = 0; h < 4; ++h) {
+                    const f32x2_t d = s[2 * u + (h >> 1)][h & 1] + nmx;  // v_pk_add_f32
+                    e[h] = (f32x2_t){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                }
+                sum2 += (e[0] + e[1]) + (e[2] + e[3]);
+                union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) pk.w[h] = pack_bf16x2(e[h][0], e[h][1]);
+                pb[u] = pk.v;
             }
-            sum += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
-            union { uint32_t w[4]; bf16x8_t v; } pk;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pk.w[r] = pack_bf16x2(e[2 * r], e[2 * r + 1]);
-            pb[u] = pk.v;
-        }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = __builtin_amdgcn_rcpf(sum);
+            float sum = sum2[0] + sum2[1];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = __builtin_amdgcn_rcpf(sum);
 
-        f32x4_t o[2];
-        o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            f32x4_t o[2];
+            o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < NT / 2; ++u) {
+            for (int u = 0; u < NT / 2; ++u) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const char *vrow = vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 4 * g) * 2;
+                    union { uint2 h[2]; bf16x8_t v; } vf;
+                    vf.h[0] = *(const uint2 *)(vrow);
+                    vf.h[1] = *(const uint2 *)(vrow + 32);
+                    o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
+                }
+                if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            uint16_t *orow = out + ((int64_t)frame * res * res + qrow[qi]) * C + head * HD + g * 4;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
-                const char *vrow = vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 4 * g) * 2;
-                union { uint2 h[2]; bf16x8_t v; } vf;
-                vf.h[0] = *(const uint2 *)(vrow);
-                vf.h[1] = *(const uint2 *)(vrow + 32);
-                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
+                uint2 pk;
+                pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
+                pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
+                *(uint2 *)(orow + ct * 16) = pk;
             }
-            if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
-        uint16_t *orow = out + ((int64_t)frame * res * res + qrow[qi]) * C + head * HD + g * 4;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            uint2 pk;
-            pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
-            pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
-            *(uint2 *)(orow + ct * 16) = pk;
-        }
-    }
+    };
+    if (need_mask)
+        rows(std::true_type{});
+    else
+        rows(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------
