@@ -159,6 +159,18 @@ int vsc_range_search_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, 
                             float *out_scores_dev, int64_t *out_ids_dev, int64_t capacity,
                             int64_t *total_out, void *stream);
 
+/* Per-candidate-pair frame similarity matrices -- the temporal alignment input of the matching track
+ * (VSC22-Matching-Track-1st/infer/src/utils.py:29-51,66: np.matmul(qfeat, rfeat.T) per candidate).
+ * q_dev [nq, d], r_dev [nr, d]: row banks (all query / reference videos' frames, concatenated).
+ * pairs_host [n_pairs][4] = {q_row0, q_rows, r_row0, r_rows} (HOST memory).  Writes out_offsets_host
+ * [n_pairs + 1] (element offsets; HOST memory) and out_dev[out_offsets[p] + i * r_rows + j] =
+ * <q[q_row0 + i], r[r_row0 + j]> as the ascending-k fp32 fma chain of vsc_knn_ip_f32, so a matrix equals any
+ * slice of a larger product bit for bit.  capacity = floats available at out_dev (>= sum q_rows * r_rows;
+ * call with out_dev = NULL, capacity = 0 is an error unless the total is 0). */
+int vsc_pair_similarity_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d,
+                            const int64_t *pairs_host, int64_t n_pairs, int64_t *out_offsets_host,
+                            float *out_dev, int64_t capacity, void *stream);
+
 /* sklearn.preprocessing.normalize(x) in place (l2, axis=1; zero rows untouched):
  * infer/extract_query_feats.py:178, infer/vsc/baseline/score_normalization.py:84-88. */
 int vsc_l2_normalize_f32(float *x_dev, int64_t n, int32_t d, void *stream);

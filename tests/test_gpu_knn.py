@@ -227,3 +227,20 @@ def test_query_postprocess_on_device(dev):
     assert np.array_equal(S.view(np.uint32), knn_oracle.ip_matrix(knn_oracle.l2_normalize(frames), knn_oracle.l2_normalize(frames)).view(np.uint32)) or \
         np.allclose(S, knn_oracle.ip_matrix(knn_oracle.l2_normalize(frames), knn_oracle.l2_normalize(frames)), atol=2e-6)
     assert len(keep) == 40 and len(set(keep)) == 40
+
+
+def test_hip_pca_on_device(dev):
+    """PCA apply (2048 -> 512 in the reference) through vsc_pair_similarity_f32 vs float64."""
+    from src.query_postprocess import HipPCA
+
+    class Fitted:
+        mean_ = synth.normalish(31, (256,)) * 0.1
+        components_ = synth.normalish(32, (64, 256)) / 16.0
+        whiten = True
+        explained_variance_ = np.linspace(2.0, 0.1, 64)
+
+    x = synth.normalish(33, (130, 256))
+    got = HipPCA(Fitted).transform(x)
+    want = ((x.astype(np.float64) - Fitted.mean_) @ Fitted.components_.astype(np.float64).T) / np.sqrt(Fitted.explained_variance_)
+    assert got.shape == (130, 64) and got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)

@@ -196,6 +196,21 @@ class _NumpyOps:
     def self_similarity(x):
         return np.matmul(x, x.T)
 
+    @staticmethod
+    def similarity(a, b):
+        return np.matmul(a, b.T)
+
+
+def test_hip_pca_mirrors_sklearn_transform():
+    """HipPCA.transform == sklearn PCA.transform (plain and whitened) on the fitted attributes the reference pickles."""
+    from sklearn.decomposition import PCA
+    from src.query_postprocess import HipPCA
+    x = synth.normalish(21, (200, 48)) * np.linspace(0.2, 3.0, 48, dtype=np.float32)
+    for whiten in (False, True):
+        fitted = PCA(n_components=16, whiten=whiten, random_state=0).fit(x)
+        got = HipPCA(fitted, ops=_NumpyOps).transform(x[:50])
+        np.testing.assert_allclose(got, fitted.transform(x[:50]), rtol=1e-4, atol=1e-5)
+
 
 def test_query_postprocess_matches_reference_statement():
     """src/query_postprocess.py against a literal numpy restatement of extract_query_feats.py:176-228."""

@@ -29,6 +29,8 @@
 //     strict compare is exact.  Expected appends per query ~ k (1 + ln(n/k)).
 #include <float.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -502,12 +504,51 @@ __global__ __launch_bounds__(1024) void range_scan_kernel(long long *counts, int
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Per-candidate-pair similarity matrices: the temporal alignment input of the matching track
+// (VSC22-Matching-Track-1st/infer/src/utils.py:29-51,66 `np.matmul(qfeat, rfeat.T)` for every
+// (query video, reference video) candidate).  One workgroup per 128 x 128 tile of one pair's
+// [q_rows, r_rows] matrix; the tile table (pair, tile row, tile col) is built on the host.
+// Scores come from the same score_tile as the top-k sweep: ascending-k fp32 fma chain, so a
+// matrix is bit-identical to oracle_ip_matrix and to any slice of a larger product.
+struct PairTile {
+    int64_t q0, q_end, r0, r_end;  // packed-bank rows of this tile's first query / ref, and the pair's row ends
+    int64_t out;                   // element offset of out[(q0 - q_first) * r_rows + (r0 - r_first)]
+    int64_t ld;                    // r_rows of the pair
+};
+
+__global__ __launch_bounds__(256, 2) void pair_sim_kernel(const float *__restrict__ qp, const float *__restrict__ rp,
+                                                          int dpad, const PairTile *__restrict__ tiles,
+                                                          float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_STAGE];
+    const PairTile t = tiles[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    f32x16_t acc[2][2];
+    int cur = 0;
+    score_tile(acc, rp, qp, t.r_end, t.q_end, dpad, t.r0, -1, t.q0, lds, wave, lane, cur, false);
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t qi = wn * 64 + b * 32 + l31;  // this lane's query row inside the tile
+        if (t.q0 + qi >= t.q_end) continue;
+        float *orow = out + t.out + qi * t.ld;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t ri = wm * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+                if (t.r0 + ri < t.r_end) orow[ri] = acc[a][b][reg];
+            }
+    }
+}
+
 // ---- grow-only device scratch, one per process (one process per GPU) ----------------------
 struct Scratch {
     void *ptr = nullptr;
     size_t bytes = 0;
 };
-Scratch g_scratch[5];
+Scratch g_scratch[6];
 
 int scratch_get(int slot, size_t bytes, void **out) {
     Scratch &s = g_scratch[slot];
@@ -641,5 +682,54 @@ extern "C" int vsc_range_search_ip_f32(const float *q_dev, int64_t nq, const flo
         hipLaunchKernelGGL(range_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
         VSC_CHECK_LAUNCH();
     }
+    return VSC_OK;
+}
+
+extern "C" int vsc_pair_similarity_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d,
+                                       const int64_t *pairs_host, int64_t n_pairs, int64_t *out_offsets_host,
+                                       float *out_dev, int64_t capacity, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VSC_REQUIRE(q_dev && r_dev && pairs_host && out_offsets_host, "pair_similarity: null pointer");
+    VSC_REQUIRE(nq > 0 && nr > 0 && n_pairs >= 0, "pair_similarity: empty bank (nq=%lld nr=%lld)", (long long)nq,
+                (long long)nr);
+    VSC_REQUIRE(d > 0 && d <= 4096, "pair_similarity: dimension %d unsupported", d);
+    const int dpad = (d + KS - 1) / KS * KS;
+    // tile table
+    static thread_local std::vector<PairTile> tiles;
+    tiles.clear();
+    int64_t total = 0;
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const int64_t q0 = pairs_host[4 * p], qn = pairs_host[4 * p + 1], r0 = pairs_host[4 * p + 2],
+                      rn = pairs_host[4 * p + 3];
+        VSC_REQUIRE(q0 >= 0 && qn >= 0 && q0 + qn <= nq && r0 >= 0 && rn >= 0 && r0 + rn <= nr,
+                    "pair_similarity: pair %lld = (%lld,%lld,%lld,%lld) outside the banks", (long long)p, (long long)q0,
+                    (long long)qn, (long long)r0, (long long)rn);
+        out_offsets_host[p] = total;
+        for (int64_t tq = 0; tq < qn; tq += TQ)
+            for (int64_t tr = 0; tr < rn; tr += TR)
+                tiles.push_back(PairTile{q0 + tq, q0 + qn, r0 + tr, r0 + rn, total + tq * rn + tr, rn});
+        total += qn * rn;
+    }
+    out_offsets_host[n_pairs] = total;
+    if (total == 0) return VSC_OK;
+    VSC_REQUIRE(out_dev && capacity >= total, "pair_similarity: output holds %lld floats, %lld needed", (long long)capacity,
+                (long long)total);
+    VSC_REQUIRE(tiles.size() < (1ull << 31), "pair_similarity: too many tiles");
+    void *qp, *rp, *tt;
+    int rc;
+    if ((rc = scratch_get(0, (size_t)nq * dpad * 4, &qp))) return rc;
+    if ((rc = scratch_get(1, (size_t)nr * dpad * 4, &rp))) return rc;
+    if ((rc = scratch_get(5, tiles.size() * sizeof(PairTile), &tt))) return rc;
+    VSC_CHECK_HIP(hipMemcpyAsync(tt, tiles.data(), tiles.size() * sizeof(PairTile), hipMemcpyHostToDevice, stream));
+    VSC_CHECK_HIP(hipStreamSynchronize(stream));  // `tiles` is reused by the next call
+    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nq * (dpad / 4))), dim3(256), 0, stream, q_dev, (float *)qp, nq,
+                       d, dpad);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nr * (dpad / 4))), dim3(256), 0, stream, r_dev, (float *)rp, nr,
+                       d, dpad);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pair_sim_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, stream, (const float *)qp,
+                       (const float *)rp, dpad, (const PairTile *)tt, out_dev);
+    VSC_CHECK_LAUNCH();
     return VSC_OK;
 }

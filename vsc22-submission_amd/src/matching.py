@@ -1,0 +1,145 @@
+"""Matching-track candidate features: per-pair frame x frame similarity matrices on the HIP path.
+
+Mirrors VSC22-Matching-Track-1st/infer/src/utils.py (same function names -- including the reference's
+spellings -- arguments and return structure) for the part of `infer_matching.py` that sits between the
+candidate search and the classifier / refinement networks:
+
+  * ``generate_candidates_classfiy_feature``  utils.py:21-51   similarity maps fed to the match classifier
+  * ``generate_matching_feature``             utils.py:54-77   (query view, reference) feature pairs for refinement
+  * ``calclualte_low_var_dim``                utils.py:7-10
+  * ``transform_features``                    utils.py:12-16
+
+The reference runs one ``np.matmul(qfeat, rfeat.T)`` per candidate on the host (twice: once to pick the query
+view, once for the map).  Here every candidate of a call goes through ONE ``vsc_pair_similarity_f32`` launch
+over concatenated frame banks; each score is an independent ascending-k fp32 chain, so the map of the chosen
+view is a row slice of the full product -- bit for bit -- and nothing is multiplied twice.
+
+Not on this path (CPU post-processing of the networks' outputs, cv2 / sklearn in the reference):
+``generate_matching_result`` (connected components + RANSAC, utils.py:80-116).
+"""
+import dataclasses
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+TOP_ROWS = 10  # rows whose maxima are averaged to score a query view (utils.py:41)
+
+
+def calclualte_low_var_dim(score_norm_refs) -> int:
+    """Index of the descriptor dimension with the smallest variance over all reference frames."""
+    sn_features = np.concatenate([ref.feature for ref in score_norm_refs], axis=0)
+    return int(sn_features.var(axis=0).argmin())
+
+
+def transform_features(features, transform: Callable[[np.ndarray], np.ndarray]):
+    return [dataclasses.replace(feature, feature=transform(feature.feature)) for feature in features]
+
+
+def _hip_pair_similarity(q_bank: np.ndarray, r_bank: np.ndarray, pairs: np.ndarray):
+    import torch
+
+    from vsc_hip import _lib, ops
+    _lib.require_device()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    flat, offsets = ops.pair_similarity(torch.from_numpy(q_bank).to(dev), torch.from_numpy(r_bank).to(dev), pairs)
+    return flat.cpu().numpy(), offsets
+
+
+class _Banks:
+    """Concatenated frame banks of the videos a candidate list touches + the pair table of the launch."""
+
+    def __init__(self, query: Dict[str, np.ndarray], ref: Dict[str, np.ndarray], candidates: Sequence[Tuple]):
+        self.q_rows: Dict[str, Tuple[int, int]] = {}
+        self.r_rows: Dict[str, Tuple[int, int]] = {}
+        q_parts, r_parts = [], []
+        nq = nr = 0
+        for qid, rid, _ in candidates:
+            if qid not in self.q_rows:
+                f = np.ascontiguousarray(query[qid], dtype=np.float32)
+                self.q_rows[qid] = (nq, len(f))
+                q_parts.append(f)
+                nq += len(f)
+            if rid not in self.r_rows:
+                f = np.ascontiguousarray(ref[rid], dtype=np.float32)
+                self.r_rows[rid] = (nr, len(f))
+                r_parts.append(f)
+                nr += len(f)
+        dim = q_parts[0].shape[1] if q_parts else 0
+        self.q_bank = np.concatenate(q_parts, axis=0) if q_parts else np.zeros((0, dim), np.float32)
+        self.r_bank = np.concatenate(r_parts, axis=0) if r_parts else np.zeros((0, dim), np.float32)
+        self.pairs = np.array([[*self.q_rows[qid], *self.r_rows[rid]] for qid, rid, _ in candidates],
+                              dtype=np.int64).reshape(-1, 4)
+
+
+def pair_similarity_matrices(query: Dict[str, np.ndarray], ref: Dict[str, np.ndarray], candidates: Sequence[Tuple],
+                             pair_similarity: Optional[Callable] = None) -> List[np.ndarray]:
+    """[q_frames, r_frames] similarity matrix of every (qid, rid, score) candidate, one launch for all of them.
+    ``pair_similarity(q_bank, r_bank, pairs) -> (flat, offsets)`` is a test seam; the default is the HIP path."""
+    if len(candidates) == 0:
+        return []
+    banks = _Banks(query, ref, candidates)
+    flat, off = (pair_similarity or _hip_pair_similarity)(banks.q_bank, banks.r_bank, banks.pairs)
+    return [flat[off[i]:off[i + 1]].reshape(int(banks.pairs[i, 1]), int(banks.pairs[i, 3]))
+            for i in range(len(candidates))]
+
+
+def _best_view(sim_mat: np.ndarray, num_data: int) -> int:
+    """Start row of the query view (block of ``num_data`` rows) whose ten best row maxima have the largest mean
+    (utils.py:35-44); the first such view on ties, as np.argmax."""
+    best, best_score = 0, None
+    for start in range(0, sim_mat.shape[0], num_data):
+        maxs = np.sort(sim_mat[start:start + num_data].max(1))
+        score = maxs[-TOP_ROWS:].mean()
+        if best_score is None or score > best_score:
+            best, best_score = start, score
+    return best
+
+
+def generate_candidates_classfiy_feature(query, ref, candidate_list, query_video_len_map, pair_similarity=None):
+    """-> (features, infos): per candidate the [q, r] map and, wrapped in a list as in the reference, its [r, q]
+    transpose; infos repeats [qid, rid, score] for both."""
+    mats = pair_similarity_matrices(query, ref, candidate_list, pair_similarity)
+    features, infos = [], []
+    for (qid, rid, score), sim_mat in zip(candidate_list, mats):
+        num_data = query_video_len_map[qid]
+        if num_data != sim_mat.shape[0]:
+            start = _best_view(sim_mat, num_data)
+            sim_mat = sim_mat[start:start + num_data]
+        features.append(np.ascontiguousarray(sim_mat))
+        infos.append([qid, rid, score])
+        features.append([np.ascontiguousarray(sim_mat.T)])
+        infos.append([qid, rid, score])
+    return features, infos
+
+
+def generate_matching_feature(query, ref, query_video_len_map, candidate_score_list, pair_similarity=None):
+    """-> [[qid, rid, qfeat (the selected view's rows), rfeat], ...]"""
+    mats = pair_similarity_matrices(query, ref, candidate_score_list, pair_similarity)
+    res_list = []
+    for (qid, rid, _), sim_mat in zip(candidate_score_list, mats):
+        num_data = query_video_len_map[qid]
+        qfeat = query[qid]
+        if num_data != len(qfeat):
+            start = _best_view(sim_mat, num_data)
+            qfeat = qfeat[start:start + num_data]
+        res_list.append([qid, rid, qfeat, ref[rid]])
+    return res_list
+
+
+class MatchClassifyDataset:
+    """Similarity maps cropped / zero-padded to ``resolution`` and repeated on 3 channels (src/dataset.py:103-124)."""
+
+    def __init__(self, features, infos, resolution=(160, 160)):
+        self.features, self.infos, self.resolution = features, infos, resolution
+
+    def __len__(self):
+        return len(self.features)
+
+    def __getitem__(self, item):
+        feature = self.features[item]
+        if isinstance(feature, list):
+            feature = feature[0]
+        h, w = min(feature.shape[0], self.resolution[0]), min(feature.shape[1], self.resolution[1])
+        canvas = np.zeros(self.resolution, dtype=np.float32)
+        canvas[:h, :w] = feature[:h, :w]
+        return np.stack([canvas] * 3), self.infos[item][0], self.infos[item][1]

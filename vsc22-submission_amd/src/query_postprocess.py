@@ -34,15 +34,41 @@ class HipOps:
 
     @staticmethod
     def self_similarity(x: np.ndarray) -> np.ndarray:
-        """x x^T in the fp32 fmaf-chain order of the search kernel (n <= 1024 frames per video)."""
+        """x x^T in the fp32 fma-chain order of the search kernel (one vsc_pair_similarity_f32 launch)."""
+        return HipOps.similarity(x, x)
+
+    @staticmethod
+    def similarity(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        """a b^T, [len(a), len(b)]"""
         import torch
         from vsc_hip import ops
-        t = torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda()
-        n = t.shape[0]
-        D, I = ops.knn_ip(t, t, n)
-        out = torch.empty((n, n), dtype=torch.float32, device=t.device)
-        out.scatter_(1, I, D)
-        return out.cpu().numpy()
+        ta = torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+        tb = ta if b is a else torch.from_numpy(np.ascontiguousarray(b, np.float32)).cuda()
+        flat, _ = ops.pair_similarity(ta, tb, np.array([[0, ta.shape[0], 0, tb.shape[0]]], dtype=np.int64))
+        return flat.view(ta.shape[0], tb.shape[0]).cpu().numpy()
+
+
+class HipPCA:
+    """``pca_model.transform`` (extract_query_feats.py:203, infer_matching.py:144) on the HIP path: built from the
+    fitted sklearn ``PCA`` the reference unpickles (``mean_``, ``components_``, ``whiten``,
+    ``explained_variance_``); transform(X) = (X - mean_) @ components_.T [/ sqrt(explained_variance_)]."""
+
+    def __init__(self, fitted, ops=HipOps):
+        self.mean_ = np.asarray(fitted.mean_, dtype=np.float32) if getattr(fitted, "mean_", None) is not None else None
+        self.components_ = np.ascontiguousarray(fitted.components_, dtype=np.float32)
+        self.scale_ = None
+        if getattr(fitted, "whiten", False):
+            self.scale_ = (1.0 / np.sqrt(np.asarray(fitted.explained_variance_, dtype=np.float64))).astype(np.float32)
+        self.ops = ops
+
+    def transform(self, x: np.ndarray) -> np.ndarray:
+        x = np.asarray(x, dtype=np.float32)
+        if self.mean_ is not None:
+            x = x - self.mean_
+        out = self.ops.similarity(x, self.components_)
+        return out * self.scale_ if self.scale_ is not None else out
+
+    __call__ = transform
 
 
 def select_frames(features: np.ndarray, ops=HipOps, frame_threshold: float = FRAME_THRESHOLD) -> List[int]:

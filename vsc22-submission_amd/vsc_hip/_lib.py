@@ -72,6 +72,8 @@ SIGNATURES = {
     "vsc_gemm_ln_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_int32, c_int32, c_float, c_void_p]),
     "vsc_merge_gather_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    "vsc_pair_similarity_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p,
+                                          c_void_p, c_int64, c_void_p]),
     "vsc_knn_ip_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int64,
                                  c_void_p, c_void_p, c_void_p]),
     "vsc_range_search_ip_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_float, c_int64,

@@ -122,6 +122,28 @@ def range_search_ip(q, r, radius: float, ref_id_offset: int = 0, capacity: int =
         capacity = int(total.value)
 
 
+def pair_similarity(q, r, pairs):
+    """Frame x frame similarity matrices of candidate (query video, reference video) pairs.
+    q [nq, d], r [nr, d]: frame banks; pairs: int64 [n, 4] rows (q_row0, q_rows, r_row0, r_rows) on the host.
+    -> (flat f32 device tensor, offsets int64 numpy [n + 1]); matrix p = flat[off[p]:off[p+1]].view(q_rows, r_rows)."""
+    import numpy as np
+    lib = _lib.require_device()
+    q, r = _dev(q, torch.float32), _dev(r, torch.float32)
+    assert q.dim() == 2 and r.dim() == 2 and q.shape[1] == r.shape[1], "query / reference dimension mismatch"
+    pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int64).reshape(-1, 4))
+    n = pairs.shape[0]
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    total = int((pairs[:, 1] * pairs[:, 3]).sum())
+    out = torch.empty(total, dtype=torch.float32, device=q.device)
+    if q.shape[0] == 0 or r.shape[0] == 0:
+        if total:
+            raise ValueError("pairs reference rows of an empty bank")
+        return out, offsets
+    check(lib.vsc_pair_similarity_f32(ptr(q), q.shape[0], ptr(r), r.shape[0], q.shape[1], pairs.ctypes.data, n,
+                                      offsets.ctypes.data, ptr(out) if total else None, total, current_stream()))
+    return out, offsets
+
+
 def window_attention_bf16(qkv, bias, scale, frames: int, res: int, window: int, shift: int, heads: int):
     """Swin-V2 windowed cosine attention (head_dim 32) on image-ordered tokens."""
     lib = _lib.require_device()
