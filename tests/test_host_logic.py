@@ -202,6 +202,7 @@ class _NumpyOps:
 
 
 def test_hip_pca_mirrors_sklearn_transform():
+    from src import synth
     """HipPCA.transform == sklearn PCA.transform (plain and whitened) on the fitted attributes the reference pickles."""
     from sklearn.decomposition import PCA
     from src.query_postprocess import HipPCA
