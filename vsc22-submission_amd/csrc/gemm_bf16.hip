@@ -531,7 +531,13 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
     // Tried and dropped: 64-k stages with full 128-B line fetches (+0.6 %),
     // a 5-deep ring (+0.4 %), register staging instead of LDS-DMA (0.47x, spills), issuing the
     // LDS-DMA between the MFMA rows of the C phase (-1 %), hybrid staging with A by LDS-DMA and W
-    // through registers (-3 %).  Operand delivery sits at ~30 GB/s per CU whatever the path.
+    // through registers (-3 %), an intra-wave software pipeline (A fragments refilled from the next stage right
+    // after their MFMA group, W fragments double-buffered, one barrier per K-step: equal with DMA, 0.79x with DMA
+    // off -- anything issued between back-to-back MFMAs costs more than the phase barriers it removes), a
+    // persistent workgroup per CU with a 3-stage ring and the write-out staged behind it so the next tile's first
+    // stages fly during the write-out (+-1 %: launch, fill and drain were already hidden; 3 stages are as fast
+    // as 4).  tools/micro/fill_bench.hip: LDS-DMA alone delivers 21.6 B/clk/CU with 64-B row pieces (34-40 with
+    // full 128-B lines), VGPR staging no more; the K loop is issue/phase-bound, not delivery-bound.
     static const char *force = getenv("VSC_GEMM_CFG");
     // measured: A wins on every ViT shape (K >= 768).  With K <= 512 (Swin) the K loop is only 4-16 stages long and
     // the epilogue is a large share of a tile: the 4-wave tiles run two workgroups per CU, so one's write-out
