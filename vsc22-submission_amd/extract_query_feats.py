@@ -1,0 +1,98 @@
+"""Query-descriptor extraction with the backbone ensemble (reference: infer/extract_query_feats.py).
+
+    python extract_query_feats.py --split test \
+        --models swinv2_base_256:swin_ref:ckpt/swinv2_v115.pth swinv2_base_256:swin_ref:ckpt/swinv2_v107.pth \
+                 swinv2_base_256:swin_ref:ckpt/swinv2_v106.pth vit_v68:timm_vit:ckpt/vit_v68.pth \
+        --pca_model ckpt/pca_model.pkl --zip_prefix ../data/jpg_zips --input_file ../data/meta/test/query_ids.txt \
+        --norm_refs outputs/train_refs.npz --output_dir outputs [--video_scores video_scores.csv]
+
+Outputs, as the reference: ``<output_dir>/<model name>/<split>_query.npz`` per backbone (:238-245) and
+``<output_dir>/<split>_query_sn.npz`` after query score normalisation (:247-252).  The video-score model is an
+opaque TorchScript checkpoint in the reference (clip tower + ``vsm`` head); its scores come in through
+``--video_scores`` (csv: video_id,score), every video passes when the file is not given."""
+from __future__ import annotations
+
+import argparse
+import csv
+import io
+import os
+import pickle
+from zipfile import ZipFile
+
+import numpy as np
+import torch
+
+from src.dataset import vit_transform
+from src.matching import calclualte_low_var_dim
+from src.model_zoo import load_encoder, parse_model_spec
+from src.query_pipeline import run_query_videos
+from src.query_postprocess import HipPCA, SCORE_THRESHOLD
+from vsc.baseline.score_normalization import query_score_normalize
+from vsc.metrics import Dataset
+from vsc.storage import load_features, store_features
+
+NK, BETA = 1, 1.2  # extract_query_feats.py:56-57
+
+
+def zip_videos(video_ids, zip_prefix, sizes):
+    """(video_id, {size: frames}, timestamps) per video; frames decoded once, resized per input size."""
+    from PIL import Image
+    transforms = {s: vit_transform(s, s) for s in sizes}
+    for vid in video_ids:
+        path = "%s/%s/%s.zip" % (zip_prefix, vid[-2:], vid)
+        if not os.path.exists(path):
+            continue
+        with ZipFile(path, "r") as z:
+            images = [Image.open(io.BytesIO(z.read(n))).convert("RGB") for n in sorted(z.namelist())]
+        yield vid, {s: torch.stack([t(im) for im in images]) for s, t in transforms.items()}, np.arange(len(images))
+
+
+def read_video_scores(path):
+    if not path:
+        return {}
+    with open(path, newline="", encoding="utf-8") as f:
+        rows = [r for r in csv.reader(f) if r and r[0] != "video_id"]
+    return {r[0]: float(r[1]) for r in rows}
+
+
+def main(args):
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    specs = [parse_model_spec(s) for s in args.models]
+    encoders = [load_encoder(arch, fmt, path, args.max_batch) for arch, fmt, path in specs]
+    with open(args.pca_model, "rb") as f:
+        pca = HipPCA(pickle.load(f))
+    with open(args.input_file, encoding="utf-8") as f:
+        vids = [x.strip() for x in f if x.strip()]
+    scores = read_video_scores(args.video_scores)
+    videos = zip_videos(vids, args.zip_prefix, sorted({size for _, size in encoders}))
+    finals, per_model = run_query_videos(videos, encoders, pca.transform, scores, device, score_threshold=args.score_threshold)
+    for i, (_, _, path) in enumerate(specs):
+        key = os.path.split(path)[-1].split(".")[0]
+        os.makedirs(os.path.join(args.output_dir, key), exist_ok=True)
+        store_features(os.path.join(args.output_dir, key, f"{args.split}_query.npz"), [sub[i] for sub in per_model])
+    if args.norm_refs:
+        norm_refs = load_features(args.norm_refs, Dataset.REFS)
+        all_scores = {f.video_id: scores.get(f.video_id, 1.0) for f in finals}
+        finals = query_score_normalize(finals, norm_refs, all_scores, args.score_threshold, calclualte_low_var_dim(norm_refs),
+                                       nk=NK, beta=BETA)
+    store_features(os.path.join(args.output_dir, f"{args.split}_query_sn.npz"), finals)
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--split", default="test")
+    ap.add_argument("--models", nargs="+", required=True, help="arch:weights_format:checkpoint_path, in concatenation order")
+    ap.add_argument("--pca_model", required=True, help="pickled sklearn PCA (mean_, components_, whiten, explained_variance_)")
+    ap.add_argument("--zip_prefix", default="")
+    ap.add_argument("--input_file", required=True, help="one query video id per line")
+    ap.add_argument("--norm_refs", default="", help="score-normalisation reference descriptors (.npz)")
+    ap.add_argument("--video_scores", default="", help="csv video_id,score from the video-score model")
+    ap.add_argument("--score_threshold", type=float, default=SCORE_THRESHOLD)
+    ap.add_argument("--output_dir", default="outputs")
+    ap.add_argument("--max_batch", type=int, default=256)
+    return ap
+
+
+if __name__ == "__main__":
+    main(build_parser().parse_args())

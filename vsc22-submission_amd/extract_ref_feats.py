@@ -17,19 +17,8 @@ import torch
 from src.dataset import ZipFrames, collate_fn, vit_transform
 from src.extractor import extract_vsc_feat
 from vsc.storage import load_features, store_features
+from src.model_zoo import WEIGHT_FORMATS, load_encoder
 from vsc_hip import distributed as vdist
-from vsc_hip import weights as W
-from vsc_hip.config import get_config
-from vsc_hip.encoder import HipEncoder
-
-LOADERS = {"hf_vit": W.from_hf_vit, "timm_vit": W.from_timm_vit, "clip": W.from_clip_visual}
-
-
-def load_encoder(args) -> HipEncoder:
-    cfg = get_config(args.arch)
-    state = torch.load(args.checkpoint_path, map_location="cpu")
-    state = state.get("state_dict", state) if isinstance(state, dict) else state.state_dict()
-    return HipEncoder(cfg, LOADERS[args.weights_format](state, cfg), max_batch=args.max_batch)
 
 
 def main(args):
@@ -41,12 +30,11 @@ def main(args):
     if distributed:
         dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
     rank, world_size = vdist.world()
-    model = load_encoder(args)
+    model, image_size = load_encoder(args.arch, args.weights_format, args.checkpoint_path, args.max_batch)
     with open(args.input_file, encoding="utf-8") as f:
         vids = [x.strip() for x in f if x.strip()]
     lo, hi = vdist.shard_bounds(len(vids), rank, world_size)
-    cfg = model.cfg
-    data = ZipFrames(vids[lo:hi], args.zip_prefix, vit_transform(cfg.image_size, cfg.image_size))
+    data = ZipFrames(vids[lo:hi], args.zip_prefix, vit_transform(image_size, image_size))
     loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, num_workers=4, collate_fn=collate_fn)
     ids, feats, stamps = extract_vsc_feat(model, loader, device)
     np.savez(f"{args.save_file}_{rank}.npz", video_ids=ids, features=feats, timestamps=stamps)
@@ -68,8 +56,8 @@ if __name__ == "__main__":
     ap.add_argument("--zip_prefix", default="")
     ap.add_argument("--input_file", default="test/test_reference.txt")
     ap.add_argument("--checkpoint_path", required=True)
-    ap.add_argument("--arch", default="vit_b16_224")
-    ap.add_argument("--weights_format", default="hf_vit", choices=sorted(LOADERS))
+    ap.add_argument("--arch", default="vit_b16_224", help="ViT preset (vsc_hip.config) or Swin-V2 preset (vsc_hip.swin_config)")
+    ap.add_argument("--weights_format", default="hf_vit", choices=WEIGHT_FORMATS)
     ap.add_argument("--batch_size", type=int, default=2, help="videos per loader batch")
     ap.add_argument("--max_batch", type=int, default=332, help="frames per encoder step")
     main(ap.parse_args())

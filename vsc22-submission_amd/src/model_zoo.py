@@ -1,0 +1,47 @@
+"""Checkpoint -> HIP encoder, shared by the extract_* entry points.
+
+A model is named ``arch:weights_format:checkpoint_path``: arch is a preset of vsc_hip.config (ViT family) or
+vsc_hip.swin_config (Swin-V2); weights_format says how the checkpoint's parameters are named."""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+
+from vsc_hip import weights as W
+from vsc_hip.config import PRESETS as VIT_PRESETS, get_config
+from vsc_hip.encoder import HipEncoder
+from vsc_hip.swin_config import SWIN_PRESETS, get_swin_config
+from vsc_hip.swin_encoder import SwinHipEncoder, from_reference_state
+
+VIT_LOADERS = {"hf_vit": W.from_hf_vit, "timm_vit": W.from_timm_vit, "clip": W.from_clip_visual}
+WEIGHT_FORMATS = sorted(VIT_LOADERS) + ["swin_ref"]
+
+
+def _state_dict(path: str) -> dict:
+    state = torch.load(path, map_location="cpu")
+    if isinstance(state, dict):
+        return state.get("state_dict", state)
+    return state.state_dict()
+
+
+def load_encoder(arch: str, weights_format: str, checkpoint_path: str, max_batch: int):
+    """-> (encoder, image_size).  Raises ValueError for an unknown arch / format pairing."""
+    if arch in SWIN_PRESETS:
+        if weights_format != "swin_ref":
+            raise ValueError(f"{arch} is a Swin-V2 preset: weights_format must be swin_ref, not {weights_format}")
+        cfg = get_swin_config(arch)
+        return SwinHipEncoder(cfg, from_reference_state(_state_dict(checkpoint_path)), max_batch=max_batch), cfg.image_size
+    if arch in VIT_PRESETS:
+        if weights_format not in VIT_LOADERS:
+            raise ValueError(f"{arch} is a ViT preset: weights_format must be one of {sorted(VIT_LOADERS)}")
+        cfg = get_config(arch)
+        return HipEncoder(cfg, VIT_LOADERS[weights_format](_state_dict(checkpoint_path), cfg), max_batch=max_batch), cfg.image_size
+    raise ValueError(f"unknown arch {arch!r}; ViT presets {sorted(VIT_PRESETS)}, Swin presets {sorted(SWIN_PRESETS)}")
+
+
+def parse_model_spec(spec: str) -> Tuple[str, str, str]:
+    parts = spec.split(":", 2)
+    if len(parts) != 3 or not all(parts):
+        raise ValueError(f"model spec {spec!r} is not arch:weights_format:checkpoint_path")
+    return parts[0], parts[1], parts[2]
