@@ -26,7 +26,9 @@ def _rand(seed, shape, std=1.0):
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (200, 132, 128), (1000, 768, 768),
-                                   (5043, 2304, 768), (37, 512, 3072), (1, 4, 64)])
+                                   (5043, 2304, 768), (37, 512, 3072), (1, 4, 64),
+                                   # the short-K tile choices of launch_v2_pick: D (N % 256 = 128), C, B (N <= 128), ragged M
+                                   (1500, 384, 128), (2049, 512, 256), (1300, 128, 512), (1025, 1032, 192)])
 def test_gemm_bf16_store(dev, m, n, k):
     from vsc_hip import ops, _lib
     a = _rand(1, (m, k)).to(torch.bfloat16)
@@ -52,9 +54,9 @@ def test_gemm_is_not_transposed(dev):
 
 
 @pytest.mark.parametrize("epi", ["gelu", "qgelu"])
-def test_gemm_activation_epilogues(dev, epi):
+@pytest.mark.parametrize("m,n,k", [(300, 512, 128), (1333, 512, 128), (1100, 3072, 768)])
+def test_gemm_activation_epilogues(dev, epi, m, n, k):
     from vsc_hip import ops, _lib
-    m, n, k = 300, 512, 128
     a = _rand(4, (m, k)).to(torch.bfloat16)
     w = _rand(5, (n, k), 0.1).to(torch.bfloat16)
     b = _rand(6, (n,), 0.1)
@@ -67,9 +69,9 @@ def test_gemm_activation_epilogues(dev, epi):
     torch.testing.assert_close(out, ref, rtol=2 ** -7, atol=2e-3)
 
 
-def test_gemm_residual_epilogue_in_place(dev):
+@pytest.mark.parametrize("m,n,k", [(517, 768, 3072), (1300, 768, 768), (1100, 512, 256)])
+def test_gemm_residual_epilogue_in_place(dev, m, n, k):
     from vsc_hip import ops, _lib
-    m, n, k = 517, 768, 3072
     a = _rand(7, (m, k)).to(torch.bfloat16)
     w = _rand(8, (n, k), 0.02).to(torch.bfloat16)
     b = _rand(9, (n,), 0.1)
