@@ -34,8 +34,50 @@ for _p in (ROOT, os.path.join(ROOT, "vsc22-submission_amd")):
 import numpy as np
 import torch
 
-BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md), quoted at the 2.4 GHz peak clock
 F32_MFMA_PEAK_TFLOPS = 157.3
+PEAK_SCLK_MHZ = 2400.0
+
+
+class ClockSampler:
+    """rocm-smi shader clock / package power sampled in a thread while the timed region runs (rank 0).
+    The bf16 GEMMs are power-limited on this part (profiles/r01_clock_power_probe.txt): the sustained
+    clock, not 2.4 GHz, sets the matrix roof the kernels actually run under."""
+
+    def __init__(self, period=0.15):
+        import threading
+        self.period, self.samples, self._stop = period, [], False
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop:
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--csv"], capture_output=True, text=True,
+                                     timeout=5).stdout.strip().splitlines()
+                hdr, row = out[0].split(","), out[-1].split(",")
+                sclk = float(re.sub(r"[^0-9.]", "", row[hdr.index("sclk clock speed:")]))
+                power = float(row[-1])
+                self.samples.append((sclk, power))
+            except Exception:  # noqa: BLE001 -- no rocm-smi / other layout: report nothing rather than fail the bench
+                return
+            time.sleep(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        self._thread.join(timeout=10)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        s = self.samples[1:] or self.samples   # the first sample can predate the load
+        sclk = sum(x[0] for x in s) / len(s)
+        return {"sclk_mhz": round(sclk), "package_power_w": round(sum(x[1] for x in s) / len(s)), "samples": len(s)}
 
 
 def parse():
@@ -227,11 +269,16 @@ def main():
         enc(frames)
     barrier()
     enc.set_profiling(True)
+    sampler = ClockSampler() if rank == 0 else None
+    if sampler:
+        sampler.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = enc(frames)
     barrier()
     dt = time.perf_counter() - t0
+    if sampler:
+        sampler.__exit__()
     prof = enc.get_profile()
     enc.set_profiling(False)
     if dist is not None:
@@ -278,6 +325,12 @@ def main():
                                  "overlap, so the sum of kernel times exceeds ms_per_step"},
             "kernels": per_class,
         }
+        clk = sampler.summary() if sampler else None
+        if clk:
+            # the roof these launches ran under: peak scaled by the clock the power limit allowed
+            clk["mfma_roof_at_sustained_clock_tflops"] = round(BF16_PEAK_TFLOPS * clk["sclk_mhz"] / PEAK_SCLK_MHZ, 1)
+            clk["frac_of_sustained_roof"] = round(achieved / clk["mfma_roof_at_sustained_clock_tflops"], 4)
+            line["roofline"]["sustained"] = clk
         secondary = world == 1   # cpu baseline and the secondary metrics are rank-0, N = 1 only
         if not args.no_cpu_baseline and secondary:
             line["cpu_baseline"] = cpu_baseline(cfg, weights, base)

@@ -43,6 +43,9 @@ struct GemmArgs {
     int64_t m;
     int n, k, tokens, tiles_n, tiles_m, group_n;
     int skew;  // first-round start skew in shader cycles (see phase_skew)
+#ifdef VSC_GEMM_TIMING
+    unsigned long long *dbg;  // [8 waves][8] cycle sums of workgroup 0 (build with -DVSC_GEMM_TIMING)
+#endif
     int abl;  // diagnostic ablation bits (VSC_GEMM_ABL): 1 no loop DMA, 2 no MFMA, 4 no epilogue stores, 8 no frag reads
 };
 
@@ -437,6 +440,13 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
     if (NW == 8 && group == 1) __builtin_amdgcn_s_barrier();  // stagger
     const int fr = lane & 15, fq = lane >> 4;
     int cur = 0;  // stage of tile kt
+#ifdef VSC_GEMM_TIMING
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};
+#define VSC_T(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tsum[i] += now_ - tprev; tprev = now_; }
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#else
+#define VSC_T(i)
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         // ---- L phase
         if (kt + STAGES - 1 < nk && !(p.abl & 1)) {
@@ -446,6 +456,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
             stage_rows32<BM2, NW>(p.a, p.k, m0, a_last, (kt + STAGES - 1) * BK2, st, wave, lane);
             stage_rows32<BN2, NW>(p.w, p.k, n0, w_last, (kt + STAGES - 1) * BK2, st + A_BYTES, wave, lane);
         }
+        VSC_T(0)  // DMA issue
         const char *at = lds2 + cur * STAGE_BYTES;
         const char *wt = at + A_BYTES;
         bf16x8_t wf[TN], af[TM];
@@ -471,7 +482,9 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
 #pragma unroll
         for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[i]));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        VSC_T(1)  // fragment reads + landing wait
         __builtin_amdgcn_s_barrier();
+        VSC_T(2)  // barrier closing L
         // ---- C phase
         __builtin_amdgcn_s_setprio(1);
         if (!(p.abl & 2)) {
@@ -482,9 +495,15 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
+        VSC_T(3)  // MFMA issue
         if (NW == 8) __builtin_amdgcn_s_barrier();  // single group: the L-phase barrier alone orders RAW and WAR
+        VSC_T(4)  // barrier closing C
         cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
+#ifdef VSC_GEMM_TIMING
+    if (blockIdx.x == 300 % gridDim.x && lane == 0 && p.dbg)
+        for (int i = 0; i < 5; ++i) p.dbg[wave * 8 + i] = tsum[i];
+#endif
     if (NW == 8 && group == 0) __builtin_amdgcn_s_barrier();
     if (NW == 4) __builtin_amdgcn_s_barrier();  // every wave is past its last fragment read
 
@@ -516,8 +535,25 @@ int launch_v2(GemmArgs p, hipStream_t stream) {
     if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
     p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
     p.skew = skew_cycles(p.k);
+#ifdef VSC_GEMM_TIMING
+    static unsigned long long *dbg = nullptr;
+    if (!dbg) VSC_CHECK_HIP(hipMalloc(&dbg, 64 * 8));
+    VSC_CHECK_HIP(hipMemsetAsync(dbg, 0, 64 * 8, stream));
+    p.dbg = dbg;
+#endif
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), smem, stream, p);
     VSC_CHECK_LAUNCH();
+#ifdef VSC_GEMM_TIMING
+    if (getenv("VSC_GEMM_TIMING_PRINT")) {
+        unsigned long long h[64];
+        VSC_CHECK_HIP(hipStreamSynchronize(stream));
+        VSC_CHECK_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+        const double nk = p.k / 32.0;
+        for (int w = 0; w < NW; ++w)
+            fprintf(stderr, "timing m=%lld n=%d k=%d wave %d: per K-step cycles  dma-issue %.0f  reads+landing %.0f  barrier-L %.0f  mfma-issue %.0f  barrier-C %.0f\n",
+                    (long long)p.m, p.n, p.k, w, h[w * 8] / nk, h[w * 8 + 1] / nk, h[w * 8 + 2] / nk, h[w * 8 + 3] / nk, h[w * 8 + 4] / nk);
+    }
+#endif
     return VSC_OK;
 }
 
