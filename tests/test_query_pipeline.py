@@ -68,6 +68,23 @@ def test_run_query_videos_composes_the_reference_steps():
     assert finals[0].feature.shape[1] == 5
 
 
+def test_scorer_overrides_and_records_scores():
+    vids = _videos((8,), [6, 6])
+    for v in vids:
+        v[1]["clip"] = v[1][8]
+    enc = [(_FakeEncoder(6, 1), 8)]
+    calls = []
+
+    def scorer(frames):
+        calls.append(frames.shape[0])
+        return 0.0 if len(calls) == 1 else 0.9   # first video rejected, second accepted
+
+    scores = {"Q000000": 1.0}   # would accept the first video: the scorer's verdict wins and is written back
+    finals, _ = run_query_videos(vids, enc, lambda x: x[:, :3], scores, torch.device("cpu"), ops=_NumpyOps, scorer=scorer)
+    assert calls == [6, 6] and scores == {"Q000000": 0.0, "Q000001": 0.9}
+    assert finals[0].feature.shape == (1, 512) and finals[1].feature.shape[1] == 3
+
+
 def test_model_spec_and_zoo_errors(tmp_path):
     assert parse_model_spec("vit_v68:timm_vit:/x/y:z.pth") == ("vit_v68", "timm_vit", "/x/y:z.pth")
     with pytest.raises(ValueError, match="arch:weights_format:checkpoint_path"):
@@ -120,3 +137,24 @@ def test_ensemble_on_hip_encoders():
         assert np.array_equal(subs[0].feature, a) and np.array_equal(subs[1].feature, b)   # chunking changes nothing
         assert got.feature.shape[1] == 16 and got.feature.shape[0] <= len(stamps) and np.isfinite(got.feature).all()
         assert got.video_id == vid
+
+
+@pytest.mark.gpu
+def test_video_scorer_on_hip_path():
+    """CLIP tower (tiny_clip preset) -> MS head (a vsm preset matched to its width) -> sigmoid, vs the oracles."""
+    from oracle import vit_oracle, vsm_oracle
+    from src.query_pipeline import VideoScorer
+    from vsc_hip.config import get_config
+    from vsc_hip.encoder import HipEncoder
+    from vsc_hip.video_score import VideoScoreHead
+    from vsc_hip.vsm_config import get_vsm_config
+    dev = torch.device("cuda", 0)
+    ccfg = get_config("tiny_clip")
+    vcfg = get_vsm_config("tiny_vsm", feat_dim=ccfg.width)
+    cw, vw = synth.encoder_weights(8, ccfg), synth.vsm_weights(9, vcfg)
+    scorer = VideoScorer(HipEncoder(ccfg, cw, max_batch=8), VideoScoreHead(vcfg, vw), dev, chunk=5)
+    frames = torch.from_numpy(synth.frames(30, 14, ccfg))   # more frames than max_frames (12): truncated like the reference
+    got = scorer(frames)
+    cls = vit_oracle.descriptors({k: torch.from_numpy(v) for k, v in cw.items()}, ccfg, frames[: vcfg.max_frames], l2=False)
+    want = vsm_oracle.video_score(vw, vcfg, cls)
+    assert 0.0 < got < 1.0 and abs(got - want) < 1e-2

@@ -7,9 +7,10 @@
         --norm_refs outputs/train_refs.npz --output_dir outputs [--video_scores video_scores.csv]
 
 Outputs, as the reference: ``<output_dir>/<model name>/<split>_query.npz`` per backbone (:238-245) and
-``<output_dir>/<split>_query_sn.npz`` after query score normalisation (:247-252).  The video-score model is an
-opaque TorchScript checkpoint in the reference (clip tower + ``vsm`` head); its scores come in through
-``--video_scores`` (csv: video_id,score), every video passes when the file is not given."""
+``<output_dir>/<split>_query_sn.npz`` after query score normalisation (:247-252).  The video-score gate
+(CLIP ViT-L/14 [CLS] features -> ``MS`` head, :163-174) runs on the HIP path when ``--clip_checkpoint`` and
+``--vsm_checkpoint`` (the state dicts torch2scripts.py traces) are given; otherwise scores are read from
+``--video_scores`` (csv: video_id,score) and every video passes when neither is given."""
 from __future__ import annotations
 
 import argparse
@@ -22,10 +23,10 @@ from zipfile import ZipFile
 import numpy as np
 import torch
 
-from src.dataset import vit_transform
+from src.dataset import clip_transform, vit_transform
 from src.matching import calclualte_low_var_dim
 from src.model_zoo import load_encoder, parse_model_spec
-from src.query_pipeline import run_query_videos
+from src.query_pipeline import VideoScorer, run_query_videos
 from src.query_postprocess import HipPCA, SCORE_THRESHOLD
 from vsc.baseline.score_normalization import query_score_normalize
 from vsc.metrics import Dataset
@@ -34,10 +35,12 @@ from vsc.storage import load_features, store_features
 NK, BETA = 1, 1.2  # extract_query_feats.py:56-57
 
 
-def zip_videos(video_ids, zip_prefix, sizes):
+def zip_videos(video_ids, zip_prefix, sizes, with_clip=False):
     """(video_id, {size: frames}, timestamps) per video; frames decoded once, resized per input size."""
     from PIL import Image
     transforms = {s: vit_transform(s, s) for s in sizes}
+    if with_clip:
+        transforms[VideoScorer.KEY] = clip_transform(224)
     for vid in video_ids:
         path = "%s/%s/%s.zip" % (zip_prefix, vid[-2:], vid)
         if not os.path.exists(path):
@@ -65,8 +68,15 @@ def main(args):
     with open(args.input_file, encoding="utf-8") as f:
         vids = [x.strip() for x in f if x.strip()]
     scores = read_video_scores(args.video_scores)
-    videos = zip_videos(vids, args.zip_prefix, sorted({size for _, size in encoders}))
-    finals, per_model = run_query_videos(videos, encoders, pca.transform, scores, device, score_threshold=args.score_threshold)
+    scorer = None
+    if args.clip_checkpoint and args.vsm_checkpoint:
+        from vsc_hip.video_score import VideoScoreHead, from_reference_state
+        clip, _ = load_encoder("clip_vit_l14_224", "clip", args.clip_checkpoint, args.max_batch)
+        state = torch.load(args.vsm_checkpoint, map_location="cpu")
+        scorer = VideoScorer(clip, VideoScoreHead("vsm_roberta_base", from_reference_state(state.get("state_dict", state))), device)
+    videos = zip_videos(vids, args.zip_prefix, sorted({size for _, size in encoders}), with_clip=scorer is not None)
+    finals, per_model = run_query_videos(videos, encoders, pca.transform, scores, device, score_threshold=args.score_threshold,
+                                         scorer=scorer)
     for i, (_, _, path) in enumerate(specs):
         key = os.path.split(path)[-1].split(".")[0]
         os.makedirs(os.path.join(args.output_dir, key), exist_ok=True)
@@ -88,6 +98,8 @@ def build_parser():
     ap.add_argument("--input_file", required=True, help="one query video id per line")
     ap.add_argument("--norm_refs", default="", help="score-normalisation reference descriptors (.npz)")
     ap.add_argument("--video_scores", default="", help="csv video_id,score from the video-score model")
+    ap.add_argument("--clip_checkpoint", default="", help="CLIP ViT-L/14 visual tower state dict (video-score gate)")
+    ap.add_argument("--vsm_checkpoint", default="", help="MS video-score head state dict (epoch_*.pth of train_vid_score)")
     ap.add_argument("--score_threshold", type=float, default=SCORE_THRESHOLD)
     ap.add_argument("--output_dir", default="outputs")
     ap.add_argument("--max_batch", type=int, default=256)

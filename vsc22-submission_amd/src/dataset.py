@@ -23,6 +23,32 @@ def vit_transform(width: int, height: int):
     return apply
 
 
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_transform(size: int = 224):
+    """Resize(size, bicubic) on the short side + CenterCrop(size) + ToTensor + CLIP normalisation
+    (infer/extract_query_feats.py:97-105, the video-score model's input)."""
+    from PIL import Image
+    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(3, 1, 1)
+
+    def apply(img) -> torch.Tensor:
+        img = img.convert("RGB")
+        w, h = img.size
+        if w <= h:
+            nw, nh = size, int(size * h / w)     # torchvision Resize(int): short side -> size, long side truncated
+        else:
+            nw, nh = int(size * w / h), size
+        img = img.resize((nw, nh), Image.BICUBIC)
+        left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
+        img = img.crop((left, top, left + size, top + size))
+        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
+        return (x - mean) / std
+    return apply
+
+
 class ZipFrames(torch.utils.data.Dataset):
     """One item = all frames of one video, read from <prefix>/<vid[-2:]>/<vid>.zip of jpgs."""
 

@@ -158,3 +158,45 @@ def swin_weights(seed: int, cfg) -> dict:
 
 def swin_frames(seed: int, n: int, cfg) -> np.ndarray:
     return uniform(seed, (n, cfg.channels, cfg.image_size, cfg.image_size))
+
+
+def vsm_weights(seed: int, cfg) -> dict:
+    """Random-init video-score model weights in the reference's state-dict naming
+    (train/train_vid_score/video/model.py:63-75 ``MS``: frame_proj, bert.*, output_proj)."""
+    s = seed * 100000
+    w = {}
+
+    def nxt():
+        nonlocal s
+        s += 1
+        return s
+
+    h, m = cfg.hidden, cfg.mlp_dim
+    w["frame_proj.0.weight"] = normalish(nxt(), (h, cfg.feat_dim), 1.0 / np.sqrt(cfg.feat_dim))
+    w["frame_proj.0.bias"] = normalish(nxt(), (h,), 0.05)
+    w["frame_proj.1.weight"] = 1.0 + normalish(nxt(), (h,), 0.05)
+    w["frame_proj.1.bias"] = normalish(nxt(), (h,), 0.05)
+    e = "bert.embeddings."
+    w[e + "word_embeddings.weight"] = normalish(nxt(), (cfg.vocab, h), 0.5)
+    w[e + "position_embeddings.weight"] = normalish(nxt(), (cfg.max_position, h), 0.3)
+    w[e + "token_type_embeddings.weight"] = normalish(nxt(), (2, h), 0.3)
+    w[e + "LayerNorm.weight"] = 1.0 + normalish(nxt(), (h,), 0.05)
+    w[e + "LayerNorm.bias"] = normalish(nxt(), (h,), 0.05)
+    for i in range(cfg.layers):
+        p = f"bert.encoder.layer.{i}."
+        for name in ("query", "key", "value"):
+            w[p + f"attention.self.{name}.weight"] = normalish(nxt(), (h, h), 1.2 / np.sqrt(h))
+            w[p + f"attention.self.{name}.bias"] = normalish(nxt(), (h,), 0.05)
+        w[p + "attention.output.dense.weight"] = normalish(nxt(), (h, h), 1.0 / np.sqrt(h))
+        w[p + "attention.output.dense.bias"] = normalish(nxt(), (h,), 0.05)
+        w[p + "attention.output.LayerNorm.weight"] = 1.0 + normalish(nxt(), (h,), 0.05)
+        w[p + "attention.output.LayerNorm.bias"] = normalish(nxt(), (h,), 0.05)
+        w[p + "intermediate.dense.weight"] = normalish(nxt(), (m, h), 1.0 / np.sqrt(h))
+        w[p + "intermediate.dense.bias"] = normalish(nxt(), (m,), 0.05)
+        w[p + "output.dense.weight"] = normalish(nxt(), (h, m), 1.0 / np.sqrt(m))
+        w[p + "output.dense.bias"] = normalish(nxt(), (h,), 0.05)
+        w[p + "output.LayerNorm.weight"] = 1.0 + normalish(nxt(), (h,), 0.05)
+        w[p + "output.LayerNorm.bias"] = normalish(nxt(), (h,), 0.05)
+    w["output_proj.weight"] = normalish(nxt(), (1, 2 * h), 1.0 / np.sqrt(2 * h))
+    w["output_proj.bias"] = normalish(nxt(), (1,), 0.05)
+    return w

@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_voi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvsc_hip.so")
 
-EPI_BF16, EPI_GELU_BF16, EPI_QGELU_BF16, EPI_RESADD_F32, EPI_PATCH_F32 = range(5)
+EPI_BF16, EPI_GELU_BF16, EPI_QGELU_BF16, EPI_RESADD_F32, EPI_PATCH_F32, EPI_F32 = range(6)
 PROF_CLASSES = ("patchify", "gemm_patch", "layernorm", "gemm_qkv", "attention", "gemm_proj",
                 "gemm_fc1", "gemm_fc2", "pool_head", "misc")
 

@@ -25,7 +25,7 @@ def gemm_bf16(a, w, bias=None, *, epilogue=_lib.EPI_BF16, aux=None, tokens=0, ou
     if out is None:
         if epilogue in (_lib.EPI_BF16, _lib.EPI_GELU_BF16, _lib.EPI_QGELU_BF16):
             out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
-        elif epilogue == _lib.EPI_RESADD_F32:
+        elif epilogue in (_lib.EPI_RESADD_F32, _lib.EPI_F32):
             out = torch.empty((m, n), dtype=torch.float32, device=a.device)
         else:
             frames = m // (tokens - 1)
