@@ -51,12 +51,14 @@ def _videos(sizes, lens):
     return out
 
 
-def test_run_query_videos_composes_the_reference_steps():
+@pytest.mark.parametrize("group_frames", [1, 12, 512])   # one video per group, two groups, everything in one group
+def test_run_query_videos_composes_the_reference_steps(group_frames):
     vids = _videos((8, 12), [9, 5, 7])
     enc = [(_FakeEncoder(6, 1), 8), (_FakeEncoder(4, 2, tokens=True), 12)]   # the second returns [S, T, D]: row 0 is taken
     pca = lambda x: x[:, :5] * 2.0
     scores = {"Q000001": 0.0}  # rejected; the others default to accepted
-    finals, per_model = run_query_videos(vids, enc, pca, scores, torch.device("cpu"), ops=_NumpyOps, chunk=4)
+    finals, per_model = run_query_videos(vids, enc, pca, scores, torch.device("cpu"), ops=_NumpyOps, chunk=4,
+                                         group_frames=group_frames)
     assert [f.video_id for f in finals] == ["Q000000", "Q000001", "Q000002"] and len(per_model) == 3
     rnd = 0
     for (vid, frames, stamps), got, subs in zip(vids, finals, per_model):
