@@ -818,7 +818,13 @@ int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, co
     GemmArgs p{a, w, bias, aux, out, m, n, k, tokens, tiles_n, (int)tiles_m, 1, 0, 0};
     if (const char *e = getenv("VSC_GEMM_ABL")) p.abl = atoi(e);
     static const bool force_v1 = getenv("VSC_GEMM_V1") != nullptr;
-    const bool v2 = !force_v1 && m >= 1024 && k % 32 == 0 && n % 8 == 0;
+    static const bool force_v2 = getenv("VSC_GEMM_CFG") != nullptr;
+    // A launch that cannot put a 256-row tile on at least half the CUs runs the 128 x 128 kernel instead (four times
+    // the workgroups, two per CU): at 8 frames (M = 1576) fc2 takes 44 instead of 74 us and proj 16 instead of 27,
+    // at 32 frames the N = 768 GEMMs 26 / 57 instead of 35 / 77 us; from ~130 tiles up the big tile wins.
+    const int64_t big_tiles = ((m + 255) / 256) * ((n + 255) / 256);
+    const bool fills = big_tiles > (k <= 512 ? 64 : 128);
+    const bool v2 = !force_v1 && m >= 1024 && k % 32 == 0 && n % 8 == 0 && (fills || force_v2);
     if (epilogue == VSC_EPI_RESADD_F32) VSC_REQUIRE(aux, "gemm: RESADD needs the residual pointer");
     if (epilogue == VSC_EPI_PATCH_F32) {
         VSC_REQUIRE(aux && tokens > 1, "gemm: PATCH needs pos and tokens");
