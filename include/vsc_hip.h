@@ -5,6 +5,12 @@
  * negative vsc_status otherwise; vsc_last_error() gives the message of the last
  * failure on the calling thread.  Nothing here falls back to the CPU.
  *
+ * Concurrency: one process per GPU is the deployment model.  An encoder handle, and the
+ * search entry points as a group (vsc_knn_ip_f32, vsc_range_search_ip_f32, vsc_pair_similarity_f32
+ * share grow-only device scratch), must not be driven from two host threads at once, and
+ * consecutive calls that share a handle or that scratch must be stream-ordered (same stream, or
+ * ordered by events).  Different encoder handles are independent.
+ *
  * Each entry point names the reference interface it replaces
  * (paths relative to /root/reference/VSC22-Descriptor-Track-1st).
  */
