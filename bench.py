@@ -265,16 +265,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    tw = time.perf_counter()
     for _ in range(args.warmup):
         enc(frames)
     barrier()
+    step_est = (time.perf_counter() - tw) / max(args.warmup, 1)   # sizes the clock probe below
     enc.set_profiling(True)
     sampler = ClockSampler() if rank == 0 else None
+    spin = None
     if sampler:
         sampler.__enter__()
+        # cycle-counted shader clock under this load: one wave on a side stream spins for a fixed number of
+        # s_memtime ticks (= shader cycles) while the timed steps run; ticks / event time = the clock the
+        # kernels really ran at (rocm-smi's sclk is a smoothed reading)
+        side = torch.cuda.Stream()
+        spin = {"ticks": torch.zeros(1, dtype=torch.int64, device=dev), "e0": torch.cuda.Event(enable_timing=True),
+                "e1": torch.cuda.Event(enable_timing=True)}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         out = enc(frames)
+        if spin is not None and i == 0:
+            with torch.cuda.stream(side):
+                spin["e0"].record()
+                _lib.check(_lib.require_device().vsc_debug_spin_ticks(max(int(0.4 * args.steps * step_est * 1.2e9), 100000), spin["ticks"].data_ptr(),
+                                                                      side.cuda_stream))
+                spin["e1"].record()
     barrier()
     dt = time.perf_counter() - t0
     if sampler:
@@ -326,6 +341,13 @@ def main():
             "kernels": per_class,
         }
         clk = sampler.summary() if sampler else None
+        if clk is None and spin is not None:
+            clk = {}
+        if spin is not None:
+            torch.cuda.synchronize()
+            clk["sclk_mhz_smi"] = clk.pop("sclk_mhz", None)
+            clk["sclk_mhz"] = round(int(spin["ticks"].item()) / (spin["e0"].elapsed_time(spin["e1"]) * 1e3))
+            clk["sclk_source"] = "s_memtime cycles of a one-wave spin on a side stream / its event time, during the timed steps"
         if clk:
             # the roof these launches ran under: peak scaled by the clock the power limit allowed
             clk["mfma_roof_at_sustained_clock_tflops"] = round(BF16_PEAK_TFLOPS * clk["sclk_mhz"] / PEAK_SCLK_MHZ, 1)

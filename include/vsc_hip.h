@@ -241,6 +241,9 @@ int vsc_gemm_ln_bf16(const uint16_t *a_dev, const uint16_t *w_dev, const float *
 int vsc_merge_gather_bf16(const uint16_t *xb_dev, uint16_t *out_dev, int64_t frames, int32_t res,
                           int32_t c, void *stream);
 
+/* Measurement aid: one wave spins for `ticks` shader cycles (s_memtime) and stores the elapsed count. */
+int vsc_debug_spin_ticks(uint64_t ticks, uint64_t *out_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,3 +78,23 @@ extern "C" int vsc_merge_gather_bf16(const uint16_t *xb, uint16_t *out, int64_t 
                                      void *stream) {
     return launch_merge_gather(xb, out, frames, res, c, (hipStream_t)stream);
 }
+
+// Measurement aid (tools/micro/clock_under_load.py): one wave spins for `ticks` s_memtime ticks (= shader cycles) and
+// stores the elapsed count; timed from the host with events it gives the shader clock while other streams are busy.
+__global__ void spin_ticks_kernel(unsigned long long ticks, unsigned long long *out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long t = t0;
+    while (t - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(16);
+        t = __builtin_amdgcn_s_memtime();
+    }
+    if (threadIdx.x == 0) *out = t - t0;
+}
+
+extern "C" int vsc_debug_spin_ticks(uint64_t ticks, uint64_t *out_dev, void *stream) {
+    VSC_REQUIRE(out_dev, "spin: null pointer");
+    hipLaunchKernelGGL(spin_ticks_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)ticks,
+                       (unsigned long long *)out_dev);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}

@@ -424,6 +424,9 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
     //        ds_reads were drained (lgkmcnt(0)) before the barrier that precedes L(kt).
     const int nk = p.k / BK2;
     const int group = NW == 8 ? wave >> 2 : 0;
+#ifdef VSC_GEMM_TIMING
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) {
         if (s < nk) {
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
     const int fr = lane & 15, fq = lane >> 4;
     int cur = 0;  // stage of tile kt
 #ifdef VSC_GEMM_TIMING
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
     unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0};
 #define VSC_T(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tsum[i] += now_ - tprev; tprev = now_; }
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -501,13 +505,22 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
         cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
 #ifdef VSC_GEMM_TIMING
-    if (blockIdx.x == 300 % gridDim.x && lane == 0 && p.dbg)
-        for (int i = 0; i < 5; ++i) p.dbg[wave * 8 + i] = tsum[i];
+    const unsigned long long t_epi = __builtin_amdgcn_s_memtime();
 #endif
     if (NW == 8 && group == 0) __builtin_amdgcn_s_barrier();
     if (NW == 4) __builtin_amdgcn_s_barrier();  // every wave is past its last fragment read
 
     epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0);
+#ifdef VSC_GEMM_TIMING
+    if (blockIdx.x == 300 % gridDim.x && lane == 0 && p.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < 5; ++i) p.dbg[wave * 8 + i] = tsum[i];
+        p.dbg[wave * 8 + 5] = t_loop - t_start;
+        p.dbg[wave * 8 + 6] = t_epi - t_loop;
+        p.dbg[wave * 8 + 7] = t_end - t_epi;
+    }
+#endif
 }
 
 // one tile time in s_memtime ticks (100 MHz): VSC_GEMM_SKEW_NS_PER_K nanoseconds per unit of K
@@ -552,6 +565,7 @@ int launch_v2(GemmArgs p, hipStream_t stream) {
         for (int w = 0; w < NW; ++w)
             fprintf(stderr, "timing m=%lld n=%d k=%d wave %d: per K-step cycles  dma-issue %.0f  reads+landing %.0f  barrier-L %.0f  mfma-issue %.0f  barrier-C %.0f\n",
                     (long long)p.m, p.n, p.k, w, h[w * 8] / nk, h[w * 8 + 1] / nk, h[w * 8 + 2] / nk, h[w * 8 + 3] / nk, h[w * 8 + 4] / nk);
+        fprintf(stderr, "timing tile (wave 0): prologue %llu  K loop %llu  write-out incl. store drain %llu ticks\n", h[5], h[6], h[7]);
     }
 #endif
     return VSC_OK;
