@@ -69,6 +69,9 @@ typedef struct vsc_encoder_config {
     int32_t lanes;        /* 2: a forward call of more than max_batch frames alternates its chunks over
                              two internal streams (two workspaces) so memory-bound kernels of one
                              chunk overlap the GEMMs of the other; anything else = 1 */
+    int32_t fuse_ln;      /* 1: LayerNorm folding -- LN2 / the next layer's LN1 applied inside the fc1 / qkv GEMM
+                             epilogues from statistics the proj / fc2 write-out emits (no LN pass);
+                             same results within the bf16 rounding noise, throughput-neutral on MI355X.  0: off */
 } vsc_encoder_config;
 
 int vsc_encoder_create(const vsc_encoder_config *cfg, vsc_encoder **out);

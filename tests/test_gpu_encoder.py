@@ -121,3 +121,30 @@ def test_sscd_head_model(dev, preset, n):
     out = enc(x.to(dev)).cpu().numpy()
     assert out.shape == (n, cfg.out_dim)
     np.testing.assert_allclose(out, ref, rtol=0, atol=DESC_L2_ATOL)
+
+
+@pytest.mark.parametrize("preset", ["tiny", "tiny_clip", "vit_b16_224"])
+def test_layernorm_folding_matches_golden_and_the_unfolded_path(dev, preset, golden_dir):
+    """fuse_ln=1 (LN2 / next LN1 inside the fc1 / qkv epilogues, statistics from the proj / fc2 write-out) against the
+    golden descriptors and against fuse_ln=0 (the separate LayerNorm passes, the default) on the same frames."""
+    g = np.load(os.path.join(golden_dir, f"vit_{preset}.npz"))
+    cfg = get_config(preset)
+    x = torch.from_numpy(synth.frames(int(g["frames_seed"]), int(g["n_frames"]), cfg)).to(dev)
+    fused = _encoder(preset, int(g["weights_seed"]), max_batch=4, l2_normalize=True, fuse_ln=1)[2]
+    plain = _encoder(preset, int(g["weights_seed"]), max_batch=4, l2_normalize=True, fuse_ln=0)[2]
+    df, tf = fused(x, return_tokens=True)
+    dp, tp = plain(x, return_tokens=True)
+    df, dp, tf, tp = (t.cpu().numpy() for t in (df, dp, tf, tp))
+    np.testing.assert_allclose(df, g["desc_l2"], rtol=0, atol=DESC_L2_ATOL)
+    assert np.abs(df - dp).max() < 5e-4            # two bf16 pipelines with different rounding points
+    assert np.abs(tf - tp).max() < 0.08 and np.abs(tf - tp).mean() < 0.01
+    assert not np.array_equal(df, dp)              # the folded path really ran
+
+
+def test_layernorm_folding_ragged_rows(dev):
+    """A fold on ragged chunks (rows not a multiple of the 256-row tile, last chunk shorter) matches the default path."""
+    cfg, w, plain = _encoder("tiny", 5, max_batch=37, l2_normalize=True)
+    fused = _encoder("tiny", 5, max_batch=37, l2_normalize=True, fuse_ln=1)[2]
+    x = torch.from_numpy(synth.frames(6, 50, cfg)).to(dev)
+    dp, df = plain(x).cpu().numpy(), fused(x).cpu().numpy()
+    assert np.abs(df - dp).max() < 5e-4 and not np.array_equal(df, dp)

@@ -93,6 +93,22 @@ int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias,
                         const float *beta, const float *x_in, float *x_out, uint16_t *xb_out, int64_t m, int n,
                         int k, float eps, hipStream_t stream);
 bool gemm_ln_supported(int n, int k);
+// Internal epilogue kinds of the encoder's LayerNorm folding (not part of the public enum in vsc_hip.h):
+//   LNF_*            the A operand is bf16(x) itself and gamma is folded into W: out = act(rstd_m * (acc - mu_m * colsum_n)
+//                    + bias_n) with (mu_m, rstd_m) = rowstats[m], colsum_n = sum_k W'[n,k], bias_n = b_n + sum_k beta_k W[n,k]
+//   RESADD_STATS_F32 RESADD_F32 that also stores bf16(out) to xb and, per row and 64-column slice, (mean, centred sum of
+//                    squares) to stats[slice][m]; ln_stats_merge turns the slices into rowstats
+enum { VSC_EPI_LNF_BF16 = 6, VSC_EPI_LNF_GELU_BF16 = 7, VSC_EPI_LNF_QGELU_BF16 = 8, VSC_EPI_RESADD_STATS_F32 = 9 };
+struct GemmExtra {
+    uint16_t *xb = nullptr;          // RESADD_STATS: bf16 copy of out [m, n]
+    float *stats = nullptr;          // RESADD_STATS: [n / 64][m][2]
+    const float *rowstats = nullptr; // LNF: [m][2] = (mean, rstd)
+    const float *colsum = nullptr;   // LNF: [n]
+};
+int launch_gemm_bf16_ex(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux, void *out, int64_t m,
+                        int n, int k, int epilogue, int tokens, const GemmExtra &ex, hipStream_t stream);
+int launch_ln_stats_merge(const float *stats, float *rowstats, int64_t rows, int slices, int width, float eps,
+                          hipStream_t stream);
 int launch_attention_bf16(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int heads,
                           hipStream_t stream);
 int launch_layernorm(const float *x, const float *g, const float *b, void *out, int64_t rows,

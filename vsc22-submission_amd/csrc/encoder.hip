@@ -13,11 +13,17 @@
 #include <string>
 #include <vector>
 
+#include <string.h>
+
 #include "common.h"
 
 struct LayerW {
     uint16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
     float *qkv_b, *proj_b, *fc1_b, *fc2_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    // LayerNorm folded into the following GEMM (see fold_ln): W' = gamma o W (bf16), colsum_n = sum_k W'[n,k],
+    // bias'_n = b_n + sum_k beta_k W[n,k]
+    uint16_t *qkv_wf = nullptr, *fc1_wf = nullptr;
+    float *qkv_cs = nullptr, *qkv_bf = nullptr, *fc1_cs = nullptr, *fc1_bf = nullptr;
 };
 
 struct vsc_encoder {
@@ -38,6 +44,8 @@ struct vsc_encoder {
     struct Workspace {
         uint16_t *patches = nullptr, *y = nullptr, *qkv = nullptr, *h = nullptr, *hconv_out = nullptr;
         float *x = nullptr, *pooled = nullptr;
+        float *stats = nullptr, *rowstats = nullptr;  // LayerNorm folding: [D/64][M][2] slice partials, [M][2] (mean, rstd)
+        uint16_t *xb = nullptr;                       //                    bf16(x) [M, D]
     } ws[2];
     int lanes = 1;
     hipStream_t lane_stream[2] = {nullptr, nullptr};
@@ -89,6 +97,45 @@ int upload_bf16(vsc_encoder *e, const std::string &name, int64_t rows, int cols,
         return VSC_ERR_HIP;
     }
     return rc;
+}
+
+// round-to-nearest-even f32 -> bf16 -> f32, as v_cvt_pk_bf16_f32 / launch_f32_to_bf16 do
+inline float bf16_round(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    u &= 0xFFFF0000u;
+    memcpy(&v, &u, 4);
+    return v;
+}
+
+// LayerNorm folded into the Linear that consumes it:  Linear(LN(x)) = rstd * (x W'^T - mu * colsum) + bias'
+// with W' = gamma o W.  The GEMM then reads bf16(x) itself; colsum is taken over the bf16-rounded W' the MFMA
+// sees, so (acc - mu * colsum) is exactly sum_k (bf16(x_k) - mu) W'_nk.
+int fold_ln(vsc_encoder *e, const std::string &wname, const std::string &bname, const std::string &gname,
+            const std::string &betaname, int n, int k, uint16_t **wf, float **cs, float **bf) {
+    const std::vector<float> &W = e->host_w.at(wname), &b = e->host_w.at(bname), &g = e->host_w.at(gname),
+                             &beta = e->host_w.at(betaname);
+    std::vector<float> &Wf = e->host_w[wname + ".folded"];
+    std::vector<float> &colsum = e->host_w[wname + ".colsum"], &biasf = e->host_w[bname + ".folded"];
+    Wf.resize((size_t)n * k);
+    colsum.resize(n);
+    biasf.resize(n);
+    for (int r = 0; r < n; ++r) {
+        double s = 0.0, t = 0.0;
+        for (int c = 0; c < k; ++c) {
+            const float v = g[c] * W[(size_t)r * k + c];
+            Wf[(size_t)r * k + c] = v;
+            s += (double)bf16_round(v);
+            t += (double)beta[c] * (double)W[(size_t)r * k + c];
+        }
+        colsum[r] = (float)s;
+        biasf[r] = (float)((double)b[r] + t);
+    }
+    int rc;
+    if ((rc = upload_bf16(e, wname + ".folded", n, k, k, wf))) return rc;
+    if ((rc = upload_f32(e, wname + ".colsum", cs))) return rc;
+    return upload_f32(e, bname + ".folded", bf);
 }
 
 struct ProfScope {
@@ -241,6 +288,13 @@ extern "C" int vsc_encoder_finalize(vsc_encoder *e) {
         TRY(upload_f32(e, b + "fc1.bias", &L.fc1_b));
         TRY(upload_bf16(e, b + "fc2.weight", D, c.mlp_dim, c.mlp_dim, &L.fc2_w));
         TRY(upload_f32(e, b + "fc2.bias", &L.fc2_b));
+        if (c.fuse_ln > 0) {
+            TRY(fold_ln(e, b + "fc1.weight", b + "fc1.bias", b + "ln2.weight", b + "ln2.bias", c.mlp_dim, D, &L.fc1_wf,
+                        &L.fc1_cs, &L.fc1_bf));
+            if (i > 0)  // layer 0 reads x from the patch / cls kernels, which emit no statistics: it keeps its LN1 pass
+                TRY(fold_ln(e, b + "qkv.weight", b + "qkv.bias", b + "ln1.weight", b + "ln1.bias", 3 * D, D, &L.qkv_wf,
+                            &L.qkv_cs, &L.qkv_bf));
+        }
     }
     TRY(upload_f32(e, "ln_post.weight", &e->lnpost_g));
     TRY(upload_f32(e, "ln_post.bias", &e->lnpost_b));
@@ -267,6 +321,11 @@ extern "C" int vsc_encoder_finalize(vsc_encoder *e) {
         TRY(dev_alloc(e, sz_qkv, (void **)&w.qkv));
         TRY(dev_alloc(e, sz_h, (void **)&w.h));
         TRY(dev_alloc(e, sz_pool, (void **)&w.pooled));
+        if (c.fuse_ln > 0) {
+            TRY(dev_alloc(e, (size_t)(D / 64) * M * 2 * 4, (void **)&w.stats));
+            TRY(dev_alloc(e, M * 2 * 4, (void **)&w.rowstats));
+            TRY(dev_alloc(e, sz_y, (void **)&w.xb));
+        }
         w.hconv_out = w.h;  // [M, head_conv_dim] bf16 fits in the (idle) MLP buffer: head_conv_dim <= mlp_dim
         if (e->lanes == 2) {
             VSC_CHECK_HIP(hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking));
@@ -275,7 +334,7 @@ extern "C" int vsc_encoder_finalize(vsc_encoder *e) {
     }
     if (e->lanes == 2) VSC_CHECK_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
 #undef TRY
-    e->ws_bytes = (int64_t)(sz_patches + sz_x + sz_y + sz_qkv + sz_h + sz_pool) * e->lanes;
+    e->ws_bytes = (int64_t)(sz_patches + sz_x + sz_y + sz_qkv + sz_h + sz_pool + (c.fuse_ln > 0 ? sz_y + ((size_t)(D / 64) + 1) * M * 8 : 0)) * e->lanes;
     e->host_w.clear();
     e->finalized = true;
     return VSC_OK;
@@ -319,15 +378,44 @@ extern "C" int vsc_encoder_forward_debug(vsc_encoder *e, const float *frames, in
             ProfScope _ps(e, VSC_PROF_LAYERNORM, st);
             TRY(launch_layernorm(w.x, e->lnpre_g, e->lnpre_b, w.x, M, D, c.ln_eps, 1, st));
         }
+        // LayerNorm folding (opt-in): from the first residual GEMM on, bf16(x) and x's row statistics
+        // come out of the proj / fc2 write-out (into w.xb / w.stats) and LN2 / the next layer's LN1 are applied inside
+        // the fc1 / qkv epilogues -- no LN pass.  Layer 0's LN1 stays (x comes from the patch / cls kernels).
+        // Measured on the power-limited MI355X it is throughput-neutral (18.8 k frames/s either way: the 48 removed
+        // LayerNorm launches come back as ~25 us on each GEMM), so the separate passes remain the default.
+        const bool fold = c.fuse_ln > 0;
+        const int act_lnf = c.act == 0 ? VSC_EPI_LNF_GELU_BF16 : VSC_EPI_LNF_QGELU_BF16;
+        GemmExtra emit, take;
+        emit.xb = w.xb;
+        emit.stats = w.stats;
+        take.rowstats = w.rowstats;
         for (int l = 0; l < c.layers; ++l) {
             const LayerW &L = e->layers[l];
-            { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_layernorm(w.x, L.ln1_g, L.ln1_b, w.y, M, D, c.ln_eps, 0, st)); }
-            { ProfScope _ps(e, VSC_PROF_GEMM_QKV, st); TRY(launch_gemm_bf16(w.y, L.qkv_w, L.qkv_b, nullptr, w.qkv, M, 3 * D, D, VSC_EPI_BF16, 0, st)); }
+            if (fold && l > 0) {
+                take.colsum = L.qkv_cs;
+                ProfScope _ps(e, VSC_PROF_GEMM_QKV, st);
+                TRY(launch_gemm_bf16_ex(w.xb, L.qkv_wf, L.qkv_bf, nullptr, w.qkv, M, 3 * D, D, VSC_EPI_LNF_BF16, 0, take, st));
+            } else {
+                { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_layernorm(w.x, L.ln1_g, L.ln1_b, w.y, M, D, c.ln_eps, 0, st)); }
+                { ProfScope _ps(e, VSC_PROF_GEMM_QKV, st); TRY(launch_gemm_bf16(w.y, L.qkv_w, L.qkv_b, nullptr, w.qkv, M, 3 * D, D, VSC_EPI_BF16, 0, st)); }
+            }
             { ProfScope _ps(e, VSC_PROF_ATTENTION, st); TRY(launch_attention_bf16(w.qkv, w.y, (int)B, T, c.heads, st)); }
-            { ProfScope _ps(e, VSC_PROF_GEMM_PROJ, st); TRY(launch_gemm_bf16(w.y, L.proj_w, L.proj_b, w.x, w.x, M, D, D, VSC_EPI_RESADD_F32, 0, st)); }
-            { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_layernorm(w.x, L.ln2_g, L.ln2_b, w.y, M, D, c.ln_eps, 0, st)); }
-            { ProfScope _ps(e, VSC_PROF_GEMM_FC1, st); TRY(launch_gemm_bf16(w.y, L.fc1_w, L.fc1_b, nullptr, w.h, M, c.mlp_dim, D, act_epi, 0, st)); }
-            { ProfScope _ps(e, VSC_PROF_GEMM_FC2, st); TRY(launch_gemm_bf16(w.h, L.fc2_w, L.fc2_b, w.x, w.x, M, D, c.mlp_dim, VSC_EPI_RESADD_F32, 0, st)); }
+            if (fold) {
+                { ProfScope _ps(e, VSC_PROF_GEMM_PROJ, st); TRY(launch_gemm_bf16_ex(w.y, L.proj_w, L.proj_b, w.x, w.x, M, D, D, VSC_EPI_RESADD_STATS_F32, 0, emit, st)); }
+                { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_ln_stats_merge(w.stats, w.rowstats, M, D / 64, D, c.ln_eps, st)); }
+                take.colsum = L.fc1_cs;
+                { ProfScope _ps(e, VSC_PROF_GEMM_FC1, st); TRY(launch_gemm_bf16_ex(w.xb, L.fc1_wf, L.fc1_bf, nullptr, w.h, M, c.mlp_dim, D, act_lnf, 0, take, st)); }
+                { ProfScope _ps(e, VSC_PROF_GEMM_FC2, st); TRY(launch_gemm_bf16_ex(w.h, L.fc2_w, L.fc2_b, w.x, w.x, M, D, c.mlp_dim, l + 1 < c.layers ? VSC_EPI_RESADD_STATS_F32 : VSC_EPI_RESADD_F32, 0, emit, st)); }
+                if (l + 1 < c.layers) {
+                    ProfScope _ps(e, VSC_PROF_LAYERNORM, st);
+                    TRY(launch_ln_stats_merge(w.stats, w.rowstats, M, D / 64, D, c.ln_eps, st));
+                }
+            } else {
+                { ProfScope _ps(e, VSC_PROF_GEMM_PROJ, st); TRY(launch_gemm_bf16(w.y, L.proj_w, L.proj_b, w.x, w.x, M, D, D, VSC_EPI_RESADD_F32, 0, st)); }
+                { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_layernorm(w.x, L.ln2_g, L.ln2_b, w.y, M, D, c.ln_eps, 0, st)); }
+                { ProfScope _ps(e, VSC_PROF_GEMM_FC1, st); TRY(launch_gemm_bf16(w.y, L.fc1_w, L.fc1_b, nullptr, w.h, M, c.mlp_dim, D, act_epi, 0, st)); }
+                { ProfScope _ps(e, VSC_PROF_GEMM_FC2, st); TRY(launch_gemm_bf16(w.h, L.fc2_w, L.fc2_b, w.x, w.x, M, D, c.mlp_dim, VSC_EPI_RESADD_F32, 0, st)); }
+            }
         }
         if (c.head_conv_dim) {
             // SSCD head: final LN -> bf16 tokens -> Conv1d(D, C, 1) as a GEMM -> GeM over tokens

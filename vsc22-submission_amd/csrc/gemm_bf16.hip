@@ -47,7 +47,29 @@ struct GemmArgs {
     unsigned long long *dbg;  // [8 waves][8] cycle sums of workgroup 0 (build with -DVSC_GEMM_TIMING)
 #endif
     int abl;  // diagnostic ablation bits (VSC_GEMM_ABL): 1 no loop DMA, 2 no MFMA, 4 no epilogue stores, 8 no frag reads
+    GemmExtra ex;  // LayerNorm-folding operands (common.h)
 };
+
+constexpr bool epi_bf16_out(int e) {
+    return e == VSC_EPI_BF16 || e == VSC_EPI_GELU_BF16 || e == VSC_EPI_QGELU_BF16 || e == VSC_EPI_LNF_BF16 ||
+           e == VSC_EPI_LNF_GELU_BF16 || e == VSC_EPI_LNF_QGELU_BF16;
+}
+constexpr bool epi_lnf(int e) { return e >= VSC_EPI_LNF_BF16 && e <= VSC_EPI_LNF_QGELU_BF16; }
+constexpr bool epi_gelu(int e) { return e == VSC_EPI_GELU_BF16 || e == VSC_EPI_LNF_GELU_BF16; }
+constexpr bool epi_qgelu(int e) { return e == VSC_EPI_QGELU_BF16 || e == VSC_EPI_LNF_QGELU_BF16; }
+
+// sum over the 16 lanes of a DPP row (one matrix row of the fp32 write-out), result in every lane: two quad
+// permutes, then the half-row and the row mirror -- four v_add_f32 with a DPP operand, no LDS round trip
+__device__ __forceinline__ float row16_sum(float x) {
+    auto dpp = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    x += dpp(x, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    x += dpp(x, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    x += dpp(x, std::integral_constant<int, 0x140>{});  // row_mirror
+    return x;
+}
 
 // Stage rows [row0, row0+128) x k in [k0, k0+64) of a row-major bf16 matrix into one
 // LDS tile.  16 pieces of 1 KiB (8 rows each); wave w issues pieces w, w+4, w+8, w+12.
@@ -276,7 +298,7 @@ __device__ __forceinline__ void epilogue_frag(const GemmArgs &p, f32x4_t v, int6
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&acc)[TM][TN], char *lds2,
                                                  int wave, int lane, int wm, int wn, int64_t m0,
-                                                 int n0) {
+                                                 int n0, const float2 (&rs)[TM]) {
     const int fr = lane & 15, fq = lane >> 4;
     // ---- epilogue through LDS.  A lane's accumulators are 4 columns of 16 different rows
     // per fragment: stored directly that is 32-byte pieces of 16 rows per instruction, and the
@@ -289,19 +311,34 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
     static_assert(TN == 4, "wave tile is 64 columns wide");
     char *reg = lds2 + wave * 16384;  // NW x 16 KiB <= the ring (checked in launch_v2)
     const int ncol0 = n0 + wn * 64;
-    if (EPI == VSC_EPI_BF16 || EPI == VSC_EPI_GELU_BF16 || EPI == VSC_EPI_QGELU_BF16) {
+    if (epi_bf16_out(EPI)) {
+        float mu[TM], rstd[TM];  // LayerNorm folding: this lane's rows (loaded before the K loop)
+        if (epi_lnf(EPI)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                mu[i] = rs[i].x;
+                rstd[i] = rs[i].y;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = ncol0 + j * 16 + fq * 4;
-            f32x4_t bz = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            f32x4_t bz = (f32x4_t){0.f, 0.f, 0.f, 0.f}, cs = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             if (p.bias && n < p.n) bz = *(const f32x4_t *)(p.bias + n);
+            if (epi_lnf(EPI) && n < p.n) cs = *(const f32x4_t *)(p.ex.colsum + n);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                f32x4_t v = acc[i][j] + bz;
-                if (EPI == VSC_EPI_GELU_BF16) {
+                f32x4_t v;
+                if (epi_lnf(EPI)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(fmaf(-mu[i], cs[r], acc[i][j][r]), rstd[i], bz[r]);
+                } else {
+                    v = acc[i][j] + bz;
+                }
+                if (epi_gelu(EPI)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                } else if (EPI == VSC_EPI_QGELU_BF16) {
+                } else if (epi_qgelu(EPI)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
                 }
@@ -365,6 +402,21 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
                     }
                     if (EPI != VSC_EPI_F32) v += *(const f32x4_t *)(auxrow + n);
                     if (!((p.abl & 4) && v[0] != 12345.678f)) *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
+                    if (EPI == VSC_EPI_RESADD_STATS_F32) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(v[0], v[1]);
+                        pk.y = pack_bf16x2(v[2], v[3]);
+                        *(uint2 *)(p.ex.xb + m * p.n + n) = pk;
+                    }
+                }
+                if (EPI == VSC_EPI_RESADD_STATS_F32) {
+                    // statistics of this row's 64-column slice (n % 64 == 0 is required, so a slice is whole or absent;
+                    // rows past m are computed on stale lanes and not stored): two passes on the registers
+                    const float mean = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+                    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                    const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                    if (c == 0 && m < p.m && ncol0 < p.n)
+                        *(float2 *)(p.ex.stats + ((int64_t)(ncol0 >> 6) * p.m + m) * 2) = make_float2(mean, m2);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -424,6 +476,17 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
     //        ds_reads were drained (lgkmcnt(0)) before the barrier that precedes L(kt).
     const int nk = p.k / BK2;
     const int group = NW == 8 ? wave >> 2 : 0;
+    // LayerNorm folding: (mean, rstd) of this lane's TM rows, requested before the first DMA so they are in registers
+    // long before the write-out needs them (in-order return: they land ahead of every counted tile)
+    float2 rs[TM];
+    if (epi_lnf(EPI)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int64_t m = m0 + wm * TM * 16 + i * 16 + (lane & 15);
+            m = m < p.m ? m : p.m - 1;
+            rs[i] = *(const float2 *)(p.ex.rowstats + 2 * m);
+        }
+    }
 #ifdef VSC_GEMM_TIMING
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
@@ -510,7 +573,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
     if (NW == 8 && group == 0) __builtin_amdgcn_s_barrier();
     if (NW == 4) __builtin_amdgcn_s_barrier();  // every wave is past its last fragment read
 
-    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0);
+    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0, rs);
 #ifdef VSC_GEMM_TIMING
     if (blockIdx.x == 300 % gridDim.x && lane == 0 && p.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -822,6 +885,12 @@ int launch_ln_t(const GemmLnArgs &p, hipStream_t stream) {
 int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux,
                      void *out, int64_t m, int n, int k, int epilogue, int tokens,
                      hipStream_t stream) {
+    VSC_REQUIRE(epilogue >= VSC_EPI_BF16 && epilogue <= VSC_EPI_F32, "gemm: unknown epilogue %d", epilogue);
+    return launch_gemm_bf16_ex(a, w, bias, aux, out, m, n, k, epilogue, tokens, GemmExtra{}, stream);
+}
+
+int launch_gemm_bf16_ex(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux, void *out, int64_t m,
+                        int n, int k, int epilogue, int tokens, const GemmExtra &ex, hipStream_t stream) {
     VSC_REQUIRE(a && w && out, "gemm: null operand");
     VSC_REQUIRE(m > 0 && n > 0 && k > 0, "gemm: empty problem m=%lld n=%d k=%d", (long long)m, n, k);
     VSC_REQUIRE(k % BK == 0, "gemm: K=%d must be a multiple of %d", k, BK);
@@ -829,7 +898,9 @@ int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, co
     const int64_t tiles_m = (m + BM - 1) / BM;
     const int tiles_n = (n + BN - 1) / BN;
     VSC_REQUIRE(tiles_m * tiles_n < (1ll << 31), "gemm: grid too large");
-    GemmArgs p{a, w, bias, aux, out, m, n, k, tokens, tiles_n, (int)tiles_m, 1, 0, 0};
+    GemmArgs p{a, w, bias, aux, out, m, n, k, tokens, tiles_n, (int)tiles_m, 1, 0};
+    p.abl = 0;
+    p.ex = ex;
     if (const char *e = getenv("VSC_GEMM_ABL")) p.abl = atoi(e);
     static const bool force_v1 = getenv("VSC_GEMM_V1") != nullptr;
     static const bool force_v2 = getenv("VSC_GEMM_CFG") != nullptr;
@@ -838,7 +909,15 @@ int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, co
     // at 32 frames the N = 768 GEMMs 26 / 57 instead of 35 / 77 us; from ~130 tiles up the big tile wins.
     const int64_t big_tiles = ((m + 255) / 256) * ((n + 255) / 256);
     const bool fills = big_tiles > (k <= 512 ? 64 : 128);
-    const bool v2 = !force_v1 && m >= 1024 && k % 32 == 0 && n % 8 == 0 && (fills || force_v2);
+    const bool fused = epilogue >= VSC_EPI_LNF_BF16;  // LayerNorm-folding kinds exist in the 256-row kernels only
+    if (fused) {
+        VSC_REQUIRE(n % 64 == 0 && k % 32 == 0, "gemm: LayerNorm-folding epilogue needs N %% 64 == 0 (N=%d)", n);
+        if (epilogue == VSC_EPI_RESADD_STATS_F32)
+            VSC_REQUIRE(aux && ex.xb && ex.stats, "gemm: RESADD_STATS needs residual, xb and stats");
+        else
+            VSC_REQUIRE(ex.rowstats && ex.colsum && bias, "gemm: LNF needs rowstats, colsum and the folded bias");
+    }
+    const bool v2 = fused || (!force_v1 && m >= 1024 && k % 32 == 0 && n % 8 == 0 && (fills || force_v2));
     if (epilogue == VSC_EPI_RESADD_F32) VSC_REQUIRE(aux, "gemm: RESADD needs the residual pointer");
     if (epilogue == VSC_EPI_PATCH_F32) {
         VSC_REQUIRE(aux && tokens > 1, "gemm: PATCH needs pos and tokens");
@@ -853,6 +932,10 @@ int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, co
             case VSC_EPI_RESADD_F32: return launch_v2_pick<VSC_EPI_RESADD_F32>(p, stream);
             case VSC_EPI_PATCH_F32: return launch_v2_pick<VSC_EPI_PATCH_F32>(p, stream);
             case VSC_EPI_F32: return launch_v2_pick<VSC_EPI_F32>(p, stream);
+            case VSC_EPI_LNF_BF16: return launch_v2<VSC_EPI_LNF_BF16, 2, 4, 8, 4, 4>(p, stream);
+            case VSC_EPI_LNF_GELU_BF16: return launch_v2<VSC_EPI_LNF_GELU_BF16, 2, 4, 8, 4, 4>(p, stream);
+            case VSC_EPI_LNF_QGELU_BF16: return launch_v2<VSC_EPI_LNF_QGELU_BF16, 2, 4, 8, 4, 4>(p, stream);
+            case VSC_EPI_RESADD_STATS_F32: return launch_v2<VSC_EPI_RESADD_STATS_F32, 2, 4, 8, 4, 4>(p, stream);
             default: VSC_REQUIRE(false, "gemm: unknown epilogue %d", epilogue);
         }
     }
@@ -860,17 +943,37 @@ int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, co
         case VSC_EPI_BF16: return launch_t<VSC_EPI_BF16>(p, (int)tiles_m, stream);
         case VSC_EPI_GELU_BF16: return launch_t<VSC_EPI_GELU_BF16>(p, (int)tiles_m, stream);
         case VSC_EPI_QGELU_BF16: return launch_t<VSC_EPI_QGELU_BF16>(p, (int)tiles_m, stream);
-        case VSC_EPI_RESADD_F32:
-            VSC_REQUIRE(aux, "gemm: RESADD needs the residual pointer");
-            return launch_t<VSC_EPI_RESADD_F32>(p, (int)tiles_m, stream);
-        case VSC_EPI_PATCH_F32:
-            VSC_REQUIRE(aux && tokens > 1, "gemm: PATCH needs pos and tokens");
-            VSC_REQUIRE(m % (tokens - 1) == 0, "gemm: PATCH rows %lld not a multiple of %d patches",
-                        (long long)m, tokens - 1);
-            return launch_t<VSC_EPI_PATCH_F32>(p, (int)tiles_m, stream);
+        case VSC_EPI_RESADD_F32: return launch_t<VSC_EPI_RESADD_F32>(p, (int)tiles_m, stream);
+        case VSC_EPI_PATCH_F32: return launch_t<VSC_EPI_PATCH_F32>(p, (int)tiles_m, stream);
         case VSC_EPI_F32: return launch_t<VSC_EPI_F32>(p, (int)tiles_m, stream);
         default: VSC_REQUIRE(false, "gemm: unknown epilogue %d", epilogue);
     }
+    return VSC_OK;
+}
+
+// (mean, M2) of the width / 64 column slices of every row -> (mean, rstd) of the row (Chan's pairwise update with
+// equal counts): what the LayerNorm-folding GEMM epilogues read
+__global__ __launch_bounds__(256) void ln_stats_merge_kernel(const float *__restrict__ stats, float *__restrict__ rowstats,
+                                                             int64_t rows, int slices, int width, float eps) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= rows) return;
+    float mean = 0.f, m2 = 0.f;
+    for (int s = 0; s < slices; ++s) mean += stats[((int64_t)s * rows + m) * 2];
+    mean /= (float)slices;
+    for (int s = 0; s < slices; ++s) {
+        const float2 v = *(const float2 *)(stats + ((int64_t)s * rows + m) * 2);
+        const float d = v.x - mean;
+        m2 += v.y + 64.0f * d * d;
+    }
+    *(float2 *)(rowstats + 2 * m) = make_float2(mean, rsqrtf(m2 / (float)width + eps));
+}
+
+int launch_ln_stats_merge(const float *stats, float *rowstats, int64_t rows, int slices, int width, float eps,
+                          hipStream_t stream) {
+    VSC_REQUIRE(stats && rowstats && rows > 0 && slices * 64 == width, "ln_stats_merge: %d slices for width %d", slices, width);
+    hipLaunchKernelGGL(ln_stats_merge_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, stats, rowstats, rows,
+                       slices, width, eps);
+    VSC_CHECK_LAUNCH();
     return VSC_OK;
 }
 

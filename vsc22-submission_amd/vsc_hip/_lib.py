@@ -31,7 +31,7 @@ class EncoderConfigC(ctypes.Structure):
         ("width", c_int32), ("layers", c_int32), ("heads", c_int32), ("mlp_dim", c_int32),
         ("out_dim", c_int32), ("ln_eps", c_float), ("act", c_int32), ("pre_ln", c_int32),
         ("patch_bias", c_int32), ("pool", c_int32), ("gem_p", c_float),
-        ("max_batch", c_int32), ("l2_normalize", c_int32), ("head_conv_dim", c_int32), ("lanes", c_int32),
+        ("max_batch", c_int32), ("l2_normalize", c_int32), ("head_conv_dim", c_int32), ("lanes", c_int32), ("fuse_ln", c_int32),
     ]
 
 

@@ -18,7 +18,7 @@ from .config import EncoderConfig, get_config
 
 class HipEncoder:
     def __init__(self, cfg: EncoderConfig | str, weights: dict, *, max_batch: int = 128,
-                 l2_normalize: bool = False, lanes: int = 1):
+                 l2_normalize: bool = False, lanes: int = 1, fuse_ln: int = 0):
         if isinstance(cfg, str):
             cfg = get_config(cfg)
         self.cfg = cfg
@@ -32,7 +32,7 @@ class HipEncoder:
             out_dim=cfg.out_dim, ln_eps=cfg.ln_eps, act={"gelu": 0, "quick_gelu": 1}[cfg.act],
             pre_ln=int(cfg.pre_ln), patch_bias=int(cfg.patch_bias),
             pool={"gem": 0, "cls": 1}[cfg.pool], gem_p=cfg.gem_p, max_batch=max_batch,
-            l2_normalize=int(l2_normalize), head_conv_dim=cfg.head_conv_dim, lanes=lanes)
+            l2_normalize=int(l2_normalize), head_conv_dim=cfg.head_conv_dim, lanes=lanes, fuse_ln=int(fuse_ln))
         handle = ctypes.c_void_p()
         check(self._lib.vsc_encoder_create(ctypes.byref(c), ctypes.byref(handle)))
         self._h = handle
