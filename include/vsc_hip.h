@@ -89,6 +89,12 @@ int vsc_encoder_finalize(vsc_encoder *enc);
  * out_dim ? out_dim : width.  Asynchronous on `stream`. */
 int vsc_encoder_forward(vsc_encoder *enc, const float *frames_dev, int64_t n, float *desc_dev,
                         void *stream);
+/* The same from DECODED frames: frames_u8_dev uint8 [n, image, image, channels] (PIL / numpy layout); torchvision's
+ * ToTensor + Normalize(mean, std) (infer/src/transform.py:37-42, extract_query_feats.py:97-105) run inside the
+ * patchify kernel in the reference's fp32 op order, so the result is bit-identical to vsc_encoder_forward on the fp32
+ * tensor -- with a quarter of the bytes over PCIe and HBM.  mean / std: `channels` floats in HOST memory. */
+int vsc_encoder_forward_u8(vsc_encoder *enc, const uint8_t *frames_u8_dev, int64_t n, const float *mean,
+                           const float *std, float *desc_dev, void *stream);
 /* Same, but also copies the last hidden state (after the final LayerNorm),
  * float32 [n, tokens, width], for parity tests.  tokens_dev may be NULL. */
 int vsc_encoder_forward_debug(vsc_encoder *enc, const float *frames_dev, int64_t n,
@@ -134,6 +140,9 @@ int vsc_swin_set_weight(vsc_swin *enc, const char *name, const float *host, size
 int vsc_swin_finalize(vsc_swin *enc);
 /* frames_dev f32 [n, channels, image, image] -> desc_dev f32 [n, out_dim]; asynchronous on `stream`. */
 int vsc_swin_forward(vsc_swin *enc, const float *frames_dev, int64_t n, float *desc_dev, void *stream);
+/* uint8 [n, image, image, channels] input, normalisation fused as in vsc_encoder_forward_u8 */
+int vsc_swin_forward_u8(vsc_swin *enc, const uint8_t *frames_u8_dev, int64_t n, const float *mean, const float *std,
+                        float *desc_dev, void *stream);
 /* also returns the last-stage tokens after the final LayerNorm, f32 [n, tokens_last, width_last] */
 int vsc_swin_forward_debug(vsc_swin *enc, const float *frames_dev, int64_t n, float *desc_dev,
                            float *tokens_dev, void *stream);

@@ -148,3 +148,26 @@ def test_layernorm_folding_ragged_rows(dev):
     x = torch.from_numpy(synth.frames(6, 50, cfg)).to(dev)
     dp, df = plain(x).cpu().numpy(), fused(x).cpu().numpy()
     assert np.abs(df - dp).max() < 5e-4 and not np.array_equal(df, dp)
+
+
+def _u8_and_reference_tensor(seed, n, size, mean, std):
+    """Random decoded frames uint8 [n,H,W,3] and the fp32 tensor torchvision's ToTensor + Normalize builds from them."""
+    u8 = torch.from_numpy((synth.uniform(seed, (n, size, size, 3), 0.0, 256.0)).astype(np.uint8))
+    x = u8.permute(0, 3, 1, 2).float() / 255.0
+    x = (x - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    return u8, x
+
+
+@pytest.mark.parametrize("preset,mean,std", [("tiny", (0.5, 0.5, 0.5), (0.5, 0.5, 0.5)),
+                                             ("tiny_clip", (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)),
+                                             ("vit_b16_224", (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))])
+def test_uint8_frames_give_bit_identical_descriptors(dev, preset, mean, std):
+    """Decoded uint8 HWC frames with the normalisation fused into patchify == the fp32 tensor path, bit for bit."""
+    cfg, w, _ = _encoder(preset, 3, max_batch=4)
+    from vsc_hip.encoder import HipEncoder
+    enc = HipEncoder(cfg, w, max_batch=4, l2_normalize=True, u8_mean=mean, u8_std=std)
+    u8, x = _u8_and_reference_tensor(17, 6, cfg.image_size, mean, std)
+    a, b = enc(u8.to(dev)).cpu().numpy(), enc(x.to(dev)).cpu().numpy()
+    assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        enc(u8.permute(0, 3, 1, 2).contiguous().to(dev))   # uint8 must be HWC

@@ -142,3 +142,13 @@ def test_swin_encoder_vs_oracle_and_batching(dev):
     del w2["layers.1.blocks.0.attn.logit_scale"]
     with pytest.raises(KeyError):
         SwinHipEncoder(cfg, w2)
+
+
+def test_swin_uint8_frames_bit_identical(dev):
+    from vsc_hip.swin_config import get_swin_config
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    cfg = get_swin_config("tiny_swin")
+    enc = SwinHipEncoder(cfg, synth.swin_weights(4, cfg), max_batch=3, l2_normalize=True)
+    u8 = torch.from_numpy((synth.uniform(19, (5, cfg.image_size, cfg.image_size, 3), 0.0, 256.0)).astype(np.uint8))
+    x = (u8.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5
+    assert np.array_equal(enc(u8.to(dev)).cpu().numpy(), enc(x.to(dev)).cpu().numpy())

@@ -130,5 +130,7 @@ int launch_ln_residual(const float *t, const float *gamma, const float *beta, co
                        uint16_t *xb, int64_t rows, int width, float eps, hipStream_t stream);
 int launch_merge_gather(const uint16_t *xb, uint16_t *out, int64_t frames, int res, int c, hipStream_t stream);
 int launch_l2_normalize(float *x, int64_t n, int d, hipStream_t stream);
+int launch_patchify_u8(const uint8_t *frames, uint16_t *patches, int64_t n, int channels, int image, int patch, int kpad,
+                       const float *mean, const float *std, hipStream_t stream);
 int launch_f32_to_bf16(const float *src, uint16_t *dst, int64_t rows, int cols, int cols_pad,
                        hipStream_t stream);

@@ -339,6 +339,70 @@ int launch_patchify(const float *frames, uint16_t *patches, int64_t n, int chann
     return VSC_OK;
 }
 
+// The same patches from DECODED frames: uint8 [n, H, W, C] (the layout PIL / numpy hand out), with torchvision's
+// ToTensor + Normalize (infer/src/transform.py:37-42; extract_query_feats.py:97-105 for the CLIP statistics) applied
+// here in their fp32 op order -- u8 / 255 (IEEE divide), minus mean, IEEE divide by std -- so the bf16 patches are
+// bit-identical to patchify_kernel on the fp32 tensor the reference would have built, from a quarter of the bytes
+// over PCIe and HBM.
+struct Norm3 {
+    float mean[4], std[4];
+};
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t *__restrict__ frames, uint16_t *__restrict__ patches,
+                                                          int64_t total_chunks, int channels, int image, int patch,
+                                                          int kpad, Norm3 nm) {
+    const int grid = image / patch;
+    const int kc = kpad >> 3;
+    const int pp = patch * patch;
+    const int kreal = channels * pp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total_chunks; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / kc;
+        const int k0 = (int)(e - row * kc) * 8;
+        const int64_t f = row / (grid * grid);
+        const int pidx = (int)(row - f * grid * grid);
+        const int gy = pidx / grid, gx = pidx - gy * grid;
+        const uint8_t *fb = frames + f * (int64_t)channels * image * image;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            if (k < kreal) {
+                const int c = k / pp, rem = k - c * pp;
+                const int py = rem / patch, px = rem - py * patch;
+                const float t = __fdiv_rn((float)fb[((int64_t)(gy * patch + py) * image + gx * patch + px) * channels + c], 255.0f);
+                v[j] = __fdiv_rn(t - nm.mean[c], nm.std[c]);
+            } else {
+                v[j] = 0.f;
+            }
+        }
+        uint4 pk;
+        pk.x = pack_bf16x2(v[0], v[1]);
+        pk.y = pack_bf16x2(v[2], v[3]);
+        pk.z = pack_bf16x2(v[4], v[5]);
+        pk.w = pack_bf16x2(v[6], v[7]);
+        *(uint4 *)(patches + row * kpad + k0) = pk;
+    }
+}
+
+int launch_patchify_u8(const uint8_t *frames, uint16_t *patches, int64_t n, int channels, int image, int patch, int kpad,
+                       const float *mean, const float *std, hipStream_t stream) {
+    VSC_REQUIRE(frames && patches && mean && std, "patchify_u8: null pointer");
+    VSC_REQUIRE(channels >= 1 && channels <= 4, "patchify_u8: %d channels", channels);
+    VSC_REQUIRE(patch > 0 && image % patch == 0 && kpad % 8 == 0 && kpad >= channels * patch * patch,
+                "patchify_u8: image %d patch %d kpad %d", image, patch, kpad);
+    Norm3 nm{};
+    for (int c = 0; c < channels; ++c) {
+        VSC_REQUIRE(std[c] > 0.f, "patchify_u8: std[%d] = %g", c, (double)std[c]);
+        nm.mean[c] = mean[c];
+        nm.std[c] = std[c];
+    }
+    const int g = image / patch;
+    const int64_t chunks = n * g * g * (kpad / 8);
+    hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for(chunks)), dim3(256), 0, stream, frames, patches, chunks, channels,
+                       image, patch, kpad, nm);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
 int launch_f32_to_bf16(const float *src, uint16_t *dst, int64_t rows, int cols, int cols_pad,
                        hipStream_t stream) {
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(rows * cols_pad)), dim3(256), 0, stream, src,

@@ -342,9 +342,10 @@ extern "C" int vsc_encoder_finalize(vsc_encoder *e) {
 
 extern "C" int64_t vsc_encoder_workspace_bytes(const vsc_encoder *e) { return e ? e->ws_bytes : 0; }
 
-extern "C" int vsc_encoder_forward_debug(vsc_encoder *e, const float *frames, int64_t n, float *desc,
-                                         float *tokens_out, void *stream_) {
-    VSC_REQUIRE(e && frames && desc, "forward: null argument");
+// frames: fp32 [n,C,H,W] already normalised, or (frames == nullptr) frames_u8: uint8 [n,H,W,C] + mean/std
+static int encoder_forward_impl(vsc_encoder *e, const float *frames, const uint8_t *frames_u8, const float *mean,
+                                const float *std, int64_t n, float *desc, float *tokens_out, void *stream_) {
+    VSC_REQUIRE(e && (frames || frames_u8) && desc, "forward: null argument");
     VSC_REQUIRE(n >= 0, "forward: negative frame count");
     if (!e->finalized) {
         vsc_set_error("forward before finalize");
@@ -369,8 +370,14 @@ extern "C" int vsc_encoder_forward_debug(vsc_encoder *e, const float *frames, in
         vsc_encoder::Workspace &w = e->ws[lane];
         const int64_t B = (n - off) < c.max_batch ? (n - off) : c.max_batch;
         const int64_t M = B * T, Mp = B * (T - 1);
-        { ProfScope _ps(e, VSC_PROF_PATCHIFY, st); TRY(launch_patchify(frames + off * frame_elems, w.patches, B, c.channels, c.image_size,
-                            c.patch_size, e->kpad, st)); }
+        {
+            ProfScope _ps(e, VSC_PROF_PATCHIFY, st);
+            if (frames)
+                TRY(launch_patchify(frames + off * frame_elems, w.patches, B, c.channels, c.image_size, c.patch_size, e->kpad, st));
+            else
+                TRY(launch_patchify_u8(frames_u8 + off * frame_elems, w.patches, B, c.channels, c.image_size, c.patch_size,
+                                       e->kpad, mean, std, st));
+        }
         { ProfScope _ps(e, VSC_PROF_GEMM_PATCH, st); TRY(launch_gemm_bf16(w.patches, e->patch_w, e->patch_b, e->pos, w.x, Mp, D, e->kpad,
                              VSC_EPI_PATCH_F32, T, st)); }
         { ProfScope _ps(e, VSC_PROF_MISC, st); TRY(launch_cls_rows(w.x, e->cls, e->pos, B, T, D, st)); }
@@ -446,9 +453,21 @@ extern "C" int vsc_encoder_forward_debug(vsc_encoder *e, const float *frames, in
     return VSC_OK;
 }
 
+extern "C" int vsc_encoder_forward_debug(vsc_encoder *e, const float *frames, int64_t n, float *desc,
+                                         float *tokens_out, void *stream) {
+    VSC_REQUIRE(frames, "forward: null frames");
+    return encoder_forward_impl(e, frames, nullptr, nullptr, nullptr, n, desc, tokens_out, stream);
+}
+
 extern "C" int vsc_encoder_forward(vsc_encoder *e, const float *frames, int64_t n, float *desc,
                                    void *stream) {
     return vsc_encoder_forward_debug(e, frames, n, desc, nullptr, stream);
+}
+
+extern "C" int vsc_encoder_forward_u8(vsc_encoder *e, const uint8_t *frames_u8, int64_t n, const float *mean,
+                                      const float *std, float *desc, void *stream) {
+    VSC_REQUIRE(frames_u8 && mean && std, "forward_u8: null argument");
+    return encoder_forward_impl(e, nullptr, frames_u8, mean, std, n, desc, nullptr, stream);
 }
 
 extern "C" int vsc_encoder_set_profiling(vsc_encoder *e, int32_t on) {

@@ -298,9 +298,9 @@ static int gemm_ln(vsc_swin *e, const uint16_t *a, const uint16_t *w, const floa
     return launch_ln_residual(e->t, g, b, x_in, e->x, e->xb, m, n, e->cfg.ln_eps, st);
 }
 
-extern "C" int vsc_swin_forward_debug(vsc_swin *e, const float *frames, int64_t n, float *desc, float *tokens_out,
-                                      void *stream_) {
-    VSC_REQUIRE(e && frames && desc && n >= 0, "swin forward: bad argument");
+static int swin_forward_impl(vsc_swin *e, const float *frames, const uint8_t *frames_u8, const float *mean, const float *std,
+                             int64_t n, float *desc, float *tokens_out, void *stream_) {
+    VSC_REQUIRE(e && (frames || frames_u8) && desc && n >= 0, "swin forward: bad argument");
     if (!e->finalized) {
         vsc_set_error("swin forward before finalize");
         return VSC_ERR_STATE;
@@ -314,8 +314,11 @@ extern "C" int vsc_swin_forward_debug(vsc_swin *e, const float *frames, int64_t 
     for (int64_t off = 0; off < n; off += c.max_batch) {
         const int64_t B = (n - off) < c.max_batch ? (n - off) : c.max_batch;
         int64_t M = B * e->res(0) * e->res(0);
-        TRY(launch_patchify(frames + off * frame_elems, e->patches, B, c.channels, c.image_size, c.patch_size,
-                            e->kpad, st));
+        if (frames)
+            TRY(launch_patchify(frames + off * frame_elems, e->patches, B, c.channels, c.image_size, c.patch_size, e->kpad, st));
+        else
+            TRY(launch_patchify_u8(frames_u8 + off * frame_elems, e->patches, B, c.channels, c.image_size, c.patch_size,
+                                   e->kpad, mean, std, st));
         TRY(gemm_ln(e, e->patches, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, nullptr, M, c.embed_dim, e->kpad, st));
         for (int s = 0; s < c.stages; ++s) {
             const int C = e->dim(s), R = e->res(s), W = e->window(s), H = c.heads[s];
@@ -342,6 +345,18 @@ extern "C" int vsc_swin_forward_debug(vsc_swin *e, const float *frames, int64_t 
     return VSC_OK;
 }
 
+extern "C" int vsc_swin_forward_debug(vsc_swin *e, const float *frames, int64_t n, float *desc, float *tokens_out,
+                                      void *stream) {
+    VSC_REQUIRE(frames, "swin forward: null frames");
+    return swin_forward_impl(e, frames, nullptr, nullptr, nullptr, n, desc, tokens_out, stream);
+}
+
 extern "C" int vsc_swin_forward(vsc_swin *e, const float *frames, int64_t n, float *desc, void *stream) {
     return vsc_swin_forward_debug(e, frames, n, desc, nullptr, stream);
+}
+
+extern "C" int vsc_swin_forward_u8(vsc_swin *e, const uint8_t *frames_u8, int64_t n, const float *mean, const float *std,
+                                   float *desc, void *stream) {
+    VSC_REQUIRE(frames_u8 && mean && std, "swin forward_u8: null argument");
+    return swin_forward_impl(e, nullptr, frames_u8, mean, std, n, desc, nullptr, stream);
 }

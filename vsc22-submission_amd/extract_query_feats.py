@@ -23,7 +23,7 @@ from zipfile import ZipFile
 import numpy as np
 import torch
 
-from src.dataset import clip_transform, vit_transform
+from src.dataset import CLIP_MEAN, CLIP_STD, clip_transform_u8, vit_transform_u8
 from src.matching import calclualte_low_var_dim
 from src.model_zoo import load_encoder, parse_model_spec
 from src.query_pipeline import VideoScorer, run_query_videos
@@ -36,11 +36,12 @@ NK, BETA = 1, 1.2  # extract_query_feats.py:56-57
 
 
 def zip_videos(video_ids, zip_prefix, sizes, with_clip=False):
-    """(video_id, {size: frames}, timestamps) per video; frames decoded once, resized per input size."""
+    """(video_id, {size: uint8 frames [S,size,size,3]}, timestamps) per video; frames decoded once, resized per input size.
+    They stay uint8 until they are on the GPU: ToTensor + Normalize run inside the encoders' patchify kernels."""
     from PIL import Image
-    transforms = {s: vit_transform(s, s) for s in sizes}
+    transforms = {s: vit_transform_u8(s, s) for s in sizes}
     if with_clip:
-        transforms[VideoScorer.KEY] = clip_transform(224)
+        transforms[VideoScorer.KEY] = clip_transform_u8(224)
     for vid in video_ids:
         path = "%s/%s/%s.zip" % (zip_prefix, vid[-2:], vid)
         if not os.path.exists(path):
@@ -71,7 +72,7 @@ def main(args):
     scorer = None
     if args.clip_checkpoint and args.vsm_checkpoint:
         from vsc_hip.video_score import VideoScoreHead, from_reference_state
-        clip, _ = load_encoder("clip_vit_l14_224", "clip", args.clip_checkpoint, args.max_batch)
+        clip, _ = load_encoder("clip_vit_l14_224", "clip", args.clip_checkpoint, args.max_batch, u8_norm=(CLIP_MEAN, CLIP_STD))
         state = torch.load(args.vsm_checkpoint, map_location="cpu")
         scorer = VideoScorer(clip, VideoScoreHead("vsm_roberta_base", from_reference_state(state.get("state_dict", state))), device)
     videos = zip_videos(vids, args.zip_prefix, sorted({size for _, size in encoders}), with_clip=scorer is not None)

@@ -14,7 +14,7 @@ import os
 import numpy as np
 import torch
 
-from src.dataset import ZipFrames, collate_fn, vit_transform
+from src.dataset import ZipFrames, collate_fn, vit_transform_u8
 from src.extractor import extract_vsc_feat
 from vsc.storage import load_features, store_features
 from src.model_zoo import WEIGHT_FORMATS, load_encoder
@@ -34,7 +34,7 @@ def main(args):
     with open(args.input_file, encoding="utf-8") as f:
         vids = [x.strip() for x in f if x.strip()]
     lo, hi = vdist.shard_bounds(len(vids), rank, world_size)
-    data = ZipFrames(vids[lo:hi], args.zip_prefix, vit_transform(image_size, image_size))
+    data = ZipFrames(vids[lo:hi], args.zip_prefix, vit_transform_u8(image_size, image_size))   # uint8 to the GPU; normalised in patchify
     loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, num_workers=4, collate_fn=collate_fn)
     ids, feats, stamps = extract_vsc_feat(model, loader, device)
     np.savez(f"{args.save_file}_{rank}.npz", video_ids=ids, features=feats, timestamps=stamps)

@@ -23,6 +23,16 @@ def vit_transform(width: int, height: int):
     return apply
 
 
+def vit_transform_u8(width: int, height: int):
+    """The resize of ``vit_transform`` only: uint8 [H, W, 3].  ToTensor + Normalize(0.5, 0.5) then run inside the encoder's
+    patchify kernel (HipEncoder / SwinHipEncoder take uint8 [n,H,W,C]) -- same descriptors, a quarter of the bytes."""
+    from PIL import Image
+
+    def apply(img) -> torch.Tensor:
+        return torch.from_numpy(np.asarray(img.convert("RGB").resize((height, width), Image.BICUBIC), dtype=np.uint8).copy())
+    return apply
+
+
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
@@ -46,6 +56,20 @@ def clip_transform(size: int = 224):
         img = img.crop((left, top, left + size, top + size))
         x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0
         return (x - mean) / std
+    return apply
+
+
+def clip_transform_u8(size: int = 224):
+    """Resize + CenterCrop of ``clip_transform`` only: uint8 [size, size, 3] (normalise with CLIP_MEAN / CLIP_STD on the GPU)."""
+    from PIL import Image
+
+    def apply(img) -> torch.Tensor:
+        img = img.convert("RGB")
+        w, h = img.size
+        nw, nh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
+        img = img.resize((nw, nh), Image.BICUBIC)
+        left, top = int(round((nw - size) / 2.0)), int(round((nh - size) / 2.0))
+        return torch.from_numpy(np.asarray(img.crop((left, top, left + size, top + size)), dtype=np.uint8).copy())
     return apply
 
 

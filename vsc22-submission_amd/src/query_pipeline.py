@@ -36,19 +36,61 @@ class VideoScorer:
         self.clip, self.head, self.device, self.chunk = clip, head, device, chunk
 
     def __call__(self, frames: torch.Tensor) -> float:
-        n = min(frames.shape[0], self.head.cfg.max_frames)
-        feats = [self.clip(frames[lo:min(lo + self.chunk, n)].to(self.device)) for lo in range(0, n, self.chunk)]
-        return self.head.score(torch.cat(feats))
+        return self.batch([frames])[0]
+
+    def batch(self, frames_list: Sequence[torch.Tensor]) -> List[float]:
+        """Scores of several videos: the CLIP tower runs over all their (first 256) frames as one stream of
+        ``chunk``-frame calls, the MS head once per video."""
+        clipped = [f[: self.head.cfg.max_frames] for f in frames_list]
+        feats = encode_group([self.clip], clipped, self.device, self.chunk)[0]
+        return [self.head.score(torch.from_numpy(f).to(self.device)) for f in feats]
 
 
 def encode_many(model, frames_list: Sequence[torch.Tensor], device, chunk: int = 256) -> List[np.ndarray]:
     """Frames of several videos through one backbone as ONE stream of ``chunk``-frame calls (a 40-frame video alone
     fills a quarter of the chip: 8 / 32 / 64 / 128-frame calls run at 14 / 46 / 74 / 83 % of the large-batch rate),
     split back per video.  The encoders are frame-independent, so this equals per-video ``encode_frames``."""
+    return encode_group([model], frames_list, device, chunk)[0]
+
+
+def encode_group(models: Sequence, frames_list: Sequence[torch.Tensor], device, chunk: int = 256) -> List[List[np.ndarray]]:
+    """Like ``encode_many`` for several backbones that take the SAME frames (the three Swin-V2 models of the ensemble):
+    every chunk is uploaded once and goes through all of them.  -> per model, per video arrays."""
     lens = [f.shape[0] for f in frames_list]
-    out = encode_frames(model, torch.cat(list(frames_list)), device, chunk)
+    total = sum(lens)
+    outs = [[] for _ in models]
+    # walk the videos chunk by chunk without materialising the concatenation on the host
+    buf, have = [], 0
+
+    def flush():
+        nonlocal buf, have
+        if not buf:
+            return
+        x = torch.cat(buf).to(device, non_blocking=True) if len(buf) > 1 else buf[0].to(device, non_blocking=True)
+        for i, model in enumerate(models):
+            out = model(x)
+            if out.dim() == 3:
+                out = out[:, 0]
+            outs[i].append(out.detach().float())
+        buf, have = [], 0
+
+    for f in frames_list:
+        lo = 0
+        while lo < f.shape[0]:
+            take = min(chunk - have, f.shape[0] - lo)
+            buf.append(f[lo:lo + take])
+            have += take
+            lo += take
+            if have == chunk:
+                flush()
+    flush()
     cuts = np.cumsum(lens)[:-1]
-    return np.split(out, cuts)
+    result = []
+    for o in outs:
+        full = torch.cat(o).cpu().numpy() if o else np.zeros((0, 0), np.float32)
+        assert full.shape[0] == total
+        result.append(np.split(full, cuts))
+    return result
 
 
 def _video_groups(videos, min_frames: int):
@@ -77,11 +119,18 @@ def run_query_videos(videos: Iterable[Tuple[str, Dict[int, torch.Tensor], np.nda
     finals, per_model = [], []
     rnd_idx = 0
     for group in _video_groups(videos, group_frames):
-        subs_by_model = [encode_many(model, [v[1][size] for v in group], device, chunk) for model, size in encoders]
+        # backbones that share an input size share the upload of every chunk
+        subs_by_model = [None] * len(encoders)
+        for size in dict.fromkeys(sz for _, sz in encoders):
+            idx = [i for i, (_, sz) in enumerate(encoders) if sz == size]
+            for i, per_video in zip(idx, encode_group([encoders[i][0] for i in idx], [v[1][size] for v in group], device, chunk)):
+                subs_by_model[i] = per_video
+        if scorer is not None:
+            clip_frames = [v[1][VideoScorer.KEY] for v in group]
+            scores = scorer.batch(clip_frames) if hasattr(scorer, "batch") else [scorer(f) for f in clip_frames]
+            video_scores.update({v[0]: sc for v, sc in zip(group, scores)})
         for i, (video_id, frames_by_size, timestamps) in enumerate(group):
             subs = [m[i] for m in subs_by_model]
-            if scorer is not None:
-                video_scores[video_id] = scorer(frames_by_size[VideoScorer.KEY])
             feat, sub_feats, rnd_idx = process_query_video(video_id, subs, np.asarray(timestamps), video_scores.get(video_id, 1.0),
                                                            pca_transform, rnd_idx, ops=ops, score_threshold=score_threshold)
             finals.append(feat)

@@ -18,12 +18,16 @@ from .config import EncoderConfig, get_config
 
 class HipEncoder:
     def __init__(self, cfg: EncoderConfig | str, weights: dict, *, max_batch: int = 128,
-                 l2_normalize: bool = False, lanes: int = 1, fuse_ln: int = 0):
+                 l2_normalize: bool = False, lanes: int = 1, fuse_ln: int = 0,
+                 u8_mean=(0.5, 0.5, 0.5), u8_std=(0.5, 0.5, 0.5)):
         if isinstance(cfg, str):
             cfg = get_config(cfg)
         self.cfg = cfg
         self.max_batch = max_batch
         self.l2 = l2_normalize
+        # Normalize(mean, std) applied to uint8 [n,H,W,C] inputs inside the patchify kernel (vit_transform: 0.5 / 0.5)
+        self.u8_mean = (ctypes.c_float * cfg.channels)(*u8_mean[: cfg.channels])
+        self.u8_std = (ctypes.c_float * cfg.channels)(*u8_std[: cfg.channels])
         self._lib = _lib.require_device()
         wnames.check_complete(weights, cfg)
         c = EncoderConfigC(
@@ -63,20 +67,28 @@ class HipEncoder:
         return int(self._lib.vsc_encoder_workspace_bytes(self._h))
 
     def __call__(self, frames: torch.Tensor, return_tokens: bool = False):
+        """frames: float32 [n,C,H,W] already normalised (the reference's tensors), or uint8 [n,H,W,C] decoded frames
+        (ToTensor + Normalize(u8_mean, u8_std) then happen on the GPU; bit-identical descriptors, 4x fewer bytes)."""
         assert self._h is not None, "encoder was closed"
         cfg = self.cfg
-        if frames.dim() != 4 or tuple(frames.shape[1:]) != (cfg.channels, cfg.image_size, cfg.image_size):
-            raise ValueError(f"expected frames [n,{cfg.channels},{cfg.image_size},{cfg.image_size}], "
-                             f"got {tuple(frames.shape)}")
+        u8 = frames.dtype == torch.uint8
+        want = (cfg.image_size, cfg.image_size, cfg.channels) if u8 else (cfg.channels, cfg.image_size, cfg.image_size)
+        if frames.dim() != 4 or tuple(frames.shape[1:]) != want:
+            raise ValueError(f"expected frames [n,{cfg.channels},{cfg.image_size},{cfg.image_size}] float32 or "
+                             f"[n,{cfg.image_size},{cfg.image_size},{cfg.channels}] uint8, got {tuple(frames.shape)} {frames.dtype}")
         if not frames.is_cuda:
             raise _lib.HipPathUnavailable("frames must be on the GPU; there is no CPU path")
-        frames = frames.to(torch.float32).contiguous()
+        frames = frames.contiguous() if u8 else frames.to(torch.float32).contiguous()
         n = frames.shape[0]
         desc = torch.empty((n, cfg.desc_dim), dtype=torch.float32, device=frames.device)
         tokens = None
         if return_tokens:
+            if u8:
+                raise ValueError("return_tokens is a debug path of the float32 entry point")
             tokens = torch.empty((n, cfg.tokens, cfg.width), dtype=torch.float32, device=frames.device)
-        if n:
+        if n and u8:
+            check(self._lib.vsc_encoder_forward_u8(self._h, ptr(frames), n, self.u8_mean, self.u8_std, ptr(desc), current_stream()))
+        elif n:
             check(self._lib.vsc_encoder_forward_debug(self._h, ptr(frames), n, ptr(desc), ptr(tokens),
                                                       current_stream()))
         return (desc, tokens) if return_tokens else desc

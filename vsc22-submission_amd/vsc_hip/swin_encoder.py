@@ -41,10 +41,13 @@ def from_reference_state(state: dict) -> dict:
 
 
 class SwinHipEncoder:
-    def __init__(self, cfg: SwinConfig | str, weights: dict, *, max_batch: int = 32, l2_normalize: bool = False):
+    def __init__(self, cfg: SwinConfig | str, weights: dict, *, max_batch: int = 32, l2_normalize: bool = False,
+                 u8_mean=(0.5, 0.5, 0.5), u8_std=(0.5, 0.5, 0.5)):
         if isinstance(cfg, str):
             cfg = get_swin_config(cfg)
         self.cfg, self.max_batch = cfg, max_batch
+        self.u8_mean = (ctypes.c_float * cfg.channels)(*u8_mean[: cfg.channels])   # Normalize() of uint8 inputs
+        self.u8_std = (ctypes.c_float * cfg.channels)(*u8_std[: cfg.channels])
         self._lib = _lib.require_device()
         names = swin_weight_names(cfg)
         missing = [n for n in names if n not in weights]
@@ -84,19 +87,27 @@ class SwinHipEncoder:
         return int(self._lib.vsc_swin_workspace_bytes(self._h))
 
     def __call__(self, frames: torch.Tensor, return_tokens: bool = False):
+        """frames: float32 [n,C,H,W] normalised, or uint8 [n,H,W,C] decoded (normalisation fused on the GPU)."""
         cfg = self.cfg
-        if frames.dim() != 4 or tuple(frames.shape[1:]) != (cfg.channels, cfg.image_size, cfg.image_size):
-            raise ValueError(f"expected frames [n,{cfg.channels},{cfg.image_size},{cfg.image_size}], got {tuple(frames.shape)}")
+        u8 = frames.dtype == torch.uint8
+        want = (cfg.image_size, cfg.image_size, cfg.channels) if u8 else (cfg.channels, cfg.image_size, cfg.image_size)
+        if frames.dim() != 4 or tuple(frames.shape[1:]) != want:
+            raise ValueError(f"expected frames [n,{cfg.channels},{cfg.image_size},{cfg.image_size}] float32 or "
+                             f"[n,{cfg.image_size},{cfg.image_size},{cfg.channels}] uint8, got {tuple(frames.shape)} {frames.dtype}")
         if not frames.is_cuda:
             raise _lib.HipPathUnavailable("frames must be on the GPU; there is no CPU path")
-        frames = frames.to(torch.float32).contiguous()
+        frames = frames.contiguous() if u8 else frames.to(torch.float32).contiguous()
         n = frames.shape[0]
         desc = torch.empty((n, cfg.out_dim), dtype=torch.float32, device=frames.device)
         tokens = None
         if return_tokens:
+            if u8:
+                raise ValueError("return_tokens is a debug path of the float32 entry point")
             last = cfg.stages - 1
             tokens = torch.empty((n, cfg.resolution(last) ** 2, cfg.dim(last)), dtype=torch.float32, device=frames.device)
-        if n:
+        if n and u8:
+            check(self._lib.vsc_swin_forward_u8(self._h, ptr(frames), n, self.u8_mean, self.u8_std, ptr(desc), current_stream()))
+        elif n:
             check(self._lib.vsc_swin_forward_debug(self._h, ptr(frames), n, ptr(desc), ptr(tokens), current_stream()))
         return (desc, tokens) if return_tokens else desc
 
