@@ -17,7 +17,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
   cpu_baseline  the fp32 oracle (oracle/vit_oracle.py, a port) on the host cores, on a
                 bounded sample of the same frames.
   search        secondary metric: exact 512-d inner-product top-100 sweep
-                (vsc_knn_ip_f32), Mpairs/s, with its own fp32-MFMA roofline.
+                (vsc_knn_ip_f32), Mpairs/s, with its own fp32-MFMA roofline.  With N > 1 ranks: the sharded form
+                (each rank holds nr / N references, one RCCL all_gather assembles the bank, every rank sweeps its
+                own nq queries; weak scaling, all_gather inside the timed region).
   swin          secondary metric: Swin-V2-B 256 encode (vsc_swin_forward), frames/s.
 """
 import argparse
@@ -100,6 +102,8 @@ def parse():
     ap.add_argument("--search-k", type=int, default=100)
     ap.add_argument("--search-steps", type=int, default=3)
     ap.add_argument("--no-swin", action="store_true")
+    ap.add_argument("--force-sharded-search", action="store_true",
+                    help="run the N > 1 search leg (RCCL all_gather + sweep) even with one rank; needs torchrun's env")
     ap.add_argument("--swin-batch", type=int, default=256)
     return ap.parse_args()
 
@@ -203,6 +207,38 @@ def bench_search(dev, args):
                          "note": "event time covers pack + knn_kernel + merge of one call"}}
 
 
+def bench_search_sharded(dev, args, dist, rank, world):
+    """N > 1: the path of BASELINE.json configs[3] at bench size -- every rank holds nr / N reference descriptors and
+    its own nq queries; one RCCL all_gather assembles the bank, then each rank sweeps its queries against all of it
+    (vsc_hip.distributed.sharded_knn).  Weak scaling: per-GPU sweep work is fixed.  Collective: runs on every rank."""
+    from vsc_hip import ops
+    from vsc_hip.distributed import sharded_knn
+    d, k = 512, args.search_k
+    nq, nr_local = args.search_nq, args.search_nr // world
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    r = torch.randn(nr_local, d, generator=g, device=dev)
+    q = torch.randn(nq, d, generator=g, device=dev)
+    ops.l2_normalize_(r)
+    ops.l2_normalize_(q)
+    sharded_knn(q[:256], r, k, gather_to=None)   # warm: RCCL communicator, scratch
+    times = []
+    for _ in range(max(args.search_steps, 1)):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        D, I = sharded_knn(q, r, k, gather_to=None)
+        torch.cuda.synchronize()
+        dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        times.append(float(dt.item()))
+    t = sum(times) / len(times)
+    pairs = float(world) * nq * (nr_local * world)
+    return {"metric": "Mpairs/s (512-d exact top-k, bank all_gathered over RCCL, every rank sweeps its own queries)",
+            "value": round(pairs / t / 1e6, 1), "unit": "Mpairs/s", "n_gpus": world, "nq_per_gpu": nq,
+            "nr_total": nr_local * world, "k": k, "dtype": "f32", "ms_per_sweep_incl_all_gather": round(t * 1e3, 3),
+            "scaling": "weak", "all_gather_bytes_per_rank": nr_local * d * 4 * (world - 1)}
+
+
 def bench_swin(dev, args):
     """Secondary: the reference's other backbone family (swinv2_v1xx), same contract as the ViT step."""
     from src import synth
@@ -248,7 +284,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded_search:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
 
@@ -301,6 +337,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out).all()
+
+    search_multi = None
+    if (world > 1 or args.force_sharded_search) and not args.no_search:
+        try:
+            search_multi = bench_search_sharded(dev, args, dist, rank, world)
+        except Exception as exc:  # noqa: BLE001 -- the primary line must still be printed
+            search_multi = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         total_frames = args.steps * args.batch * world
@@ -364,6 +407,8 @@ def main():
             torch.cuda.empty_cache()
         if not args.no_search and secondary:
             line["search"] = bench_search(dev, args)
+        if search_multi is not None:
+            line["search"] = search_multi
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
