@@ -160,3 +160,26 @@ def test_video_scorer_on_hip_path():
     cls = vit_oracle.descriptors({k: torch.from_numpy(v) for k, v in cw.items()}, ccfg, frames[: vcfg.max_frames], l2=False)
     want = vsm_oracle.video_score(vw, vcfg, cls)
     assert 0.0 < got < 1.0 and abs(got - want) < 1e-2
+
+
+def test_query_videos_dataset_reads_zips(tmp_path):
+    """zip of jpgs -> uint8 frames per input size, through the DataLoader the entry point uses."""
+    import io
+    from zipfile import ZipFile
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
+    import extract_query_feats as E
+    rng = np.random.RandomState(0)
+    for vid, n in (("Q100001", 3), ("Q100002", 2)):
+        d = tmp_path / vid[-2:]
+        d.mkdir(exist_ok=True)
+        with ZipFile(d / f"{vid}.zip", "w") as z:
+            for i in range(n):
+                buf = io.BytesIO()
+                Image.fromarray(rng.randint(0, 255, (40, 60, 3), dtype=np.uint8)).save(buf, format="JPEG")
+                z.writestr(f"{i:04d}.jpg", buf.getvalue())
+    items = list(E.zip_videos(["Q100001", "Q100002", "Q100099"], str(tmp_path), [16, 24], with_clip=True, workers=0))
+    assert [v[0] for v in items] == ["Q100001", "Q100002"]           # the missing video is skipped, as ZipFrames does
+    vid, frames, stamps = items[0]
+    assert frames[16].shape == (3, 16, 16, 3) and frames[24].shape == (3, 24, 24, 3) and frames["clip"].shape == (3, 224, 224, 3)
+    assert all(f.dtype == torch.uint8 for f in frames.values()) and stamps.tolist() == [0, 1, 2]

@@ -35,20 +35,38 @@ from vsc.storage import load_features, store_features
 NK, BETA = 1, 1.2  # extract_query_feats.py:56-57
 
 
-def zip_videos(video_ids, zip_prefix, sizes, with_clip=False):
-    """(video_id, {size: uint8 frames [S,size,size,3]}, timestamps) per video; frames decoded once, resized per input size.
-    They stay uint8 until they are on the GPU: ToTensor + Normalize run inside the encoders' patchify kernels."""
-    from PIL import Image
-    transforms = {s: vit_transform_u8(s, s) for s in sizes}
-    if with_clip:
-        transforms[VideoScorer.KEY] = clip_transform_u8(224)
-    for vid in video_ids:
-        path = "%s/%s/%s.zip" % (zip_prefix, vid[-2:], vid)
-        if not os.path.exists(path):
-            continue
-        with ZipFile(path, "r") as z:
+class QueryVideos(torch.utils.data.Dataset):
+    """One item = (video_id, {size: uint8 frames [S,size,size,3]}, timestamps): the jpgs of
+    <prefix>/<vid[-2:]>/<vid>.zip decoded once and resized per input size (bicubic, as vit_transform / the CLIP
+    transform do).  Frames stay uint8 until they are on the GPU: ToTensor + Normalize run inside the encoders'
+    patchify kernels.  Decoding is the slow part of the whole pipeline, so main() reads this through a DataLoader with
+    worker processes, as the reference does (extract_query_feats.py:138-140)."""
+
+    def __init__(self, video_ids, zip_prefix, sizes, with_clip=False):
+        self.zip_prefix = zip_prefix
+        self.video_ids = [v for v in video_ids if os.path.exists(self._path(v))]
+        self.transforms = {s: vit_transform_u8(s, s) for s in sizes}
+        if with_clip:
+            self.transforms[VideoScorer.KEY] = clip_transform_u8(224)
+
+    def _path(self, vid):
+        return "%s/%s/%s.zip" % (self.zip_prefix, vid[-2:], vid)
+
+    def __len__(self):
+        return len(self.video_ids)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        vid = self.video_ids[i]
+        with ZipFile(self._path(vid), "r") as z:
             images = [Image.open(io.BytesIO(z.read(n))).convert("RGB") for n in sorted(z.namelist())]
-        yield vid, {s: torch.stack([t(im) for im in images]) for s, t in transforms.items()}, np.arange(len(images))
+        return vid, {s: torch.stack([t(im) for im in images]) for s, t in self.transforms.items()}, np.arange(len(images))
+
+
+def zip_videos(video_ids, zip_prefix, sizes, with_clip=False, workers=0):
+    data = QueryVideos(video_ids, zip_prefix, sizes, with_clip)
+    kw = {"prefetch_factor": 4} if workers > 0 else {}
+    return torch.utils.data.DataLoader(data, batch_size=1, shuffle=False, num_workers=workers, collate_fn=lambda b: b[0], **kw)
 
 
 def read_video_scores(path):
@@ -75,7 +93,8 @@ def main(args):
         clip, _ = load_encoder("clip_vit_l14_224", "clip", args.clip_checkpoint, args.max_batch, u8_norm=(CLIP_MEAN, CLIP_STD))
         state = torch.load(args.vsm_checkpoint, map_location="cpu")
         scorer = VideoScorer(clip, VideoScoreHead("vsm_roberta_base", from_reference_state(state.get("state_dict", state))), device)
-    videos = zip_videos(vids, args.zip_prefix, sorted({size for _, size in encoders}), with_clip=scorer is not None)
+    videos = zip_videos(vids, args.zip_prefix, sorted({size for _, size in encoders}), with_clip=scorer is not None,
+                        workers=args.workers)
     finals, per_model = run_query_videos(videos, encoders, pca.transform, scores, device, score_threshold=args.score_threshold,
                                          scorer=scorer)
     for i, (_, _, path) in enumerate(specs):
@@ -104,6 +123,7 @@ def build_parser():
     ap.add_argument("--score_threshold", type=float, default=SCORE_THRESHOLD)
     ap.add_argument("--output_dir", default="outputs")
     ap.add_argument("--max_batch", type=int, default=256)
+    ap.add_argument("--workers", type=int, default=6, help="decode / resize worker processes (the reference uses 6)")
     return ap
 
 
