@@ -1,5 +1,7 @@
 """Similarity search parity: vsc_knn_ip_f32 must be BIT-EXACT with oracle/knn_oracle.c
 (scores as uint32 patterns, ids as int64), including ties, ragged shapes and k > nr."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -244,3 +246,36 @@ def test_hip_pca_on_device(dev):
     want = ((x.astype(np.float64) - Fitted.mean_) @ Fitted.components_.astype(np.float64).T) / np.sqrt(Fitted.explained_variance_)
     assert got.shape == (130, 64) and got.dtype == np.float32
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_concat_pca_sn_entry_point(dev, tmp_path):
+    """infer/concat_pca_sn.py mirror end to end on small synthetic per-model .npz files: merged descriptors equal the
+    numpy statement (normalise, concatenate, sklearn PCA.transform), score-normalised files carry the extra column."""
+    import argparse
+    import concat_pca_sn as C
+    from sklearn.decomposition import PCA
+    from sklearn.preprocessing import normalize
+    from vsc.index import VideoFeature
+    from vsc.storage import load_features, store_features
+    models, dims = ["m_a", "m_b"], [24, 40]
+    vids = {"train_refs": ["R100001", "R100002", "R100003"], "test_refs": ["R200001", "R200002"]}
+    raw = {}
+    for mi, (m, d) in enumerate(zip(models, dims)):
+        os.makedirs(tmp_path / m)
+        for si, (name, ids) in enumerate(vids.items()):
+            feats = [VideoFeature(video_id=v, timestamps=np.arange(6 + vi, dtype=np.float64),
+                                  feature=synth.normalish(1000 * mi + 100 * si + vi, (6 + vi, d)) * (1 + vi)) for vi, v in enumerate(ids)]
+            raw[(m, name)] = feats
+            store_features(str(tmp_path / m / f"{name}.npz"), feats)
+    args = argparse.Namespace(root=str(tmp_path), models=models, pca_model=str(tmp_path / "pca.pkl"), fit_pca=True, dim=16)
+    C.main(args)
+    import pickle
+    fitted = pickle.load(open(tmp_path / "pca.pkl", "rb"))
+    for name, ids in vids.items():
+        merged = {vf.video_id: vf for vf in load_features(str(tmp_path / f"{name}.npz"))}
+        assert sorted(merged) == sorted(ids)
+        for vi, v in enumerate(ids):
+            cat = np.concatenate([normalize(raw[(m, name)][vi].feature) for m in models], axis=1)
+            np.testing.assert_allclose(merged[v].feature, fitted.transform(cat), rtol=1e-4, atol=2e-5)
+        sn = load_features(str(tmp_path / f"{name}_sn.npz"))
+        assert all(vf.feature.shape[1] == 16 for vf in sn)   # one low-variance dim replaced by the bias column
