@@ -46,7 +46,7 @@ class ClockSampler:
     The bf16 GEMMs are power-limited on this part (profiles/r01_clock_power_probe.txt): the sustained
     clock, not 2.4 GHz, sets the matrix roof the kernels actually run under."""
 
-    def __init__(self, period=0.15):
+    def __init__(self, period=0.25):
         import threading
         self.period, self.samples, self._stop = period, [], False
         self._thread = threading.Thread(target=self._run, daemon=True)
