@@ -183,3 +183,26 @@ def test_query_videos_dataset_reads_zips(tmp_path):
     vid, frames, stamps = items[0]
     assert frames[16].shape == (3, 16, 16, 3) and frames[24].shape == (3, 24, 24, 3) and frames["clip"].shape == (3, 224, 224, 3)
     assert all(f.dtype == torch.uint8 for f in frames.values()) and stamps.tolist() == [0, 1, 2]
+
+
+def test_model_zoo_reads_torchscript_and_plain_checkpoints(tmp_path):
+    """The reference ships traced .torchscript.pt files: their state dict keeps the module's parameter names."""
+    from src.model_zoo import _state_dict
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = torch.nn.Linear(4, 3)
+            self.norm = torch.nn.LayerNorm(3)
+
+        def forward(self, x):
+            return self.norm(self.proj(x))
+
+    m = Tiny().eval()
+    torch.jit.save(torch.jit.trace(m, torch.zeros(2, 4)), str(tmp_path / "m.torchscript.pt"))
+    torch.save({"state_dict": m.state_dict()}, str(tmp_path / "m.pth"))
+    torch.save(m.state_dict(), str(tmp_path / "plain.pth"))
+    want = {k: v for k, v in m.state_dict().items()}
+    for name in ("m.torchscript.pt", "m.pth", "plain.pth"):
+        got = _state_dict(str(tmp_path / name))
+        assert sorted(got) == sorted(want) and all(torch.equal(got[k], want[k]) for k in want), name

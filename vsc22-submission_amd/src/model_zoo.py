@@ -19,6 +19,15 @@ WEIGHT_FORMATS = sorted(VIT_LOADERS) + ["swin_ref"]
 
 
 def _state_dict(path: str) -> dict:
+    """Parameters of a checkpoint: a plain state dict, a training checkpoint ({"state_dict": ...}), a pickled module,
+    or the TorchScript archives the reference ships (checkpoints/*.torchscript.pt, written by torch2scripts.py) --
+    a traced module keeps the parameter names of the nn.Module it was traced from."""
+    try:
+        scripted = torch.jit.load(path, map_location="cpu")
+    except Exception:  # noqa: BLE001 -- not a TorchScript archive
+        scripted = None
+    if scripted is not None:
+        return dict(scripted.state_dict())
     state = torch.load(path, map_location="cpu")
     if isinstance(state, dict):
         return state.get("state_dict", state)
