@@ -367,6 +367,27 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
     } else {
         const int c = lane & 15;
         const int n = ncol0 + c * 4;
+        f32x4_t ax[8];  // residual / position rows of the next eight write-out steps
+        int orow8[8];   // PATCH: output row (frame * tokens + token) of those steps, from the same division
+        auto load_aux = [&](int g) {  // g = pass * 2 + group
+            const int nc = n < p.n ? n : 0;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int64_t m = m0 + wm * TM * 16 + (g >> 1) * 64 + ((g & 1) * 8 + it) * 4 + (lane >> 4);
+                m = m < p.m ? m : p.m - 1;
+                const float *auxrow;
+                if (EPI == VSC_EPI_PATCH_F32) {
+                    const int pt = p.tokens - 1;
+                    const int f = (int)m / pt, tok = (int)m - f * pt + 1;  // rows < 2^31 (checked by the launcher)
+                    orow8[it] = f * p.tokens + tok;
+                    auxrow = p.aux + (int64_t)tok * p.n;
+                } else {
+                    auxrow = p.aux + m * p.n;
+                }
+                ax[it] = *(const f32x4_t *)(auxrow + nc);
+            }
+        };
+        if (EPI != VSC_EPI_F32) load_aux(0);
 #pragma unroll
         for (int pass = 0; pass < TM / 4; ++pass) {
 #pragma unroll
@@ -382,42 +403,39 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int row = it * 4 + (lane >> 4);
-                f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ (row & 15)) << 4));
-                const int64_t m = m0 + wm * TM * 16 + pass * 64 + row;
-                if (m < p.m && n < p.n) {
-                    int64_t orow = m;
-                    const float *auxrow = nullptr;
-                    if (EPI == VSC_EPI_F32) {
-                    } else if (EPI == VSC_EPI_PATCH_F32) {
-                        const int pt = p.tokens - 1;
-                        const int64_t f = m / pt;
-                        const int tok = (int)(m - f * pt) + 1;
-                        orow = f * p.tokens + tok;
-                        auxrow = p.aux + (int64_t)tok * p.n;
-                    } else {
-                        auxrow = p.aux + m * p.n;
+            // `out` may alias the residual (x is updated in place), so the compiler orders every residual load behind
+            // the previous step's store and waits for it at once -- one exposed memory round trip per 4-row step, which
+            // was most of what the residual write-out cost.  The rows of eight steps are requested together instead
+            // (ax, filled by load_aux before the staging / after the previous group's stores).
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = (grp * 8 + it) * 4 + (lane >> 4);
+                    f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ (row & 15)) << 4));
+                    const int64_t m = m0 + wm * TM * 16 + pass * 64 + row;
+                    if (EPI != VSC_EPI_F32) v += ax[it];
+                    if (m < p.m && n < p.n) {
+                        const int64_t orow = EPI == VSC_EPI_PATCH_F32 ? (int64_t)orow8[it] : m;
+                        if (!((p.abl & 4) && v[0] != 12345.678f)) *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
+                        if (EPI == VSC_EPI_RESADD_STATS_F32) {
+                            uint2 pk;
+                            pk.x = pack_bf16x2(v[0], v[1]);
+                            pk.y = pack_bf16x2(v[2], v[3]);
+                            *(uint2 *)(p.ex.xb + m * p.n + n) = pk;
+                        }
                     }
-                    if (EPI != VSC_EPI_F32) v += *(const f32x4_t *)(auxrow + n);
-                    if (!((p.abl & 4) && v[0] != 12345.678f)) *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
                     if (EPI == VSC_EPI_RESADD_STATS_F32) {
-                        uint2 pk;
-                        pk.x = pack_bf16x2(v[0], v[1]);
-                        pk.y = pack_bf16x2(v[2], v[3]);
-                        *(uint2 *)(p.ex.xb + m * p.n + n) = pk;
+                        // statistics of this row's 64-column slice (n % 64 == 0 is required, so a slice is whole or absent;
+                        // rows past m are computed on stale lanes and not stored): two passes on the registers
+                        const float mean = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+                        const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                        const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                        if (c == 0 && m < p.m && ncol0 < p.n)
+                            *(float2 *)(p.ex.stats + ((int64_t)(ncol0 >> 6) * p.m + m) * 2) = make_float2(mean, m2);
                     }
                 }
-                if (EPI == VSC_EPI_RESADD_STATS_F32) {
-                    // statistics of this row's 64-column slice (n % 64 == 0 is required, so a slice is whole or absent;
-                    // rows past m are computed on stale lanes and not stored): two passes on the registers
-                    const float mean = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
-                    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-                    const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
-                    if (c == 0 && m < p.m && ncol0 < p.n)
-                        *(float2 *)(p.ex.stats + ((int64_t)(ncol0 >> 6) * p.m + m) * 2) = make_float2(mean, m2);
-                }
+                if (EPI != VSC_EPI_F32 && pass * 2 + grp + 1 < (TM / 4) * 2) load_aux(pass * 2 + grp + 1);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -693,16 +711,24 @@ struct GemmLnArgs {
     float eps;
 };
 
+#ifdef VSC_GEMM_TIMING
+__device__ unsigned long long g_ln_dbg[8];
+#endif
+
 template <int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
+#ifdef VSC_GEMM_TIMING
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int TM = 4, TN = 8, NW = 8, BK2 = 32;
     constexpr int BM2 = WAVES_M * 64, BN2 = WAVES_N * 128;
     constexpr int A_BYTES = BM2 * 64, W_BYTES = BN2 * 64, STAGE_BYTES = A_BYTES + W_BYTES;
     constexpr int L = (BM2 + BN2) / (16 * NW);
     constexpr int OUT_BYTES = 8 * 16384;  // write-out regions; the row-statistic partials sit behind them
     static_assert(WAVES_M * WAVES_N == 8, "8 waves");
-    static_assert(STAGES * STAGE_BYTES <= OUT_BYTES + 8192, "ring fits the allocation");
+    static_assert(STAGES * STAGE_BYTES <= 160 * 1024, "ring fits the CU's LDS");  // launch_ln_t allocates max(ring, write-out)
     extern __shared__ __attribute__((aligned(16))) char lds2[];
+    // (a first-round start skew as in gemm_bf16_v2_kernel was measured here: no gain at 0.3 tile times, a loss beyond)
     float *part = (float *)(lds2 + OUT_BYTES);             // [WAVES_N][BM2] row sums
     float *part2 = part + WAVES_N * BM2;                   // [WAVES_N][BM2] centred squares
 
@@ -736,6 +762,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
     if (group == 1) __builtin_amdgcn_s_barrier();  // stagger
     const int fr = lane & 15, fq = lane >> 4;
     int cur = 0;
+#ifdef VSC_GEMM_TIMING
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + STAGES - 1 < nk) {
             int ns = cur + STAGES - 1;
@@ -773,6 +802,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
         cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
     if (group == 0) __builtin_amdgcn_s_barrier();
+#ifdef VSC_GEMM_TIMING
+    const unsigned long long t_epi = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- bias, then row statistics over the full N = BN2 columns
 #pragma unroll
@@ -831,6 +863,17 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] - mean[i]) * rstd[i] * gm[r] + bt[r];
     }
     // ---- write-out through LDS, one 64-column half at a time (64 rows x 64 cols fp32 = 16 KiB per wave)
+    f32x4_t xin[8];
+    auto load_xin = [&](int grp) {  // group = (column half, row half): 8 write-out steps of 4 rows
+        const int nn = wn * 128 + (grp >> 1) * 64 + (lane & 15) * 4;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            int64_t m = m0 + wm * 64 + ((grp & 1) * 8 + it) * 4 + (lane >> 4);
+            m = m < p.m ? m : p.m - 1;
+            xin[it] = *(const f32x4_t *)(p.x_in + m * p.n + nn);
+        }
+    };
+    if (p.x_in) load_xin(0);
     char *reg = lds2 + wave * 16384;
     const int c = lane & 15;
 #pragma unroll
@@ -845,28 +888,46 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int n = wn * 128 + hj * 64 + c * 4;
-#pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 4 + (lane >> 4);
-            f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ (row & 15)) << 4));
-            const int64_t m = m0 + wm * 64 + row;
-            if (m < p.m) {
-                if (p.x_in) v += *(const f32x4_t *)(p.x_in + m * p.n + n);
-                *(f32x4_t *)(p.x_out + m * p.n + n) = v;
-                uint2 pk;
-                pk.x = pack_bf16x2(v[0], v[1]);
-                pk.y = pack_bf16x2(v[2], v[3]);
-                *(uint2 *)(p.xb_out + m * p.n + n) = pk;
+        // x_out may alias x_in, so the compiler keeps every residual load behind the previous step's stores and waits
+        // for it at once: one exposed HBM round trip per 4-row step, 65 % of a K = 512 tile's cycles.  The rows of a
+        // group of eight steps are therefore requested together (they are distinct from anything stored so far).
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = (rh * 8 + it) * 4 + (lane >> 4);
+                f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ (row & 15)) << 4));
+                const int64_t m = m0 + wm * 64 + row;
+                if (p.x_in) v += xin[it];
+                if (m < p.m) {
+                    *(f32x4_t *)(p.x_out + m * p.n + n) = v;
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *(uint2 *)(p.xb_out + m * p.n + n) = pk;
+                }
             }
+            if (p.x_in && hj * 2 + rh < 3) load_xin(hj * 2 + rh + 1);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+#ifdef VSC_GEMM_TIMING
+    if (blockIdx.x == 300 % gridDim.x && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        g_ln_dbg[0] = t_loop - t_start;
+        g_ln_dbg[1] = t_epi - t_loop;
+        g_ln_dbg[2] = t_end - t_epi;
+    }
+#endif
 }
 
 template <int WAVES_M, int WAVES_N, int STAGES>
 int launch_ln_t(const GemmLnArgs &p, hipStream_t stream) {
-    constexpr int smem = 8 * 16384 + 8192;
+    // the write-out regions + row-statistic partials alias the ring once the K loop is done
+    constexpr int ring = STAGES * (WAVES_M * 64 + WAVES_N * 128) * 64;
+    constexpr int smem = ring > 8 * 16384 + 8192 ? ring : 8 * 16384 + 8192;
     auto kern = gemm_ln_kernel<WAVES_M, WAVES_N, STAGES>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -877,6 +938,15 @@ int launch_ln_t(const GemmLnArgs &p, hipStream_t stream) {
     VSC_REQUIRE(blocks < (1ll << 31), "gemm_ln: grid too large");
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), smem, stream, p);
     VSC_CHECK_LAUNCH();
+#ifdef VSC_GEMM_TIMING
+    if (getenv("VSC_GEMM_TIMING_PRINT")) {
+        unsigned long long h[8];
+        VSC_CHECK_HIP(hipStreamSynchronize(stream));
+        VSC_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ln_dbg), sizeof(h)));
+        fprintf(stderr, "timing gemm_ln m=%lld n=%d k=%d (%d K-steps): prologue %llu  K loop %llu (%.0f per step)  LN + write-out %llu ticks\n",
+                (long long)p.m, p.n, p.k, p.k / 32, h[0], h[1], (double)h[1] / (p.k / 32), h[2]);
+    }
+#endif
     return VSC_OK;
 }
 
@@ -923,6 +993,7 @@ int launch_gemm_bf16_ex(const uint16_t *a, const uint16_t *w, const float *bias,
         VSC_REQUIRE(aux && tokens > 1, "gemm: PATCH needs pos and tokens");
         VSC_REQUIRE(m % (tokens - 1) == 0, "gemm: PATCH rows %lld not a multiple of %d patches",
                     (long long)m, tokens - 1);
+        VSC_REQUIRE(m / (tokens - 1) * tokens < (1ll << 31), "gemm: PATCH output rows exceed 2^31");
     }
     if (v2) {
         switch (epilogue) {
@@ -984,9 +1055,9 @@ int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias,
     VSC_REQUIRE(m > 0 && k > 0 && k % 32 == 0, "gemm_ln: m=%lld k=%d (k must be a multiple of 32)", (long long)m, k);
     GemmLnArgs p{a, w, bias, gamma, beta, x_in, x_out, xb_out, m, n, k, eps};
     switch (n) {
-        case 128: return launch_ln_t<8, 1, 3>(p, stream);
+        case 128: return launch_ln_t<8, 1, 4>(p, stream);  // 4 x 40 KiB = the whole 160 KiB: two tiles stay in flight across a barrier
         case 256: return launch_ln_t<4, 2, 4>(p, stream);
-        case 512: return launch_ln_t<2, 4, 3>(p, stream);
+        case 512: return launch_ln_t<2, 4, 4>(p, stream);
         default: VSC_REQUIRE(false, "gemm_ln: N=%d unsupported (row-owning tiles exist for 128, 256, 512)", n);
     }
     return VSC_OK;
