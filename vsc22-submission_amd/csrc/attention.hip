@@ -57,12 +57,22 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
         qf[i][0] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8);
         qf[i][1] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8 + 32);
     }
-    // ---- stage K (row-major, swizzled); pad rows are zero ----
-    for (int e = tid; e < TP * 8; e += 512) {
-        const int row = e >> 3, c = e & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < tokens) v = *(const uint4 *)(kptr + row * ld + c * 8);
-        *(uint4 *)(klds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = v;
+    // ---- stage K (row-major, swizzled); pad rows are zero.  All of a thread's rows are requested before the first
+    //      LDS write (as a plain loop each 16-B load was waited for before the next one was issued).
+    {
+        constexpr int KIT = (TP * 8 + 511) / 512;
+        uint4 kv[KIT];
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+            const int e = tid + i * 512, row = e >> 3, c = e & 7;
+            kv[i] = make_uint4(0, 0, 0, 0);
+            if (e < TP * 8 && row < tokens) kv[i] = *(const uint4 *)(kptr + row * ld + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+            const int e = tid + i * 512, row = e >> 3, c = e & 7;
+            if (e < TP * 8) *(uint4 *)(klds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kv[i];
+        }
     }
     // ---- stage V transposed: task = (4 keys) x (8 head-dim columns).  16 consecutive lanes
     //      take 16 consecutive key groups of one column block, so every ds_write_b64 of a

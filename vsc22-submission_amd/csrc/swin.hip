@@ -91,9 +91,19 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
         qf[qi] = pk.v;
     }
     // ---- stage K-hat: 4 threads per key row (16 B each), norm over the row by two shuffles
-    for (int e = tid; e < N * 4; e += NTHREADS) {
+    constexpr int KIT = (N * 4) / NTHREADS;  // = 2: both rows of a thread are requested before either is normalised
+    static_assert(KIT * NTHREADS == N * 4, "K staging covers the window exactly");
+    bf16x8_t kraw[KIT];
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+        const int e = tid + it * NTHREADS;
+        kraw[it] = *(const bf16x8_t *)(base + C + rowmap[e >> 2] * ld + (e & 3) * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+        const int e = tid + it * NTHREADS;
         const int i = e >> 2, c = e & 3;
-        const bf16x8_t raw = *(const bf16x8_t *)(base + C + rowmap[i] * ld + c * 8);
+        const bf16x8_t raw = kraw[it];
         float v[8], ss = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
