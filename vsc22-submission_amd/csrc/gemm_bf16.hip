@@ -862,6 +862,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] - mean[i]) * rstd[i] * gm[r] + bt[r];
     }
+#ifdef VSC_GEMM_TIMING
+    const unsigned long long t_norm = __builtin_amdgcn_s_memtime();
+#endif
     // ---- write-out through LDS, one 64-column half at a time (64 rows x 64 cols fp32 = 16 KiB per wave)
     f32x4_t xin[8];
     auto load_xin = [&](int grp) {  // group = (column half, row half): 8 write-out steps of 4 rows
@@ -919,6 +922,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
         g_ln_dbg[0] = t_loop - t_start;
         g_ln_dbg[1] = t_epi - t_loop;
         g_ln_dbg[2] = t_end - t_epi;
+        g_ln_dbg[3] = t_norm - t_epi;
     }
 #endif
 }
@@ -943,8 +947,8 @@ int launch_ln_t(const GemmLnArgs &p, hipStream_t stream) {
         unsigned long long h[8];
         VSC_CHECK_HIP(hipStreamSynchronize(stream));
         VSC_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ln_dbg), sizeof(h)));
-        fprintf(stderr, "timing gemm_ln m=%lld n=%d k=%d (%d K-steps): prologue %llu  K loop %llu (%.0f per step)  LN + write-out %llu ticks\n",
-                (long long)p.m, p.n, p.k, p.k / 32, h[0], h[1], (double)h[1] / (p.k / 32), h[2]);
+        fprintf(stderr, "timing gemm_ln m=%lld n=%d k=%d (%d K-steps): prologue %llu  K loop %llu (%.0f per step)  LN + write-out %llu ticks (statistics + normalise %llu)\n",
+                (long long)p.m, p.n, p.k, p.k / 32, h[0], h[1], (double)h[1] / (p.k / 32), h[2], h[3]);
     }
 #endif
     return VSC_OK;
