@@ -166,21 +166,39 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
 
     // Epilogue.  acc[i][j][r]: row m = m0 + wm*64 + i*16 + (lane & 15),
     //                          col n = n0 + wn*64 + j*16 + (lane >> 4)*4 + r.
+    // The residual / position rows of all 16 fragments are requested first: `out` may alias the residual, and a load
+    // issued between the stores is waited for at once (see epilogue_via_lds).
+    constexpr bool HAS_AUX = EPI == VSC_EPI_RESADD_F32 || EPI == VSC_EPI_PATCH_F32;
+    f32x4_t axv[HAS_AUX ? 4 : 1][4];
+    int64_t orows[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wm * 64 + i * 16 + fr;
-        if (m >= p.m) continue;
-        int64_t orow = m;
+        int64_t m = m0 + wm * 64 + i * 16 + fr;
+        m = m < p.m ? m : p.m - 1;
+        orows[i] = m;
         const float *auxrow = nullptr;
         if (EPI == VSC_EPI_PATCH_F32) {
             const int pt = p.tokens - 1;
             const int64_t f = m / pt;
             const int tok = (int)(m - f * pt) + 1;
-            orow = f * p.tokens + tok;
+            orows[i] = f * p.tokens + tok;
             auxrow = p.aux + (int64_t)tok * p.n;
         } else if (EPI == VSC_EPI_RESADD_F32) {
             auxrow = p.aux + m * p.n;
         }
+        if (HAS_AUX) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fq * 4;
+                axv[i][j] = *(const f32x4_t *)(auxrow + (n < p.n ? n : 0));
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + wm * 64 + i * 16 + fr;
+        if (m >= p.m) continue;
+        const int64_t orow = orows[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + fq * 4;
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
                 pk.y = pack_bf16x2(v[2], v[3]);
                 *(uint2 *)((uint16_t *)p.out + orow * p.n + n) = pk;
             } else {
-                if (EPI != VSC_EPI_F32) v += *(const f32x4_t *)(auxrow + n);
+                if (HAS_AUX) v += axv[i][j];
                 *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
             }
         }
