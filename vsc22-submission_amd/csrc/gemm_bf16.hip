@@ -316,7 +316,7 @@ __device__ __forceinline__ void epilogue_frag(const GemmArgs &p, f32x4_t v, int6
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&acc)[TM][TN], char *lds2,
                                                  int wave, int lane, int wm, int wn, int64_t m0,
-                                                 int n0, const float2 (&rs)[TM]) {
+                                                 int n0, const float2 (&rs)[TM], const f32x4_t (&bzp)[TN]) {
     const int fr = lane & 15, fq = lane >> 4;
     // ---- epilogue through LDS.  A lane's accumulators are 4 columns of 16 different rows
     // per fragment: stored directly that is 32-byte pieces of 16 rows per instruction, and the
@@ -341,8 +341,8 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = ncol0 + j * 16 + fq * 4;
-            f32x4_t bz = (f32x4_t){0.f, 0.f, 0.f, 0.f}, cs = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            if (p.bias && n < p.n) bz = *(const f32x4_t *)(p.bias + n);
+            const f32x4_t bz = bzp[j];
+            f32x4_t cs = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             if (epi_lnf(EPI) && n < p.n) cs = *(const f32x4_t *)(p.ex.colsum + n);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -411,8 +411,8 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int nb = ncol0 + j * 16 + fq * 4;
-                f32x4_t bz = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                if (p.bias && nb < p.n) bz = *(const f32x4_t *)(p.bias + nb);
+                const f32x4_t bz = bzp[j];
+                (void)nb;
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     const int row = ii * 16 + fr, chunk = 4 * j + fq;
@@ -523,6 +523,15 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
             rs[i] = *(const float2 *)(p.ex.rowstats + 2 * m);
         }
     }
+    // the bias of this lane's TN column groups, requested before the first DMA as well (it was the first thing the
+    // write-out waited for)
+    f32x4_t bzp[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + wn * TN * 16 + j * 16 + (lane >> 4) * 4;
+        bzp[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (p.bias && nb < p.n) bzp[j] = *(const f32x4_t *)(p.bias + nb);
+    }
 #ifdef VSC_GEMM_TIMING
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
     if (NW == 8 && group == 0) __builtin_amdgcn_s_barrier();
     if (NW == 4) __builtin_amdgcn_s_barrier();  // every wave is past its last fragment read
 
-    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0, rs);
+    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0, rs, bzp);
 #ifdef VSC_GEMM_TIMING
     if (blockIdx.x == 300 % gridDim.x && lane == 0 && p.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
