@@ -13,11 +13,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int N> __device__ __forceinline__ void vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MODE, int ROWB>  // ROWB: bytes of one tile row per step (64 = BK 32, 128 = BK 64)
-__global__ __launch_bounds__(512, 2) void fill_kernel(const char *a, const char *w, int64_t kbytes, int nk, int tiles_n, u32x4 *sink) {
+template <int MODE, int ROWB, int THREADS = 512>  // ROWB: bytes of one tile row per step (64 = BK 32, 128 = BK 64)
+__global__ __launch_bounds__(THREADS, 1) void fill_kernel(const char *a, const char *w, int64_t kbytes, int nk, int tiles_n, u32x4 *sink) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int ROWS = 512, STAGE = ROWS * ROWB, STAGES = ROWB == 128 ? 2 : (MODE == 0 ? 4 : 3);
-    constexpr int PIECES = STAGE / (512 * 16);  // 16-B pieces per thread per step
+    constexpr int PIECES = STAGE / (THREADS * 16);  // 16-B pieces per thread per step
+    constexpr int NWV = THREADS / 64;
     constexpr int LPR = ROWB / 16;              // lanes per row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(512, 2) void fill_kernel(const char *a, const char 
     int dst[PIECES];
 #pragma unroll
     for (int p = 0; p < PIECES; ++p) {
-        const int e = (p * 8 + wave) * 64 + lane;  // piece p of this wave: 64 lanes -> 64/LPR rows
+        const int e = (p * NWV + wave) * 64 + lane;  // piece p of this wave: 64 lanes -> 64/LPR rows
         const int row = e / LPR, c = e % LPR;
         const char *base = row < 256 ? a + (int64_t)(tm * 256 + row) * kbytes : w + (int64_t)(tn * 256 + row - 256) * kbytes;
         src[p] = base + c * 16;
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(512, 2) void fill_kernel(const char *a, const char 
         auto issue = [&](int kt, int st) {
 #pragma unroll
             for (int p = 0; p < PIECES; ++p) {
-                char *l = lds + st * STAGE + ((p * 8 + wave) * 64) * 16;  // wave-uniform base, lane * 16 implied
+                char *l = lds + st * STAGE + ((p * NWV + wave) * 64) * 16;  // wave-uniform base, lane * 16 implied
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[p] + (int64_t)kt * ROWB),
                                                  (__attribute__((address_space(3))) void *)l, 16, 0, 0);
             }
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(512, 2) void fill_kernel(const char *a, const char 
             acc ^= *(const u32x4 *)(lds + (kt % STAGES) * STAGE + tid * 16);
             __builtin_amdgcn_s_barrier();
         }
-    } else {
+    } else if (THREADS == 512) {
         u32x4 g[2][PIECES];
         auto load = [&](int kt, int b) {
 #pragma unroll
@@ -79,23 +80,23 @@ __global__ __launch_bounds__(512, 2) void fill_kernel(const char *a, const char 
             __builtin_amdgcn_s_barrier();
         }
     }
-    if (acc[0] == 0x12345678 && acc[1] == 0x9abcdef0) sink[blockIdx.x * 512 + tid] = acc;
+    if (acc[0] == 0x12345678 && acc[1] == 0x9abcdef0) sink[blockIdx.x * THREADS + tid] = acc;
 }
 
-template <int MODE, int ROWB>
+template <int MODE, int ROWB, int THREADS = 512>
 void run(const char *name, const char *a, const char *w, int m, int n, int k, u32x4 *sink, double mhz) {
     const int tiles_m = m / 256, tiles_n = n / 256, nk = k * 2 / ROWB;
     const int smem = (ROWB == 128 ? 2 : (MODE == 0 ? 4 : 3)) * 512 * ROWB;
-    CHECK(hipFuncSetAttribute((const void *)fill_kernel<MODE, ROWB>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    CHECK(hipFuncSetAttribute((const void *)fill_kernel<MODE, ROWB, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i)
-        hipLaunchKernelGGL((fill_kernel<MODE, ROWB>), dim3(tiles_m * tiles_n), dim3(512), smem, 0, a, w, (int64_t)k * 2, nk, tiles_n, sink);
+        hipLaunchKernelGGL((fill_kernel<MODE, ROWB, THREADS>), dim3(tiles_m * tiles_n), dim3(THREADS), smem, 0, a, w, (int64_t)k * 2, nk, tiles_n, sink);
     CHECK(hipEventRecord(e0));
     const int it = 10;
     for (int i = 0; i < it; ++i)
-        hipLaunchKernelGGL((fill_kernel<MODE, ROWB>), dim3(tiles_m * tiles_n), dim3(512), smem, 0, a, w, (int64_t)k * 2, nk, tiles_n, sink);
+        hipLaunchKernelGGL((fill_kernel<MODE, ROWB, THREADS>), dim3(tiles_m * tiles_n), dim3(THREADS), smem, 0, a, w, (int64_t)k * 2, nk, tiles_n, sink);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms;
@@ -123,6 +124,8 @@ int main() {
         run<0, 128>("lds-dma 128-B rows", a, w, m, n, k, sink, mhz);
         run<1, 64>("vgpr+ds_write  64-B rows", a, w, m, n, k, sink, mhz);
         run<1, 128>("vgpr+ds_write 128-B rows", a, w, m, n, k, sink, mhz);
+        run<0, 128, 256>("lds-dma 128-B rows, 4 waves", a, w, m, n, k, sink, mhz);
+        run<0, 64, 256>("lds-dma  64-B rows, 4 waves", a, w, m, n, k, sink, mhz);
     }
     return 0;
 }
