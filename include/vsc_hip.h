@@ -6,8 +6,8 @@
  * failure on the calling thread.  Nothing here falls back to the CPU.
  *
  * Concurrency: one process per GPU is the deployment model.  An encoder handle, and the
- * search entry points as a group (vsc_knn_ip_f32, vsc_range_search_ip_f32, vsc_pair_similarity_f32
- * share grow-only device scratch), must not be driven from two host threads at once, and
+ * search entry points as a group (vsc_knn_ip_f32, vsc_range_search_ip_f32, vsc_pair_similarity_f32,
+ * vsc_video_pair_max_f32 share grow-only device scratch), must not be driven from two host threads at once, and
  * consecutive calls that share a handle or that scratch must be stream-ordered (same stream, or
  * ordered by events).  Different encoder handles are independent.
  *
@@ -188,6 +188,23 @@ int vsc_range_search_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, 
 int vsc_pair_similarity_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d,
                             const int64_t *pairs_host, int64_t n_pairs, int64_t *out_offsets_host,
                             float *out_dev, int64_t capacity, void *stream);
+
+/* Video-pair maxima -- the candidate retrieval of the matching track
+ * (VSC22-Matching-Track-1st/infer/infer_matching.py:229-262: per query frame top-1024, range_search where the
+ * 1024th score still clears SEARCH_THRESHOLD, then max per (query video, reference video) in a dict).  The
+ * union of the two faiss branches is {(qf, rf): <qf, rf> > threshold}; this entry point sweeps all pairs once
+ * and keeps, per video pair, the largest frame score above `threshold` (strict, as in the reference).
+ * q_video_dev [nq] / r_video_dev [nr]: int32 video index of every row (0 <= index < n_*_videos).
+ * lims_dev [n_q_videos + 1] int64 receives CSR offsets over query videos, *total_out (host) the number of
+ * video pairs.  Pairs of query video v go to [lims[v], lims[v+1]) of out_rvideo_dev / out_score_dev in
+ * ascending reference video, but only if total <= capacity; otherwise nothing is written and the caller
+ * calls again with capacity >= *total_out (capacity 0 = count only).  Scores are the fp32 chains of
+ * vsc_knn_ip_f32 (bit-exact).  Uses a dense n_q_videos x n_r_videos uint32 table in scratch.
+ * Synchronises `stream` once (to read the total). */
+int vsc_video_pair_max_f32(const float *q_dev, int64_t nq, const int32_t *q_video_dev, int32_t n_q_videos,
+                           const float *r_dev, int64_t nr, const int32_t *r_video_dev, int32_t n_r_videos,
+                           int32_t d, float threshold, int64_t *lims_dev, int32_t *out_rvideo_dev,
+                           float *out_score_dev, int64_t capacity, int64_t *total_out, void *stream);
 
 /* sklearn.preprocessing.normalize(x) in place (l2, axis=1; zero rows untouched):
  * infer/extract_query_feats.py:178, infer/vsc/baseline/score_normalization.py:84-88. */

@@ -125,3 +125,140 @@ def test_generate_features_on_hip_path():
     for got, want in zip(feats, want_f):
         g, w = (got[0], want[0]) if isinstance(want, list) else (got, want)
         assert np.array_equal(g, w)
+
+
+# ---- candidate retrieval (infer_matching.py:229-262) ----------------------------------------------------------
+def _sn_videos(seed, lens, prefix, d=64, copies=()):
+    """Score-normalised-looking video features: unit rows scaled so random pairs sit below the -0.1 threshold
+    of the reference only by a shift the test applies; `copies` = (video, frame, source rows) planted matches."""
+    from vsc.index import VideoFeature
+    vids = []
+    for i, n in enumerate(lens):
+        f = synth.descriptor_bank(seed * 1000 + i, n, d)
+        vids.append(VideoFeature(video_id=f"{prefix}{i:04d}", timestamps=np.arange(float(n)), feature=f))
+    for n, (vid, frame, rows) in enumerate(copies):   # scaled so that no two planted pairs tie bit for bit
+        vids[vid].feature[frame:frame + len(rows)] = rows * np.float32(0.97 - 0.06 * n)
+    return vids
+
+
+def _planted(seed=7, d=64):
+    refs = _sn_videos(seed, [20, 7, 150, 1, 64, 33], "R", d)
+    queries = _sn_videos(seed + 1, [12, 36, 5, 130], "Q", d, copies=[
+        (0, 3, refs[2].feature[40:46]), (1, 30, refs[0].feature[5:9]), (3, 100, refs[4].feature[:25]),
+        (3, 0, refs[2].feature[100:103])])
+    return queries, refs
+
+
+def _threshold_for(queries, refs, frac):
+    """A radius that a fraction `frac` of all frame pairs exceed (so both faiss branches are exercised)."""
+    q = np.concatenate([v.feature for v in queries]).astype(np.float64)
+    r = np.concatenate([v.feature for v in refs]).astype(np.float64)
+    return float(np.quantile(q @ r.T, 1.0 - frac))
+
+
+def test_candidate_oracle_agrees_with_float64_statement():
+    from oracle import matching_oracle
+    queries, refs = _planted()
+    thr = 0.35
+    got = matching_oracle.candidate_pairs(queries, refs, thr, top=16)
+    want = {}
+    for qv in queries:
+        for rv in refs:
+            s = (qv.feature.astype(np.float64) @ rv.feature.astype(np.float64).T).max()
+            if s > thr:
+                want[(qv.video_id, rv.video_id)] = s
+    assert len(got) >= 4 and {(q, r) for q, r, _ in got} == set(want)   # the planted copies score 0.8-0.97
+    for q, r, s in got:
+        assert abs(float(s) - want[(q, r)]) < 1e-5
+    assert all(got[i][2] >= got[i + 1][2] for i in range(len(got) - 1))
+
+
+@pytest.mark.parametrize("frac,top", [(0.002, 16), (0.05, 8), (0.5, 4)])
+def test_search_candidate_pairs_equals_reference_loop(frac, top):
+    """Host logic with the oracle behind the seam == the reference loop (top-k + range fallback + dict + sort)."""
+    from oracle import matching_oracle
+    queries, refs = _planted()
+    thr = _threshold_for(queries, refs, frac)
+    want = matching_oracle.candidate_pairs(queries, refs, thr, top=top)
+    got = matching.search_candidate_pairs(queries, refs, thr, video_pair_max=matching_oracle.video_pair_max)
+    scores = [s for _, _, s in want]
+    assert len(set(np.array(scores).view(np.uint32).tolist())) == len(scores), "test data must not tie"
+    assert [(q, r) for q, r, _ in got] == [(q, r) for q, r, _ in want]
+    assert np.array_equal(np.array([s for _, _, s in got]).view(np.uint32), np.array(scores).view(np.uint32))
+
+
+def test_search_candidate_pairs_empty_and_no_hits():
+    from oracle import matching_oracle
+    queries, refs = _planted()
+    assert matching.search_candidate_pairs([], refs, video_pair_max=matching_oracle.video_pair_max) == []
+    assert matching.search_candidate_pairs(queries, [], video_pair_max=matching_oracle.video_pair_max) == []
+    assert matching.search_candidate_pairs(queries, refs, 2.0, video_pair_max=matching_oracle.video_pair_max) == []
+
+
+def test_match_refine_dataset_matches_reference_items():
+    query, ref = _videos(7, [200, 30]), _videos(8, [170, 12])
+    meta = [[qid, rid, query[qid], ref[rid]] for qid, rid in zip(query, ref)]
+    ds = matching.MatchRefineDataset(meta, resolution=(160, 160), pair_similarity=_oracle_pairs)
+    assert len(ds) == 2
+    for item, (qid, rid, qf, rf) in enumerate(meta):
+        x, q, r, h, w = ds[item]
+        sim = knn_oracle.ip_matrix(qf, rf)
+        assert (q, r, h, w) == (qid, rid, min(len(qf), 160), min(len(rf), 160)) and x.shape == (3, 160, 160)
+        assert np.array_equal(x[0, :h, :w], sim[:h, :w]) and np.array_equal(x[0], x[2])
+        assert x[0, h:].sum() == 0 and x[0, :, w:].sum() == 0
+
+
+def _bank(videos):
+    return (np.concatenate([v.feature for v in videos]).astype(np.float32),
+            np.repeat(np.arange(len(videos), dtype=np.int32), [len(v.feature) for v in videos]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,frac", [(64, 0.01), (512, 0.002), (100, 0.3)])
+def test_video_pair_max_bit_exact(d, frac):
+    import torch
+    from oracle import matching_oracle
+    from vsc_hip import ops
+    refs = _sn_videos(21, [37] * 60 + [1, 2, 300, 129], "R", d)
+    queries = _sn_videos(22, [50, 3, 128, 1, 260], "Q", d, copies=[(0, 10, refs[5].feature[:20]), (4, 200, refs[62].feature[100:140])])
+    thr = _threshold_for(queries, refs, frac)
+    (qb, qv), (rb, rv) = _bank(queries), _bank(refs)
+    want = matching_oracle.video_pair_max(qb, qv, len(queries), rb, rv, len(refs), thr)
+    for capacity in (1 << 20, 1):      # 1: the count-then-recall protocol
+        lims, rvid, score = ops.video_pair_max(torch.from_numpy(qb).cuda(), torch.from_numpy(qv).cuda(), len(queries),
+                                               torch.from_numpy(rb).cuda(), torch.from_numpy(rv).cuda(), len(refs), thr,
+                                               capacity=capacity)
+        assert np.array_equal(lims.cpu().numpy(), want[0])
+        assert np.array_equal(rvid.cpu().numpy(), want[1])
+        assert np.array_equal(score.cpu().numpy().view(np.uint32), want[2].view(np.uint32))
+    assert want[0][-1] > 2
+
+
+@pytest.mark.gpu
+def test_video_pair_max_every_pair_and_none():
+    """threshold below every score: the dense table is full (negative maxima included); above: empty."""
+    import torch
+    from oracle import matching_oracle
+    from vsc_hip import ops
+    queries, refs = _planted()
+    (qb, qv), (rb, rv) = _bank(queries), _bank(refs)
+    args = (torch.from_numpy(qb).cuda(), torch.from_numpy(qv).cuda(), len(queries), torch.from_numpy(rb).cuda(),
+            torch.from_numpy(rv).cuda(), len(refs))
+    lims, rvid, score = ops.video_pair_max(*args, -3.0)
+    want = matching_oracle.video_pair_max(qb, qv, len(queries), rb, rv, len(refs), -3.0)
+    assert lims[-1].item() == len(queries) * len(refs) and np.array_equal(rvid.cpu().numpy(), want[1])
+    assert np.array_equal(score.cpu().numpy().view(np.uint32), want[2].view(np.uint32))
+    lims, rvid, score = ops.video_pair_max(*args, 5.0)
+    assert lims.tolist() == [0] * (len(queries) + 1) and rvid.numel() == 0 and score.numel() == 0
+
+
+@pytest.mark.gpu
+def test_search_candidate_pairs_on_hip_path():
+    from oracle import matching_oracle
+    queries, refs = _planted(seed=9, d=512)
+    thr = _threshold_for(queries, refs, 0.01)
+    want = matching_oracle.candidate_pairs(queries, refs, thr, top=8)
+    got = matching.search_candidate_pairs(queries, refs, thr)
+    assert [(q, r) for q, r, _ in got] == [(q, r) for q, r, _ in want]
+    assert np.array_equal(np.array([s for _, _, s in got]).view(np.uint32),
+                          np.array([s for _, _, s in want]).view(np.uint32))

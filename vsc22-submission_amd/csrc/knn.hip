@@ -543,12 +543,143 @@ __global__ __launch_bounds__(256, 2) void pair_sim_kernel(const float *__restric
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Video-pair maxima: the candidate retrieval of the matching track
+// (VSC22-Matching-Track-1st/infer/infer_matching.py:229-262).  The reference searches top-1024 per query
+// frame, falls back to range_search where the 1024th score still clears the threshold, and keeps per
+// (query video, reference video) the largest frame score: the union of both branches is exactly
+// {(qf, rf): <qf, rf> > threshold}, so one sweep with the range kernel's score tiles and an atomic max per
+// hit into a dense [query videos][reference videos] table replaces search + range_search + the Python dict.
+// Table entries are order-preserving uint32 images of the fp32 score (0 = no hit), so atomicMax(uint)
+// is the float max; scores are the same ascending-k fma chains as every other sweep (bit-exact).
+//   sweep   pair_max_kernel           hits -> table
+//   count   pair_max_count_kernel     hits per query video
+//   scan    range_scan_kernel         lims
+//   fill    pair_max_fill_kernel      (reference video, score) per query video, ascending reference video
+struct PairMaxArgs {
+    const float *qp;
+    const float *rp;
+    const int *qvid;
+    const int *rvid;
+    int64_t nq, nr;
+    int dpad, nqb, splits;
+    int64_t total_tiles, tiles_per_split;
+    float threshold;
+    unsigned *table;
+    int64_t n_rvid;
+};
+
+__device__ __forceinline__ unsigned ordered_bits(float s) {
+    const unsigned u = __float_as_uint(s);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned u) {
+    return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+__global__ __launch_bounds__(256, 2) void pair_max_kernel(PairMaxArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    for (int64_t work = blockIdx.x; work < (int64_t)p.nqb * p.splits; work += gridDim.x) {
+        const int qb = (int)(work / p.splits), sp = (int)(work - (int64_t)qb * p.splits);
+        const int64_t q0 = (int64_t)qb * TQ;
+        const int64_t t_begin = sp * p.tiles_per_split;
+        int64_t t_end = t_begin + p.tiles_per_split;
+        t_end = t_end > p.total_tiles ? p.total_tiles : t_end;
+        int64_t qrow[2];  // table row of this lane's two queries, -1 past the end
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t qi = q0 + wn * 64 + b * 32 + l31;
+            qrow[b] = qi < p.nq ? (int64_t)p.qvid[qi] * p.n_rvid : -1;
+        }
+        int cur = 0;
+        bool primed = false;
+        for (int64_t rt = t_begin; rt < t_end; ++rt) {
+            const int64_t r0 = rt * TR;
+            f32x16_t acc[2][2];
+            score_tile(acc, p.rp, p.qp, p.nr, p.nq, p.dpad, r0, rt + 1 < t_end ? r0 + TR : -1, q0, lds, wave, lane,
+                       cur, primed);
+            primed = rt + 1 < t_end;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                // hits are rare: test the 32 scores of this lane before touching the video ids
+                float best = acc[a][0][0];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) best = fmaxf(best, acc[a][b][reg]);
+                if (!(best > p.threshold)) continue;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int64_t ref = r0 + wm * 64 + a * 32 + 8 * (reg >> 2) + 4 * hi + (reg & 3);
+                    if (ref >= p.nr) continue;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        if (acc[a][b][reg] > p.threshold && qrow[b] >= 0)
+                            atomicMax(p.table + qrow[b] + p.rvid[ref], ordered_bits(acc[a][b][reg]));
+                }
+            }
+        }
+    }
+}
+
+// one workgroup per query video (grid-stride): hits of the row
+__global__ __launch_bounds__(256) void pair_max_count_kernel(const unsigned *__restrict__ table, int64_t n_qvid,
+                                                             int64_t n_rvid, long long *__restrict__ counts) {
+    __shared__ int part[4];
+    for (int64_t row = blockIdx.x; row < n_qvid; row += gridDim.x) {
+        int n = 0;
+        for (int64_t c = threadIdx.x; c < n_rvid; c += 256) n += table[row * n_rvid + c] != 0;
+#pragma unroll
+        for (int off = 32; off; off >>= 1) n += __shfl_xor(n, off);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+        __syncthreads();
+        if (threadIdx.x == 0) counts[row] = part[0] + part[1] + part[2] + part[3];
+        __syncthreads();
+    }
+}
+
+// ordered compaction of a row: 256 columns at a time, rank = hits in earlier chunks + earlier waves + lower lanes
+__global__ __launch_bounds__(256) void pair_max_fill_kernel(const unsigned *__restrict__ table, int64_t n_qvid,
+                                                            int64_t n_rvid, const long long *__restrict__ base,
+                                                            int *__restrict__ out_rvid, float *__restrict__ out_score) {
+    __shared__ int part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t row = blockIdx.x; row < n_qvid; row += gridDim.x) {
+        long long at = base[row];
+        for (int64_t c0 = 0; c0 < n_rvid; c0 += 256) {
+            const int64_t c = c0 + threadIdx.x;
+            const unsigned u = c < n_rvid ? table[row * n_rvid + c] : 0u;
+            const unsigned long long m = __ballot(u != 0);
+            if (lane == 0) part[wave] = __popcll(m);
+            __syncthreads();
+            int before = __popcll(m & ((1ull << lane) - 1ull));
+            int total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                before += w < wave ? part[w] : 0;
+                total += part[w];
+            }
+            if (u != 0) {
+                out_rvid[at + before] = (int)c;
+                out_score[at + before] = from_ordered_bits(u);
+            }
+            at += total;
+            __syncthreads();
+        }
+    }
+}
+
 // ---- grow-only device scratch, one per process (one process per GPU) ----------------------
 struct Scratch {
     void *ptr = nullptr;
     size_t bytes = 0;
 };
-Scratch g_scratch[6];
+Scratch g_scratch[8];
 
 int scratch_get(int slot, size_t bytes, void **out) {
     Scratch &s = g_scratch[slot];
@@ -731,5 +862,67 @@ extern "C" int vsc_pair_similarity_f32(const float *q_dev, int64_t nq, const flo
     hipLaunchKernelGGL(pair_sim_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, stream, (const float *)qp,
                        (const float *)rp, dpad, (const PairTile *)tt, out_dev);
     VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+extern "C" int vsc_video_pair_max_f32(const float *q_dev, int64_t nq, const int32_t *q_video_dev, int32_t n_q_videos,
+                                      const float *r_dev, int64_t nr, const int32_t *r_video_dev, int32_t n_r_videos,
+                                      int32_t d, float threshold, int64_t *lims_dev, int32_t *out_rvideo_dev,
+                                      float *out_score_dev, int64_t capacity, int64_t *total_out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VSC_REQUIRE(q_dev && r_dev && q_video_dev && r_video_dev && lims_dev && total_out, "video_pair_max: null pointer");
+    VSC_REQUIRE(nq > 0 && nr > 0, "video_pair_max: empty query or reference set");
+    VSC_REQUIRE(n_q_videos > 0 && n_r_videos > 0, "video_pair_max: no videos (%d x %d)", n_q_videos, n_r_videos);
+    VSC_REQUIRE(d > 0 && d <= 4096, "video_pair_max: dimension %d unsupported", d);
+    VSC_REQUIRE(capacity >= 0 && (capacity == 0 || (out_rvideo_dev && out_score_dev)),
+                "video_pair_max: capacity %lld without output buffers", (long long)capacity);
+    const int dpad = (d + KS - 1) / KS * KS;
+    const int nqb = (int)((nq + TQ - 1) / TQ);
+    const int64_t total_tiles = (nr + TR - 1) / TR;
+    int64_t want = (512 + nqb - 1) / nqb;
+    if (want > 256) want = 256;
+    if (want > total_tiles) want = total_tiles;
+    if (want < 1) want = 1;
+    const int64_t tiles_per_split = (total_tiles + want - 1) / want;
+    const int splits = (int)((total_tiles + tiles_per_split - 1) / tiles_per_split);
+    const int64_t work = (int64_t)nqb * splits;
+    const int grid = (int)(work < 512 ? work : 512);
+    const size_t table_bytes = (size_t)n_q_videos * n_r_videos * 4;
+
+    void *qp, *rp, *table, *counts;
+    int rc;
+    if ((rc = scratch_get(0, (size_t)nq * dpad * 4, &qp))) return rc;
+    if ((rc = scratch_get(1, (size_t)nr * dpad * 4, &rp))) return rc;
+    if ((rc = scratch_get(6, table_bytes, &table))) return rc;
+    if ((rc = scratch_get(7, (size_t)n_q_videos * 8, &counts))) return rc;
+    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nq * (dpad / 4))), dim3(256), 0, stream, q_dev, (float *)qp, nq,
+                       d, dpad);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nr * (dpad / 4))), dim3(256), 0, stream, r_dev, (float *)rp, nr,
+                       d, dpad);
+    VSC_CHECK_LAUNCH();
+    VSC_CHECK_HIP(hipMemsetAsync(table, 0, table_bytes, stream));
+    PairMaxArgs a{(const float *)qp, (const float *)rp, q_video_dev, r_video_dev, nq, nr, dpad, nqb, splits,
+                  total_tiles, tiles_per_split, threshold, (unsigned *)table, n_r_videos};
+    hipLaunchKernelGGL(pair_max_kernel, dim3(grid), dim3(256), 0, stream, a);
+    VSC_CHECK_LAUNCH();
+    const int rows_grid = n_q_videos < 4096 ? n_q_videos : 4096;
+    hipLaunchKernelGGL(pair_max_count_kernel, dim3(rows_grid), dim3(256), 0, stream, (const unsigned *)table,
+                       (int64_t)n_q_videos, (int64_t)n_r_videos, (long long *)counts);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(range_scan_kernel, dim3(1), dim3(1024), 0, stream, (long long *)counts, (int64_t)n_q_videos, 1,
+                       (int64_t)n_q_videos, lims_dev);
+    VSC_CHECK_LAUNCH();
+    int64_t total = 0;
+    VSC_CHECK_HIP(hipMemcpyAsync(&total, lims_dev + n_q_videos, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    VSC_CHECK_HIP(hipStreamSynchronize(stream));
+    *total_out = total;
+    if (total > capacity) return VSC_OK;  // caller re-calls with capacity >= total
+    if (total > 0) {
+        hipLaunchKernelGGL(pair_max_fill_kernel, dim3(rows_grid), dim3(256), 0, stream, (const unsigned *)table,
+                           (int64_t)n_q_videos, (int64_t)n_r_videos, (const long long *)counts, out_rvideo_dev,
+                           out_score_dev);
+        VSC_CHECK_LAUNCH();
+    }
     return VSC_OK;
 }

@@ -8,6 +8,8 @@ candidate search and the classifier / refinement networks:
   * ``generate_matching_feature``             utils.py:54-77   (query view, reference) feature pairs for refinement
   * ``calclualte_low_var_dim``                utils.py:7-10
   * ``transform_features``                    utils.py:12-16
+  * ``search_candidate_pairs``                infer_matching.py:229-262   candidate (query video, reference video) search
+  * ``MatchRefineDataset``                    src/dataset.py:127-144      padded maps fed to the refinement networks
 
 The reference runs one ``np.matmul(qfeat, rfeat.T)`` per candidate on the host (twice: once to pick the query
 view, once for the map).  Here every candidate of a call goes through ONE ``vsc_pair_similarity_f32`` launch
@@ -23,6 +25,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 TOP_ROWS = 10  # rows whose maxima are averaged to score a query view (utils.py:41)
+SEARCH_THRESHOLD = -0.1  # infer_matching.py:62
 
 
 def calclualte_low_var_dim(score_norm_refs) -> int:
@@ -33,6 +36,52 @@ def calclualte_low_var_dim(score_norm_refs) -> int:
 
 def transform_features(features, transform: Callable[[np.ndarray], np.ndarray]):
     return [dataclasses.replace(feature, feature=transform(feature.feature)) for feature in features]
+
+
+def _hip_video_pair_max(q_bank, q_video, n_q_videos, r_bank, r_video, n_r_videos, threshold):
+    import torch
+
+    from vsc_hip import _lib, ops
+    _lib.require_device()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lims, rv, sc = ops.video_pair_max(torch.from_numpy(q_bank).to(dev), torch.from_numpy(q_video).to(dev), n_q_videos,
+                                      torch.from_numpy(r_bank).to(dev), torch.from_numpy(r_video).to(dev), n_r_videos,
+                                      threshold)
+    return lims.cpu().numpy(), rv.cpu().numpy(), sc.cpu().numpy()
+
+
+def _bank_with_video_index(videos):
+    feats = [np.ascontiguousarray(v.feature, dtype=np.float32) for v in videos]
+    dim = feats[0].shape[1] if feats else 0
+    bank = np.concatenate(feats, axis=0) if feats else np.zeros((0, dim), np.float32)
+    index = np.repeat(np.arange(len(feats), dtype=np.int32), [len(f) for f in feats])
+    return bank, index
+
+
+def search_candidate_pairs(sn_query_list, sn_refs, threshold: float = SEARCH_THRESHOLD,
+                           video_pair_max: Optional[Callable] = None) -> List[Tuple[str, str, np.float32]]:
+    """Candidate (query_id, ref_id, score) triples, best first (infer_matching.py:229-262).
+
+    The reference searches the flat inner-product index per query video for the top 1024 references of every
+    frame, re-runs ``range_search`` for the frames whose 1024th score still exceeds the threshold, and keeps the
+    best frame score of every (query video, reference video) in a dict.  Both branches together select exactly
+    the frame pairs scoring above ``threshold``, so one ``vsc_video_pair_max_f32`` sweep over all query frames
+    and all reference frames yields the dict's contents; what remains here is the sort.  Order: descending
+    score; pairs with bit-equal scores follow (query video, reference video) order where the reference keeps
+    their first-encounter order -- the only difference, and one that needs an exact fp32 tie across pairs.
+    ``video_pair_max(q_bank, q_video, n_q, r_bank, r_video, n_r, threshold) -> (lims, ref_video, score)`` is a
+    test seam; the default is the HIP path."""
+    if len(sn_query_list) == 0 or len(sn_refs) == 0:
+        return []
+    q_bank, q_video = _bank_with_video_index(sn_query_list)
+    r_bank, r_video = _bank_with_video_index(sn_refs)
+    if len(q_bank) == 0 or len(r_bank) == 0:
+        return []
+    lims, ref_video, score = (video_pair_max or _hip_video_pair_max)(
+        q_bank, q_video, len(sn_query_list), r_bank, r_video, len(sn_refs), float(threshold))
+    query_video = np.repeat(np.arange(len(sn_query_list)), np.diff(lims))
+    order = np.lexsort((ref_video, query_video, -score.astype(np.float64)))
+    return [(sn_query_list[query_video[i]].video_id, sn_refs[ref_video[i]].video_id, score[i]) for i in order]
 
 
 def _hip_pair_similarity(q_bank: np.ndarray, r_bank: np.ndarray, pairs: np.ndarray):
@@ -143,3 +192,32 @@ class MatchClassifyDataset:
         canvas = np.zeros(self.resolution, dtype=np.float32)
         canvas[:h, :w] = feature[:h, :w]
         return np.stack([canvas] * 3), self.infos[item][0], self.infos[item][1]
+
+
+class MatchRefineDataset:
+    """(query view, reference) similarity maps cropped / zero-padded to ``resolution``, repeated on 3 channels, with
+    the valid height and width (src/dataset.py:127-144).  The reference multiplies ``qfeat @ rfeat.T`` per item on
+    the host; here the maps of all items come from one ``vsc_pair_similarity_f32`` launch on first access."""
+
+    def __init__(self, meta, resolution=(160, 160), pair_similarity: Optional[Callable] = None):
+        self.meta, self.resolution, self._pair_similarity = meta, resolution, pair_similarity
+        self._maps: Optional[List[np.ndarray]] = None
+
+    def __len__(self):
+        return len(self.meta)
+
+    def _similarity_maps(self) -> List[np.ndarray]:
+        if self._maps is None:
+            query = {i: m[2] for i, m in enumerate(self.meta)}
+            ref = {i: m[3] for i, m in enumerate(self.meta)}
+            self._maps = pair_similarity_matrices(query, ref, [(i, i, 0.0) for i in range(len(self.meta))],
+                                                  self._pair_similarity)
+        return self._maps
+
+    def __getitem__(self, item):
+        qid, rid = self.meta[item][0], self.meta[item][1]
+        sim_mat = self._similarity_maps()[item]
+        h, w = min(sim_mat.shape[0], self.resolution[0]), min(sim_mat.shape[1], self.resolution[1])
+        feat = np.zeros(self.resolution, dtype=np.float32)
+        feat[:h, :w] = sim_mat[:h, :w]
+        return np.stack([feat, feat, feat]), qid, rid, h, w

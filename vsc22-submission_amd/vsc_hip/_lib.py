@@ -74,6 +74,9 @@ SIGNATURES = {
     "vsc_merge_gather_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "vsc_pair_similarity_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p,
                                           c_void_p, c_int64, c_void_p]),
+    "vsc_video_pair_max_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int32,
+                                         c_int32, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                         c_void_p]),
     "vsc_encoder_forward_u8": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vsc_swin_forward_u8": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vsc_debug_spin_ticks": (c_int32, [ctypes.c_uint64, c_void_p, c_void_p]),

@@ -144,6 +144,33 @@ def pair_similarity(q, r, pairs):
     return out, offsets
 
 
+def video_pair_max(q, q_video, n_q_videos: int, r, r_video, n_r_videos: int, threshold: float, capacity: int = 1 << 20):
+    """Largest frame score above ``threshold`` per (query video, reference video).
+    q [nq, d], r [nr, d] float32; q_video [nq], r_video [nr] int32 video index of every row.
+    -> (lims [n_q_videos + 1] int64, ref_video int32, score float32): pairs of query video v in
+    lims[v]:lims[v+1], ascending reference video."""
+    import ctypes
+    lib = _lib.require_device()
+    q, r = _dev(q, torch.float32), _dev(r, torch.float32)
+    assert q.dim() == 2 and r.dim() == 2 and q.shape[1] == r.shape[1], "query / reference dimension mismatch"
+    q_video, r_video = _dev(q_video, torch.int32), _dev(r_video, torch.int32)
+    assert q_video.shape == (q.shape[0],) and r_video.shape == (r.shape[0],)
+    lims = torch.zeros(n_q_videos + 1, dtype=torch.int64, device=q.device)
+    if q.shape[0] == 0 or r.shape[0] == 0 or n_q_videos == 0 or n_r_videos == 0:
+        return (lims, torch.empty(0, dtype=torch.int32, device=q.device),
+                torch.empty(0, dtype=torch.float32, device=q.device))
+    total = ctypes.c_int64(0)
+    while True:
+        rv = torch.empty(capacity, dtype=torch.int32, device=q.device)
+        sc = torch.empty(capacity, dtype=torch.float32, device=q.device)
+        check(lib.vsc_video_pair_max_f32(ptr(q), q.shape[0], ptr(q_video), n_q_videos, ptr(r), r.shape[0], ptr(r_video),
+                                         n_r_videos, q.shape[1], float(threshold), ptr(lims), ptr(rv), ptr(sc), capacity,
+                                         ctypes.byref(total), current_stream()))
+        if total.value <= capacity:
+            return lims, rv[: total.value], sc[: total.value]
+        capacity = int(total.value)
+
+
 def window_attention_bf16(qkv, bias, scale, frames: int, res: int, window: int, shift: int, heads: int):
     """Swin-V2 windowed cosine attention (head_dim 32) on image-ordered tokens."""
     lib = _lib.require_device()
