@@ -262,3 +262,107 @@ def test_search_candidate_pairs_on_hip_path():
     assert [(q, r) for q, r, _ in got] == [(q, r) for q, r, _ in want]
     assert np.array_equal(np.array([s for _, _, s in got]).view(np.uint32),
                           np.array([s for _, _, s in want]).view(np.uint32))
+
+
+# ---- generate_matching_result (utils.py:80-116): host code, scipy in cv2's place ------------------------------
+def _flood_components8(mask):
+    """Independent 8-connected labelling (stack flood fill), raster order of the first pixel."""
+    labels = np.zeros(mask.shape, np.int32)
+    n = 0
+    for i, j in zip(*np.nonzero(mask)):
+        if labels[i, j]:
+            continue
+        n += 1
+        stack = [(i, j)]
+        labels[i, j] = n
+        while stack:
+            a, b = stack.pop()
+            for da in (-1, 0, 1):
+                for db in (-1, 0, 1):
+                    u, v = a + da, b + db
+                    if 0 <= u < mask.shape[0] and 0 <= v < mask.shape[1] and mask[u, v] and not labels[u, v]:
+                        labels[u, v] = n
+                        stack.append((u, v))
+    return n + 1, labels
+
+
+def _matching_result_restated(res_list, threshold, std_ratio):
+    """utils.py:80-116 statement by statement, with the flood fill above standing in for cv2."""
+    from sklearn.linear_model import RANSACRegressor
+    match_res = []
+    for qid, rid, sim_mat, _ in res_list:
+        qmat = sim_mat > threshold
+        num_label, conn_label = _flood_components8(sim_mat > threshold)
+        label_cnt = {}
+        for i in range(1, num_label):
+            cnt = (conn_label == i).sum()
+            if cnt > 10:
+                label_cnt[i] = cnt
+                x_, y_ = np.where(conn_label == i)
+                qmat[x_, y_] = False
+        if not label_cnt:
+            conn_label = qmat.astype(np.int32)
+            label_cnt[1] = conn_label.sum()
+        for i in label_cnt:
+            x, y = np.where((conn_label == i) + qmat)
+            if len(set(x)) > 3:
+                ransac = RANSACRegressor(max_trials=200, random_state=2023, residual_threshold=2)
+                prob = sim_mat[x, y]
+                ransac.fit(x[:, np.newaxis], y[:, np.newaxis], sample_weight=np.square(prob))
+                pred = ransac.predict(x[:, np.newaxis]).flatten()
+                qualify = abs(y - pred) < 1
+                coef = ransac.estimator_.coef_[0][0]
+                if coef <= 0:
+                    continue
+                coef = max(1 / coef, coef)
+                if qualify.sum() > 5 and len(set(x[qualify])) > 3 and len(set(y[qualify])) > 3:
+                    top_sim = sim_mat[x[qualify], y[qualify]]
+                    score = top_sim.max() - top_sim.std() * std_ratio - abs(coef - 1) / 10
+                    match_res.append([qid, rid, x[qualify][0], y[qualify][0], x[qualify][-1], y[qualify][-1], score])
+    return match_res
+
+
+def _probability_map(seed, h, w, bands, noise=0.03):
+    rng = np.random.default_rng(seed)
+    m = (rng.random((h, w)) * noise).astype(np.float32)
+    for q0, r0, n, slope, p in bands:                     # a copied segment: a (thick) line of high probability
+        for t in range(n):
+            i, j = q0 + t, int(round(r0 + slope * t))
+            if 0 <= i < h and 0 <= j < w:
+                m[i, j] = p - 0.002 * t
+                if j + 1 < w and t % 3 == 0:
+                    m[i, j + 1] = p - 0.1
+    specks = rng.integers(0, [h, w], size=(12, 2))          # isolated hits: the "small components"
+    m[specks[:, 0], specks[:, 1]] = 0.5
+    return m
+
+
+def test_matching_result_single_diagonal():
+    m = np.zeros((40, 50), np.float32)
+    for t in range(20):
+        m[5 + t, 8 + t] = 0.9
+    res = matching.generate_matching_result([["Q1", "R1", m, None]], threshold=0.35, std_ratio=0.5)
+    assert len(res) == 1
+    qid, rid, qs, rs, qe, re, score = res[0]
+    assert (qid, rid, qs, rs, qe, re) == ("Q1", "R1", 5, 8, 24, 27) and abs(score - 0.9) < 1e-6
+    assert matching.generate_matching_result([["Q1", "R1", np.zeros((8, 8), np.float32), None]], 0.35, 0.5) == []
+    assert matching.generate_matching_result([], 0.35, 0.5) == []
+
+
+@pytest.mark.parametrize("threshold,std_ratio", [(0.35, 0.5), (0.1, 1.25), (0.001, 2)])   # infer_matching.py:291-293
+def test_matching_result_equals_restatement(threshold, std_ratio):
+    maps = [
+        ["Q1", "R1", _probability_map(1, 60, 80, [(3, 10, 30, 1.0, 0.95), (35, 50, 20, 1.0, 0.8)]), None],
+        ["Q1", "R2", _probability_map(2, 48, 48, [(0, 0, 40, 1.0, 0.7)]), None],
+        ["Q2", "R1", _probability_map(3, 70, 40, [(10, 5, 24, 0.5, 0.9)]), None],          # slope 1/2
+        ["Q2", "R3", _probability_map(4, 30, 30, [(20, 5, 9, -1.0, 0.9)]), None],           # anti-diagonal: rejected
+        ["Q3", "R3", _probability_map(5, 25, 25, []), None],                                # specks only
+    ]
+    got = matching.generate_matching_result(maps, threshold=threshold, std_ratio=std_ratio)
+    want = _matching_result_restated(maps, threshold, std_ratio)
+    key = lambda r: (r[0], r[1], int(r[2]), int(r[3]), int(r[4]), int(r[5]))
+    got, want = sorted(got, key=key), sorted(want, key=key)
+    assert [key(r) for r in got] == [key(r) for r in want]
+    assert np.allclose([r[6] for r in got], [r[6] for r in want], rtol=0, atol=1e-12)
+    if threshold >= 0.1:
+        assert len(got) >= 3

@@ -16,8 +16,9 @@ view, once for the map).  Here every candidate of a call goes through ONE ``vsc_
 over concatenated frame banks; each score is an independent ascending-k fp32 chain, so the map of the chosen
 view is a row slice of the full product -- bit for bit -- and nothing is multiplied twice.
 
-Not on this path (CPU post-processing of the networks' outputs, cv2 / sklearn in the reference):
-``generate_matching_result`` (connected components + RANSAC, utils.py:80-116).
+``generate_matching_result`` (utils.py:80-116) -- CPU post-processing of the refinement networks' probability
+maps, cv2 connected components + sklearn RANSAC in the reference -- is mirrored as host code with
+``scipy.ndimage.label`` in cv2's place (cv2 is not a dependency here); it is not part of the GPU path.
 """
 import dataclasses
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -221,3 +222,62 @@ class MatchRefineDataset:
         feat = np.zeros(self.resolution, dtype=np.float32)
         feat[:h, :w] = sim_mat[:h, :w]
         return np.stack([feat, feat, feat]), qid, rid, h, w
+
+
+# ---- localisation from the refinement maps (host code, utils.py:80-116) ---------------------------------------
+MIN_COMPONENT = 10      # a connected component needs more pixels than this to be fitted on its own
+RANSAC_TRIALS, RANSAC_SEED, RANSAC_RESIDUAL = 200, 2023, 2
+
+
+def _components8(mask: np.ndarray):
+    """8-connected components of a boolean map -> (labels, count); 0 = background, components numbered in raster
+    order of their first pixel (cv2 may number them differently; nothing downstream depends on the numbering)."""
+    from scipy import ndimage
+    labels, count = ndimage.label(mask, structure=np.ones((3, 3), dtype=np.int32))
+    return labels.astype(np.int32), int(count)
+
+
+def _fit_segment(prob_map: np.ndarray, x: np.ndarray, y: np.ndarray, std_ratio: float):
+    """Weighted RANSAC line y = f(x) through the pixels (x = query frame, y = reference frame) -> the matched
+    segment [q_start, r_start, q_end, r_end, score] or None."""
+    from sklearn.linear_model import RANSACRegressor
+    if len(set(x)) <= 3:
+        return None
+    ransac = RANSACRegressor(max_trials=RANSAC_TRIALS, random_state=RANSAC_SEED, residual_threshold=RANSAC_RESIDUAL)
+    ransac.fit(x[:, np.newaxis], y[:, np.newaxis], sample_weight=np.square(prob_map[x, y]))
+    on_line = abs(y - ransac.predict(x[:, np.newaxis]).flatten()) < 1
+    slope = ransac.estimator_.coef_[0][0]
+    if slope <= 0:
+        return None
+    slope = max(1 / slope, slope)
+    xs, ys = x[on_line], y[on_line]
+    if not (on_line.sum() > 5 and len(set(xs)) > 3 and len(set(ys)) > 3):
+        return None
+    top = prob_map[xs, ys]
+    return [xs[0], ys[0], xs[-1], ys[-1], top.max() - top.std() * std_ratio - abs(slope - 1) / 10]
+
+
+def generate_matching_result(res_list, threshold=0.05, std_ratio=2):
+    """[[qid, rid, probability map, similarity map], ...] -> [[qid, rid, q_start, r_start, q_end, r_end, score], ...].
+
+    Per map: pixels above ``threshold`` are split into 8-connected components; each component of more than ten
+    pixels is fitted together with ALL pixels of the small components (or, when there is no large component, the
+    small ones are fitted as one set); a fit yields a segment when its slope is positive and enough distinct
+    frames lie within one frame of the line.  Same sklearn estimator, seed and thresholds as the reference."""
+    match_res = []
+    for qid, rid, prob_map, _ in res_list:
+        loose = prob_map > threshold                 # ends up holding the pixels of the small components only
+        labels, count = _components8(loose)
+        large = []
+        for i in range(1, count + 1):
+            member = labels == i
+            if member.sum() > MIN_COMPONENT:
+                large.append(member)
+                loose = loose & ~member
+        groups = [member | loose for member in large] if large else [loose]
+        for group in groups:
+            x, y = np.where(group)
+            seg = _fit_segment(prob_map, x, y, std_ratio)
+            if seg is not None:
+                match_res.append([qid, rid, *seg])
+    return match_res
