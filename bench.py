@@ -122,10 +122,12 @@ def gemm_flops_per_frame(cfg):
 def gemm_traffic(cfg, chunk):
     """(measured HBM bytes per GEMM launch from the committed PMC profile, algorithmic bytes per launch).
 
-    PMC counters need rocprofv3, so they are not collected live: profiles/r01_pmc_per_launch.json holds
-    FETCH_SIZE / WRITE_SIZE per launch of this same configuration.  Calibration on a known byte count in
-    this access pattern (64-byte row pieces by LDS-DMA): the residual GEMMs read 431 MB algorithmically and
-    FETCH_SIZE says 425 MB, so the guide's x2 correction for wide coalesced streams is NOT applied."""
+    PMC counters need rocprofv3, so they are not collected live: profiles/r01_pmc_per_launch_v2.json holds
+    FETCH_SIZE / WRITE_SIZE per launch of this same configuration (separate --pmc passes).  Correction as
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes for gfx950: FETCH_SIZE reports half of a 16-byte-per-lane
+    stream, so reads = 2 x FETCH_SIZE -- confirmed in the same run on kernels with known byte counts (layernorm:
+    196,212 KiB read, FETCH_SIZE 98,163; attention: 294,318 KiB, 147,246); WRITE_SIZE needs none.  These are the L2's
+    memory-side requests, Infinity-Cache hits included."""
     t, d, m = cfg.tokens, cfg.width, cfg.mlp_dim
     rows = chunk * t
     launches = {"0": cfg.layers, "1": cfg.layers, "3": 2 * cfg.layers, "4": 1}   # EPI class -> launches per chunk
@@ -136,12 +138,12 @@ def gemm_traffic(cfg, chunk):
     n = sum(launches.values())
     algorithmic = sum(launches[k] * algo[k] for k in launches) / n
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")))["per_launch"]
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_per_launch_v2.json")))["per_launch"]
         meas = 0.0
         for key, v in prof.items():
             if "gemm_bf16_v2_kernel<" in key:
                 epi = key.split("<")[1].split(",")[0]
-                meas += launches.get(epi, 0) * (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+                meas += launches.get(epi, 0) * (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
         return meas / n, algorithmic
     except (OSError, KeyError, ValueError):
         return None, algorithmic
@@ -376,7 +378,7 @@ def main():
                          "frac": round(achieved / BF16_PEAK_TFLOPS, 4),
                          "traffic": None if traffic is None else round(traffic),
                          "traffic_unit": "HBM bytes per GEMM launch (mean over the 49 launches of one 332-frame chunk; "
-                                         "PMC FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_per_launch.json, calibrated on the residual GEMMs)",
+                                         "2 x FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_per_launch_v2.json: memory-side L2 requests, Infinity-Cache hits included)",
                          "algorithmic_bytes_per_launch": round(algo_bytes),
                          "gemm_ms_per_step": round(gemm_ms / args.steps, 3),
                          "note": "per-launch HIP-event time; with lanes=2 launches of the two chunks "

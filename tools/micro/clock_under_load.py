@@ -39,4 +39,18 @@ g = torch.ones(768, device=dev)
 clock(lambda: None, "idle", 1)
 clock(lambda: ops.gemm_bf16(a, w, None), "bf16 GEMM, random operands", 60)
 clock(lambda: ops.gemm_bf16(z, z, None), "bf16 GEMM, zero operands", 60)
+# the library's kernel on the same operands (calibration only): which clock does a 1.5 PF/s GEMM run at?
+o = torch.empty(8192, 8192, device=dev, dtype=torch.bfloat16)
+clock(lambda: torch.matmul(a, w.t(), out=o), "hipBLASLt, random operands", 60)
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for name, fn in (("ours", lambda: ops.gemm_bf16(a, w, None)), ("hipBLASLt", lambda: torch.matmul(a, w.t(), out=o))):
+    for _ in range(10):
+        fn()
+    ev0.record()
+    for _ in range(60):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / 60
+    print(f"{name:10s} 8192 x 8192 x 4096: {ms * 1e3:.1f} us  {2 * 8192 * 8192 * 4096 / ms / 1e9:.0f} TF/s")
 clock(lambda: ops.layernorm(x, g, g, 1e-6), "layernorm (HBM-bound)", 400)

@@ -651,8 +651,11 @@ int launch_v2(GemmArgs p, hipStream_t stream) {
     }
     p.tiles_m = (int)((p.m + BM2 - 1) / BM2);
     p.tiles_n = (p.n + BN2 - 1) / BN2;
-    // W panel of one N-group (G tiles x K) should sit in a 4 MiB XCD L2 next to the A panels
+    // W panel of one N-group (G tiles x K) should sit in a 4 MiB XCD L2 next to the A panels: every N-group is one
+    // more pass over A.  With few N tiles the whole width is one group whatever K is -- fc2 (N = 768, K = 3072) ran
+    // 3 passes over its 402 MB A (larger than the Infinity Cache) under the L2 rule: 395 -> 330 us with one.
     int g = (int)((int64_t)(3 << 19) / ((int64_t)BN2 * p.k * 2));
+    if (p.tiles_n <= 4) g = p.tiles_n;
     if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
     p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
     p.skew = skew_cycles(p.k);
