@@ -269,6 +269,12 @@ def bench_swin(dev, args):
 
 def main():
     args = parse()
+    # The contract is ONE line on stdout.  Libraries write there too (RCCL prints its version banner to the C stdout,
+    # flushed at exit, i.e. after the JSON line): keep a private handle on the real stdout for the result and point
+    # fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -411,7 +417,7 @@ def main():
             line["search"] = bench_search(dev, args)
         if search_multi is not None:
             line["search"] = search_multi
-        print(json.dumps(line), flush=True)
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

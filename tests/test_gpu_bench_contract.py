@@ -28,3 +28,18 @@ def test_bench_json_contract():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["value"] > 0 and abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01
     assert d["swin"]["value"] > 0 and d["search"]["value"] > 0 and d["search"]["roofline"]["bound"] == "mfma"
+
+
+def test_bench_stdout_is_one_line_with_a_process_group():
+    """The N > 1 launch initialises RCCL, which prints a version banner on the C stdout at exit: stdout must still
+    hold the JSON line and nothing else (exercised with world size 1 and the sharded-search leg forced on)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded-search", "--steps", "2", "--warmup", "1",
+           "--batch", "64", "--max-batch", "64", "--search-nq", "1024", "--search-nr", "50000", "--search-steps", "1",
+           "--no-swin", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["search"]["value"] > 0
