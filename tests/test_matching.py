@@ -366,3 +366,87 @@ def test_matching_result_equals_restatement(threshold, std_ratio):
     assert np.allclose([r[6] for r in got], [r[6] for r in want], rtol=0, atol=1e-12)
     if threshold >= 0.1:
         assert len(got) >= 3
+
+
+# ---- vsc.baseline.localization (reference tests/test_localization.py, with a stand-in alignment model) --------
+class _BoxModel:
+    """Alignment stand-in with the VCSL model interface (forward_sim): one box around the entries above a threshold."""
+
+    def __init__(self, threshold):
+        self.threshold = threshold
+
+    def forward_sim(self, sims):
+        out = []
+        for key, sim in sims:
+            x, y = np.nonzero(sim > self.threshold)
+            out.append((key, [[int(x.min()), int(y.min()), int(x.max()), int(y.max())]] if len(x) else []))
+        return out
+
+
+def _localization_case():
+    """make_test_case_1 of the reference's test: query frames 20..29 copy frames 30..39 of the second reference."""
+    from vsc.index import VideoFeature
+    a, b, c = (synth.descriptor_bank(s, n, 64) for s, n in ((31, 45), (32, 30), (33, 60)))
+    a[20:30] = c[30:40]
+    mk = lambda i, f: VideoFeature(video_id=i, feature=f, timestamps=np.arange(len(f)) * 1.0)
+    return [mk("Q1", a)], [mk("R2", b), mk("R3", c)]
+
+
+def _check_localization(pair_similarity):
+    from vsc.baseline.localization import VCSLLocalizationCandidateScore, VCSLLocalizationMaxSim
+    from vsc.metrics import CandidatePair, Match
+    queries, refs = _localization_case()
+    loc = VCSLLocalizationMaxSim(queries, refs, "TN", similarity_bias=0.5, model=_BoxModel(1.4), pair_similarity=pair_similarity)
+    assert loc.localize(CandidatePair("Q1", "R2", 1.0)) == []                 # no copy in this pair
+    matches = loc.localize_all([CandidatePair("Q1", "R2", 1.0), CandidatePair("Q1", "R3", 2.0)])
+    assert len(matches) == 1 and isinstance(matches[0], Match)
+    m = matches[0]
+    assert (m.query_id, m.ref_id, m.query_start, m.query_end, m.ref_start, m.ref_end) == ("Q1", "R3", 20.0, 29.0, 30.0, 39.0)
+    sim = knn_oracle.ip_matrix(queries[0].feature, refs[1].feature)
+    assert m.score == pytest.approx((sim + 0.5)[20:29, 30:39].max() - 0.5, abs=1e-6)   # the reference's half-open box
+    assert np.array_equal(loc.similarity(CandidatePair("Q1", "R3", 2.0)), sim + np.float32(0.5))
+    cs = VCSLLocalizationCandidateScore(queries, refs, "TN", model=_BoxModel(0.9), pair_similarity=pair_similarity)
+    assert cs.localize(CandidatePair("Q1", "R3", 2.0))[0].score == 2.0
+    assert loc.localize_all([]) == []
+
+
+def test_localization_with_stand_in_model():
+    _check_localization(_oracle_pairs)
+
+
+def test_localization_needs_vcsl_or_a_model():
+    from vsc.baseline.localization import VCSLLocalization
+    queries, refs = _localization_case()
+    with pytest.raises(ImportError, match="VCSL"):
+        VCSLLocalization(queries, refs, "TN")
+
+
+def test_match_csv_round_trip(tmp_path):
+    from vsc.metrics import Match, candidate_pairs_from_matches
+    ms = [Match("Q000001", "R000003", 0.75, 20, 29, 30, 39), Match("Q000001", "R000003", 0.5, 1, 2, 3, 4),
+          Match("Q000002", "R000001", 0.25, 0, 5.5, 2, 7)]
+    f = tmp_path / "matches.csv"
+    Match.write_csv(ms, f)
+    assert f.read_text().splitlines()[0] == "query_id,ref_id,query_start,query_end,ref_start,ref_end,score"
+    assert Match.read_csv(f) == ms
+    pairs = candidate_pairs_from_matches(ms)
+    assert [(p.query_id, p.ref_id, p.score) for p in pairs] == [("Q000001", "R000003", 0.75), ("Q000002", "R000001", 0.25)]
+
+
+@pytest.mark.gpu
+def test_localization_on_hip_path():
+    _check_localization(None)
+
+
+@pytest.mark.gpu
+def test_localize_and_verify_on_hip_path():
+    """sscd_baseline.localize_and_verify (:107-152) with the stand-in model: both scoring branches, batches, csv."""
+    import vsc.baseline.sscd_baseline as entry
+    from vsc.metrics import CandidatePair
+    queries, refs = _localization_case()
+    cands = [CandidatePair("Q1", "R3", 0.8), CandidatePair("Q1", "R2", 0.1)]
+    got = entry.localize_and_verify(queries, refs, cands, score_normalization=True, model=_BoxModel(1.4))
+    assert len(got) == 1 and got[0].ref_id == "R3" and (got[0].query_start, got[0].ref_end) == (20.0, 39.0)
+    got = entry.localize_and_verify(queries, refs, cands, score_normalization=False, model=_BoxModel(0.9))
+    assert len(got) == 1 and got[0].score == 0.8
+    assert entry.localize_and_verify(queries, refs, cands, localize_per_query=0.0, model=_BoxModel(0.9)) == []

@@ -4,9 +4,10 @@ run by infer/eval.sh as `python3 -m vsc.baseline.sscd_baseline --query_features 
 
 On the HIP path: optional score normalisation, the exhaustive candidate search
 (`search`, sscd_baseline.py:89-103 -> CandidateGeneration.query) and, with ground truth, the
-descriptor-track micro-AP (:219-224).  The matching-track localisation that follows in the
-reference (`localize_and_verify`, VCSL temporal alignment) is outside this path: candidates.csv
-is written in the reference's format so the reference's own localisation can consume it.
+descriptor-track micro-AP (:219-224).  `localize_and_verify` (:107-152) follows as in the reference when its
+VCSL package is importable: the per-candidate similarity matrices come from one HIP launch per batch
+(vsc.baseline.localization), the temporal alignment is the reference's own CPU code; without VCSL only
+candidates.csv is written (in the reference's format) and matches.csv is skipped with a log line.
 """
 from __future__ import annotations
 
@@ -18,7 +19,7 @@ from typing import List
 from vsc.baseline.score_normalization import score_normalize
 from vsc.candidates import CandidateGeneration, MaxScoreAggregation
 from vsc.index import VideoFeature
-from vsc.metrics import CandidatePair, Dataset, micro_average_precision
+from vsc.metrics import CandidatePair, Dataset, Match, micro_average_precision
 from vsc.storage import load_features, store_features
 
 logger = logging.getLogger("sscd_baseline.py")
@@ -31,6 +32,30 @@ def search(queries: List[VideoFeature], refs: List[VideoFeature], retrieve_per_q
     candidates = candidates[: int(candidates_per_query * len(queries))]
     logger.info("Got %d candidates", len(candidates))
     return candidates
+
+
+def localize_and_verify(queries: List[VideoFeature], refs: List[VideoFeature], candidates: List[CandidatePair],
+                        localize_per_query: float = 5.0, score_normalization: bool = False, model=None) -> List[Match]:
+    """sscd_baseline.py:107-152: the best `localize_per_query * len(queries)` candidates, aligned in batches of 512."""
+    from sklearn.preprocessing import normalize
+
+    from src.matching import transform_features
+    from vsc.baseline.localization import VCSLLocalizationCandidateScore, VCSLLocalizationMaxSim
+    candidates = candidates[: int(len(queries) * localize_per_query)]
+    if score_normalization:
+        alignment = VCSLLocalizationMaxSim(queries, refs, model_type="TN", tn_max_step=5, min_length=4, concurrency=16,
+                                           similarity_bias=0.5, model=model)
+    else:
+        alignment = VCSLLocalizationCandidateScore(transform_features(queries, normalize),
+                                                   transform_features(refs, normalize), model_type="TN",
+                                                   tn_max_step=5, min_length=4, concurrency=16, model=model)
+    matches: List[Match] = []
+    logger.info("Aligning %s candidate pairs", len(candidates))
+    for i in range(0, len(candidates), 512):
+        matches.extend(alignment.localize_all(candidates[i:i + 512]))
+        logger.info("Aligned %d pairs of %d; %d predictions so far", min(i + 512, len(candidates)), len(candidates),
+                    len(matches))
+    return matches
 
 
 def read_ground_truth_pairs(path: str) -> List[CandidatePair]:
@@ -58,6 +83,14 @@ def main(args) -> None:
     candidate_file = os.path.join(args.output_path, "candidates.csv")
     CandidatePair.write_csv(candidates, candidate_file)
     logger.info("Candidates: %s", candidate_file)
+    try:
+        matches = localize_and_verify(queries, refs, candidates, score_normalization=bool(args.score_norm_features))
+    except ImportError as exc:
+        logger.warning("matches.csv not written: %s", exc)
+    else:
+        matches_file = os.path.join(args.output_path, "matches.csv")
+        Match.write_csv(matches, matches_file)
+        logger.info("Matches: %s", matches_file)
     if args.ground_truth:
         uap = micro_average_precision(read_ground_truth_pairs(args.ground_truth), candidates)
         logger.info("Candidate uAP: %.4f", uap)

@@ -1,12 +1,12 @@
 """The slice of the reference's vsc/metrics.py that the descriptor path touches:
-video-id formatting, candidate pairs, and the descriptor-track micro-AP
-(infer/vsc/metrics.py:21-95, 423-455).  The matching-track segment metric is out of
-scope of this path."""
+video-id formatting, candidate pairs, predicted matches (the rows of matches.csv) and the
+descriptor-track micro-AP (infer/vsc/metrics.py:21-95, 183-243, 423-455).  The matching-track
+segment metric is out of scope of this path."""
 from __future__ import annotations
 
 import dataclasses
 import enum
-from typing import Collection, List, Optional, Union
+from typing import Collection, List, NamedTuple, Optional, Union
 
 import numpy as np
 
@@ -53,6 +53,51 @@ class CandidatePair:
         df = pd.read_csv(file)
         return [CandidatePair(format_video_id(q, Dataset.QUERIES), format_video_id(r, Dataset.REFS), s)
                 for q, r, s in zip(df.query_id, df.ref_id, df.score)]
+
+
+class Match(NamedTuple):
+    """A predicted (or ground-truth) copied segment: one row of matches.csv (metrics.py:183-243)."""
+    query_id: str
+    ref_id: str
+    score: float
+    query_start: float
+    query_end: float
+    ref_start: float
+    ref_end: float
+
+    def pair_id(self):
+        return (self.query_id, self.ref_id)
+
+    @classmethod
+    def write_csv(cls, matches: Collection["Match"], file) -> None:
+        import pandas as pd
+        df = pd.DataFrame([m._asdict() for m in matches], columns=cls._fields)
+        df = df.loc[:, ["query_id", "ref_id", "query_start", "query_end", "ref_start", "ref_end", "score"]]
+        for col in ("query_start", "query_end", "ref_start", "ref_end"):
+            df[col] = df[col].astype(np.float64)
+        df.to_csv(file, index=False)
+
+    @classmethod
+    def read_csv(cls, file, is_gt: bool = False, check: bool = True) -> List["Match"]:
+        import pandas as pd
+        df = pd.read_csv(file)
+        df["query_id"] = df.query_id.map(lambda x: format_video_id(x, Dataset.QUERIES))
+        df["ref_id"] = df.ref_id.map(lambda x: format_video_id(x, Dataset.REFS))
+        if is_gt:
+            df["score"] = 1.0
+        if check:
+            for field in cls._fields:
+                assert not df[field].isna().any()
+        return [Match(**{f: rec[f] for f in cls._fields}) for rec in df.to_dict("records")]
+
+
+def candidate_pairs_from_matches(matches: Collection[Match]) -> List[CandidatePair]:
+    """Best score per (query, ref) over a list of matches (CandidatePair.from_matches, metrics.py:84-93)."""
+    scores: dict = {}
+    for m in matches:
+        key = (m.query_id, m.ref_id)
+        scores[key] = max(m.score, scores.get(key, 0.0))
+    return [CandidatePair(q, r, s) for (q, r), s in scores.items()]
 
 
 def micro_average_precision(ground_truth: Collection[CandidatePair],
