@@ -38,17 +38,21 @@ def all_gather_rows(local: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     if ws == 1:
         return local, torch.tensor([0, local.shape[0]])
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    sizes = [torch.zeros_like(n) for _ in range(ws)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
+    all_n = torch.zeros(ws, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(all_n, n)
+    sizes = [int(v) for v in all_n.tolist()]
     longest = max(sizes)
-    padded = local
+    padded = local.contiguous()
     if local.shape[0] < longest:
         pad = torch.zeros((longest - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         padded = torch.cat([local, pad])
-    parts = [torch.empty_like(padded) for _ in range(ws)]
-    dist.all_gather(parts, padded.contiguous())
-    bank = torch.cat([p[:s] for p, s in zip(parts, sizes)])
+    # one collective into one flat buffer: with equal shards (the usual case) that buffer IS the bank, no second copy
+    flat = torch.empty((ws * longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(flat, padded)
+    if all(s == longest for s in sizes):
+        bank = flat
+    else:
+        bank = torch.cat([flat[r * longest: r * longest + s] for r, s in enumerate(sizes)])
     offsets = torch.tensor([0] + sizes).cumsum(0)
     return bank, offsets
 
