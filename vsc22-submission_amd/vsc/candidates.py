@@ -1,36 +1,46 @@
-"""Candidate generation: best frame-pair score per (query video, ref video)
-(reference: infer/vsc/candidates.py:15-40)."""
+"""Video-pair candidates from frame-level search hits (interface of the reference's infer/vsc/candidates.py:15-40).
+
+`CandidateGeneration(refs, aggregation).query(queries, global_k)` is what `sscd_baseline.search` calls: the globally
+best `global_k` frame pairs come from the HIP sweep behind `VideoIndex.search`, every (query video, reference video)
+pair that owns at least one of them becomes a `CandidatePair` whose score is `aggregation.aggregate(hits)`, best first.
+"""
 from __future__ import annotations
 
-from abc import ABC, abstractmethod
-from typing import List
-
-import numpy as np
+from typing import List, Sequence
 
 from vsc.index import PairMatches, VideoFeature, VideoIndex
 from vsc.metrics import CandidatePair
 
 
-class ScoreAggregation(ABC):
-    @abstractmethod
+class ScoreAggregation:
+    """How the frame-pair hits of one video pair collapse into the pair's score."""
+
     def aggregate(self, match: PairMatches) -> float:
-        ...
+        raise NotImplementedError(f"{type(self).__name__} must implement aggregate()")
 
     def score(self, match: PairMatches) -> CandidatePair:
-        return CandidatePair(query_id=match.query_id, ref_id=match.ref_id, score=self.aggregate(match))
+        return CandidatePair(match.query_id, match.ref_id, self.aggregate(match))
 
 
 class MaxScoreAggregation(ScoreAggregation):
+    """The pair is as good as its best frame pair."""
+
     def aggregate(self, match: PairMatches) -> float:
-        return float(np.max([m.score for m in match.matches]))
+        best = match.matches[0].score
+        for hit in match.matches[1:]:
+            if hit.score > best:
+                best = hit.score
+        return float(best)
 
 
 class CandidateGeneration:
-    def __init__(self, references: List[VideoFeature], aggregation: ScoreAggregation):
+    def __init__(self, references: Sequence[VideoFeature], aggregation: ScoreAggregation):
+        if not references:
+            raise ValueError("CandidateGeneration needs at least one reference video")
         self.aggregation = aggregation
         self.index = VideoIndex(references[0].dimensions())
-        self.index.add(references)
+        self.index.add(list(references))
 
     def query(self, queries: List[VideoFeature], global_k: int) -> List[CandidatePair]:
-        pairs = [self.aggregation.score(m) for m in self.index.search(queries, global_k=global_k)]
-        return sorted(pairs, key=lambda c: c.score, reverse=True)
+        scored = map(self.aggregation.score, self.index.search(queries, global_k=global_k))
+        return sorted(scored, key=lambda pair: -pair.score)   # stable: ties keep the index's pair order

@@ -12,31 +12,37 @@ from vsc.metrics import Dataset, format_video_id
 
 
 def store_features(f, features: List[VideoFeature], dataset: Optional[Dataset] = None) -> None:
-    ids, feats, stamps = [], [], []
-    for vf in features:
-        ids.append(np.full(len(vf), format_video_id(vf.video_id, dataset)))
-        feats.append(vf.feature)
-        stamps.append(vf.timestamps)
-    np.savez(f, video_ids=np.concatenate(ids), features=np.concatenate(feats).astype(np.float32),
-             timestamps=np.concatenate(stamps))
+    """One row per frame; the id column repeats each video's (formatted) id over its rows."""
+    names = np.array([format_video_id(video.video_id, dataset) for video in features])
+    rows = np.array([len(video) for video in features], dtype=np.int64)
+    np.savez(f,
+             video_ids=np.repeat(names, rows),
+             features=np.concatenate([video.feature for video in features]).astype(np.float32),
+             timestamps=np.concatenate([video.timestamps for video in features]))
 
 
 def same_value_ranges(values):
-    """(value, start, end) for each run of equal consecutive values."""
-    start = 0
-    for i in range(1, len(values) + 1):
-        if i == len(values) or values[i] != values[start]:
-            yield values[start], start, i
-            start = i
+    """(value, start, end) for each run of equal consecutive values (vectorised: banks hold millions of rows)."""
+    values = np.asarray(values)
+    if values.shape[0] == 0:
+        return
+    cuts = np.flatnonzero(values[1:] != values[:-1]) + 1
+    starts = np.concatenate(([0], cuts))
+    ends = np.concatenate((cuts, [values.shape[0]]))
+    for a, b in zip(starts.tolist(), ends.tolist()):
+        yield values[a], a, b
 
 
 def load_features(f, dataset: Optional[Dataset] = None) -> List[VideoFeature]:
-    data = np.load(f, allow_pickle=False)
-    ids, feats, stamps = data["video_ids"], data["features"].astype(np.float32), data["timestamps"]
-    if stamps.shape[0] != feats.shape[0]:
-        raise ValueError(f"Expected the same number of timestamps as features: got {stamps.shape[0]} "
-                         f"timestamps for {feats.shape[0]} features")
-    if not (stamps.ndim == 1 or stamps.shape[1:] == (2,)):
+    with np.load(f, allow_pickle=False) as data:
+        ids, feats, stamps = data["video_ids"], data["features"].astype(np.float32), data["timestamps"]
+    if len(stamps) != len(feats):
+        raise ValueError(f"Expected the same number of timestamps as features: got {len(stamps)} timestamps for "
+                         f"{len(feats)} features")
+    per_frame_scalar = stamps.ndim == 1
+    if not per_frame_scalar and stamps.shape[1:] != (2,):
         raise ValueError(f"Unexpected timestamp shape. Got {stamps.shape}")
-    return [VideoFeature(video_id=format_video_id(v, dataset), timestamps=stamps[a:b], feature=feats[a:b, :])
-            for v, a, b in same_value_ranges(ids)]
+    videos = []
+    for name, lo, hi in same_value_ranges(ids):
+        videos.append(VideoFeature(video_id=format_video_id(name, dataset), timestamps=stamps[lo:hi], feature=feats[lo:hi]))
+    return videos
