@@ -265,63 +265,6 @@ def test_search_candidate_pairs_on_hip_path():
 
 
 # ---- generate_matching_result (utils.py:80-116): host code, scipy in cv2's place ------------------------------
-def _flood_components8(mask):
-    """Independent 8-connected labelling (stack flood fill), raster order of the first pixel."""
-    labels = np.zeros(mask.shape, np.int32)
-    n = 0
-    for i, j in zip(*np.nonzero(mask)):
-        if labels[i, j]:
-            continue
-        n += 1
-        stack = [(i, j)]
-        labels[i, j] = n
-        while stack:
-            a, b = stack.pop()
-            for da in (-1, 0, 1):
-                for db in (-1, 0, 1):
-                    u, v = a + da, b + db
-                    if 0 <= u < mask.shape[0] and 0 <= v < mask.shape[1] and mask[u, v] and not labels[u, v]:
-                        labels[u, v] = n
-                        stack.append((u, v))
-    return n + 1, labels
-
-
-def _matching_result_restated(res_list, threshold, std_ratio):
-    """utils.py:80-116 statement by statement, with the flood fill above standing in for cv2."""
-    from sklearn.linear_model import RANSACRegressor
-    match_res = []
-    for qid, rid, sim_mat, _ in res_list:
-        qmat = sim_mat > threshold
-        num_label, conn_label = _flood_components8(sim_mat > threshold)
-        label_cnt = {}
-        for i in range(1, num_label):
-            cnt = (conn_label == i).sum()
-            if cnt > 10:
-                label_cnt[i] = cnt
-                x_, y_ = np.where(conn_label == i)
-                qmat[x_, y_] = False
-        if not label_cnt:
-            conn_label = qmat.astype(np.int32)
-            label_cnt[1] = conn_label.sum()
-        for i in label_cnt:
-            x, y = np.where((conn_label == i) + qmat)
-            if len(set(x)) > 3:
-                ransac = RANSACRegressor(max_trials=200, random_state=2023, residual_threshold=2)
-                prob = sim_mat[x, y]
-                ransac.fit(x[:, np.newaxis], y[:, np.newaxis], sample_weight=np.square(prob))
-                pred = ransac.predict(x[:, np.newaxis]).flatten()
-                qualify = abs(y - pred) < 1
-                coef = ransac.estimator_.coef_[0][0]
-                if coef <= 0:
-                    continue
-                coef = max(1 / coef, coef)
-                if qualify.sum() > 5 and len(set(x[qualify])) > 3 and len(set(y[qualify])) > 3:
-                    top_sim = sim_mat[x[qualify], y[qualify]]
-                    score = top_sim.max() - top_sim.std() * std_ratio - abs(coef - 1) / 10
-                    match_res.append([qid, rid, x[qualify][0], y[qualify][0], x[qualify][-1], y[qualify][-1], score])
-    return match_res
-
-
 def _probability_map(seed, h, w, bands, noise=0.03):
     rng = np.random.default_rng(seed)
     m = (rng.random((h, w)) * noise).astype(np.float32)
@@ -359,7 +302,8 @@ def test_matching_result_equals_restatement(threshold, std_ratio):
         ["Q3", "R3", _probability_map(5, 25, 25, []), None],                                # specks only
     ]
     got = matching.generate_matching_result(maps, threshold=threshold, std_ratio=std_ratio)
-    want = _matching_result_restated(maps, threshold, std_ratio)
+    from oracle import matching_oracle
+    want = matching_oracle.matching_result(maps, threshold, std_ratio)
     key = lambda r: (r[0], r[1], int(r[2]), int(r[3]), int(r[4]), int(r[5]))
     got, want = sorted(got, key=key), sorted(want, key=key)
     assert [key(r) for r in got] == [key(r) for r in want]
