@@ -106,7 +106,7 @@ def test_video_scores_csv(tmp_path):
     p.write_text("video_id,score\nQ000001,0.25\nQ000002,1e-4\n")
     assert E.read_video_scores(str(p)) == {"Q000001": 0.25, "Q000002": 1e-4} and E.read_video_scores("") == {}
     a = E.build_parser().parse_args(["--models", "tiny:hf_vit:a.pth", "--pca_model", "p.pkl", "--input_file", "q.txt"])
-    assert a.split == "test" and a.score_threshold == 0.001 and a.max_batch == 256
+    assert a.split == "test" and a.score_threshold == 0.001 and a.max_batch is None
 
 
 @pytest.mark.gpu

@@ -14,7 +14,7 @@ import torch
 from src import synth
 from src.query_pipeline import VideoScorer, run_query_videos
 from src.query_postprocess import HipPCA
-from vsc_hip.config import get_config
+from vsc_hip.config import aligned_batch, get_config
 from vsc_hip.encoder import HipEncoder
 from vsc_hip.swin_config import get_swin_config
 from vsc_hip.swin_encoder import SwinHipEncoder
@@ -27,10 +27,10 @@ n_frames = int(_pos[1]) if len(_pos) > 1 else 40
 dev = torch.device("cuda:0")
 scfg, vcfg, ccfg, mcfg = get_swin_config("swinv2_base_256"), get_config("vit_v68"), get_config("clip_vit_l14_224"), get_vsm_config("vsm_roberta_base")
 t0 = time.perf_counter()
-swins = [SwinHipEncoder(scfg, synth.swin_weights(40 + i, scfg), max_batch=256) for i in range(3)]
-vit = HipEncoder(vcfg, synth.encoder_weights(50, vcfg), max_batch=256)
+swins = [SwinHipEncoder(scfg, synth.swin_weights(40 + i, scfg), max_batch=256) for i in range(3)]   # 256 = its aligned batch
+vit = HipEncoder(vcfg, synth.encoder_weights(50, vcfg), max_batch=aligned_batch(vcfg.tokens))
 from src.dataset import CLIP_MEAN, CLIP_STD  # noqa: E402
-scorer = VideoScorer(HipEncoder(ccfg, synth.encoder_weights(51, ccfg), max_batch=256, u8_mean=CLIP_MEAN, u8_std=CLIP_STD),
+scorer = VideoScorer(HipEncoder(ccfg, synth.encoder_weights(51, ccfg), max_batch=aligned_batch(ccfg.tokens), u8_mean=CLIP_MEAN, u8_std=CLIP_STD),
                      VideoScoreHead(mcfg, synth.vsm_weights(52, mcfg)), dev)
 U8 = "--f32" not in sys.argv   # decoded uint8 HWC frames (default) or the reference's fp32 CHW tensors
 print(f"ensemble built in {time.perf_counter() - t0:.1f} s")

@@ -122,7 +122,8 @@ def build_parser():
     ap.add_argument("--vsm_checkpoint", default="", help="MS video-score head state dict (epoch_*.pth of train_vid_score)")
     ap.add_argument("--score_threshold", type=float, default=SCORE_THRESHOLD)
     ap.add_argument("--output_dir", default="outputs")
-    ap.add_argument("--max_batch", type=int, default=256)
+    ap.add_argument("--max_batch", type=int, default=None,
+                    help="frames per encoder call; default: each backbone's tile-aligned batch (332 / 451 / 255 / 256)")
     ap.add_argument("--workers", type=int, default=6, help="decode / resize worker processes (the reference uses 6)")
     return ap
 

@@ -59,5 +59,6 @@ if __name__ == "__main__":
     ap.add_argument("--arch", default="vit_b16_224", help="ViT preset (vsc_hip.config) or Swin-V2 preset (vsc_hip.swin_config)")
     ap.add_argument("--weights_format", default="hf_vit", choices=WEIGHT_FORMATS)
     ap.add_argument("--batch_size", type=int, default=2, help="videos per loader batch")
-    ap.add_argument("--max_batch", type=int, default=332, help="frames per encoder step")
+    ap.add_argument("--max_batch", type=int, default=None,
+                    help="frames per encoder step; default: the backbone's tile-aligned batch (ViT-B/16: 332)")
     main(ap.parse_args())

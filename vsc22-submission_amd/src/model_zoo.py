@@ -9,7 +9,7 @@ from typing import Tuple
 import torch
 
 from vsc_hip import weights as W
-from vsc_hip.config import PRESETS as VIT_PRESETS, get_config
+from vsc_hip.config import PRESETS as VIT_PRESETS, aligned_batch, get_config
 from vsc_hip.encoder import HipEncoder
 from vsc_hip.swin_config import SWIN_PRESETS, get_swin_config
 from vsc_hip.swin_encoder import SwinHipEncoder, from_reference_state
@@ -34,21 +34,25 @@ def _state_dict(path: str) -> dict:
     return state.state_dict()
 
 
-def load_encoder(arch: str, weights_format: str, checkpoint_path: str, max_batch: int, u8_norm=None):
+def load_encoder(arch: str, weights_format: str, checkpoint_path: str, max_batch: int = None, u8_norm=None):
     """-> (encoder, image_size).  ``u8_norm`` = (mean, std) applied to uint8 frames on the GPU (default 0.5 / 0.5, the
-    reference's vit_transform; pass dataset.CLIP_MEAN / CLIP_STD for the CLIP tower).
+    reference's vit_transform; pass dataset.CLIP_MEAN / CLIP_STD for the CLIP tower).  ``max_batch`` = None sizes the
+    workspace for the architecture's tile-aligned batch (vsc_hip.config.aligned_batch).
     Raises ValueError for an unknown arch / format pairing."""
     kw = {} if u8_norm is None else {"u8_mean": tuple(u8_norm[0]), "u8_std": tuple(u8_norm[1])}
     if arch in SWIN_PRESETS:
         if weights_format != "swin_ref":
             raise ValueError(f"{arch} is a Swin-V2 preset: weights_format must be swin_ref, not {weights_format}")
         cfg = get_swin_config(arch)
-        return SwinHipEncoder(cfg, from_reference_state(_state_dict(checkpoint_path)), max_batch=max_batch, **kw), cfg.image_size
+        deepest = max(range(cfg.stages), key=lambda st: cfg.depths[st])
+        batch = max_batch or aligned_batch(cfg.resolution(deepest) ** 2)
+        return SwinHipEncoder(cfg, from_reference_state(_state_dict(checkpoint_path)), max_batch=batch, **kw), cfg.image_size
     if arch in VIT_PRESETS:
         if weights_format not in VIT_LOADERS:
             raise ValueError(f"{arch} is a ViT preset: weights_format must be one of {sorted(VIT_LOADERS)}")
         cfg = get_config(arch)
-        return HipEncoder(cfg, VIT_LOADERS[weights_format](_state_dict(checkpoint_path), cfg), max_batch=max_batch, **kw), cfg.image_size
+        batch = max_batch or aligned_batch(cfg.tokens)
+        return HipEncoder(cfg, VIT_LOADERS[weights_format](_state_dict(checkpoint_path), cfg), max_batch=batch, **kw), cfg.image_size
     raise ValueError(f"unknown arch {arch!r}; ViT presets {sorted(VIT_PRESETS)}, Swin presets {sorted(SWIN_PRESETS)}")
 
 

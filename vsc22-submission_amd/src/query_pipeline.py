@@ -32,7 +32,7 @@ class VideoScorer:
 
     KEY = "clip"   # frames_by_size key holding the CLIP-normalised frames
 
-    def __init__(self, clip, head, device, chunk: int = 256):
+    def __init__(self, clip, head, device, chunk: int = None):
         self.clip, self.head, self.device, self.chunk = clip, head, device, chunk
 
     def __call__(self, frames: torch.Tensor) -> float:
@@ -46,16 +46,25 @@ class VideoScorer:
         return [self.head.score(torch.from_numpy(f).to(self.device)) for f in feats]
 
 
-def encode_many(model, frames_list: Sequence[torch.Tensor], device, chunk: int = 256) -> List[np.ndarray]:
+def encode_many(model, frames_list: Sequence[torch.Tensor], device, chunk: int = None) -> List[np.ndarray]:
     """Frames of several videos through one backbone as ONE stream of ``chunk``-frame calls (a 40-frame video alone
     fills a quarter of the chip: 8 / 32 / 64 / 128-frame calls run at 14 / 46 / 74 / 83 % of the large-batch rate),
     split back per video.  The encoders are frame-independent, so this equals per-video ``encode_frames``."""
     return encode_group([model], frames_list, device, chunk)[0]
 
 
-def encode_group(models: Sequence, frames_list: Sequence[torch.Tensor], device, chunk: int = 256) -> List[List[np.ndarray]]:
+def preferred_chunk(models: Sequence, default: int = 256) -> int:
+    """Frames per call for backbones that share an upload: the smallest ``preferred_batch`` among them (encoders
+    expose the frame count that fills whole rounds of GEMM tiles: 332 / 451 / 255 / 256 for ViT-B/16, ViT-B/32-384,
+    CLIP ViT-L/14, Swin-V2-B); ``default`` for models that do not say."""
+    return min(int(getattr(m, "preferred_batch", default)) for m in models)
+
+
+def encode_group(models: Sequence, frames_list: Sequence[torch.Tensor], device, chunk: int = None) -> List[List[np.ndarray]]:
     """Like ``encode_many`` for several backbones that take the SAME frames (the three Swin-V2 models of the ensemble):
-    every chunk is uploaded once and goes through all of them.  -> per model, per video arrays."""
+    every chunk is uploaded once and goes through all of them.  -> per model, per video arrays.
+    ``chunk`` = None: ``preferred_chunk(models)``."""
+    chunk = chunk or preferred_chunk(models)
     lens = [f.shape[0] for f in frames_list]
     total = sum(lens)
     outs = [[] for _ in models]
@@ -108,9 +117,9 @@ def _video_groups(videos, min_frames: int):
 
 def run_query_videos(videos: Iterable[Tuple[str, Dict[int, torch.Tensor], np.ndarray]], encoders: Sequence[Tuple[object, int]],
                      pca_transform: Callable[[np.ndarray], np.ndarray], video_scores: Dict[str, float], device,
-                     ops=HipOps, score_threshold: float = SCORE_THRESHOLD, chunk: int = 256,
+                     ops=HipOps, score_threshold: float = SCORE_THRESHOLD, chunk: int = None,
                      scorer: Callable[[torch.Tensor], float] = None,
-                     group_frames: int = 512) -> Tuple[List[VideoFeature], List[List[VideoFeature]]]:
+                     group_frames: int = 1024) -> Tuple[List[VideoFeature], List[List[VideoFeature]]]:
     """videos yields (video_id, {image_size: frames [S,3,size,size]}, timestamps); encoders = [(model, image_size)].
     The video score comes from ``scorer(frames_by_size[VideoScorer.KEY])`` when a scorer is given (and is recorded
     in ``video_scores``), else from ``video_scores``; a video missing there is treated as accepted (score 1.0).

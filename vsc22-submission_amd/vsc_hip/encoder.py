@@ -13,7 +13,7 @@ import torch
 
 from . import _lib, weights as wnames
 from ._lib import EncoderConfigC, check, current_stream, ptr
-from .config import EncoderConfig, get_config
+from .config import EncoderConfig, aligned_batch, get_config
 
 
 class HipEncoder:
@@ -65,6 +65,11 @@ class HipEncoder:
     @property
     def workspace_bytes(self) -> int:
         return int(self._lib.vsc_encoder_workspace_bytes(self._h))
+
+    @property
+    def preferred_batch(self) -> int:
+        """Frames per call that fill whole rounds of GEMM tiles (config.aligned_batch), within max_batch."""
+        return min(self.max_batch, aligned_batch(self.cfg.tokens))
 
     def __call__(self, frames: torch.Tensor, return_tokens: bool = False):
         """frames: float32 [n,C,H,W] already normalised (the reference's tensors), or uint8 [n,H,W,C] decoded frames

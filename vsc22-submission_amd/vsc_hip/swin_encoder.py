@@ -12,6 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import SwinConfigC, check, current_stream, ptr
+from .config import aligned_batch
 from .swin_config import SwinConfig, get_swin_config
 
 
@@ -85,6 +86,13 @@ class SwinHipEncoder:
     @property
     def workspace_bytes(self) -> int:
         return int(self._lib.vsc_swin_workspace_bytes(self._h))
+
+    @property
+    def preferred_batch(self) -> int:
+        """Frames per call that fill whole rounds of GEMM tiles in the deepest stage (where most of the time goes:
+        swinv2_base_256 has 16 x 16 = 256 tokens per frame there -> 256 frames), within max_batch."""
+        deepest = max(range(self.cfg.stages), key=lambda s: self.cfg.depths[s])
+        return min(self.max_batch, aligned_batch(self.cfg.resolution(deepest) ** 2))
 
     def __call__(self, frames: torch.Tensor, return_tokens: bool = False):
         """frames: float32 [n,C,H,W] normalised, or uint8 [n,H,W,C] decoded (normalisation fused on the GPU)."""
