@@ -264,8 +264,9 @@ __device__ __forceinline__ bf16x8_t lds_frag32(const char *region, int row, int 
 // All 256 CUs start their first tile together and every tile takes the same time, so the
 // chip runs in lockstep rounds: compute, then 256 workgroups write 32 MiB at once while no
 // MFMA issues.  Delaying first-round workgroup b by (b / 256) of a tile time spreads the CUs'
-// phases for the rest of the launch, so one CU's write-out overlaps the others' K loops.
-// Speed only: results never depend on it.
+// phases for the rest of the launch, so one CU's write-out overlaps the others' K loops -- in
+// principle; measured, the delay is never recovered (see skew_cycles), so the skew is 0 unless
+// VSC_GEMM_SKEW_NS_PER_K is set.  Speed only: results never depend on it.
 __device__ __forceinline__ void phase_skew(int skew_cycles) {
     if (skew_cycles > 0 && blockIdx.x < 256 && gridDim.x > 256) {
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -631,9 +632,11 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
 #endif
 }
 
-// one tile time in s_memtime ticks (100 MHz): VSC_GEMM_SKEW_NS_PER_K nanoseconds per unit of K
+// first-round start skew (diagnostic, off by default): VSC_GEMM_SKEW_NS_PER_K * K / 10 shader cycles spread over the
+// first 256 workgroups.  Re-measured in the ViT step with skews from 0.6 us to a whole tile time: 0 is as fast as any
+// (19.7 k frames/s), a tile time costs 6 % -- the start-up delay is never recovered.
 inline int skew_cycles(int k) {
-    static const int ns_per_k = [] { const char *e = getenv("VSC_GEMM_SKEW_NS_PER_K"); return e ? atoi(e) : 20; }();  // measured: +7 % on qkv, neutral elsewhere
+    static const int ns_per_k = [] { const char *e = getenv("VSC_GEMM_SKEW_NS_PER_K"); return e ? atoi(e) : 0; }();
     return (int)((int64_t)ns_per_k * k / 10);
 }
 
