@@ -167,6 +167,66 @@ def test_global_threshold_search_is_the_global_top_k(dev):
         assert all(s == S[i, j] for i, j, s in hits)
 
 
+def test_global_threshold_search_when_the_probe_is_smaller_than_global_k(dev):
+    """nq * k' < global_k <= nq * nr (few query rows, the per-row probe capped at MAX_K): the reference returns
+    min(global_k, nq * nr) pairs (index.py:145-165); the probe alone would truncate to nq * k'."""
+    from oracle import knn_oracle
+    from vsc.index import VideoFeature, VideoIndex
+    import vsc.index as vi
+    r = synth.descriptor_bank(15, 3000, 48)
+    for nq, gk, probe in ((1, 1500, 1024), (3, 700, 128), (2, 5999, 64), (2, 10000, 64)):
+        q = synth.descriptor_bank(16 + nq, nq, 48)
+        idx = VideoIndex(48)
+        idx.add([VideoFeature("R1", np.arange(3000.0), r)])
+        S = knn_oracle.ip_matrix(q, r)
+        old, vi.MAX_K = vi.MAX_K, probe
+        try:
+            hits = idx._global_threshold_knn_search(q, gk)
+        finally:
+            vi.MAX_K = old
+        n = min(gk, nq * 3000)
+        assert len(hits) == n
+        flat = np.argsort(-S.ravel().astype(np.float64), kind="stable")[:n]
+        assert sorted((i, j) for i, j, _ in hits) == sorted((int(f // 3000), int(f % 3000)) for f in flat)
+        assert all(s == S[i, j] for i, j, s in hits)
+        assert all(a[2] >= b[2] for a, b in zip(hits, hits[1:]))
+
+
+def test_flat_l2_index(dev):
+    """METRIC_L2 (the reference's tests/test_index.py builds VideoIndex(3, "Flat", faiss.METRIC_L2) on UN-normalised
+    vectors): exact squared distances ascending, ids of a brute-force float64 scan, through search, range_search and
+    both VideoIndex search modes."""
+    from vsc.index import METRIC_L2, FlatIPBank, VideoFeature, VideoIndex
+    rng = np.random.RandomState(3)
+    r = (rng.randn(500, 24) * 3).astype(np.float32)
+    q = (rng.randn(17, 24) * 3).astype(np.float32)
+    q[5] = r[77]
+    bank = FlatIPBank(24, METRIC_L2)
+    bank.add(r[:200])
+    bank.add(r[200:])
+    D, I = bank.search(q, 9)
+    d64 = ((q[:, None, :].astype(np.float64) - r[None].astype(np.float64)) ** 2).sum(-1)
+    want = np.argsort(d64, axis=1, kind="stable")[:, :9]
+    assert np.array_equal(I, want) and I[5, 0] == 77 and D[5, 0] == 0.0
+    assert np.allclose(D, np.take_along_axis(d64, want, 1), rtol=1e-5, atol=1e-5) and (np.diff(D, axis=1) >= 0).all()
+    rows, ids, dist = bank.range_search(q, 120.0)
+    assert sorted(zip(rows.tolist(), ids.tolist())) == sorted(map(tuple, np.argwhere(d64 < 120.0).tolist()))
+    assert np.allclose(dist, d64[rows, ids], rtol=1e-5, atol=1e-5)
+    assert bank.range_count(q, 120.0) == len(rows)
+
+    feats = np.array([[[1, 2, 3], [4, 5, 6], [7, 8, 9]], [[11, 12, 13], [14, 15, 16], [17, 18, 19]],
+                      [[111, 112, 113], [114, 115, 116], [117, 118, 119]]], np.float32)   # tests/test_index.py, verbatim data
+    mk = lambda pre: [VideoFeature(video_id=f"{pre}{i:06d}", feature=f, timestamps=np.arange(3, dtype=np.float32))
+                      for i, f in enumerate(feats)]
+    for gk in (1, -1, 4):
+        idx = VideoIndex(3, "Flat", METRIC_L2)
+        idx.add(mk("R"))
+        res = idx.search(mk("Q"), gk)
+        assert res and all(x.query_id[1:] == x.ref_id[1:] for x in res)
+    hits = idx._global_threshold_knn_search(feats.reshape(9, 3), 9)
+    assert sorted((i, j) for i, j, _ in hits) == [(i, i) for i in range(9)] and all(s == 0.0 for _, _, s in hits)
+
+
 def test_eval_entry_point_end_to_end(dev, tmp_path):
     """`python -m vsc.baseline.sscd_baseline` (what infer/eval.sh runs): .npz in, candidates.csv out;
     planted copies are the top candidates and uAP is 1.0; score-normalised run agrees with the

@@ -70,6 +70,29 @@ def test_run_query_videos_composes_the_reference_steps(group_frames):
     assert finals[0].feature.shape[1] == 5
 
 
+@pytest.mark.parametrize("two_d", [True, False])
+def test_rejected_video_round_trips_through_store_features(tmp_path, two_d):
+    """The gate's placeholder ([1, 2] timestamps in the reference, extract_query_feats.py:214-217) must concatenate
+    with the accepted videos' timestamps in store_features -- the query entry point stores `finals` as its last step."""
+    from vsc.storage import load_features, store_features
+    vids = _videos((8,), [6, 4, 5])
+    if two_d:   # the layout QueryVideos / the reference's FFmpeg reader yields: [start, end] per frame
+        vids = [(v, f, np.stack([t, t + 1], axis=1).astype(np.float32)) for v, f, t in vids]
+    enc = [(_FakeEncoder(6, 1), 8)]
+    finals, _ = run_query_videos(vids, enc, lambda x: x[:, :6], {"Q000001": 0.0}, torch.device("cpu"), ops=_NumpyOps)
+    finals = [f._replace(feature=np.pad(f.feature, ((0, 0), (0, 512 - f.feature.shape[1])))) if hasattr(f, "_replace")
+              else type(f)(video_id=f.video_id, timestamps=f.timestamps,
+                           feature=np.pad(f.feature, ((0, 0), (0, 512 - f.feature.shape[1])))) for f in finals]
+    path = str(tmp_path / "q.npz")
+    store_features(path, finals)
+    back = load_features(path)
+    assert [b.video_id for b in back] == [f.video_id for f in finals]
+    for a, b in zip(finals, back):
+        assert np.array_equal(np.asarray(a.timestamps, np.float32), np.asarray(b.timestamps, np.float32))
+        assert np.array_equal(a.feature, b.feature)
+    assert back[1].feature.shape == (1, 512) and back[1].timestamps.shape == ((1, 2) if two_d else (1,))
+
+
 def test_scorer_overrides_and_records_scores():
     vids = _videos((8,), [6, 6])
     for v in vids:
@@ -182,7 +205,7 @@ def test_query_videos_dataset_reads_zips(tmp_path):
     assert [v[0] for v in items] == ["Q100001", "Q100002"]           # the missing video is skipped, as ZipFrames does
     vid, frames, stamps = items[0]
     assert frames[16].shape == (3, 16, 16, 3) and frames[24].shape == (3, 24, 24, 3) and frames["clip"].shape == (3, 224, 224, 3)
-    assert all(f.dtype == torch.uint8 for f in frames.values()) and stamps.tolist() == [0, 1, 2]
+    assert all(f.dtype == torch.uint8 for f in frames.values()) and stamps.tolist() == [[0, 1], [1, 2], [2, 3]]
 
 
 def test_model_zoo_reads_torchscript_and_plain_checkpoints(tmp_path):

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "mainloop64.h"
 
 namespace {
 
@@ -632,6 +633,88 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3: the 256 x 256 x 64 four-phase main loop of mainloop64.h (full 128-byte line fetches, 16-MFMA segments,
+// counted vmcnt that keeps four 16-KiB units in flight) under the same tile order, staggered wave groups and
+// LDS-staged write-out as v2.  K % 64 == 0.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs p) {
+    constexpr int TM = 8, TN = 4;
+    extern __shared__ __attribute__((aligned(16))) char lds2[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    {
+        const int G = p.group_n;
+        const int per_group = G * p.tiles_m;
+        const int grp = t / per_group;
+        const int first = grp * G;
+        const int width = (p.tiles_n - first) < G ? (p.tiles_n - first) : G;
+        const int rem = t - grp * per_group;
+        tm = rem / width;
+        tn = first + (rem - tm * width);
+    }
+    const int64_t m0 = (int64_t)tm * 256;
+    const int n0 = tn * 256;
+
+    f32x4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    float2 rs[TM];
+    if (epi_lnf(EPI)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int64_t m = m0 + wm * TM * 16 + i * 16 + (lane & 15);
+            m = m < p.m ? m : p.m - 1;
+            rs[i] = *(const float2 *)(p.ex.rowstats + 2 * m);
+        }
+    }
+    f32x4_t bzp[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + wn * TN * 16 + j * 16 + (lane >> 4) * 4;
+        bzp[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (p.bias && nb < p.n) bzp[j] = *(const f32x4_t *)(p.bias + nb);
+    }
+    ml64::Ctx c;
+    const int64_t a_rows = p.m - m0;
+    const int w_rows = p.n - n0;
+    ml64::init(c, p.a + m0 * p.k, p.k, (int)(a_rows < 256 ? a_rows : 256), p.w + (int64_t)n0 * p.k, p.k,
+               w_rows < 256 ? w_rows : 256, lds2, wave, lane);
+    ml64::run(c, acc, p.k / 64);
+    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0, rs, bzp);
+}
+
+template <int EPI>
+int launch_v3(GemmArgs p, hipStream_t stream) {
+    constexpr int smem = ml64::RING_BYTES;   // == 8 waves x 16 KiB of write-out staging
+    auto kern = gemm_bf16_v3_kernel<EPI>;
+    static bool attr_set[16] = {};
+    int dev = 0;
+    VSC_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 16 && !attr_set[dev]) {
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set[dev] = true;
+    } else if (dev >= 16) {
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    }
+    p.tiles_m = (int)((p.m + 255) / 256);
+    p.tiles_n = (p.n + 255) / 256;
+    int g = (int)((int64_t)(3 << 19) / ((int64_t)256 * p.k * 2));
+    if (p.tiles_n <= 4) g = p.tiles_n;
+    if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
+    p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
+    p.skew = 0;
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, stream, p);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
 // first-round start skew (diagnostic, off by default): VSC_GEMM_SKEW_NS_PER_K * K / 10 shader cycles spread over the
 // first 256 workgroups.  Re-measured in the ViT step with skews from 0.6 us to a whole tile time: 0 is as fast as any
 // (19.7 k frames/s), a tile time costs 6 % -- the start-up delay is never recovered.
@@ -709,6 +792,9 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
     char cfg = p.n > 128 ? 'A' : 'B';
     if (p.k <= 512 && p.n > 128) cfg = (p.n % 256 != 0 && p.n % 128 == 0) ? 'D' : 'C';
     if (force) cfg = force[0];
+    const char *v3e = getenv("VSC_GEMM_V3");   // diagnostic A/B switch, read per launch
+    const bool no_v3 = v3e && v3e[0] == '0';
+    if (cfg == 'A' && p.k % 64 == 0 && !no_v3) return launch_v3<EPI>(p, stream);
     switch (cfg) {
         case 'A': return launch_v2<EPI, 2, 4, 8, 4, 4>(p, stream);
         case 'B': return launch_v2<EPI, 4, 2, 4, 4, 4>(p, stream);

@@ -1,0 +1,209 @@
+// 256 x 256 x 64 bf16 MFMA main loop shared by the encoder GEMM (gemm_bf16.hip, v3) and the similarity
+// pre-filter sweep (knn.hip): acc[8][4] (wave tile 128 x 64, 16x16x32 MFMAs) += A[256, K] . W[256, K]^T.
+//
+// Eight waves (2 along M x 4 along N), one workgroup per CU.  K advances 64 per tile (full 128-byte lines
+// from L2, where the BK = 32 loop of v2 fetched every line in two halves), and a K-tile is worked off in
+// FOUR phases of 16 MFMAs -- one quadrant (64 x 32) of the wave tile each:
+//
+//     phase  fragment reads (ds_read_b128)        LDS-DMA issued (2 x 1 KiB per wave)   MFMAs
+//       0    W-sub0 (4), A-sub0 (8)               unit (t+1, W-h1)                      A0 x W0
+//       1    W-sub1 (4)                           unit (t+1, A-h1)                      A0 x W1
+//       2    A-sub1 (8)                           unit (t+2, W-h0)                      A1 x W1
+//       3    --                                   unit (t+2, A-h0)                      A1 x W0
+//
+// Every phase is an L segment (reads + DMA issue + counted vmcnt) and a C segment (16 MFMAs under s_setprio),
+// each closed by a raw s_barrier; waves 4-7 (the M-half wm = 1, the second wave of every SIMD) run one
+// segment behind waves 0-3, so on each SIMD one wave computes while the other loads.
+//
+// LDS: a ring of 8 units of 16 KiB (128 rows x 128 B); a K-tile is 4 units in first-use order
+//     j = 0: W-h0 (columns wn*64 + 0..31 of every wn)      j = 1: A-h0 (rows wm*128 + 0..63 of every wm)
+//     j = 2: W-h1 (columns wn*64 + 32..63)                 j = 3: A-h1 (rows wm*128 + 64..127)
+// unit u = 4 t + j sits in slot u & 7 and is issued SIX units ahead of the phase that first needs it:
+//   RAW  unit u is first read in phase >= u - 1; the L segment of phase g ends with a vmcnt that leaves only the
+//        four newest units (8 instructions) of this wave in flight, i.e. units <= g + 2 have landed, and the
+//        barrier(s) that follow cover the other waves' pieces (one barrier more for the staggered group);
+//   WAR  phase g overwrites the slot of unit g - 2, last read in phase <= g - 2 by either group: at least two
+//        barriers lie between those reads' lgkmcnt wait (ahead of their MFMAs) and the DMA issue.
+// 16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7): conflict-free for ds_read_b128's lane groups
+// on 128-byte rows; LDS-DMA writes lane-linear, so the permutation is applied to the per-lane SOURCE address
+// and again on the read.
+#pragma once
+#include "common.h"
+
+namespace ml64 {
+
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+constexpr int UNIT_BYTES = 16384;
+constexpr int RING_BYTES = 8 * UNIT_BYTES;   // 128 KiB
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct Ctx {
+    __amdgpu_buffer_rsrc_t a_rsrc;   // A tile: base = row origin of the tile, extent = its existing rows (reads past it return 0)
+    __amdgpu_buffer_rsrc_t w_rsrc;
+    uint32_t a_off[2][2];  // [half][piece]: this lane's source byte offset inside the tile (k = 0)
+    uint32_t w_off[2][2];
+    char *lds;             // ring base
+    uint32_t rd_a;         // LDS byte offset of this lane's A fragment chunk (kh = 0) inside its unit: wm * 8192 + lane part
+    uint32_t rd_w;         // same for W: wn * 4096 + lane part
+    int wave;
+};
+
+// a_rows / w_rows: rows of the tile that exist (>= 1).  Rows past the edge are outside the buffer descriptor's
+// extent: the LDS-DMA delivers zeros for them and the write-out never stores them.
+__device__ __forceinline__ void init(Ctx &c, const uint16_t *a_tile, int64_t lda, int a_rows, const uint16_t *w_tile,
+                                     int64_t ldw, int w_rows, char *lds, int wave, int lane) {
+    c.a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a_tile, 0, (int)(a_rows * lda * 2), 0x00020000);
+    c.w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)w_tile, 0, (int)(w_rows * ldw * 2), 0x00020000);
+    c.lds = lds;
+    c.wave = wave;
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int piece = wave + 8 * jj;
+            const int lr = piece * 8 + (lane >> 3);                 // row inside the unit
+            const int ch = (lane & 7) ^ ((lr >> 1) & 7);            // source chunk for LDS chunk (lane & 7)
+            const int ar = (lr >> 6) * 128 + half * 64 + (lr & 63);
+            const int wr = (lr >> 5) * 64 + half * 32 + (lr & 31);
+            c.a_off[half][jj] = (uint32_t)(ar * (int)lda * 2 + ch * 16);
+            c.w_off[half][jj] = (uint32_t)(wr * (int)ldw * 2 + ch * 16);
+        }
+    const int wm = wave >> 2, wn = wave & 3;
+    const uint32_t lane_part = (uint32_t)((lane & 15) * 128 + (((lane >> 4) ^ ((lane >> 1) & 7)) << 4));
+    c.rd_a = wm * 8192 + lane_part;
+    c.rd_w = wn * 4096 + lane_part;
+}
+
+template <int KIND, int HALF>   // KIND 0 = A, 1 = W
+__device__ __forceinline__ void stage_unit(const Ctx &c, int slot, int ktile) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const uint32_t off = KIND == 0 ? c.a_off[HALF][jj] : c.w_off[HALF][jj];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(KIND == 0 ? c.a_rsrc : c.w_rsrc,
+                                                 (lptr_t)(c.lds + slot * UNIT_BYTES + (c.wave + 8 * jj) * 1024), 16, off,
+                                                 ktile * 128, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8_t frag(const Ctx &c, int slot, uint32_t rd, int f, int kh) {
+    return *(const bf16x8_t *)(c.lds + slot * UNIT_BYTES + ((rd + f * 2048) ^ (kh * 64)));
+}
+
+// fragments of one K-tile: af[i][kh] (i = 0..3: the A sub-tile in use), wf[j][kh] (j = 0..3: both W sub-tiles)
+struct Frags {
+    bf16x8_t af[4][2];
+    bf16x8_t wf[4][2];
+};
+
+template <int ASUB, int WSUB>
+__device__ __forceinline__ void mfma_quadrant(f32x4_t (&acc)[8][4], const Frags &f) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[ASUB * 4 + i][WSUB * 2 + j] =
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wf[WSUB * 2 + j][kh], f.af[i][kh], acc[ASUB * 4 + i][WSUB * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// closes an L segment: counted wait for this wave's DMA pieces (steady state: the four newest units stay in flight;
+// the last two tiles drain: `tail_vm` instructions may stay), then the workgroup barrier
+template <bool STEADY, int TAIL1, int TAIL2>
+__device__ __forceinline__ void end_l(int rem) {
+    if (STEADY || rem > 2) wait_vmcnt<8>();
+    else if (rem == 2) wait_vmcnt<TAIL1>();
+    else wait_vmcnt<TAIL2>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void end_c() {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// One K-tile (four phases).  B = t & 1 (slot parity); rem = nk - t (K-tiles left including this one); STEADY: rem > 2
+// is known (no tail branches in the body).
+template <int B, bool STEADY>
+__device__ __forceinline__ void ktile(const Ctx &c, f32x4_t (&acc)[8][4], Frags &f, int t, int rem) {
+    constexpr int S_W0 = 4 * B + 0, S_A0 = 4 * B + 1, S_W1 = 4 * B + 2, S_A1 = 4 * B + 3;   // this tile's slots
+    constexpr int N_W1 = 4 * (B ^ 1) + 2, N_A1 = 4 * (B ^ 1) + 3;                          // tile t+1, j = 2, 3
+    // ---- phase 0
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) f.wf[j][kh] = frag(c, S_W0, c.rd_w, j, kh);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) f.af[i][kh] = frag(c, S_A0, c.rd_a, i, kh);
+    if (STEADY || rem > 1) stage_unit<1, 1>(c, N_W1, t + 1);
+    end_l<STEADY, 8, 2>(rem);
+    mfma_quadrant<0, 0>(acc, f);
+    end_c();
+    // ---- phase 1
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) f.wf[2 + j][kh] = frag(c, S_W1, c.rd_w, j, kh);
+    if (STEADY || rem > 1) stage_unit<0, 1>(c, N_A1, t + 1);
+    end_l<STEADY, 8, 0>(rem);
+    mfma_quadrant<0, 1>(acc, f);
+    end_c();
+    // ---- phase 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) f.af[i][kh] = frag(c, S_A1, c.rd_a, i, kh);
+    if (STEADY || rem > 2) stage_unit<1, 0>(c, S_W0, t + 2);
+    end_l<STEADY, 6, 0>(rem);
+    mfma_quadrant<1, 1>(acc, f);
+    end_c();
+    // ---- phase 3
+    if (STEADY || rem > 2) stage_unit<0, 0>(c, S_A0, t + 2);
+    end_l<STEADY, 4, 0>(rem);
+    mfma_quadrant<1, 0>(acc, f);
+    end_c();
+}
+
+// acc += A_tile . W_tile^T over nk K-tiles of 64.  Ends with every wave past its last fragment read and every
+// DMA landed (one extra barrier for the leading group), so the ring may be reused at once.
+__device__ __forceinline__ void run(const Ctx &c, f32x4_t (&acc)[8][4], int nk) {
+    // prologue: units 0..5 (tile 0 whole, tile 1 j = 0, 1)
+    stage_unit<1, 0>(c, 0, 0);
+    stage_unit<0, 0>(c, 1, 0);
+    stage_unit<1, 1>(c, 2, 0);
+    stage_unit<0, 1>(c, 3, 0);
+    if (nk > 1) {
+        stage_unit<1, 0>(c, 4, 1);
+        stage_unit<0, 0>(c, 5, 1);
+        wait_vmcnt<8>();   // units 0, 1 landed
+    } else {
+        wait_vmcnt<4>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const int group = c.wave >> 2;
+    if (group == 1) __builtin_amdgcn_s_barrier();   // stagger: waves 4-7 run one segment behind
+    __builtin_amdgcn_sched_barrier(0);
+    Frags f;
+    int t = 0;
+    for (; t + 4 <= nk; t += 2) {   // both tiles have at least two more behind them
+        ktile<0, true>(c, acc, f, t, 0);
+        ktile<1, true>(c, acc, f, t + 1, 0);
+    }
+    for (; t < nk; t += 2) {        // the last 1..3 tiles: staging stops, the waits drain
+        ktile<0, false>(c, acc, f, t, nk - t);
+        if (t + 1 < nk) ktile<1, false>(c, acc, f, t + 1, nk - t - 1);
+    }
+    if (group == 0) __builtin_amdgcn_s_barrier();
+}
+
+}  // namespace ml64

@@ -60,7 +60,12 @@ class QueryVideos(torch.utils.data.Dataset):
         vid = self.video_ids[i]
         with ZipFile(self._path(vid), "r") as z:
             images = [Image.open(io.BytesIO(z.read(n))).convert("RGB") for n in sorted(z.namelist())]
-        return vid, {s: torch.stack([t(im) for im in images]) for s, t in self.transforms.items()}, np.arange(len(images))
+        # [start, end] seconds per frame at 1 fps, the layout the reference's FFmpeg reader yields (infer/src/dataset.py:97-102):
+        # a video rejected by the score gate gets a [1, 2] placeholder, so every video's timestamps must be 2-D for
+        # store_features to concatenate them
+        n = len(images)
+        stamps = np.stack([np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32) + 1.0], axis=1)
+        return vid, {s: torch.stack([t(im) for im in images]) for s, t in self.transforms.items()}, stamps
 
 
 def zip_videos(video_ids, zip_prefix, sizes, with_clip=False, workers=0):

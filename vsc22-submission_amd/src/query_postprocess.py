@@ -100,4 +100,7 @@ def process_query_video(video_id: str, sub_features: Sequence[np.ndarray], times
     rnd_idx += 1
     np.random.seed(rnd_idx)
     rnd = np.random.uniform(-1e-5, 1e-5, size=512).astype(np.float32)
-    return VideoFeature(video_id=video_id, timestamps=np.array([0, 1])[None, ...], feature=rnd[None, ...]), per_model, rnd_idx
+    # the reference's placeholder is one [start, end] row (extract_query_feats.py:214-217); callers that pass 1-D
+    # per-frame timestamps get a 1-D placeholder so that store_features can still concatenate all videos
+    placeholder = np.array([0, 1])[None, ...] if stamps.ndim == 2 else np.zeros(1, dtype=stamps.dtype)
+    return VideoFeature(video_id=video_id, timestamps=placeholder, feature=rnd[None, ...]), per_model, rnd_idx

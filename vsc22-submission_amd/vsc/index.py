@@ -67,20 +67,27 @@ class PairMatches:
 
 
 class FlatIPBank:
-    """What `faiss.index_factory(dim, "Flat", METRIC_INNER_PRODUCT)` is to the reference:
-    add() appends rows, search() is the exact top-k.  Rows live in HBM as one float32
-    matrix (bigger, fewer allocations: sized for 288 GB)."""
+    """What `faiss.index_factory(dim, "Flat", metric)` is to the reference: add() appends rows, search() is the exact
+    top-k.  Rows live in HBM as one float32 matrix (bigger, fewer allocations: sized for 288 GB).
+
+    METRIC_L2 (the reference's own unit test builds one, tests/test_index.py) runs on the same inner-product sweep:
+    rows are stored as r' = [r, |r|^2, 1] and a query is presented as q' = [2q, -1, -|q|^2], so <q', r'> = -|q - r|^2
+    and "largest inner product" is "smallest distance".  The sweep SELECTS; the squared distances handed back are
+    recomputed on the host from the selected rows as sum((q - r)^2) in float32 (what faiss's flat L2 scan returns), so
+    no cancellation error of the expanded form reaches the caller."""
 
     def __init__(self, dim: int, metric: int = METRIC_INNER_PRODUCT):
-        if metric != METRIC_INNER_PRODUCT:
-            raise NotImplementedError(
-                "only METRIC_INNER_PRODUCT is on the HIP path (the descriptor track never uses L2; "
-                "for unit vectors L2 ranking == inner-product ranking)")
+        if metric not in (METRIC_INNER_PRODUCT, METRIC_L2):
+            raise NotImplementedError(f"metric {metric}: the reference only builds inner-product and L2 flat indexes")
         self.d = dim
         self.metric_type = metric
         self._chunks: list = []
         self._bank = None
         self.ntotal = 0
+
+    @property
+    def is_similarity(self) -> bool:
+        return self.metric_type == METRIC_INNER_PRODUCT
 
     def add(self, x: np.ndarray) -> None:
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -92,37 +99,81 @@ class FlatIPBank:
     def reset(self) -> None:
         self._chunks, self._bank, self.ntotal = [], None, 0
 
+    def _host_rows(self) -> np.ndarray:
+        if len(self._chunks) > 1:
+            self._chunks = [np.concatenate(self._chunks)]
+        return self._chunks[0] if self._chunks else np.zeros((0, self.d), np.float32)
+
     def device_bank(self):
         import torch
         from vsc_hip import _lib
         _lib.require_device()
         if self._bank is None:
-            host = np.concatenate(self._chunks) if self._chunks else np.zeros((0, self.d), np.float32)
+            host = self._host_rows()
+            if not self.is_similarity:
+                sq = np.einsum("ij,ij->i", host, host, dtype=np.float32)[:, None]
+                host = np.concatenate([host, sq, np.ones_like(sq)], axis=1)
             self._bank = torch.from_numpy(host).cuda()
         return self._bank
 
-    def range_search(self, x: np.ndarray, radius: float):
-        """All (query row, ref row, score) with score > radius -> three flat arrays, query-major,
-        ascending ref row inside a query (faiss.Index.range_search, flattened)."""
+    def _device_queries(self, x: np.ndarray):
         import torch
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if not self.is_similarity:
+            sq = np.einsum("ij,ij->i", x, x, dtype=np.float32)[:, None]
+            x = np.concatenate([2.0 * x, -np.ones_like(sq), -sq], axis=1)
+        return torch.from_numpy(x).cuda()
+
+    def _exact_l2(self, x: np.ndarray, rows: np.ndarray, ids: np.ndarray) -> np.ndarray:
+        """float32 sum((x[rows] - bank[ids])^2); ids < 0 (padding) -> FLT_MAX as faiss does."""
+        bank = self._host_rows()
+        out = np.full(ids.shape, np.finfo(np.float32).max, np.float32)
+        ok = ids >= 0
+        diff = np.asarray(x, np.float32)[rows[ok]] - bank[ids[ok]]
+        out[ok] = np.einsum("ij,ij->i", diff, diff, dtype=np.float32)
+        return out
+
+    def range_count(self, x: np.ndarray, radius: float) -> int:
+        """Number of pairs range_search(x, radius) would return (one sweep, nothing materialised)."""
+        from vsc_hip import ops
+        radius = float(radius) if self.is_similarity else -float(radius)
+        return ops.range_count_ip(self._device_queries(x), self.device_bank(), radius)
+
+    def range_search(self, x: np.ndarray, radius: float):
+        """All (query row, ref row, score) with score > radius (inner product) / distance < radius (L2) -> three flat
+        arrays, query-major, ascending ref row inside a query (faiss.Index.range_search, flattened)."""
         from vsc_hip import ops
         bank = self.device_bank()
-        q = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
-        lims, D, I = ops.range_search_ip(q, bank, float(radius))
+        q = self._device_queries(x)
+        lims, D, I = ops.range_search_ip(q, bank, float(radius) if self.is_similarity else -float(radius))
         lims = lims.cpu().numpy()
         rows = np.repeat(np.arange(len(lims) - 1), np.diff(lims))
-        return rows, I.cpu().numpy(), D.cpu().numpy()
+        ids = I.cpu().numpy()
+        if self.is_similarity:
+            return rows, ids, D.cpu().numpy()
+        return rows, ids, self._exact_l2(x, rows, ids)
 
     def search(self, x: np.ndarray, k: int):
-        """-> (D [nq,k] float32 descending, I [nq,k] int64), faiss.Index.search semantics."""
-        import torch
+        """-> (D [nq,k] float32, I [nq,k] int64), faiss.Index.search semantics: inner products descending, or squared
+        L2 distances ascending."""
         from vsc_hip import ops
         bank = self.device_bank()
-        q = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+        q = self._device_queries(x)
         if k > MAX_K:
             raise NotImplementedError(f"k={k} > {MAX_K} is not supported by vsc_knn_ip_f32")
-        D, I = ops.knn_ip(q, bank, k)
-        return D.cpu().numpy(), I.cpu().numpy()
+        if self.is_similarity:
+            D, I = ops.knn_ip(q, bank, k)
+            return D.cpu().numpy(), I.cpu().numpy()
+        # the sweep ranks by the expanded form, whose rounding can swap near-equal neighbours: probe a few ranks past k,
+        # order by the exact distances handed back, then cut (lexsort: ties keep the lower id, as the IP path does)
+        kk = int(min(max(k + 8, 2 * k), MAX_K, max(self.ntotal, k)))
+        _, I = ops.knn_ip(q, bank, kk)
+        I = I.cpu().numpy()
+        rows = np.broadcast_to(np.arange(I.shape[0])[:, None], I.shape)
+        dist = self._exact_l2(x, rows.reshape(-1), I.reshape(-1)).reshape(I.shape)
+        ids_key = np.where(I >= 0, I, np.iinfo(np.int64).max)
+        order = np.lexsort((ids_key, dist), axis=1)[:, :k]
+        return np.take_along_axis(dist, order, 1), np.take_along_axis(I, order, 1)
 
 
 class VideoIndex:
@@ -174,26 +225,70 @@ class VideoIndex:
                 if I[i, j] >= 0]
 
     def _global_threshold_knn_search(self, feats: np.ndarray, global_k: int):
-        """The reference keeps every pair above an adaptively tightened radius, sorts all of
-        them by score and truncates to global_k (index.py:145-165): the result is the
-        global_k best (query row, ref row) pairs over ALL pairs.  Here: per-row exact
-        top-k', then the same sort/truncate on the host; if a query row could own
-        more than k' of the winners, the exact range sweep at the provisional threshold
-        replaces the candidate set (always exact)."""
-        nr = self.index.ntotal
+        """The reference keeps every pair inside an adaptively tightened radius, sorts all of them by score and
+        truncates to global_k (index.py:145-165): the result is the min(global_k, nq * nr) best (query row, ref row)
+        pairs over ALL pairs.  Here: per-row exact top-k' (k' <= MAX_K), the same sort/truncate on the host, and
+        whenever the probe cannot be shown to contain every winner -- a query row may own more than k' of them, or the
+        probe holds fewer than global_k pairs in total -- an exact range sweep at a radius found by counting replaces
+        the candidate set.  Always exact."""
+        sim = self.index.is_similarity
+        nr, nq = self.index.ntotal, feats.shape[0]
         kk = int(min(global_k, nr, MAX_K))
-        if kk <= 0 or feats.shape[0] == 0:
+        if kk <= 0 or nq == 0:
             return []
+        want = int(min(global_k, nq * nr))
         D, I = self.index.search(feats, kk)
         valid = I >= 0
         rows = np.broadcast_to(np.arange(I.shape[0])[:, None], I.shape)[valid]
         refs, scores = I[valid], D[valid]
-        order = np.lexsort((refs, rows, -scores.astype(np.float64)))[:global_k]
-        if len(order) == global_k and kk < min(global_k, nr):
-            threshold = scores[order[-1]]
-            if (D[:, kk - 1] > threshold).any():
-                # some query row owns more than kk of the winners: sweep every pair scoring
-                # >= threshold (the reference's radius search) and redo the sort/truncate
-                rows, refs, scores = self.index.range_search(feats, np.nextafter(threshold, -np.inf))
-                order = np.lexsort((refs, rows, -scores.astype(np.float64)))[:global_k]
+        key = (lambda s: -s.astype(np.float64)) if sim else (lambda s: s.astype(np.float64))
+        order = np.lexsort((refs, rows, key(scores)))[:want]
+        if kk < min(global_k, nr):   # the probe was capped: rows may hold winners beyond their k'-th hit
+            radius = None
+            if len(order) == want:
+                threshold = scores[order[-1]]
+                beyond = D[:, kk - 1] > threshold if sim else D[:, kk - 1] < threshold
+                if beyond.any():
+                    # some query row owns more than kk of the winners: every pair at least as good as the
+                    # provisional threshold (one float32 step outwards: the sweep's comparison is strict)
+                    radius = np.nextafter(np.float32(threshold), np.float32(-np.inf if sim else np.inf))
+            else:
+                radius = self._radius_for(feats, want, scores)
+            if radius is not None:
+                rows, refs, scores = self.index.range_search(feats, radius)
+                order = np.lexsort((refs, rows, key(scores)))[:want]
         return [(int(rows[o]), int(refs[o]), float(scores[o])) for o in order]
+
+    def _radius_for(self, feats: np.ndarray, want: int, probe_scores: np.ndarray) -> float:
+        """A radius whose range sweep returns at least `want` pairs and, ties permitting, at most 2 * want (the
+        reference's min_results / max_results window, index.py:150-156), found by count-only sweeps: step outwards
+        from the worst probe score until enough pairs are inside, then bisect."""
+        sim = self.index.is_similarity
+        out = -1.0 if sim else 1.0                      # direction of "looser"
+        loose = np.float32(-3.0e38 if sim else 3.0e38)  # finite stand-in for the reference's -1e10 / 1e10 start
+        if feats.shape[0] * self.index.ntotal <= 2 * want:
+            return float(loose)
+        tight = float(probe_scores.min() if sim else probe_scores.max())
+        step = max(abs(tight), 1.0) * 2.0 ** -6
+        lo = tight                                      # known: count(lo) < want (the probe found every pair inside it)
+        hi = None
+        for _ in range(64):
+            cand = lo + out * step
+            if not np.isfinite(np.float32(cand)):
+                return float(loose)
+            if self.index.range_count(feats, cand) >= want:
+                hi = cand
+                break
+            lo, step = cand, step * 2.0
+        if hi is None:
+            return float(loose)
+        for _ in range(48):                             # bisect [lo (too few), hi (enough)] until the count fits the window
+            n_hi = self.index.range_count(feats, hi)
+            mid = 0.5 * (lo + hi)
+            if n_hi <= 2 * want or np.float32(mid) in (np.float32(lo), np.float32(hi)):
+                break
+            if self.index.range_count(feats, mid) >= want:
+                hi = mid
+            else:
+                lo = mid
+        return float(hi)

@@ -122,6 +122,23 @@ def range_search_ip(q, r, radius: float, ref_id_offset: int = 0, capacity: int =
         capacity = int(total.value)
 
 
+def range_count_ip(q, r, radius: float) -> int:
+    """Number of pairs with <q, r> > radius: the counting pass of vsc_range_search_ip_f32 alone (capacity 0)."""
+    import ctypes
+    lib = _lib.require_device()
+    q, r = _dev(q, torch.float32), _dev(r, torch.float32)
+    nq, d = q.shape
+    nr = r.shape[0]
+    assert r.shape[1] == d, "query / reference dimension mismatch"
+    if nq == 0 or nr == 0:
+        return 0
+    lims = torch.zeros(nq + 1, dtype=torch.int64, device=q.device)
+    total = ctypes.c_int64(0)
+    check(lib.vsc_range_search_ip_f32(ptr(q), nq, ptr(r), nr, d, float(radius), 0, ptr(lims), None, None, 0,
+                                      ctypes.byref(total), current_stream()))
+    return int(total.value)
+
+
 def pair_similarity(q, r, pairs):
     """Frame x frame similarity matrices of candidate (query video, reference video) pairs.
     q [nq, d], r [nr, d]: frame banks; pairs: int64 [n, 4] rows (q_row0, q_rows, r_row0, r_rows) on the host.
