@@ -705,8 +705,10 @@ int launch_v3(GemmArgs p, hipStream_t stream) {
     }
     p.tiles_m = (int)((p.m + 255) / 256);
     p.tiles_n = (p.n + 255) / 256;
-    int g = (int)((int64_t)(3 << 19) / ((int64_t)256 * p.k * 2));
-    if (p.tiles_n <= 4) g = p.tiles_n;
+    // N-group width (tile order): groups of 4 N-tiles whatever K is.  Swept on the ViT shapes with this loop (G = 1..12,
+    // gpurun_out/gemm_ab_groups.txt -> profiles/r02_gemm_ab_groups.txt): 4 is fastest for qkv / fc1, equal for the
+    // N = 768 GEMMs (3 N-tiles: one group), and the L2-capacity rule of v2 picked 1 at K = 8192 (1186 vs 1561 TF/s).
+    int g = 4;
     if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
     p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
     p.skew = 0;
