@@ -165,6 +165,12 @@ int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t n
                    int32_t k, int64_t ref_id_offset, float *out_scores_dev,
                    int64_t *out_ids_dev, void *stream);
 
+/* Diagnostic: which sweep the last vsc_knn_ip_f32 call of this process took -- 1 the exact fp32 MFMA sweep, 2 the
+ * bf16 pre-filter sweep + exact re-scoring (large problems, k <= 512; results are bit-identical to 1; synchronises
+ * `stream` once to read its fallback flag), 3 the pre-filter ran, but some 256-query blocks (a candidate band did not fit,
+ * or non-finite operands) were redone on the exact sweep.  VSC_KNN_PATH=exact|bf16 in the environment forces a path. */
+int vsc_knn_last_path(void);
+
 /* Range search: every pair with <q,r> > radius -- faiss IndexFlat.range_search
  * (infer/vsc/exhaustive_search.py:78,250; the radius sweep behind
  * infer/vsc/index.py:145-165).  lims_dev [nq+1] int64 receives the CSR offsets, *total_out

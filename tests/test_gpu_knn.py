@@ -47,6 +47,89 @@ def test_knn_bit_exact(dev, nq, nr, d, k):
         assert (I[:, nr:] == -1).all() and (D[:, nr:] == np.finfo(np.float32).min).all()
 
 
+def _last_path():
+    from vsc_hip import _lib
+    return _lib.require_device().vsc_knn_last_path()
+
+
+@pytest.mark.parametrize("nq,nr,d,k", [
+    (3, 5, 3, 2), (64, 1000, 512, 10), (130, 1001, 511, 7), (1, 70000, 512, 1), (257, 20000, 512, 100),
+    (5, 40, 16, 64), (300, 3000, 64, 500), (700, 9000, 100, 257), (513, 4097, 512, 33),
+])
+def test_knn_prefilter_path_bit_exact(dev, monkeypatch, nq, nr, d, k):
+    """The bf16 pre-filter sweep + exact re-scoring (VSC_KNN_PATH=bf16 forces it at every size) returns the same bits
+    as the oracle's fp32 chain: scores as uint32 patterns, ids, tie order, ragged tiles, k > nr padding."""
+    monkeypatch.setenv("VSC_KNN_PATH", "bf16")
+    q = synth.descriptor_bank(100 + nq, nq, d)
+    r = synth.descriptor_bank(200 + nr, nr, d)
+    D, I = _check(dev, q, r, k)
+    assert _last_path() == 2, "the pre-filter path did not run (or fell back)"
+    if k > nr:
+        assert (I[:, nr:] == -1).all() and (D[:, nr:] == np.finfo(np.float32).min).all()
+
+
+def test_knn_prefilter_unnormalised_ties_and_fallback(dev, monkeypatch):
+    """Pre-filter path on inputs that stress its error bound and its lists: rows of very different norms, exact
+    duplicates across the bank (ties -> lower id first), and a bank with thousands of near-duplicates of a query, whose
+    candidate band cannot fit: the device flag must send the call to the exact sweep (path 3), result still exact."""
+    monkeypatch.setenv("VSC_KNN_PATH", "bf16")
+    rng = np.random.RandomState(5)
+    r = synth.descriptor_bank(31, 6000, 96) * rng.uniform(0.01, 30.0, size=(6000, 1)).astype(np.float32)
+    q = synth.descriptor_bank(32, 70, 96) * rng.uniform(0.1, 5.0, size=(70, 1)).astype(np.float32)
+    r[10] *= 40.0 / np.linalg.norm(r[10])    # the longest row: <r10, r10> beats every other pair of query 0
+    r[4000:4100] = r[10]
+    r[5999] = r[10]
+    q[0] = r[10]
+    D, I = _check(dev, q, r, 50)
+    assert _last_path() == 2
+    assert I[0, 0] == 10 and (I[0, 1:50] == np.arange(4000, 4049)).all()
+    # 600 queries (3 blocks) x 524288 refs = 8 tiles per reference split; 4000 consecutive refs glued to query 300 put
+    # ~2000 candidates into two bands of block 1 (KEEP = 512): that block alone is redone on the exact sweep
+    r2 = synth.descriptor_bank(33, 524288, 32)
+    q2 = synth.descriptor_bank(34, 600, 32)
+    r2[100000:104000] = q2[300] + 1e-4 * synth.normalish(35, (4000, 32))
+    from oracle import knn_oracle
+    from vsc_hip import ops
+    D, I = ops.knn_ip(torch.from_numpy(q2).to(dev), torch.from_numpy(r2).to(dev), 20)
+    assert _last_path() == 3
+    sub = np.r_[0:8, 296:304, 592:600]
+    Dr, Ir = knn_oracle.knn_ip(q2[sub], r2, 20)
+    assert np.array_equal(I.cpu().numpy()[sub], Ir) and np.array_equal(D.cpu().numpy()[sub].view(np.uint32), Dr.view(np.uint32))
+    q2[5, 7] = np.inf                                                  # no finite bound: exact sweep for that block
+    ops.knn_ip(torch.from_numpy(q2[:64]).to(dev), torch.from_numpy(r2[:8192]).to(dev), 5)
+    assert _last_path() == 3
+
+
+def test_knn_auto_path_and_full_size_properties(dev):
+    """BASELINE configs[2]'s shape of problem at a size the default path switches on (nq * nr >= 2^24): a 64-query
+    subset against the oracle, self-match and permutation invariance on everything."""
+    from oracle import knn_oracle
+    from vsc_hip import ops
+    nr, nq, k = 300_000, 2048, 100
+    r = synth.descriptor_bank(91, nr, 512)
+    q = synth.descriptor_bank(92, nq, 512)
+    q[:64] = r[np.arange(0, 64) * 4001]
+    rt, qt = torch.from_numpy(r).to(dev), torch.from_numpy(q).to(dev)
+    D, I = ops.knn_ip(qt, rt, k)
+    assert _last_path() == 2
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    assert (I[:64, 0] == np.arange(0, 64) * 4001).all()
+    sub = np.r_[0:32, nq - 32:nq]
+    Dr, Ir = knn_oracle.knn_ip(q[sub], r, k)
+    assert np.array_equal(I[sub], Ir) and np.array_equal(D[sub].view(np.uint32), Dr.view(np.uint32))
+    perm = np.random.RandomState(1).permutation(nr)
+    D2, I2 = ops.knn_ip(qt, rt[torch.from_numpy(perm).to(dev)], k)
+    assert np.array_equal(D2.cpu().numpy().view(np.uint32), D.view(np.uint32))
+    # same references behind the same scores; two references of one query may tie bit for bit (a few do, among 2048 x
+    # 100 fp32 scores), and a tie is ordered by the id inside the bank that was searched: compare per score group
+    back = perm[I2.cpu().numpy()]
+    same = back == I
+    assert same.mean() > 0.999
+    for row, col in np.argwhere(~same):
+        tie = D[row] == D[row, col]
+        assert tie.sum() > 1 and sorted(back[row, tie]) == sorted(I[row, tie])
+
+
 def test_knn_ties_rank_lower_index_first(dev):
     r = synth.descriptor_bank(7, 3000, 64)
     r[1500:1600] = r[10]          # 100 exact duplicates of row 10, far away in the bank

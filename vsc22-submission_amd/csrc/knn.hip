@@ -31,7 +31,10 @@
 
 #include <vector>
 
+#include <mutex>
+
 #include "common.h"
+#include "mainloop64.h"
 
 namespace {
 
@@ -674,15 +677,335 @@ __global__ __launch_bounds__(256) void pair_max_fill_kernel(const unsigned *__re
     }
 }
 
-// ---- grow-only device scratch, one per process (one process per GPU) ----------------------
+// ------------------------------------------------------------------------------------------
+// Top-k on the bf16 matrix pipe, still exact ("pre-filter" path of vsc_knn_ip_f32).
+//
+// The fp32 MFMA sweep above is bound by v_mfma_f32_32x32x2_f32 (157 TF/s, 1/16 of the bf16 rate).  Here the SWEEP
+// runs on bf16 copies of both banks through the 256 x 256 x 64 main loop of the encoder GEMM (mainloop64.h), and only
+// selects; every score that is handed back is recomputed with the exact ascending-k fp32 fmaf chain, so the result is
+// bit-identical to the fp32 sweep and to oracle/knn_oracle.c:
+//
+//   pack     knn_pack_bf16_kernel  x -> bf16(x) (RNE), rows padded to a multiple of 64; |x|_2 per row, max over refs
+//   sweep    knn_sweep_bf16_kernel approximate scores s~ = <bf16 q, bf16 r> (fp32 accumulate); a pair survives when
+//                                  s~ >= tau~_q - 2 eps_q, tau~_q = the running k-th best approximate score of query q
+//   rescore  knn_rescore_kernel    exact fmaf chain for the survivors, rank on (score, lower id first), best k
+//   merge    knn_merge_kernel      across reference splits (unchanged)
+//
+// Why the survivors contain the exact top-k.  With qh = bf16(q), dq = q - qh (exact in fp32; likewise rh, dr):
+//   <q, r> - <qh, rh> = <dq, r> + <qh, dr>,   so   |<q, r> - <qh, rh>| <= |dq| |r| + |qh| |dr|      (Cauchy-Schwarz),
+// and the MFMA's fp32 accumulation of the (exact) bf16 products and the oracle's own fmaf chain each stay within
+// d 2^-23 |q| |r| of their real-number values.  The pack pass measures |q|, |qh|, |dq| per query and max |r|, max |dr|
+// over the references (RNE rounding leaves |dx| ~ 0.0016 |x|, 2.4 x below the worst case 2^-8), and
+//   eps_q = 1.02 (|dq| max|r| + |qh| max|dr|) + d (2^-22 + 2^-24) |q| max|r|
+// (the 2 % cover the fp32 evaluation of the norms and of tau - 2 eps) bounds |s~ - s| for the exact score s of every pair
+// of query q.  The k best pairs by s~ have s >= tau~ - eps, so the exact k-th best score T >= tau~ - eps; a pair of the
+// exact top-k (ties included) has s >= T, hence s~ >= s - eps >= tau~ - 2 eps: it survives.  tau~ only grows during
+// the sweep, so filtering on its running value keeps a superset.  For 1M unit-norm 512-d references and k = 100 the band
+// holds ~200 candidates per query.
+//
+// Candidate lists live in global memory ([workgroup][256 queries][CAP] 64-bit keys, LDS counters).  When a list could
+// overflow, one wave selects its k-th largest score by a 32-step radix search on the order-preserving score bits
+// (ballot-free counting, registers only), raises the threshold and compacts the list to the band.  If a band itself
+// does not fit (pathological duplicates) or eps is not finite, a device flag is raised and the host re-runs the call
+// on the exact fp32 sweep: correctness never depends on the data.
+constexpr int SQ = 256, SR = 256;   // sweep tile: queries x refs
+
+struct SweepArgs {
+    const uint16_t *qb, *rb;     // bf16 [nq, dp], [nr, dp]
+    const float *qstats;         // [nq][4] = (|q|, |bf16 q|, |q - bf16 q|, 0)
+    const unsigned *rmax_bits;   // [0] max |r|, [1] max |r - bf16 r| as float bits
+    int64_t nq, nr;
+    int dp, k, nqb, splits;
+    int64_t total_tiles, tiles_per_split;
+    float cd;                    // d (2^-22 + 2^-24): accumulation / chain rounding per unit |q| |r|
+    unsigned long long *lists;   // [grid][256][CAP]
+    unsigned long long *cand;    // [nq * splits][KEEP]
+    int *ncand;                  // [nq * splits]
+    int *fallback;               // [1 + nqb]: [0] any, [1 + qb] this query block must be redone on the exact sweep
+};
+
+// stats (queries): [n][4] = (|x|, |bf16 x|, |x - bf16 x|, 0); max_bits (refs): [0] max |x|, [1] max |x - bf16 x| as float bits
+__global__ __launch_bounds__(256) void knn_pack_bf16_kernel(const float *__restrict__ src, uint16_t *__restrict__ dst,
+                                                            float *__restrict__ stats, unsigned *__restrict__ max_bits,
+                                                            int64_t n, int d, int dp) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * 4) {
+        float ss = 0.f, sh = 0.f, sd = 0.f;
+        for (int k0 = lane * 2; k0 < dp; k0 += 128) {
+            const float a = k0 < d ? src[row * d + k0] : 0.f;
+            const float b = k0 + 1 < d ? src[row * d + k0 + 1] : 0.f;
+            const uint32_t pk = pack_bf16x2(a, b);
+            const float ah = __uint_as_float(pk << 16), bh = __uint_as_float(pk & 0xFFFF0000u);
+            const float da = a - ah, db = b - bh;   // exact: the residual of an 8-bit rounding fits fp32
+            ss = fmaf(a, a, fmaf(b, b, ss));
+            sh = fmaf(ah, ah, fmaf(bh, bh, sh));
+            sd = fmaf(da, da, fmaf(db, db, sd));
+            *(uint32_t *)(dst + row * dp + k0) = pk;
+        }
+        ss = wave_sum(ss);
+        sh = wave_sum(sh);
+        sd = wave_sum(sd);
+        if (lane == 0) {
+            if (stats) *(float4 *)(stats + row * 4) = make_float4(sqrtf(ss), sqrtf(sh), sqrtf(sd), 0.f);
+            if (max_bits) {   // norms are >= 0, so their float bits order like unsigned ints (NaN sorts above everything)
+                atomicMax(max_bits, __float_as_uint(sqrtf(ss)));
+                atomicMax(max_bits + 1, __float_as_uint(sqrtf(sd)));
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int wave_sum_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Keep the band [k-th best - eps2, ...] of one candidate list (n <= 64 * EPL keys), one wave.  Survivors go to dst
+// (may be the list itself: everything is in registers before the first store).  Returns the number kept.
+template <int EPL>
+__device__ __forceinline__ int compact_band(const unsigned long long *list, int n, int k, float eps2,
+                                            unsigned long long *dst, int dst_cap, float *thr_out, int lane) {
+    unsigned long long e[EPL];
+    unsigned u[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int idx = lane + 64 * i;
+        e[i] = idx < n ? list[idx] : 0ull;
+        u[i] = (unsigned)(e[i] >> 32);
+    }
+    float thr = -INFINITY;
+    unsigned thr_u = 0u;
+    if (n >= k) {
+        unsigned pfx = 0u;   // largest v with #(u >= v) >= k == the k-th largest u
+        for (int b = 31; b >= 0; --b) {
+            const unsigned trial = pfx | (1u << b);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) c += (lane + 64 * i < n && u[i] >= trial) ? 1 : 0;
+            if (wave_sum_int(c) >= k) pfx = trial;
+        }
+        thr = key_score((unsigned long long)pfx << 32) - eps2;
+        unsigned t = __float_as_uint(thr);
+        thr_u = t ^ ((t >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+    }
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const bool keep = lane + 64 * i < n && u[i] >= thr_u;
+        const unsigned long long m = __ballot(keep);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && pos < dst_cap) dst[pos] = e[i];
+        base += __popcll(m);
+    }
+    *thr_out = thr;
+    return base;
+}
+
+template <int EPL>
+__global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
+    constexpr int CAP = 64 * EPL, KEEP = CAP / 2;
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // ONE shared array: ring, then the per-query slots
+    int *cnt_s = (int *)(lds + ml64::RING_BYTES);
+    float *thr_s = (float *)(lds + ml64::RING_BYTES + 1024);
+    float *eps_s = (float *)(lds + ml64::RING_BYTES + 2048);
+    int *flag_s = (int *)(lds + ml64::RING_BYTES + 3072);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    unsigned long long *mylists = p.lists + (size_t)blockIdx.x * SQ * CAP;
+    const float rmax = __uint_as_float(p.rmax_bits[0]), drmax = __uint_as_float(p.rmax_bits[1]);
+
+    for (int64_t work = blockIdx.x; work < (int64_t)p.nqb * p.splits; work += gridDim.x) {
+        const int qb = (int)(work / p.splits), sp = (int)(work - (int64_t)qb * p.splits);
+        const int64_t q0 = (int64_t)qb * SQ;
+        const int64_t t_begin = sp * p.tiles_per_split;
+        int64_t t_end = t_begin + p.tiles_per_split;
+        t_end = t_end > p.total_tiles ? p.total_tiles : t_end;
+        if (tid < SQ) {
+            cnt_s[tid] = 0;
+            thr_s[tid] = -INFINITY;
+            float e2 = 0.f;
+            if (q0 + tid < p.nq) {
+                const float4 st = *(const float4 *)(p.qstats + (q0 + tid) * 4);
+                e2 = 2.0f * (1.02f * (st.z * rmax + st.y * drmax) + p.cd * st.x * rmax);
+                if (!(e2 < INFINITY)) p.fallback[0] = p.fallback[1 + qb] = 1;   // NaN / Inf operands: no bound, the exact sweep decides
+            }
+            eps_s[tid] = e2;
+        }
+        if (tid == 0) *flag_s = 0;
+        __syncthreads();
+
+        const int q_rows = (int)(p.nq - q0 < SQ ? p.nq - q0 : SQ);
+        for (int64_t rt = t_begin; rt < t_end; ++rt) {
+            const int64_t r0 = rt * SR;
+            const int r_rows = (int)(p.nr - r0 < SR ? p.nr - r0 : SR);
+            f32x4_t acc[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            ml64::Ctx c;
+            ml64::init(c, p.qb + q0 * p.dp, p.dp, q_rows, p.rb + r0 * p.dp, p.dp, r_rows, lds, wave, lane);
+            ml64::run(c, acc, p.dp / 64);
+
+            // ---- filter.  acc[i][j][x] = s~(query q0 + wm*128 + i*16 + (lane & 15), ref r0 + wn*64 + j*16 + (lane >> 4)*4 + x)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ql = wm * 128 + i * 16 + (lane & 15);
+                const float thr = thr_s[ql];
+                float best = acc[i][0][0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) best = fmaxf(best, acc[i][j][x]);
+                if (!(best >= thr) || ql >= q_rows) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const float sc = acc[i][j][x];
+                        const int rl = wn * 64 + j * 16 + (lane >> 4) * 4 + x;
+                        if (sc >= thr && rl < r_rows) {
+                            const int pos = atomicAdd(&cnt_s[ql], 1);
+                            if (pos < CAP) mylists[(size_t)ql * CAP + pos] = make_key(sc, (unsigned)(r0 + rl));
+                        }
+                    }
+            }
+            __syncthreads();
+            if (tid < SQ && cnt_s[tid] + SR > CAP) *flag_s = 1;
+            __syncthreads();
+            if (*flag_s) {
+                for (int ql = wave * 32; ql < wave * 32 + 32; ++ql) {
+                    const int n = cnt_s[ql];
+                    if (n + SR > CAP) {
+                        unsigned long long *l = mylists + (size_t)ql * CAP;
+                        float thr;
+                        const int kept = compact_band<EPL>(l, n < CAP ? n : CAP, p.k, eps_s[ql], l, CAP, &thr, lane);
+                        if (lane == 0) {
+                            cnt_s[ql] = kept;
+                            thr_s[ql] = thr;
+                            if (kept + SR > CAP || n > CAP) p.fallback[0] = p.fallback[1 + qb] = 1;   // the band does not fit: exact sweep
+                        }
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) *flag_s = 0;
+                __syncthreads();
+            }
+        }
+
+        // ---- emit the band of every list of this (query block, split)
+        for (int ql = wave * 32; ql < wave * 32 + 32; ++ql) {
+            if (q0 + ql >= p.nq) continue;
+            const int n = cnt_s[ql];
+            const size_t slot = (size_t)(q0 + ql) * p.splits + sp;
+            float thr;
+            const int kept = compact_band<EPL>(mylists + (size_t)ql * CAP, n < CAP ? n : CAP, p.k, eps_s[ql],
+                                               p.cand + slot * KEEP, KEEP, &thr, lane);
+            if (lane == 0) {
+                p.ncand[slot] = kept < KEEP ? kept : KEEP;
+                if (kept > KEEP || n > CAP) p.fallback[0] = p.fallback[1 + qb] = 1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Exact scores of the survivors of one (query, split) list and their best k, one wave per list.  The chain is the
+// oracle's: acc = fmaf(q[k], r[k], acc) for k = 0 .. d-1 from acc = 0 (oracle/knn_oracle.c), one lane per candidate.
+template <int EPL>
+__global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restrict__ q, const float *__restrict__ r,
+                                                          int64_t nlists, int d, int splits, int k,
+                                                          const unsigned long long *__restrict__ cand,
+                                                          const int *__restrict__ ncand,
+                                                          unsigned long long *__restrict__ part) {
+    constexpr int KEEP = 64 * EPL;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t list = (int64_t)blockIdx.x * 4 + wave;
+    if (list >= nlists) return;
+    const int64_t qi = list / splits;
+    const int n = ncand[list];
+    const float *qrow = q + qi * d;
+    unsigned ids[EPL];
+    float acc[EPL];
+    const float *rrow[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int idx = lane + 64 * i;
+        ids[i] = idx < n ? key_index(cand[list * KEEP + idx]) : 0u;
+        rrow[i] = r + (int64_t)ids[i] * d;
+        acc[i] = 0.f;
+    }
+    const int live = (n + 63) >> 6;   // register rows that hold at least one candidate (wave-uniform)
+    if ((d & 3) == 0) {
+        for (int kk = 0; kk < d; kk += 4) {
+            const float q0 = qrow[kk], q1 = qrow[kk + 1], q2 = qrow[kk + 2], q3 = qrow[kk + 3];
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) {
+                if (i < live) {
+                    const float4 v = *(const float4 *)(rrow[i] + kk);
+                    acc[i] = fmaf(q0, v.x, acc[i]);
+                    acc[i] = fmaf(q1, v.y, acc[i]);
+                    acc[i] = fmaf(q2, v.z, acc[i]);
+                    acc[i] = fmaf(q3, v.w, acc[i]);
+                }
+            }
+        }
+    } else {
+        for (int kk = 0; kk < d; ++kk) {
+            const float qv = qrow[kk];
+#pragma unroll
+            for (int i = 0; i < EPL; ++i)
+                if (i < live) acc[i] = fmaf(qv, rrow[i][kk], acc[i]);
+        }
+    }
+    // rank on the exact keys (score, then lower id), best k out in order
+    unsigned long long *scratch = (unsigned long long *)lds + (size_t)wave * KEEP;
+    unsigned long long e[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int idx = lane + 64 * i;
+        e[i] = idx < n ? make_key(acc[i], ids[i]) : 0ull;
+        if (idx < n) scratch[idx] = e[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int rank[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) rank[i] = 0;
+    for (int j = 0; j < n; ++j) {
+        const unsigned long long kj = scratch[j];
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) rank[i] += kj > e[i] ? 1 : 0;
+    }
+    unsigned long long *dst = part + list * k;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i)
+        if (lane + 64 * i < n && rank[i] < k) dst[rank[i]] = e[i];
+    for (int i = (n < k ? n : k) + lane; i < k; i += 64) dst[i] = 0ull;
+}
+
+// ---- grow-only device scratch, one set per device.  Calls on one device must be ordered by the caller (one stream,
+// or streams synchronised around the call): the packed banks and candidate lists are shared between calls.
 struct Scratch {
     void *ptr = nullptr;
     size_t bytes = 0;
 };
-Scratch g_scratch[8];
+constexpr int MAX_DEVICES = 16, SCRATCH_SLOTS = 24;
+Scratch g_scratch[MAX_DEVICES][SCRATCH_SLOTS];
+std::mutex g_scratch_mutex;
 
 int scratch_get(int slot, size_t bytes, void **out) {
-    Scratch &s = g_scratch[slot];
+    int dev = 0;
+    VSC_CHECK_HIP(hipGetDevice(&dev));
+    VSC_REQUIRE(dev >= 0 && dev < MAX_DEVICES && slot < SCRATCH_SLOTS, "knn: device %d / slot %d out of range", dev, slot);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    Scratch &s = g_scratch[dev][slot];
+    if (bytes < 16) bytes = 16;
     if (s.bytes < bytes) {
         if (s.ptr) {
             VSC_CHECK_HIP(hipDeviceSynchronize());
@@ -709,17 +1032,9 @@ inline int blocks_for(int64_t items) {
 
 }  // namespace
 
-extern "C" int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr,
-                              int32_t d, int32_t k, int64_t ref_id_offset, float *out_scores_dev,
-                              int64_t *out_ids_dev, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    VSC_REQUIRE(q_dev && r_dev && out_scores_dev && out_ids_dev, "knn: null pointer");
-    VSC_REQUIRE(nq > 0 && nr > 0, "knn: empty query or reference set (nq=%lld nr=%lld)", (long long)nq,
-                (long long)nr);
-    VSC_REQUIRE(d > 0 && d <= 4096, "knn: dimension %d unsupported", d);
-    VSC_REQUIRE(k >= 1 && k <= 1024, "knn: k=%d out of range [1,1024]", k);
-    VSC_REQUIRE(nr < (1ll << 32) - 1, "knn: more than 2^32-2 references in one call");
-
+// exact fp32 MFMA sweep (the only path of round 1; now the path for small problems, k > 512 and the fallback)
+static int knn_exact(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d, int32_t k,
+                     int64_t ref_id_offset, float *out_scores_dev, int64_t *out_ids_dev, hipStream_t stream) {
     const int dpad = (d + KS - 1) / KS * KS;
     const int epl = k + TR <= 512 ? 8 : (k + TR <= 1024 ? 16 : 32);
     const int cap = 64 * epl;
@@ -762,6 +1077,121 @@ extern "C" int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev
                        out_ids_dev);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
+}
+
+template <int EPL>
+static int launch_sweep(const SweepArgs &a, int grid, hipStream_t stream) {
+    constexpr int smem = ml64::RING_BYTES + 4096;
+    auto kern = knn_sweep_bf16_kernel<EPL>;
+    VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+// bf16 pre-filter sweep + exact re-scoring.  Query blocks (256 queries) whose candidate bands did not fit, or whose
+// bound is not finite, are redone on the exact sweep; *fell_back = number of such blocks.
+static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d, int32_t k,
+                         int64_t ref_id_offset, float *out_scores_dev, int64_t *out_ids_dev, hipStream_t stream,
+                         int *fell_back) {
+    const int dp = (d + 63) / 64 * 64;
+    const int epl = k <= 256 ? 16 : 32;          // CAP = 1024 / 2048 keys per list, KEEP = CAP / 2 survivors
+    const int cap = 64 * epl, keep = cap / 2;
+    const int nqb = (int)((nq + SQ - 1) / SQ);
+    const int64_t total_tiles = (nr + SR - 1) / SR;
+    int64_t want = (256 + nqb - 1) / nqb;        // enough (query block, ref split) items for one workgroup per CU
+    if (want > 256) want = 256;
+    if (want > total_tiles) want = total_tiles;
+    if (want < 1) want = 1;
+    const int64_t tiles_per_split = (total_tiles + want - 1) / want;
+    const int splits = (int)((total_tiles + tiles_per_split - 1) / tiles_per_split);
+    const int64_t work = (int64_t)nqb * splits;
+    const int grid = (int)(work < 256 ? work : 256);
+    const int64_t nlists = nq * splits;
+
+    void *qb, *rb, *qstats, *flags, *lists, *cand, *ncand, *part;
+    int rc;
+    const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4;   // [0..1] max |r|, max |dr| bits; [4..] fallback flags
+    if ((rc = scratch_get(12, (size_t)nq * dp * 2, &qb))) return rc;
+    if ((rc = scratch_get(13, (size_t)nr * dp * 2, &rb))) return rc;
+    if ((rc = scratch_get(14, (size_t)nq * 16, &qstats))) return rc;
+    if ((rc = scratch_get(15, flag_bytes, &flags))) return rc;
+    if ((rc = scratch_get(16, (size_t)grid * SQ * cap * 8, &lists))) return rc;
+    if ((rc = scratch_get(17, (size_t)nlists * keep * 8, &cand))) return rc;
+    if ((rc = scratch_get(18, (size_t)nlists * 4, &ncand))) return rc;
+    if ((rc = scratch_get(3, (size_t)nlists * k * 8, &part))) return rc;
+    int *fb_dev = (int *)flags + 4;
+
+    VSC_CHECK_HIP(hipMemsetAsync(flags, 0, flag_bytes, stream));
+    hipLaunchKernelGGL(knn_pack_bf16_kernel, dim3(blocks_for(nq * 64)), dim3(256), 0, stream, q_dev, (uint16_t *)qb,
+                       (float *)qstats, (unsigned *)nullptr, nq, d, dp);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(knn_pack_bf16_kernel, dim3(blocks_for(nr * 64)), dim3(256), 0, stream, r_dev, (uint16_t *)rb,
+                       (float *)nullptr, (unsigned *)flags, nr, d, dp);
+    VSC_CHECK_LAUNCH();
+    const float cd = (float)d * (2.384185791015625e-7f + 5.9604644775390625e-8f);   // d (2^-22 + 2^-24)
+    SweepArgs a{(const uint16_t *)qb, (const uint16_t *)rb, (const float *)qstats, (const unsigned *)flags, nq, nr, dp, k, nqb,
+                splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
+                (int *)ncand, fb_dev};
+    if ((rc = epl == 16 ? launch_sweep<16>(a, grid, stream) : launch_sweep<32>(a, grid, stream))) return rc;
+    const unsigned rgrid = (unsigned)((nlists + 3) / 4);
+    if (epl == 16)
+        hipLaunchKernelGGL(knn_rescore_kernel<8>, dim3(rgrid), dim3(256), 4 * 512 * 8, stream, q_dev, r_dev, nlists, d, splits,
+                           k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part);
+    else
+        hipLaunchKernelGGL(knn_rescore_kernel<16>, dim3(rgrid), dim3(256), 4 * 1024 * 8, stream, q_dev, r_dev, nlists, d,
+                           splits, k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream,
+                       (const unsigned long long *)part, nq, splits, k, ref_id_offset, out_scores_dev, out_ids_dev);
+    VSC_CHECK_LAUNCH();
+    std::vector<int> fb(1 + nqb);
+    VSC_CHECK_HIP(hipMemcpyAsync(fb.data(), fb_dev, fb.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+    VSC_CHECK_HIP(hipStreamSynchronize(stream));
+    *fell_back = 0;
+    if (!fb[0]) return VSC_OK;
+    // redo the flagged query blocks (contiguous rows in, contiguous rows out) on the exact sweep, runs of blocks at a time
+    for (int b = 0; b < nqb;) {
+        if (!fb[1 + b]) { ++b; continue; }
+        int e = b;
+        while (e < nqb && fb[1 + e]) ++e;
+        const int64_t row0 = (int64_t)b * SQ, rows = ((int64_t)e * SQ < nq ? (int64_t)e * SQ : nq) - row0;
+        if ((rc = knn_exact(q_dev + row0 * d, rows, r_dev, nr, d, k, ref_id_offset, out_scores_dev + row0 * k,
+                            out_ids_dev + row0 * k, stream))) return rc;
+        *fell_back += e - b;
+        b = e;
+    }
+    return VSC_OK;
+}
+
+static int g_knn_last_path = 0;   // 1 exact fp32 sweep, 2 bf16 pre-filter, 3 pre-filter with some query blocks redone on the exact sweep
+extern "C" int vsc_knn_last_path(void) { return g_knn_last_path; }
+
+extern "C" int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr,
+                              int32_t d, int32_t k, int64_t ref_id_offset, float *out_scores_dev,
+                              int64_t *out_ids_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VSC_REQUIRE(q_dev && r_dev && out_scores_dev && out_ids_dev, "knn: null pointer");
+    VSC_REQUIRE(nq > 0 && nr > 0, "knn: empty query or reference set (nq=%lld nr=%lld)", (long long)nq,
+                (long long)nr);
+    VSC_REQUIRE(d > 0 && d <= 4096, "knn: dimension %d unsupported", d);
+    VSC_REQUIRE(k >= 1 && k <= 1024, "knn: k=%d out of range [1,1024]", k);
+    VSC_REQUIRE(nr < (1ll << 32) - 1, "knn: more than 2^32-2 references in one call");
+    // Path: the pre-filter pays once the sweep dominates (its fixed costs: two pack passes, the re-scoring launch and
+    // one host synchronisation for the fallback flag).  VSC_KNN_PATH=exact|bf16 forces one (tests run both).
+    bool prefilter = k <= 512 && nr >= 4096 && nq * nr >= (1ll << 24);
+    if (const char *e = getenv("VSC_KNN_PATH")) {
+        if (e[0] == 'e') prefilter = false;
+        if (e[0] == 'b') prefilter = k <= 512;
+    }
+    if (prefilter) {
+        int fb = 0;
+        const int rc = knn_prefilter(q_dev, nq, r_dev, nr, d, k, ref_id_offset, out_scores_dev, out_ids_dev, stream, &fb);
+        g_knn_last_path = fb ? 3 : 2;
+        return rc;
+    }
+    g_knn_last_path = 1;
+    return knn_exact(q_dev, nq, r_dev, nr, d, k, ref_id_offset, out_scores_dev, out_ids_dev, stream);
 }
 
 extern "C" int vsc_range_search_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr,

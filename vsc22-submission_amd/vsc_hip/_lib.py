@@ -82,6 +82,7 @@ SIGNATURES = {
     "vsc_debug_spin_ticks": (c_int32, [ctypes.c_uint64, c_void_p, c_void_p]),
     "vsc_knn_ip_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int64,
                                  c_void_p, c_void_p, c_void_p]),
+    "vsc_knn_last_path": (c_int32, []),
     "vsc_range_search_ip_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_float, c_int64,
                                           c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int64), c_void_p]),
     "vsc_l2_normalize_f32": (c_int32, [c_void_p, c_int64, c_int32, c_void_p]),
