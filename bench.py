@@ -85,7 +85,8 @@ class ClockSampler:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=151,
+                    help="timed steps; the default 151 x 664 = 100 264 frames is BASELINE.json configs[1] (100k frames)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=664, help="frames per step per GPU")
     ap.add_argument("--max-batch", type=int, default=332,
@@ -97,10 +98,13 @@ def parse():
     ap.add_argument("--preset", default="vit_b16_224")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true")
-    ap.add_argument("--search-nq", type=int, default=65536)
+    ap.add_argument("--profile-steps", type=int, default=8,
+                    help="steps of the separate loop that brackets every launch with HIP events (kernels{} / roofline); "
+                         "the headline loop runs without them")
+    ap.add_argument("--search-nq", type=int, default=1_000_000, help="BASELINE.json configs[2]: 1M queries x 1M refs")
     ap.add_argument("--search-nr", type=int, default=1_000_000)
     ap.add_argument("--search-k", type=int, default=100)
-    ap.add_argument("--search-steps", type=int, default=3)
+    ap.add_argument("--search-steps", type=int, default=1)
     ap.add_argument("--no-swin", action="store_true")
     ap.add_argument("--force-sharded-search", action="store_true",
                     help="run the N > 1 search leg (RCCL all_gather + sweep) even with one rank; needs torchrun's env")
@@ -137,16 +141,21 @@ def gemm_traffic(cfg, chunk):
             "4": chunk * (t - 1) * cfg.patch_dim * 2 + cfg.patch_dim * d * 2 + chunk * (t - 1) * d * 4}
     n = sum(launches.values())
     algorithmic = sum(launches[k] * algo[k] for k in launches) / n
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_per_launch_v2.json")))["per_launch"]
-        meas = 0.0
-        for key, v in prof.items():
-            if "gemm_bf16_v2_kernel<" in key:
-                epi = key.split("<")[1].split(",")[0]
-                meas += launches.get(epi, 0) * (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
-        return meas / n, algorithmic
-    except (OSError, KeyError, ValueError):
-        return None, algorithmic
+    for name, prefix in (("r02_pmc_per_launch.json", "gemm_bf16_v3_kernel<"), ("r01_pmc_per_launch_v2.json", "gemm_bf16_v2_kernel<")):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))["per_launch"]
+            meas = 0.0
+            seen = 0
+            for key, v in prof.items():
+                if prefix in key:
+                    epi = key.split("<")[1].split(",")[0].split(">")[0]
+                    meas += launches.get(epi, 0) * (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+                    seen += launches.get(epi, 0)
+            if seen == n:
+                return meas / n, algorithmic, name
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, algorithmic, None
 
 
 def cpu_baseline(cfg, weights, frames_np, budget_s=15.0):
@@ -177,9 +186,22 @@ def cpu_baseline(cfg, weights, frames_np, budget_s=15.0):
             "kind": "port", "sample": f"{n} frames (bench frames, cycled), fp32 torch oracle, batches of 4, {dt:.1f} s"}
 
 
+def search_traffic():
+    """HBM-side bytes per sweep-kernel launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes over tools/knn_bench.py; reads = 2 x FETCH_SIZE on gfx950, see gemm_traffic).  -> (bytes, nq, nr) of
+    the profiled launch, or None."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_knn.json")))
+        v = prof["per_launch"][prof["sweep_kernel_key"]]
+        return (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024, prof["nq"], prof["nr"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def bench_search(dev, args):
-    from src import synth
-    from vsc_hip import ops
+    import ctypes
+    from vsc_hip import _lib, ops
+    lib = _lib.require_device()
     d = 512
     nq, nr, k = args.search_nq, args.search_nr, args.search_k
     g = torch.Generator(device=dev).manual_seed(1)
@@ -190,23 +212,42 @@ def bench_search(dev, args):
     ops.knn_ip(q[:256], r[:4096], k)  # allocate + warm
     ops.knn_ip(q, r, k)
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
+    lib.vsc_knn_set_profiling(1)
+    t0 = time.perf_counter()
     for _ in range(args.search_steps):
         D, I = ops.knn_ip(q, r, k)
-    ev1.record()
     torch.cuda.synchronize()
-    ms = ev0.elapsed_time(ev1) / args.search_steps
+    ms = (time.perf_counter() - t0) * 1e3 / args.search_steps
+    phases = (ctypes.c_float * 4)()
+    _lib.check(lib.vsc_knn_last_profile(phases))
+    lib.vsc_knn_set_profiling(0)
+    path = lib.vsc_knn_last_path()
+    # cheap self-checks on the full-size result (the parity tests proper are tests/test_gpu_knn.py)
+    assert bool((D[:, :-1] >= D[:, 1:]).all()) and int(I.min()) >= 0 and int(I.max()) < nr
     pairs = nq * nr
-    tflops = 2.0 * pairs * d / (ms * 1e-3) / 1e12
-    return {"metric": "Mpairs/s (512-d exact inner-product top-k sweep)",
+    sweep_ms = float(phases[1])
+    if path == 1:   # exact fp32 MFMA sweep
+        peak, kern, dtype = F32_MFMA_PEAK_TFLOPS, "knn_kernel (v_mfma_f32_32x32x2_f32)", "f32"
+    else:           # bf16 pre-filter sweep (selection) + exact fp32 re-scoring of the survivors
+        peak, kern, dtype = BF16_PEAK_TFLOPS, "knn_sweep_bf16_kernel (v_mfma_f32_16x16x32_bf16, 256x256x64 main loop)", "bf16 sweep / f32 re-score"
+    tflops = 2.0 * pairs * d / (sweep_ms * 1e-3) / 1e12
+    algo_bytes = (nq + nr) * d * 2   # both bf16 banks once; every query block re-reads the reference bank through L2 / Infinity Cache
+    traffic = search_traffic()
+    return {"metric": "Mpairs/s (512-d exact inner-product top-k sweep, BASELINE.json configs[2])",
             "value": round(pairs / (ms * 1e-3) / 1e6, 1), "unit": "Mpairs/s", "nq": nq, "nr": nr,
-            "k": k, "dtype": "f32", "ms_per_sweep": round(ms, 3),
-            "roofline": {"bound": "mfma", "kernel": "knn_kernel (v_mfma_f32_32x32x2_f32)",
-                         "achieved": round(tflops, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(tflops / F32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None,
-                         "note": "event time covers pack + knn_kernel + merge of one call"}}
+            "k": k, "dtype": dtype, "ms_per_sweep": round(ms, 3), "path": {1: "exact fp32 sweep", 2: "bf16 pre-filter + exact re-score", 3: "pre-filter, some blocks redone exactly"}[path],
+            "phases_ms": {"pack": round(float(phases[0]), 3), "sweep": round(sweep_ms, 3), "rescore": round(float(phases[2]), 3),
+                          "merge": round(float(phases[3]), 3)},
+            "roofline": {"bound": "mfma", "kernel": kern,
+                         "achieved": round(tflops, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
+                         "traffic": None if traffic is None else round(traffic[0]),
+                         "traffic_note": None if traffic is None else
+                         f"memory-side bytes of one sweep launch at nq={traffic[1]}, nr={traffic[2]} (profiles/r02_pmc_knn.json); "
+                         f"algorithmic operand bytes of that launch: {(traffic[1] + traffic[2]) * d * 2}",
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "achieved = 2 nq nr d / HIP-event time of the sweep kernel alone (vsc_knn_last_profile); value covers the whole call "
+                                 "(pack + sweep + exact re-scoring + merge + one host sync)"}}
 
 
 def bench_search_sharded(dev, args, dist, rank, world):
@@ -264,7 +305,11 @@ def bench_swin(dev, args):
     return {"metric": "frames/s (Swin-V2-B 256x256 window-16 encode -> L2-normalised 512-d descriptors)",
             "value": round(b / dt, 1), "unit": "frames/s", "frames_per_step": b, "ms_per_step": round(dt * 1e3, 3),
             "dtype": "bf16", "gflop_per_frame": round(cfg.flops_per_frame() / 1e9, 2),
-            "model_tflops": round(cfg.flops_per_frame() * b / dt / 1e12, 1)}
+            "model_tflops": round(cfg.flops_per_frame() * b / dt / 1e12, 1),
+            "roofline": {"bound": "mfma", "kernel": "whole Swin-V2-B step (GEMMs 77 % of it: gemm_bf16_v3 / v2 / gemm_ln kernels)",
+                         "achieved": round(cfg.flops_per_frame() * b / dt / 1e12, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(cfg.flops_per_frame() * b / dt / 1e12 / BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "note": "model FLOPs / wall time of the step (no per-launch events in the Swin encoder)"}}
 
 
 def main():
@@ -314,7 +359,6 @@ def main():
         enc(frames)
     barrier()
     step_est = (time.perf_counter() - tw) / max(args.warmup, 1)   # sizes the clock probe below
-    enc.set_profiling(True)
     sampler = ClockSampler() if rank == 0 else None
     spin = None
     if sampler:
@@ -325,6 +369,8 @@ def main():
         side = torch.cuda.Stream()
         spin = {"ticks": torch.zeros(1, dtype=torch.int64, device=dev), "e0": torch.cuda.Event(enable_timing=True),
                 "e1": torch.cuda.Event(enable_timing=True)}
+    # ---- the headline: EXACTLY args.steps steps, no per-launch events, barrier + synchronize on both sides
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = enc(frames)
@@ -338,13 +384,19 @@ def main():
     dt = time.perf_counter() - t0
     if sampler:
         sampler.__exit__()
-    prof = enc.get_profile()
-    enc.set_profiling(False)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out).all()
+    # ---- a separate short loop with HIP events around every launch (on the launch stream): kernels{} and roofline
+    psteps = max(1, min(args.profile_steps, args.steps))
+    enc.set_profiling(True)
+    for _ in range(psteps):
+        enc(frames)
+    torch.cuda.synchronize()
+    prof = enc.get_profile()
+    enc.set_profiling(False)
 
     search_multi = None
     if (world > 1 or args.force_sharded_search) and not args.no_search:
@@ -357,38 +409,41 @@ def main():
         total_frames = args.steps * args.batch * world
         fpf = gemm_flops_per_frame(cfg)
         gemm_ms = sum(prof[k][0] for k in fpf)
-        gemm_flops = sum(fpf.values()) * args.steps * args.batch
+        gemm_flops = sum(fpf.values()) * psteps * args.batch
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        per_class = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // args.steps,
+        per_class = {k: {"ms_per_step": round(v[0] / psteps, 4), "launches_per_step": v[1] // psteps,
                          "avg_launch_us": round(1e3 * v[0] / max(v[1], 1), 2)}
                      for k, v in prof.items() if v[1]}
         for k in fpf:
-            per_class[k]["tflops"] = round(fpf[k] * args.batch * args.steps / (prof[k][0] * 1e-3) / 1e12, 1)
-        traffic, algo_bytes = gemm_traffic(cfg, min(args.max_batch, args.batch))
+            per_class[k]["tflops"] = round(fpf[k] * args.batch * psteps / (prof[k][0] * 1e-3) / 1e12, 1)
+        traffic, algo_bytes, traffic_src = gemm_traffic(cfg, min(args.max_batch, args.batch))
         line = {
             "metric": "frames/s (ViT-B/16 224x224 encode -> L2-normalised 512-d descriptors)",
             "value": round(total_frames / dt, 1), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{cfg.name} bf16 encode, {args.batch} synthetic "
-                                   f"{cfg.image_size}x{cfg.image_size} frames per step per GPU "
-                                   "(BASELINE.json configs[1])",
+            "config": {"workload": f"{cfg.name} bf16 encode of {args.steps * args.batch} synthetic "
+                                   f"{cfg.image_size}x{cfg.image_size} frames per GPU in {args.steps} steps of {args.batch} "
+                                   "(BASELINE.json configs[1]: 100k frames)",
+                       "frames_per_gpu": args.steps * args.batch,
                        "frames_per_step_per_gpu": args.batch, "encoder_chunk": args.max_batch,
                        "lanes": args.lanes, "tokens": cfg.tokens,
                        "gflop_per_frame": round(cfg.flops_per_frame() / 1e9, 2),
                        "parallelism": f"frames sharded over {world} rank(s), no data-path collective"},
             "model_tflops": round(cfg.flops_per_frame() * total_frames / dt / 1e12 / world, 1),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_v2_kernel (patch/qkv/proj/fc1/fc2 launches)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_v3_kernel (patch/qkv/proj/fc1/fc2 launches)",
                          "achieved": round(achieved, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_PEAK_TFLOPS, 4),
                          "traffic": None if traffic is None else round(traffic),
                          "traffic_unit": "HBM bytes per GEMM launch (mean over the 49 launches of one 332-frame chunk; "
-                                         "2 x FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_per_launch_v2.json: memory-side L2 requests, Infinity-Cache hits included)",
+                                         f"2 x FETCH_SIZE + WRITE_SIZE from profiles/{traffic_src}: memory-side L2 requests, Infinity-Cache hits included)",
                          "algorithmic_bytes_per_launch": round(algo_bytes),
-                         "gemm_ms_per_step": round(gemm_ms / args.steps, 3),
-                         "note": "per-launch HIP-event time; with lanes=2 launches of the two chunks "
-                                 "overlap, so the sum of kernel times exceeds ms_per_step"},
+                         "gemm_ms_per_step": round(gemm_ms / psteps, 3),
+                         "profiled_steps": psteps,
+                         "note": "per-launch HIP-event time on the launch stream, taken in a separate loop of profiled_steps steps right "
+                                 "after the timed region (the headline loop carries no events); with lanes=2 launches of the two "
+                                 "chunks overlap, so the sum of kernel times exceeds ms_per_step"},
             "kernels": per_class,
         }
         clk = sampler.summary() if sampler else None

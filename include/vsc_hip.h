@@ -171,6 +171,12 @@ int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t n
  * or non-finite operands) were redone on the exact sweep.  VSC_KNN_PATH=exact|bf16 in the environment forces a path. */
 int vsc_knn_last_path(void);
 
+/* Diagnostic (bench.py): with profiling on, every vsc_knn_ip_f32 call records HIP events on its stream around its phases;
+ * vsc_knn_last_profile waits for the last call and returns ms_out = {pack, sweep (the dominant kernel: knn_sweep_bf16_kernel
+ * on path 2, knn_kernel on path 1), exact re-scoring (0 on path 1), merge}. */
+void vsc_knn_set_profiling(int on);
+int vsc_knn_last_profile(float ms_out[4]);
+
 /* Range search: every pair with <q,r> > radius -- faiss IndexFlat.range_search
  * (infer/vsc/exhaustive_search.py:78,250; the radius sweep behind
  * infer/vsc/index.py:145-165).  lims_dev [nq+1] int64 receives the CSR offsets, *total_out

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round profile on the GPU box (run through gpurun from the repo root): the default bench line, the rocprofv3 kernel-trace
+# summary of the same command at 3 steps, and separate --pmc passes (FETCH_SIZE / WRITE_SIZE) for the encoder GEMMs and the
+# similarity sweep.  Outputs under gpurun_out/<tag>/; copy what is to be judged into profiles/.
+set -u
+TAG=${1:-r02}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+SHORT="--steps 3 --warmup 1 --profile-steps 3 --no-cpu-baseline --no-search --no-swin"
+python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+tail -c 600 "$OUT/bench_default.json"
+(cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o enc -- python $OLDPWD/bench.py $SHORT > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err")
+(cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats_knn" -o knn -- python $OLDPWD/tools/knn_bench.py 65536 1000000 100 2 > "$OUT/knn_under_rocprof.txt" 2> "$OUT/stats_knn.err")
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && rocprofv3 --pmc $c -d "$OUT/pmc_$c" -o enc --output-format csv -- python $OLDPWD/bench.py $SHORT > /dev/null 2> "$OUT/pmc_$c.err")
+  (cd /tmp && timeout 600 rocprofv3 --pmc $c -d "$OUT/pmcknn_$c" -o knn --output-format csv -- python $OLDPWD/tools/knn_bench.py 8192 1000000 100 1 > /dev/null 2> "$OUT/pmcknn_$c.err")
+done
+python tools/pmc_summarize.py "$OUT/pmc_per_launch.json" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" > "$OUT/pmc_summary.txt" 2>&1
+python tools/pmc_summarize.py "$OUT/pmc_knn.json" "$OUT/pmcknn_FETCH_SIZE" "$OUT/pmcknn_WRITE_SIZE" > "$OUT/pmc_knn_summary.txt" 2>&1
+find "$OUT" -name "*.db" | while read f; do python profiles/summarize_rocpd.py "$f" > "${f%.db}_summary.txt" 2>&1; done
+find "$OUT" -name "*_kernel_stats.csv" -o -name "*summary.txt" | head
+# keep the merge-back small: drop raw traces
+find "$OUT" -name "*.db" -size +8M -delete
+find "$OUT" -name "*kernel_trace.csv" -size +8M -delete
+find "$OUT" -name "*counter_collection.csv" -size +8M -delete
+du -sh "$OUT"

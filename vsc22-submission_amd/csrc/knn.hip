@@ -1032,6 +1032,28 @@ inline int blocks_for(int64_t items) {
 
 }  // namespace
 
+// ---- per-phase HIP events of the last top-k call (bench.py: duration of the dominant kernel, on the caller's stream)
+static bool g_knn_profiling = false;
+static hipEvent_t g_knn_ev[5];
+static bool g_knn_ev_made = false, g_knn_ev_valid = false;
+static void knn_mark(int i, hipStream_t stream) {
+    if (!g_knn_profiling) return;
+    if (!g_knn_ev_made) {
+        for (auto &e : g_knn_ev) (void)hipEventCreate(&e);
+        g_knn_ev_made = true;
+    }
+    (void)hipEventRecord(g_knn_ev[i], stream);
+    if (i == 4) g_knn_ev_valid = true;
+}
+extern "C" void vsc_knn_set_profiling(int on) { g_knn_profiling = on != 0; g_knn_ev_valid = false; }
+extern "C" int vsc_knn_last_profile(float ms_out[4]) {
+    VSC_REQUIRE(ms_out, "knn_last_profile: null pointer");
+    VSC_REQUIRE(g_knn_ev_valid, "knn_last_profile: no profiled vsc_knn_ip_f32 call (vsc_knn_set_profiling(1) first)");
+    VSC_CHECK_HIP(hipEventSynchronize(g_knn_ev[4]));
+    for (int i = 0; i < 4; ++i) VSC_CHECK_HIP(hipEventElapsedTime(&ms_out[i], g_knn_ev[i], g_knn_ev[i + 1]));
+    return VSC_OK;
+}
+
 // exact fp32 MFMA sweep (the only path of round 1; now the path for small problems, k > 512 and the fallback)
 static int knn_exact(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d, int32_t k,
                      int64_t ref_id_offset, float *out_scores_dev, int64_t *out_ids_dev, hipStream_t stream) {
@@ -1056,12 +1078,14 @@ static int knn_exact(const float *q_dev, int64_t nq, const float *r_dev, int64_t
     if ((rc = scratch_get(2, (size_t)grid * 128 * cap * 8, &lists))) return rc;
     if ((rc = scratch_get(3, (size_t)nq * splits * k * 8, &part))) return rc;
 
+    knn_mark(0, stream);
     hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nq * (dpad / 4))), dim3(256), 0, stream, q_dev,
                        (float *)qp, nq, d, dpad);
     VSC_CHECK_LAUNCH();
     hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nr * (dpad / 4))), dim3(256), 0, stream, r_dev,
                        (float *)rp, nr, d, dpad);
     VSC_CHECK_LAUNCH();
+    knn_mark(1, stream);
 
     KnnArgs a{(const float *)qp, (const float *)rp, nq, nr, dpad, k, nqb, splits, total_tiles,
               tiles_per_split, (unsigned long long *)lists, (unsigned long long *)part};
@@ -1072,10 +1096,13 @@ static int knn_exact(const float *q_dev, int64_t nq, const float *r_dev, int64_t
     else
         hipLaunchKernelGGL(knn_kernel<32>, dim3(grid), dim3(256), 0, stream, a);
     VSC_CHECK_LAUNCH();
+    knn_mark(2, stream);
+    knn_mark(3, stream);   // no re-scoring phase on this path
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream,
                        (const unsigned long long *)part, nq, splits, k, ref_id_offset, out_scores_dev,
                        out_ids_dev);
     VSC_CHECK_LAUNCH();
+    knn_mark(4, stream);
     return VSC_OK;
 }
 
@@ -1123,17 +1150,20 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     int *fb_dev = (int *)flags + 4;
 
     VSC_CHECK_HIP(hipMemsetAsync(flags, 0, flag_bytes, stream));
+    knn_mark(0, stream);
     hipLaunchKernelGGL(knn_pack_bf16_kernel, dim3(blocks_for(nq * 64)), dim3(256), 0, stream, q_dev, (uint16_t *)qb,
                        (float *)qstats, (unsigned *)nullptr, nq, d, dp);
     VSC_CHECK_LAUNCH();
     hipLaunchKernelGGL(knn_pack_bf16_kernel, dim3(blocks_for(nr * 64)), dim3(256), 0, stream, r_dev, (uint16_t *)rb,
                        (float *)nullptr, (unsigned *)flags, nr, d, dp);
     VSC_CHECK_LAUNCH();
+    knn_mark(1, stream);
     const float cd = (float)d * (2.384185791015625e-7f + 5.9604644775390625e-8f);   // d (2^-22 + 2^-24)
     SweepArgs a{(const uint16_t *)qb, (const uint16_t *)rb, (const float *)qstats, (const unsigned *)flags, nq, nr, dp, k, nqb,
                 splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
                 (int *)ncand, fb_dev};
     if ((rc = epl == 16 ? launch_sweep<16>(a, grid, stream) : launch_sweep<32>(a, grid, stream))) return rc;
+    knn_mark(2, stream);
     const unsigned rgrid = (unsigned)((nlists + 3) / 4);
     if (epl == 16)
         hipLaunchKernelGGL(knn_rescore_kernel<8>, dim3(rgrid), dim3(256), 4 * 512 * 8, stream, q_dev, r_dev, nlists, d, splits,
@@ -1142,9 +1172,14 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
         hipLaunchKernelGGL(knn_rescore_kernel<16>, dim3(rgrid), dim3(256), 4 * 1024 * 8, stream, q_dev, r_dev, nlists, d,
                            splits, k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part);
     VSC_CHECK_LAUNCH();
+    knn_mark(3, stream);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream,
                        (const unsigned long long *)part, nq, splits, k, ref_id_offset, out_scores_dev, out_ids_dev);
     VSC_CHECK_LAUNCH();
+    knn_mark(4, stream);
+    const bool was_profiling = g_knn_profiling;
+    g_knn_profiling = false;   // the events of this call stay those of the pre-filter phases if blocks are redone below
+    struct Restore { bool v; ~Restore() { g_knn_profiling = v; } } restore{was_profiling};
     std::vector<int> fb(1 + nqb);
     VSC_CHECK_HIP(hipMemcpyAsync(fb.data(), fb_dev, fb.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
     VSC_CHECK_HIP(hipStreamSynchronize(stream));
