@@ -941,7 +941,52 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
         acc[i] = 0.f;
     }
     const int live = (n + 63) >> 6;   // register rows that hold at least one candidate (wave-uniform)
-    if ((d & 3) == 0) {
+    if ((d & 31) == 0) {
+        // Coalesced gather.  A lane per candidate walking its own row touches 64 different lines per load instruction
+        // and re-fetches every line eight times (PMC: 7 x the algorithmic bytes).  Instead the wave fetches, for 64
+        // candidates at a time, one whole 128-byte line per candidate and 32-float chunk (8 lanes x 16 B per line, 8
+        // instructions), transposes through LDS (rows of 36 floats: conflict-free for both the 16-byte row-major
+        // writes and the lane-per-row reads) and every lane runs its candidate's chain on its own row.  Chunk c + 1 is
+        // in flight while chunk c is multiplied.
+        float *buf = (float *)lds + (size_t)wave * (2 * 64 * 36);
+        const int sub = lane >> 3, col = (lane & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            if (i >= live) continue;   // wave-uniform; `continue` keeps the loop unrollable (acc / ids stay in registers)
+            const float *src[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) src[j] = r + (int64_t)__shfl(ids[i], j * 8 + sub, 64) * d + col;
+            f32x4_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4_t *)(src[j]);
+            float a = 0.f;
+            const int nch = d >> 5;
+            for (int ch = 0; ch < nch; ++ch) {
+                float *b = buf + (ch & 1) * (64 * 36);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *(f32x4_t *)(b + (j * 8 + sub) * 36 + col) = v[j];
+                const int nx = (ch + 1 < nch ? ch + 1 : ch) * 32;   // the last chunk is fetched twice rather than branching
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = *(const f32x4_t *)(src[j] + nx);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float *qc = qrow + ch * 32;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const f32x4_t x = *(const f32x4_t *)(b + lane * 36 + t * 4);
+                    a = fmaf(qc[4 * t], x[0], a);
+                    a = fmaf(qc[4 * t + 1], x[1], a);
+                    a = fmaf(qc[4 * t + 2], x[2], a);
+                    a = fmaf(qc[4 * t + 3], x[3], a);
+                }
+                // the buffer written two chunks from now is this one: its reads above are complete before the
+                // writes of chunk ch + 2 are issued (in-order LDS queue of the same wave)
+            }
+            acc[i] = a;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else if ((d & 3) == 0) {
         for (int kk = 0; kk < d; kk += 4) {
             const float q0 = qrow[kk], q1 = qrow[kk + 1], q2 = qrow[kk + 2], q3 = qrow[kk + 3];
 #pragma unroll
@@ -964,7 +1009,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
         }
     }
     // rank on the exact keys (score, then lower id), best k out in order
-    unsigned long long *scratch = (unsigned long long *)lds + (size_t)wave * KEEP;
+    static_assert(KEEP * 8 <= 2 * 64 * 36 * 4, "rank scratch fits the wave's gather buffer");
+    unsigned long long *scratch = (unsigned long long *)(lds + (size_t)wave * (2 * 64 * 36 * 4));
     unsigned long long e[EPL];
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
@@ -1166,10 +1212,10 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     knn_mark(2, stream);
     const unsigned rgrid = (unsigned)((nlists + 3) / 4);
     if (epl == 16)
-        hipLaunchKernelGGL(knn_rescore_kernel<8>, dim3(rgrid), dim3(256), 4 * 512 * 8, stream, q_dev, r_dev, nlists, d, splits,
+        hipLaunchKernelGGL(knn_rescore_kernel<8>, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d, splits,
                            k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part);
     else
-        hipLaunchKernelGGL(knn_rescore_kernel<16>, dim3(rgrid), dim3(256), 4 * 1024 * 8, stream, q_dev, r_dev, nlists, d,
+        hipLaunchKernelGGL(knn_rescore_kernel<16>, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d,
                            splits, k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part);
     VSC_CHECK_LAUNCH();
     knn_mark(3, stream);
