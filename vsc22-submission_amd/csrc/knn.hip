@@ -722,6 +722,8 @@ struct SweepArgs {
     unsigned long long *cand;    // [nq * splits][KEEP]
     int *ncand;                  // [nq * splits]
     int *fallback;               // [1 + nqb]: [0] any, [1 + qb] this query block must be redone on the exact sweep
+    int abl;                     // diagnostic (VSC_KNN_ABL): 1 = skip the filter, 2 = skip the appends (timing only; results invalid), 8 = count
+    unsigned long long *dbg;     // [4] appends, compaction rounds, lists compacted, filter bodies entered (abl & 8)
 };
 
 // stats (queries): [n][4] = (|x|, |bf16 x|, |x - bf16 x|, 0); max_bits (refs): [0] max |x|, [1] max |x - bf16 x| as float bits
@@ -778,12 +780,12 @@ __device__ __forceinline__ int compact_band(const unsigned long long *list, int 
     unsigned thr_u = 0u;
     if (n >= k) {
         unsigned pfx = 0u;   // largest v with #(u >= v) >= k == the k-th largest u
-        for (int b = 31; b >= 0; --b) {
+        for (int b = 31; b >= 0; --b) {   // counting on the scalar unit: one ballot + popcount per register row
             const unsigned trial = pfx | (1u << b);
             int c = 0;
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) c += (lane + 64 * i < n && u[i] >= trial) ? 1 : 0;
-            if (wave_sum_int(c) >= k) pfx = trial;
+            for (int i = 0; i < EPL; ++i) c += __popcll(__ballot(lane + 64 * i < n && u[i] >= trial));
+            if (c >= k) pfx = trial;
         }
         thr = key_score((unsigned long long)pfx << 32) - eps2;
         unsigned t = __float_as_uint(thr);
@@ -802,9 +804,9 @@ __device__ __forceinline__ int compact_band(const unsigned long long *list, int 
     return base;
 }
 
-template <int EPL>
+template <int EPL, bool STREAM>
 __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
-    constexpr int CAP = 64 * EPL, KEEP = CAP / 2;
+    constexpr int CAP = 64 * EPL, KEEP = CAP / 2, TRIG = CAP - 2 * SR;
     extern __shared__ __attribute__((aligned(16))) char lds[];   // ONE shared array: ring, then the per-query slots
     int *cnt_s = (int *)(lds + ml64::RING_BYTES);
     float *thr_s = (float *)(lds + ml64::RING_BYTES + 1024);
@@ -834,10 +836,26 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
             }
             eps_s[tid] = e2;
         }
-        if (tid == 0) *flag_s = 0;
+        if (tid < 3) flag_s[tid] = 0;
         __syncthreads();
 
         const int q_rows = (int)(p.nq - q0 < SQ ? p.nq - q0 : SQ);
+        // One LDS-DMA stream over all reference tiles of this split: the K-tile sequence (ref tile, k) is walked
+        // without a prologue per tile -- while a tile is filtered the first units of the next one are already landing.
+        // Needs a power-of-two number (>= 2) of K-tiles per row (dp = 128, 256, 512, ...); otherwise tile by tile.
+        const int nkt = p.dp / 64;
+        constexpr bool stream = STREAM;   // chosen by the launcher (launch_sweep)
+        const int64_t split_rows = (t_end * SR < p.nr ? t_end * SR : p.nr) - t_begin * SR;
+        ml64::Ctx c;
+        ml64::Frags fr;
+        const int ntl = (int)(t_end - t_begin);
+        if (stream) {
+            ml64::init(c, p.qb + q0 * p.dp, p.dp, q_rows, p.rb + t_begin * SR * p.dp, p.dp, (int)split_rows, lds, wave, lane);
+            c.kt_shift = __builtin_ctz(nkt);
+            c.kt_mask = nkt - 1;
+            c.w_tile_stride = (uint32_t)(SR * p.dp * 2);
+            ml64::prologue(c, ntl * nkt);
+        }
         for (int64_t rt = t_begin; rt < t_end; ++rt) {
             const int64_t r0 = rt * SR;
             const int r_rows = (int)(p.nr - r0 < SR ? p.nr - r0 : SR);
@@ -846,55 +864,124 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            ml64::Ctx c;
-            ml64::init(c, p.qb + q0 * p.dp, p.dp, q_rows, p.rb + r0 * p.dp, p.dp, r_rows, lds, wave, lane);
-            ml64::run(c, acc, p.dp / 64);
+            if (stream) {
+                ml64::tiles(c, acc, fr, (int)(rt - t_begin) * nkt, nkt, ntl * nkt);
+            } else {
+                ml64::init(c, p.qb + q0 * p.dp, p.dp, q_rows, p.rb + r0 * p.dp, p.dp, r_rows, lds, wave, lane);
+                ml64::run(c, acc, nkt);
+            }
 
             // ---- filter.  acc[i][j][x] = s~(query q0 + wm*128 + i*16 + (lane & 15), ref r0 + wn*64 + j*16 + (lane >> 4)*4 + x)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int ql = wm * 128 + i * 16 + (lane & 15);
-                const float thr = thr_s[ql];
-                float best = acc[i][0][0];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) best = fmaxf(best, acc[i][j][x]);
-                if (!(best >= thr) || ql >= q_rows) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        const float sc = acc[i][j][x];
-                        const int rl = wn * 64 + j * 16 + (lane >> 4) * 4 + x;
-                        if (sc >= thr && rl < r_rows) {
-                            const int pos = atomicAdd(&cnt_s[ql], 1);
-                            if (pos < CAP) mylists[(size_t)ql * CAP + pos] = make_key(sc, (unsigned)(r0 + rl));
+            // Lists that are getting full are compacted here, one tile late: an append at position >= TRIG raises
+            // flag[tile % 3], which every wave reads at the start of the NEXT tile's filter (stable by then: all appends
+            // of the raising tile precede the barrier that closed this tile's K loop), so the common path has no
+            // barrier of its own.  A list holds at most TRIG - 1 + SR < CAP keys when it is compacted.
+            {
+                const int tl = (int)(rt - t_begin);
+                const int fprev = (tl + 2) % 3, fcur = tl % 3, fnext = (tl + 1) % 3;
+                if (tid == 0) flag_s[fnext] = 0;   // last read one tile ago, next written one tile from now
+                if (tl > 0 && flag_s[fprev]) {
+                    // A round stalls the whole workgroup, so it takes every list that is at least half-way to the
+                    // trigger with it: the lists of a block fill at similar rates, and rounds become ~10 per split
+                    // instead of one per list and compaction.
+                    if ((p.abl & 8) && tid == 0) atomicAdd(p.dbg + 1, 1ull);
+                    for (int ql = wave * 32; ql < wave * 32 + 32; ++ql) {
+                        const int n = cnt_s[ql];
+                        if (n >= TRIG / 2 && n >= p.k) {
+                            if ((p.abl & 8) && lane == 0) atomicAdd(p.dbg + 2, 1ull);
+                            unsigned long long *l = mylists + (size_t)ql * CAP;
+                            float thr;
+                            const int kept = compact_band<EPL>(l, n < CAP ? n : CAP, p.k, eps_s[ql], l, CAP, &thr, lane);
+                            if (lane == 0) {
+                                cnt_s[ql] = kept;
+                                thr_s[ql] = thr;
+                                if (kept + SR > CAP || n > CAP) p.fallback[0] = p.fallback[1 + qb] = 1;   // the band does not fit: exact sweep
+                            }
                         }
                     }
-            }
-            __syncthreads();
-            if (tid < SQ && cnt_s[tid] + SR > CAP) *flag_s = 1;
-            __syncthreads();
-            if (*flag_s) {
-                for (int ql = wave * 32; ql < wave * 32 + 32; ++ql) {
-                    const int n = cnt_s[ql];
-                    if (n + SR > CAP) {
-                        unsigned long long *l = mylists + (size_t)ql * CAP;
-                        float thr;
-                        const int kept = compact_band<EPL>(l, n < CAP ? n : CAP, p.k, eps_s[ql], l, CAP, &thr, lane);
-                        if (lane == 0) {
-                            cnt_s[ql] = kept;
-                            thr_s[ql] = thr;
-                            if (kept + SR > CAP || n > CAP) p.fallback[0] = p.fallback[1 + qb] = 1;   // the band does not fit: exact sweep
+                    __syncthreads();
+                }
+                if (!(p.abl & 1)) {
+                    // Everything per-lane below derives from an opaque copy of the lane id: otherwise the compiler hoists
+                    // the eight list pointers / counter addresses out of the tile loop, spills them around the K loop
+                    // (256 VGPRs are in use there) and reloads them here -- and a scratch reload is a vmcnt(0) wait, i.e.
+                    // a stall until every LDS-DMA unit in flight for the next tile has landed.
+                    int lv = lane;
+                    asm volatile("" : "+v"(lv));
+                    const unsigned l15 = lv & 15, lq = lv >> 4;
+                    // (1) hit masks of this lane's 8 queries x 16 scores; the 16 compares of a query run only when some lane
+                    //     of the wave has a score above its threshold (wave-uniform branch)
+                    unsigned mask[8];
+                    bool any_hit = false;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int ql = wm * 128 + i * 16 + l15;
+                        const float thr = thr_s[ql];
+                        float best = acc[i][0][0];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int x = 0; x < 4; ++x) best = fmaxf(best, acc[i][j][x]);
+                        mask[i] = 0;
+                        if (__any(best >= thr && ql < q_rows)) {
+                            unsigned m = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int x = 0; x < 4; ++x) {
+                                    const int rl = wn * 64 + j * 16 + (int)lq * 4 + x;
+                                    m |= (acc[i][j][x] >= thr && rl < r_rows) ? 1u << (j * 4 + x) : 0u;
+                                }
+                            mask[i] = ql < q_rows ? m : 0u;
+                            any_hit = true;
+                        }
+                    }
+                    if (any_hit && !(p.abl & 2)) {
+                        // (2) ALL counter updates of the tile back to back (a lane without hits adds 0), one wait: an LDS
+                        //     atomic round trip per query in sequence was most of the filter's time.  Inline asm: for the
+                        //     builtin the compiler cannot tell these addresses from the ring the LDS-DMA is writing and
+                        //     puts s_waitcnt vmcnt(0) in front of every one.
+                        int base[8];
+                        {
+                            typedef __attribute__((address_space(3))) int *lds_int_t;
+                            const unsigned a0 = (unsigned)(uintptr_t)(lds_int_t)(cnt_s + wm * 128 + l15);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const unsigned inc = __popc(mask[i]);
+                                asm volatile("ds_add_rtn_u32 %0, %1, %2 offset:%3" : "=v"(base[i]) : "v"(a0), "v"(inc), "n"(i * 64) : "memory");
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(base[0]), "+v"(base[1]), "+v"(base[2]), "+v"(base[3]), "+v"(base[4]), "+v"(base[5]),
+                                           "+v"(base[6]), "+v"(base[7])
+                                         :
+                                         : "memory");
+                        }
+                        // (3) the keys
+                        const unsigned ref0 = (unsigned)r0 + wn * 64 + lq * 4;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            if (!__any(mask[i] != 0)) continue;
+                            const int ql = wm * 128 + i * 16 + l15;
+                            const unsigned cntm = __popc(mask[i]);
+                            if (mask[i] && base[i] + (int)cntm >= TRIG) flag_s[fcur] = 1;
+                            if ((p.abl & 8) && mask[i]) atomicAdd(p.dbg, (unsigned long long)cntm);
+                            const unsigned slot0 = (unsigned)ql * CAP + (unsigned)base[i];   // 32-bit offset from the uniform list base
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int x = 0; x < 4; ++x) {
+                                    const int bit = j * 4 + x;
+                                    const unsigned rank = __popc(mask[i] & ((1u << bit) - 1u));
+                                    if ((mask[i] >> bit & 1u) && base[i] + (int)rank < CAP && !(p.abl & 4))
+                                        mylists[slot0 + rank] = make_key(acc[i][j][x], ref0 + j * 16 + x);
+                                }
                         }
                     }
                 }
-                __syncthreads();
-                if (tid == 0) *flag_s = 0;
-                __syncthreads();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // counter / flag updates are in LDS before this wave's next barrier
             }
         }
+        __syncthreads();   // the last tile's appends
 
         // ---- emit the band of every list of this (query block, split)
         for (int ql = wave * 32; ql < wave * 32 + 32; ++ql) {
@@ -1152,14 +1239,20 @@ static int knn_exact(const float *q_dev, int64_t nq, const float *r_dev, int64_t
     return VSC_OK;
 }
 
-template <int EPL>
-static int launch_sweep(const SweepArgs &a, int grid, hipStream_t stream) {
+template <int EPL, bool STREAM>
+static int launch_sweep_t(const SweepArgs &a, int grid, hipStream_t stream) {
     constexpr int smem = ml64::RING_BYTES + 4096;
-    auto kern = knn_sweep_bf16_kernel<EPL>;
+    auto kern = knn_sweep_bf16_kernel<EPL, STREAM>;
     VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
+}
+template <int EPL>
+static int launch_sweep(const SweepArgs &a, int grid, hipStream_t stream) {
+    const int nkt = a.dp / 64;
+    const bool streamed = nkt >= 2 && (nkt & (nkt - 1)) == 0;   // one LDS-DMA stream over the split (see the kernel)
+    return streamed ? launch_sweep_t<EPL, true>(a, grid, stream) : launch_sweep_t<EPL, false>(a, grid, stream);
 }
 
 // bf16 pre-filter sweep + exact re-scoring.  Query blocks (256 queries) whose candidate bands did not fit, or whose
@@ -1176,7 +1269,9 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     if (want > 256) want = 256;
     if (want > total_tiles) want = total_tiles;
     if (want < 1) want = 1;
-    const int64_t tiles_per_split = (total_tiles + want - 1) / want;
+    int64_t tiles_per_split = (total_tiles + want - 1) / want;
+    const int64_t max_tiles = ((1ll << 31) - 1) / ((int64_t)SR * dp * 2);   // a split is one buffer descriptor (32-bit extent)
+    if (tiles_per_split > max_tiles) tiles_per_split = max_tiles;
     const int splits = (int)((total_tiles + tiles_per_split - 1) / tiles_per_split);
     const int64_t work = (int64_t)nqb * splits;
     const int grid = (int)(work < 256 ? work : 256);
@@ -1184,7 +1279,7 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
 
     void *qb, *rb, *qstats, *flags, *lists, *cand, *ncand, *part;
     int rc;
-    const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4;   // [0..1] max |r|, max |dr| bits; [4..] fallback flags
+    const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 32;   // [0..1] max |r|, max |dr| bits; [4..] fallback flags; debug counters behind them
     if ((rc = scratch_get(12, (size_t)nq * dp * 2, &qb))) return rc;
     if ((rc = scratch_get(13, (size_t)nr * dp * 2, &rb))) return rc;
     if ((rc = scratch_get(14, (size_t)nq * 16, &qstats))) return rc;
@@ -1207,7 +1302,9 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     const float cd = (float)d * (2.384185791015625e-7f + 5.9604644775390625e-8f);   // d (2^-22 + 2^-24)
     SweepArgs a{(const uint16_t *)qb, (const uint16_t *)rb, (const float *)qstats, (const unsigned *)flags, nq, nr, dp, k, nqb,
                 splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
-                (int *)ncand, fb_dev};
+                (int *)ncand, fb_dev, 0, nullptr};
+    a.dbg = (unsigned long long *)(((uintptr_t)(fb_dev + 1 + nqb) + 7) & ~(uintptr_t)7);
+    if (const char *e = getenv("VSC_KNN_ABL")) a.abl = atoi(e);
     if ((rc = epl == 16 ? launch_sweep<16>(a, grid, stream) : launch_sweep<32>(a, grid, stream))) return rc;
     knn_mark(2, stream);
     const unsigned rgrid = (unsigned)((nlists + 3) / 4);
@@ -1230,6 +1327,12 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     VSC_CHECK_HIP(hipMemcpyAsync(fb.data(), fb_dev, fb.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
     VSC_CHECK_HIP(hipStreamSynchronize(stream));
     *fell_back = 0;
+    if (a.abl & 8) {
+        unsigned long long h[4];
+        VSC_CHECK_HIP(hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "knn sweep counters: appends %llu (%.1f per query and split), compaction rounds %llu, lists compacted %llu, filter bodies entered %llu\n",
+                h[0], (double)h[0] / (double)nlists, h[1], h[2], h[3]);
+    }
     if (!fb[0]) return VSC_OK;
     // redo the flagged query blocks (contiguous rows in, contiguous rows out) on the exact sweep, runs of blocks at a time
     for (int b = 0; b < nqb;) {

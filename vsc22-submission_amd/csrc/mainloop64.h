@@ -52,6 +52,12 @@ struct Ctx {
     uint32_t rd_a;         // LDS byte offset of this lane's A fragment chunk (kh = 0) inside its unit: wm * 8192 + lane part
     uint32_t rd_w;         // same for W: wn * 4096 + lane part
     int wave;
+    // K-tile index t -> source offsets.  One tile pair (GEMM): A and W both advance 128 bytes per K-tile.  Stream
+    // (similarity sweep): t = (W tile index << kt_shift) | k-tile inside it; A restarts with every W tile, W moves on by
+    // w_tile_stride bytes (256 rows).
+    int kt_shift = 31;
+    uint32_t kt_mask = 0x7fffffffu;
+    uint32_t w_tile_stride = 0;
 };
 
 // a_rows / w_rows: rows of the tile that exist (>= 1).  Rows past the edge are outside the buffer descriptor's
@@ -85,9 +91,10 @@ __device__ __forceinline__ void stage_unit(const Ctx &c, int slot, int ktile) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const uint32_t off = KIND == 0 ? c.a_off[HALF][jj] : c.w_off[HALF][jj];
+        const uint32_t soff = ((uint32_t)ktile & c.kt_mask) * 128u + (KIND == 0 ? 0u : ((uint32_t)ktile >> c.kt_shift) * c.w_tile_stride);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(KIND == 0 ? c.a_rsrc : c.w_rsrc,
                                                  (lptr_t)(c.lds + slot * UNIT_BYTES + (c.wave + 8 * jj) * 1024), 16, off,
-                                                 ktile * 128, 0, 0);
+                                                 soff, 0, 0);
     }
 }
 
@@ -174,10 +181,8 @@ __device__ __forceinline__ void ktile(const Ctx &c, f32x4_t (&acc)[8][4], Frags 
     end_c();
 }
 
-// acc += A_tile . W_tile^T over nk K-tiles of 64.  Ends with every wave past its last fragment read and every
-// DMA landed (one extra barrier for the leading group), so the ring may be reused at once.
-__device__ __forceinline__ void run(const Ctx &c, f32x4_t (&acc)[8][4], int nk) {
-    // prologue: units 0..5 (tile 0 whole, tile 1 j = 0, 1)
+// staging of units 0..5 (tile 0 whole, tile 1 j = 0, 1), wait for the first two, workgroup barrier
+__device__ __forceinline__ void prologue(const Ctx &c, int nk) {
     stage_unit<1, 0>(c, 0, 0);
     stage_unit<0, 0>(c, 1, 0);
     stage_unit<1, 1>(c, 2, 0);
@@ -190,20 +195,34 @@ __device__ __forceinline__ void run(const Ctx &c, f32x4_t (&acc)[8][4], int nk) 
         wait_vmcnt<4>();
     }
     __builtin_amdgcn_s_barrier();
+}
+
+// K-tiles [t0, t0 + n) of a sequence of `total` (t0 even).  Opens with the stagger barrier of waves 4-7 and closes with
+// the matching barrier of waves 0-3, so on return every wave is past its last fragment read of these tiles; LDS-DMA
+// for the tiles behind them (if any) stays in flight.
+__device__ __forceinline__ void tiles(const Ctx &c, f32x4_t (&acc)[8][4], Frags &f, int t0, int n, int total) {
     const int group = c.wave >> 2;
     if (group == 1) __builtin_amdgcn_s_barrier();   // stagger: waves 4-7 run one segment behind
     __builtin_amdgcn_sched_barrier(0);
-    Frags f;
-    int t = 0;
-    for (; t + 4 <= nk; t += 2) {   // both tiles have at least two more behind them
+    int t = t0;
+    const int end = t0 + n;
+    for (; t + 2 <= end && t + 4 <= total; t += 2) {   // both tiles have at least two more behind them
         ktile<0, true>(c, acc, f, t, 0);
         ktile<1, true>(c, acc, f, t + 1, 0);
     }
-    for (; t < nk; t += 2) {        // the last 1..3 tiles: staging stops, the waits drain
-        ktile<0, false>(c, acc, f, t, nk - t);
-        if (t + 1 < nk) ktile<1, false>(c, acc, f, t + 1, nk - t - 1);
+    for (; t < end; t += 2) {                          // the last 1..3 tiles of the sequence: staging stops, the waits drain
+        ktile<0, false>(c, acc, f, t, total - t);
+        if (t + 1 < end) ktile<1, false>(c, acc, f, t + 1, total - t - 1);
     }
     if (group == 0) __builtin_amdgcn_s_barrier();
+}
+
+// acc += A_tile . W_tile^T over nk K-tiles of 64.  Ends with every wave past its last fragment read and every
+// DMA landed, so the ring may be reused at once.
+__device__ __forceinline__ void run(const Ctx &c, f32x4_t (&acc)[8][4], int nk) {
+    prologue(c, nk);
+    Frags f;
+    tiles(c, acc, f, 0, nk, nk);
 }
 
 }  // namespace ml64
