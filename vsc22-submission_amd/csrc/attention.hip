@@ -17,6 +17,10 @@
 //     that MFMA is permuted to match (slot (g,j<4) = key 32u+4g+j, slot (g,j>=4) = key
 //     32u+16+4g+j-4), which only changes WHICH V elements a lane loads.
 //   * O^T puts 4 consecutive head-dim columns of one query in a lane: 8-byte bf16 stores.
+//   * waves per workgroup: measured again in round 2 with one wave per query tile (13 waves for 197 tokens, all chains
+//     side by side): 139 us per launch against 121 with these 8 waves, and a runtime tile loop with fewer waves is slower
+//     too (tools/micro/attn_bench.py).  The launch moves 392 MB (qkv in, context out): ~71 us at HBM speed, so the kernel
+//     sits at 1.7 x its memory floor; what is left is the K / V staging of the second resident workgroup.
 //   * softmax runs in fp32 with exp2 and a folded scale (1/8 * log2 e); probabilities are
 //     rounded to bf16 for the PV MFMA, the row sum is kept in fp32 from the unrounded values.
 #include "common.h"
@@ -192,11 +196,13 @@ int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int he
               hipStream_t stream) {
     constexpr int TP = KT * 32;
     constexpr int smem = TP * 128 + 64 * (TP * 2 + 8);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {};   // per device (one process may drive several)
+    int dev = 0;
+    VSC_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 16 || !attr_set[dev]) {
         VSC_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel<KT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        if (dev < 16) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(attention_kernel<KT>, dim3(frames * heads), dim3(512), smem, stream, qkv, out,
                        tokens, heads);

@@ -732,10 +732,12 @@ int launch_v2(GemmArgs p, hipStream_t stream) {
     constexpr int ring = STAGES * (BM2 + BN2) * 64;
     constexpr int smem = ring > NW * 16384 ? ring : NW * 16384;
     auto kern = gemm_bf16_v2_kernel<EPI, WAVES_M, WAVES_N, TM, TN, STAGES>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {};   // per device
+    int dev = 0;
+    VSC_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
         VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     p.tiles_m = (int)((p.m + BM2 - 1) / BM2);
     p.tiles_n = (p.n + BN2 - 1) / BN2;
@@ -1054,10 +1056,12 @@ int launch_ln_t(const GemmLnArgs &p, hipStream_t stream) {
     constexpr int ring = STAGES * (WAVES_M * 64 + WAVES_N * 128) * 64;
     constexpr int smem = ring > 8 * 16384 + 8192 ? ring : 8 * 16384 + 8192;
     auto kern = gemm_ln_kernel<WAVES_M, WAVES_N, STAGES>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {};   // per device
+    int dev = 0;
+    VSC_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
         VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     const int64_t blocks = (p.m + WAVES_M * 64 - 1) / (WAVES_M * 64);
     VSC_REQUIRE(blocks < (1ll << 31), "gemm_ln: grid too large");
