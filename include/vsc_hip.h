@@ -285,6 +285,38 @@ int vsc_merge_gather_bf16(const uint16_t *xb_dev, uint16_t *out_dev, int64_t fra
 /* Measurement aid: one wave spins for `ticks` shader cycles (s_memtime) and stores the elapsed count. */
 int vsc_debug_spin_ticks(uint64_t ticks, uint64_t *out_dev, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Matching track: the fp32 convolution layers of the pair classifier (timm mobilenetv3_small_100) and the refinement
+ * net (timm hrnet_w18 features + 1x1 fuse head) that the reference runs as TorchScript modules on similarity maps
+ *   VSC22-Matching-Track-1st/infer/infer_matching.py:158-175 (match_classify), :177-204 (match_refine),
+ *   train/models.py:6-40 (ClassifyModel, HRnet).
+ * Activations are NHWC float32; BatchNorm is folded into weight / bias by the host (vsc_hip/cnn.py).
+ * ------------------------------------------------------------------------ */
+enum { VSC_ACT_NONE = 0, VSC_ACT_RELU = 1, VSC_ACT_HARDSWISH = 2, VSC_ACT_HARDSIGMOID = 3 };
+
+/* floats per packed weight row: cin * kh * kw rounded up to a multiple of 32 */
+int vsc_conv_packed_k(int32_t cin, int32_t kh, int32_t kw);
+/* w_dev [cout, k] float32 with k = (kh, kw, cin) order (torch's [cout, cin, kh, kw] permuted to [cout, kh, kw, cin]) ->
+ * packed_dev [cout, vsc_conv_packed_k] in the operand layout of the fp32 MFMA tiles; done once per layer. */
+int vsc_conv_pack_weight_f32(const float *w_dev, float *packed_dev, int32_t cout, int32_t k, void *stream);
+/* out[n, ho, wo, 0:cout] (row stride ldo) = act(conv2d(x[n, h, w, 0:cin] (row stride ldx), W) + bias [+ res[.., 0:cout]
+ * (row stride ldr)]) -- torch.nn.functional.conv2d(stride, padding) + the fused tail of a BN/ReLU/residual block. */
+int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t w, int32_t cin, int32_t ldx, const float *w_packed_dev,
+                   const float *bias_dev, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                   const float *res_dev, int32_t ldr, int32_t act, float *out_dev, int32_t ldo, void *stream);
+/* depthwise convolution: w_dev [c, kh * kw], x / out dense NHWC */
+int vsc_dwconv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t w, int32_t c, const float *w_dev,
+                     const float *bias_dev, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t act,
+                     float *out_dev, void *stream);
+/* out[n, c] = mean over the hw positions of x[n, hw, c] (AdaptiveAvgPool2d(1)) */
+int vsc_global_avgpool_f32(const float *x_dev, int64_t n, int32_t hw, int32_t c, float *out_dev, void *stream);
+/* x[n, hw, c] *= scale[n, c] (squeeze-excite gate) */
+int vsc_channel_scale_f32(float *x_dev, const float *scale_dev, int64_t n, int32_t hw, int32_t c, void *stream);
+/* out[n, y, x, coff + ch] = act((accumulate ? out : 0) + src[n, y / factor, x / factor, ch]) for the h x w output grid:
+ * nn.Upsample(scale_factor, 'nearest') fused with the sum of an HRNet fuse layer or with torch.cat along channels. */
+int vsc_upsample_add_f32(const float *src_dev, int64_t n, int32_t h, int32_t w, int32_t c, int32_t factor, float *out_dev,
+                         int32_t ldo, int32_t coff, int32_t accumulate, int32_t act, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

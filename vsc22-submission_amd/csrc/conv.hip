@@ -1,0 +1,298 @@
+// fp32 convolution building blocks of the matching track's networks: the MobileNetV3 pair classifier and the HRNet
+// refinement net that score / localise copies on frame x frame similarity maps
+// (VSC22-Matching-Track-1st/infer/infer_matching.py:158-204 match_classify / match_refine; train/models.py:6-40).
+// The reference runs them as TorchScript fp32 modules; here every layer is one of
+//
+//   vsc_conv2d_f32        dense convolution (any kernel / stride / padding), BatchNorm folded into weight + bias on the
+//                         host, optional residual and activation fused:  out = act(conv(x) + bias [+ residual])
+//   vsc_dwconv2d_f32      depthwise convolution + bias + activation
+//   vsc_global_avgpool_f32, vsc_channel_scale_f32 (squeeze-excite gate), vsc_upsample_add_f32 (HRNet fuse / concat)
+//
+// Activations are NHWC float32 (a pixel's channels are contiguous: a convolution is a GEMM whose rows are pixels).
+//
+// CDNA4 mapping of the dense convolution: implicit GEMM on the EXACT fp32 matrix pipe.  out[pixel, co] = sum_k
+// patch[pixel, k] w[co, k], k = (kh, kw, ci).  An im2col pass writes the patches straight into the packed operand layout
+// of f32_tile.h (rows padded to 32 floats, k-interleaved) and the product runs on the 128 x 128 v_mfma_f32_32x32x2_f32
+// tiles of the similarity sweep (157 TF/s peak, ascending-k fmaf chains: results match a float32 reference to rounding
+// of the summation order, ~1e-6, where a bf16 pipeline through ~60 layers would not hold the 1e-3 of the probability maps).
+// The weights are the MFMA row operand and the pixels the column operand, so a lane owns one pixel and 4 consecutive
+// output channels per register group: 16-byte stores along the channel axis.
+#include "common.h"
+#include "f32_tile.h"
+
+namespace {
+
+using namespace f32tile;
+
+__device__ __forceinline__ float activate(float v, int act) {
+    switch (act) {
+        case VSC_ACT_RELU: return fmaxf(v, 0.f);
+        case VSC_ACT_HARDSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.0f / 6.0f);
+        case VSC_ACT_HARDSIGMOID: return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.0f / 6.0f);
+        default: return v;
+    }
+}
+
+// patches of x [n, h, w, ldx >= c] -> packed [n * ho * wo, kpad], k = (i * kw + j) * c + ci, zero outside the image
+__global__ __launch_bounds__(256) void im2col_pack_kernel(const float *__restrict__ x, float *__restrict__ dst, int64_t rows,
+                                                          int h, int w, int c, int ldx, int kh, int kw, int stride, int pad,
+                                                          int ho, int wo, int k, int kpad) {
+    const int64_t total = rows * (kpad >> 2);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / (kpad >> 2);
+        const int c4 = (int)(e - row * (kpad >> 2));
+        const int base = (c4 >> 1) * 8, half = c4 & 1;
+        const int ox = (int)(row % wo);
+        const int64_t t = row / wo;
+        const int oy = (int)(t % ho);
+        const int64_t img = t / ho;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = base + 2 * u + half;
+            float val = 0.f;
+            if (kk < k) {
+                const int ci = kk % c, ij = kk / c;
+                const int j = ij % kw, i = ij / kw;
+                const int iy = oy * stride + i - pad, ix = ox * stride + j - pad;
+                if (iy >= 0 && iy < h && ix >= 0 && ix < w) val = x[((img * h + iy) * w + ix) * ldx + ci];
+            }
+            v[u] = val;
+        }
+        *(float4 *)(dst + row * kpad + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+struct ConvGemmArgs {
+    const float *wp;     // packed weights [cout, kpad]
+    const float *ap;     // packed patches [rows, kpad]
+    const float *bias;   // [cout] or null
+    const float *res;    // residual [rows, ldr] or null
+    float *out;          // [rows, ldo]
+    int64_t rows;
+    int cout, kpad, ldo, ldr, act, tiles_c;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int64_t tile = blockIdx.x;
+    const int tc = (int)(tile % p.tiles_c);
+    const int64_t tp = tile / p.tiles_c;
+    const int64_t c0 = (int64_t)tc * TR, p0 = tp * TQ;
+    f32x16_t acc[2][2];
+    int cur = 0;
+    score_tile(acc, p.wp, p.ap, p.cout, p.rows, p.kpad, c0, -1, p0, lds, wave, lane, cur, false);
+    // acc[a][b][reg] = <w[c0 + wm*64 + a*32 + 8*(reg>>2) + 4*hi + (reg&3)], patch[p0 + wn*64 + b*32 + l31]>
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t pix = p0 + wn * 64 + b * 32 + l31;
+        if (pix >= p.rows) continue;
+        float *orow = p.out + pix * p.ldo;
+        const float *rrow = p.res ? p.res + pix * p.ldr : nullptr;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = (int)c0 + wm * 64 + a * 32 + 8 * g + 4 * hi;
+                if (co >= p.cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[a][b][4 * g + r];
+                    if (co + r < p.cout) {
+                        if (p.bias) v[r] += p.bias[co + r];
+                        if (rrow) v[r] += rrow[co + r];
+                        v[r] = activate(v[r], p.act);
+                    }
+                }
+                if (co + 3 < p.cout && ((p.ldo | co) & 3) == 0) {
+                    *(float4 *)(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.cout) orow[co + r] = v[r];
+                }
+            }
+    }
+}
+
+// depthwise: one thread per (pixel, channel); w [c, kh * kw]
+__global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
+                                                     const float *__restrict__ bias, float *__restrict__ out, int64_t total,
+                                                     int h, int w, int c, int kh, int kw, int stride, int pad, int ho, int wo,
+                                                     int act) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(e % c);
+        int64_t t = e / c;
+        const int ox = (int)(t % wo);
+        t /= wo;
+        const int oy = (int)(t % ho);
+        const int64_t img = t / ho;
+        float a = 0.f;
+        for (int i = 0; i < kh; ++i) {
+            const int iy = oy * stride + i - pad;
+            if (iy < 0 || iy >= h) continue;
+            for (int j = 0; j < kw; ++j) {
+                const int ix = ox * stride + j - pad;
+                if (ix < 0 || ix >= w) continue;
+                a = fmaf(x[((img * h + iy) * w + ix) * c + ch], wgt[ch * kh * kw + i * kw + j], a);
+            }
+        }
+        if (bias) a += bias[ch];
+        out[e] = activate(a, act);
+    }
+}
+
+// x [n, hw, c] -> out [n, c] (mean over hw); one workgroup per (image, 64-channel slab)
+__global__ __launch_bounds__(256) void avgpool_kernel(const float *__restrict__ x, float *__restrict__ out, int hw, int c) {
+    __shared__ float part[4][64];
+    const int img = blockIdx.y, c0 = blockIdx.x * 64, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c0 + lane < c)
+        for (int i = wv; i < hw; i += 4) s += x[((int64_t)img * hw + i) * c + c0 + lane];
+    part[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && c0 + lane < c)
+        out[(int64_t)img * c + c0 + lane] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / (float)hw;
+}
+
+// x [n, hw, c] *= s [n, c]
+__global__ __launch_bounds__(256) void channel_scale_kernel(float *__restrict__ x, const float *__restrict__ s, int64_t total,
+                                                            int hw, int c) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(e % c);
+        const int64_t img = e / ((int64_t)hw * c);
+        x[e] *= s[img * c + ch];
+    }
+}
+
+// out[n, y, x, coff + ch] (op)= src[n, y / f, x / f, ch]   (nearest upsample by f >= 1); accumulate ? += : =; then act
+__global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restrict__ src, float *__restrict__ out, int64_t total,
+                                                           int h, int w, int c, int f, int ldo, int coff, int accumulate, int act) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(e % c);
+        int64_t t = e / c;
+        const int ox = (int)(t % w);
+        t /= w;
+        const int oy = (int)(t % h);
+        const int64_t img = t / h;
+        const float v = src[((img * (h / f) + oy / f) * (w / f) + ox / f) * c + ch];
+        float *o = out + ((img * h + oy) * w + ox) * ldo + coff + ch;
+        *o = activate(accumulate ? *o + v : v, act);
+    }
+}
+
+struct Scratch {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+Scratch g_patch[16];   // per device, grow-only: the packed patch matrix of the convolution in flight
+
+inline int blocks_for(int64_t items) {
+    int64_t b = (items + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
+}
+
+}  // namespace
+
+extern "C" int vsc_conv_packed_k(int32_t cin, int32_t kh, int32_t kw) { return (cin * kh * kw + KS - 1) / KS * KS; }
+
+extern "C" int vsc_conv_pack_weight_f32(const float *w_dev, float *packed_dev, int32_t cout, int32_t k, void *stream_) {
+    VSC_REQUIRE(w_dev && packed_dev && cout > 0 && k > 0, "conv_pack_weight: bad arguments");
+    const int kpad = (k + KS - 1) / KS * KS;
+    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for((int64_t)cout * (kpad / 4))), dim3(256), 0, (hipStream_t)stream_, w_dev,
+                       packed_dev, (int64_t)cout, k, kpad);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t w, int32_t cin, int32_t ldx,
+                              const float *w_packed_dev, const float *bias_dev, int32_t cout, int32_t kh, int32_t kw,
+                              int32_t stride, int32_t pad, const float *res_dev, int32_t ldr, int32_t act, float *out_dev,
+                              int32_t ldo, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VSC_REQUIRE(x_dev && w_packed_dev && out_dev, "conv2d: null operand");
+    VSC_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "conv2d: bad shape");
+    VSC_REQUIRE(ldx >= cin && ldo >= cout && (!res_dev || ldr >= cout), "conv2d: leading dimensions smaller than the channel counts");
+    VSC_REQUIRE(act >= VSC_ACT_NONE && act <= VSC_ACT_HARDSIGMOID, "conv2d: unknown activation %d", act);
+    const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+    VSC_REQUIRE(ho > 0 && wo > 0, "conv2d: empty output");
+    const int64_t rows = n * ho * wo;
+    const int k = cin * kh * kw, kpad = (k + KS - 1) / KS * KS;
+    int dev = 0;
+    VSC_CHECK_HIP(hipGetDevice(&dev));
+    VSC_REQUIRE(dev >= 0 && dev < 16, "conv2d: device %d out of range", dev);
+    Scratch &s = g_patch[dev];
+    const size_t need = (size_t)rows * kpad * 4;
+    if (s.bytes < need) {
+        if (s.ptr) {
+            VSC_CHECK_HIP(hipDeviceSynchronize());
+            VSC_CHECK_HIP(hipFree(s.ptr));
+            s.ptr = nullptr;
+            s.bytes = 0;
+        }
+        hipError_t e = hipMalloc(&s.ptr, need);
+        if (e != hipSuccess) {
+            s.ptr = nullptr;
+            vsc_set_error("conv2d: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+            return VSC_ERR_NOMEM;
+        }
+        s.bytes = need;
+    }
+    hipLaunchKernelGGL(im2col_pack_kernel, dim3(blocks_for(rows * (kpad / 4))), dim3(256), 0, stream, x_dev, (float *)s.ptr, rows,
+                       h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k, kpad);
+    VSC_CHECK_LAUNCH();
+    const int tiles_c = (cout + TR - 1) / TR;
+    const int64_t tiles_p = (rows + TQ - 1) / TQ;
+    VSC_REQUIRE(tiles_p * tiles_c < (1ll << 31), "conv2d: grid too large");
+    ConvGemmArgs a{w_packed_dev, (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c};
+    hipLaunchKernelGGL(conv_gemm_kernel, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+extern "C" int vsc_dwconv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t w, int32_t c, const float *w_dev,
+                                const float *bias_dev, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t act,
+                                float *out_dev, void *stream_) {
+    VSC_REQUIRE(x_dev && w_dev && out_dev, "dwconv2d: null operand");
+    VSC_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "dwconv2d: bad shape");
+    VSC_REQUIRE(act >= VSC_ACT_NONE && act <= VSC_ACT_HARDSIGMOID, "dwconv2d: unknown activation %d", act);
+    const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
+    VSC_REQUIRE(ho > 0 && wo > 0, "dwconv2d: empty output");
+    const int64_t total = n * ho * wo * c;
+    hipLaunchKernelGGL(dwconv_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream_, x_dev, w_dev, bias_dev, out_dev,
+                       total, h, w, c, kh, kw, stride, pad, ho, wo, act);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+extern "C" int vsc_global_avgpool_f32(const float *x_dev, int64_t n, int32_t hw, int32_t c, float *out_dev, void *stream_) {
+    VSC_REQUIRE(x_dev && out_dev && n > 0 && n < 65536 && hw > 0 && c > 0, "global_avgpool: bad arguments");
+    hipLaunchKernelGGL(avgpool_kernel, dim3((c + 63) / 64, (unsigned)n), dim3(256), 0, (hipStream_t)stream_, x_dev, out_dev, hw, c);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+extern "C" int vsc_channel_scale_f32(float *x_dev, const float *scale_dev, int64_t n, int32_t hw, int32_t c, void *stream_) {
+    VSC_REQUIRE(x_dev && scale_dev && n > 0 && hw > 0 && c > 0, "channel_scale: bad arguments");
+    const int64_t total = n * hw * c;
+    hipLaunchKernelGGL(channel_scale_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream_, x_dev, scale_dev, total, hw, c);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+extern "C" int vsc_upsample_add_f32(const float *src_dev, int64_t n, int32_t h, int32_t w, int32_t c, int32_t factor,
+                                    float *out_dev, int32_t ldo, int32_t coff, int32_t accumulate, int32_t act, void *stream_) {
+    VSC_REQUIRE(src_dev && out_dev && n > 0 && h > 0 && w > 0 && c > 0 && factor >= 1, "upsample_add: bad arguments");
+    VSC_REQUIRE(h % factor == 0 && w % factor == 0, "upsample_add: %d x %d is not a multiple of the factor %d", h, w, factor);
+    VSC_REQUIRE(ldo >= coff + c && coff >= 0, "upsample_add: channel window outside the output row");
+    VSC_REQUIRE(act >= VSC_ACT_NONE && act <= VSC_ACT_HARDSIGMOID, "upsample_add: unknown activation %d", act);
+    const int64_t total = n * h * w * c;
+    hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream_, src_dev, out_dev, total, h,
+                       w, c, factor, ldo, coff, accumulate, act);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}

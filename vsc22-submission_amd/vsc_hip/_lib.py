@@ -82,6 +82,16 @@ SIGNATURES = {
     "vsc_debug_spin_ticks": (c_int32, [ctypes.c_uint64, c_void_p, c_void_p]),
     "vsc_knn_ip_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int64,
                                  c_void_p, c_void_p, c_void_p]),
+    "vsc_conv_packed_k": (c_int32, [c_int32, c_int32, c_int32]),
+    "vsc_conv_pack_weight_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "vsc_conv2d_f32": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32,
+                                 c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "vsc_dwconv2d_f32": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                   c_int32, c_int32, c_void_p, c_void_p]),
+    "vsc_global_avgpool_f32": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "vsc_channel_scale_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    "vsc_upsample_add_f32": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32,
+                                       c_int32, c_int32, c_void_p]),
     "vsc_knn_last_path": (c_int32, []),
     "vsc_knn_set_profiling": (None, [c_int32]),
     "vsc_knn_last_profile": (c_int32, [c_void_p]),

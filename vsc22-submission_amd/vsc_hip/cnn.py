@@ -1,0 +1,311 @@
+"""The matching track's two networks on the HIP path: the MobileNetV3 pair classifier and the HRNet refinement net
+(reference: VSC22-Matching-Track-1st/train/models.py:6-47, used by infer/infer_matching.py:158-204 as TorchScript modules).
+
+A model is built once from the reference's state dict (timm parameter names): every Conv+BatchNorm pair is folded into
+one weight / bias, permuted to (cout, kh, kw, cin) and packed for the fp32 MFMA tiles (vsc_conv_pack_weight_f32).  The
+forward pass is a sequence of C-ABI calls on NHWC float32 buffers -- vsc_conv2d_f32 (residual and activation fused),
+vsc_dwconv2d_f32, vsc_global_avgpool_f32, vsc_channel_scale_f32, vsc_upsample_add_f32.  torch provides device memory only.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr
+
+ACT = {None: 0, "none": 0, "relu": 1, "hard_swish": 2, "hard_sigmoid": 3}
+BN_EPS = 1e-5
+
+# timm `mobilenetv3_small_100`: per stage, per block (kind, stride, activation); channel counts, kernel sizes and
+# the presence of squeeze-excite are read off the state dict
+MBV3_SMALL = (
+    (("ds", 2, "relu"),),
+    (("ir", 2, "relu"), ("ir", 1, "relu")),
+    (("ir", 2, "hard_swish"), ("ir", 1, "hard_swish"), ("ir", 1, "hard_swish")),
+    (("ir", 1, "hard_swish"), ("ir", 1, "hard_swish")),
+    (("ir", 2, "hard_swish"), ("ir", 1, "hard_swish"), ("ir", 1, "hard_swish")),
+    (("cn", 1, "hard_swish"),),
+)
+HRNET_STAGES = ((2, 1, 2), (3, 4, 3), (4, 3, 4))   # (stage, modules, branches) of hrnet_w18; 4 BasicBlocks per branch
+HRNET_BLOCKS = 4
+
+
+def _np(t) -> np.ndarray:
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def _fold(sd: dict, conv: str, bn: str | None):
+    """(weight [co, ci/groups, kh, kw], bias [co]) with the BatchNorm that follows folded in (float64 arithmetic)."""
+    w = _np(sd[conv + ".weight"]).astype(np.float64)
+    b = _np(sd[conv + ".bias"]).astype(np.float64) if conv + ".bias" in sd else np.zeros(w.shape[0])
+    if bn is not None:
+        g, beta = _np(sd[bn + ".weight"]).astype(np.float64), _np(sd[bn + ".bias"]).astype(np.float64)
+        mu, var = _np(sd[bn + ".running_mean"]).astype(np.float64), _np(sd[bn + ".running_var"]).astype(np.float64)
+        s = g / np.sqrt(var + BN_EPS)
+        w = w * s[:, None, None, None]
+        b = (b - mu) * s + beta
+    return w.astype(np.float32), b.astype(np.float32)
+
+
+class Conv:
+    """One dense convolution: packed weight + bias on the device."""
+
+    def __init__(self, sd, conv, bn, stride=1, device="cuda"):
+        lib = _lib.require_device()
+        w, b = _fold(sd, conv, bn)
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        self.stride, self.pad = stride, self.kh // 2
+        k = self.cin * self.kh * self.kw
+        flat = torch.from_numpy(np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(self.cout, k)).to(device)
+        self.w = torch.empty((self.cout, lib.vsc_conv_packed_k(self.cin, self.kh, self.kw)), dtype=torch.float32, device=device)
+        check(lib.vsc_conv_pack_weight_f32(ptr(flat), ptr(self.w), self.cout, k, current_stream()))
+        torch.cuda.current_stream().synchronize()   # `flat` is released on return
+        self.b = torch.from_numpy(b).to(device)
+
+    def __call__(self, x, act=None, residual=None, out=None, coff=0):
+        """x [n, h, w, cin] -> [n, ho, wo, cout]; with `out` [n, ho, wo, C] the result goes to channels coff : coff + cout."""
+        lib = _lib.require_device()
+        n, h, w, c = x.shape
+        assert c == self.cin and x.is_contiguous() and x.dtype == torch.float32
+        ho = (h + 2 * self.pad - self.kh) // self.stride + 1
+        wo = (w + 2 * self.pad - self.kw) // self.stride + 1
+        if out is None:
+            out = torch.empty((n, ho, wo, self.cout), dtype=torch.float32, device=x.device)
+        assert out.shape[:3] == (n, ho, wo) and out.is_contiguous()
+        ldo = out.shape[3]
+        if residual is not None:
+            assert residual.shape == (n, ho, wo, self.cout) and residual.is_contiguous()
+        view = out.view(-1)[coff:] if coff else out
+        check(lib.vsc_conv2d_f32(ptr(x), n, h, w, c, c, ptr(self.w), ptr(self.b), self.cout, self.kh, self.kw, self.stride,
+                                 self.pad, ptr(residual), self.cout, ACT[act], ptr(view), ldo, current_stream()))
+        return out
+
+
+class DwConv:
+    def __init__(self, sd, conv, bn, stride, device="cuda"):
+        w, b = _fold(sd, conv, bn)
+        self.c, _, self.kh, self.kw = w.shape
+        self.stride, self.pad = stride, self.kh // 2
+        self.w = torch.from_numpy(np.ascontiguousarray(w.reshape(self.c, self.kh * self.kw))).to(device)
+        self.b = torch.from_numpy(b).to(device)
+
+    def __call__(self, x, act=None):
+        lib = _lib.require_device()
+        n, h, w, c = x.shape
+        assert c == self.c and x.is_contiguous()
+        ho = (h + 2 * self.pad - self.kh) // self.stride + 1
+        wo = (w + 2 * self.pad - self.kw) // self.stride + 1
+        out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+        check(lib.vsc_dwconv2d_f32(ptr(x), n, h, w, c, ptr(self.w), ptr(self.b), self.kh, self.kw, self.stride, self.pad,
+                                   ACT[act], ptr(out), current_stream()))
+        return out
+
+
+def avgpool(x):
+    lib = _lib.require_device()
+    n, h, w, c = x.shape
+    out = torch.empty((n, 1, 1, c), dtype=torch.float32, device=x.device)
+    check(lib.vsc_global_avgpool_f32(ptr(x), n, h * w, c, ptr(out), current_stream()))
+    return out
+
+
+def upsample_into(src, out, factor=1, coff=0, accumulate=False, act=None):
+    """out[..., coff : coff + c] (+)= nearest-upsampled src, then act."""
+    lib = _lib.require_device()
+    n, h, w, ldo = out.shape
+    c = src.shape[3]
+    assert src.shape == (n, h // factor, w // factor, c) and src.is_contiguous() and out.is_contiguous()
+    check(lib.vsc_upsample_add_f32(ptr(src), n, h, w, c, factor, ptr(out), ldo, coff, int(accumulate), ACT[act], current_stream()))
+    return out
+
+
+class SqueezeExcite:
+    def __init__(self, sd, p, device):
+        self.reduce = Conv(sd, p + ".conv_reduce", None, device=device)
+        self.expand = Conv(sd, p + ".conv_expand", None, device=device)
+
+    def __call__(self, x):
+        lib = _lib.require_device()
+        n, h, w, c = x.shape
+        gate = self.expand(self.reduce(avgpool(x), act="relu"), act="hard_sigmoid")
+        check(lib.vsc_channel_scale_f32(ptr(x), ptr(gate), n, h * w, c, current_stream()))
+        return x
+
+
+def _nhwc(x: torch.Tensor) -> torch.Tensor:
+    assert x.is_cuda and x.dim() == 4
+    return x.float().permute(0, 2, 3, 1).contiguous()
+
+
+class MobileNetV3SmallHip:
+    """ClassifyModel (train/models.py:6-17): x [n, 3, h, w] on the GPU -> logits [n, num_classes]."""
+
+    def __init__(self, state_dict: dict, device="cuda"):
+        sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in state_dict.items()}
+        self.stem = Conv(sd, "conv_stem", "bn1", 2, device)
+        self.blocks = []
+        for s, stage in enumerate(MBV3_SMALL):
+            for b, (kind, stride, act) in enumerate(stage):
+                p = f"blocks.{s}.{b}"
+                se = SqueezeExcite(sd, p + ".se", device) if p + ".se.conv_reduce.weight" in sd else None
+                if kind == "ds":
+                    layers = (DwConv(sd, p + ".conv_dw", p + ".bn1", stride, device), se, Conv(sd, p + ".conv_pw", p + ".bn2", 1, device))
+                elif kind == "ir":
+                    layers = (Conv(sd, p + ".conv_pw", p + ".bn1", 1, device), DwConv(sd, p + ".conv_dw", p + ".bn2", stride, device), se,
+                              Conv(sd, p + ".conv_pwl", p + ".bn3", 1, device))
+                else:
+                    layers = (Conv(sd, p + ".conv", p + ".bn1", 1, device),)
+                self.blocks.append((kind, stride, act, layers))
+        self.head = Conv(sd, "conv_head", None, 1, device)
+        cw = {"c.weight": _np(sd["classifier.weight"])[:, :, None, None], "c.bias": sd["classifier.bias"]}
+        self.classifier = Conv(cw, "c", None, 1, device)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.stem(_nhwc(x), act="hard_swish")
+        for kind, stride, act, layers in self.blocks:
+            if kind == "ds":
+                dw, se, pw = layers
+                y = dw(x, act=act)
+                if se is not None:
+                    y = se(y)
+                skip = stride == 1 and pw.cout == x.shape[3]
+                x = pw(y, residual=x if skip else None)
+            elif kind == "ir":
+                pw, dw, se, pwl = layers
+                y = dw(pw(x, act=act), act=act)
+                if se is not None:
+                    y = se(y)
+                skip = stride == 1 and pwl.cout == x.shape[3]
+                x = pwl(y, residual=x if skip else None)
+            else:
+                x = layers[0](x, act=act)
+        x = self.head(avgpool(x), act="hard_swish")
+        return self.classifier(x).reshape(x.shape[0], -1)
+
+
+class _Basic:
+    def __init__(self, sd, p, device):
+        self.c1 = Conv(sd, p + ".conv1", p + ".bn1", 1, device)
+        self.c2 = Conv(sd, p + ".conv2", p + ".bn2", 1, device)
+
+    def __call__(self, x):
+        return self.c2(self.c1(x, act="relu"), act="relu", residual=x)
+
+
+class _Bottleneck:
+    def __init__(self, sd, p, device):
+        self.c1 = Conv(sd, p + ".conv1", p + ".bn1", 1, device)
+        self.c2 = Conv(sd, p + ".conv2", p + ".bn2", 1, device)
+        self.c3 = Conv(sd, p + ".conv3", p + ".bn3", 1, device)
+        self.down = Conv(sd, p + ".downsample.0", p + ".downsample.1", 1, device) if p + ".downsample.0.weight" in sd else None
+
+    def __call__(self, x):
+        sc = self.down(x) if self.down is not None else x
+        return self.c3(self.c2(self.c1(x, act="relu"), act="relu"), act="relu", residual=sc)
+
+
+class _HrModule:
+    """HighResolutionModule: BasicBlocks per branch, then every output branch sums every input branch brought to its
+    resolution / width (1x1 conv + nearest upsample downwards in index, chains of stride-2 3x3 convs upwards)."""
+
+    def __init__(self, sd, p, nbr, device):
+        self.nbr = nbr
+        self.branches = [[_Basic(sd, f"{p}.branches.{i}.{k}", device) for k in range(HRNET_BLOCKS)] for i in range(nbr)]
+        self.fuse = {}
+        for i in range(nbr):
+            for j in range(nbr):
+                if j > i:
+                    self.fuse[i, j] = Conv(sd, f"{p}.fuse_layers.{i}.{j}.0", f"{p}.fuse_layers.{i}.{j}.1", 1, device)
+                elif j < i:
+                    self.fuse[i, j] = [Conv(sd, f"{p}.fuse_layers.{i}.{j}.{k}.0", f"{p}.fuse_layers.{i}.{j}.{k}.1", 2, device)
+                                       for k in range(i - j)]
+
+    def __call__(self, xs):
+        ys = []
+        for i in range(self.nbr):
+            y = xs[i]
+            for blk in self.branches[i]:
+                y = blk(y)
+            ys.append(y)
+        outs = []
+        for i in range(self.nbr):
+            # summation order of the reference: j = 0 .. nbr-1; the running sum lives in `acc`, ReLU with the last term
+            acc = None
+            for j in range(self.nbr):
+                last = j == self.nbr - 1
+                if j == i:
+                    if acc is None:
+                        acc = ys[j].clone()
+                    else:
+                        upsample_into(ys[j], acc, 1, 0, True, "relu" if last else None)
+                elif j > i:
+                    t = self.fuse[i, j](ys[j])
+                    upsample_into(t, acc, 2 ** (j - i), 0, True, "relu" if last else None)   # acc exists: j > i >= 0
+                else:
+                    chain = self.fuse[i, j]
+                    t = ys[j]
+                    for k, conv in enumerate(chain[:-1]):
+                        t = conv(t, act="relu")
+                    if acc is None:
+                        acc = chain[-1](t)
+                    else:   # the sum so far is the residual of the last convolution of the chain
+                        acc = chain[-1](t, residual=acc, act="relu" if last else None)
+            outs.append(acc)
+        return outs
+
+
+class HRNetRefineHip:
+    """HRnet (train/models.py:20-47): x [n, 3, h, w] on the GPU (h, w multiples of 8) -> logits [n, 2, h, w]."""
+
+    def __init__(self, state_dict: dict, device="cuda"):
+        sd = {k[len("model."):]: v for k, v in state_dict.items() if k.startswith("model.")}
+        self.conv1 = Conv(sd, "conv1", "bn1", 1, device)   # stride 2 in timm, set to 1 by the reference (models.py:25-26)
+        self.conv2 = Conv(sd, "conv2", "bn2", 1, device)
+        self.layer1 = [_Bottleneck(sd, f"layer1.{k}", device) for k in range(4)]
+        self.t1 = [Conv(sd, "transition1.0.0", "transition1.0.1", 1, device), Conv(sd, "transition1.1.0.0", "transition1.1.0.1", 2, device)]
+        self.stages = []
+        for stage, nmod, nbr in HRNET_STAGES:
+            grow = Conv(sd, f"transition{stage - 1}.{nbr - 1}.0.0", f"transition{stage - 1}.{nbr - 1}.0.1", 2, device) if stage > 2 else None
+            self.stages.append((grow, [_HrModule(sd, f"stage{stage}.{m}", nbr, device) for m in range(nmod)]))
+        self.fuse0 = Conv(state_dict, "fuse.0", None, 1, device)
+        self.fuse2 = Conv(state_dict, "fuse.2", None, 1, device)
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        x = _nhwc(x)
+        n, h, w, _ = x.shape
+        assert h % 8 == 0 and w % 8 == 0, "HRNet input sides must be multiples of 8"
+        stem = self.conv1(x, act="relu")
+        x = self.conv2(stem, act="relu")
+        for blk in self.layer1:
+            x = blk(x)
+        xs = [self.t1[0](x, act="relu"), self.t1[1](x, act="relu")]
+        for grow, modules in self.stages:
+            if grow is not None:
+                xs = xs + [grow(xs[-1], act="relu")]
+            for m in modules:
+                xs = m(xs)
+        widths = [stem.shape[3]] + [y.shape[3] for y in xs]
+        cat = torch.empty((n, h, w, sum(widths)), dtype=torch.float32, device=x.device)   # torch.cat of the upsampled features
+        off = 0
+        for i, y in enumerate([stem] + xs):
+            upsample_into(y, cat, 1 if i < 2 else 2 ** (i - 1), off, False, None)
+            off += widths[i]
+        y = self.fuse2(self.fuse0(cat, act="relu"))
+        return y.permute(0, 3, 1, 2).contiguous()
+
+
+def match_classify_probability(models, feature: torch.Tensor) -> torch.Tensor:
+    """infer_matching.py:165-168: mean over the classifier models of softmax(model(x))[:, 1].  feature [n, 3, h, w] (GPU)."""
+    return sum(m(feature).softmax(dim=1)[:, 1] for m in models) / len(models)
+
+
+def match_refine_probability(models, feature: torch.Tensor) -> torch.Tensor:
+    """infer_matching.py:183-193: per model the class softmax of model(x) and of model(x^T)^T averaged, then the mean over
+    models.  feature [n, 3, h, w] (GPU) -> [n, 2, h, w]."""
+    preds = []
+    for m in models:
+        p = m(feature).softmax(dim=1)
+        pt = m(feature.transpose(3, 2).contiguous()).softmax(dim=1).transpose(3, 2)
+        preds.append((p + pt) / 2)
+    return sum(preds) / len(preds)
