@@ -105,3 +105,45 @@ def test_hrnet_refine_matches_oracle(dev, n, h, w):
     assert float((got_logits - want_logits).abs().max()) < 1e-3 * max(1.0, float(want_logits.abs().max()))
     got = cnn.match_refine_probability([model], x.to(dev)).cpu() if h <= 64 else got_logits.softmax(dim=1)
     assert float((got - want).abs().max()) < 1e-4            # probability map (tier bound 1e-3)
+
+
+def test_match_classify_and_refine_entry_points(dev):
+    """src.matching.match_classify / match_refine (infer_matching.py:158-204) end to end on synthetic candidates: datasets,
+    batching, model averaging, transposed pass, crop to the valid h x w -- against the oracle's restatement of the same steps,
+    and into generate_matching_result (a planted diagonal segment must come out as a match)."""
+    from oracle import cnn_oracle
+    from src import matching
+    rng = np.random.RandomState(3)
+    cls_sds = [cnn_synth.mobilenetv3_small_state(31), cnn_synth.mobilenetv3_small_state(32)]
+    ref_sds = [cnn_synth.hrnet_refine_state(33)]
+    cls_models, refine_models = matching.load_match_models(cls_sds, ref_sds, dev)
+    feats = [(rng.randn(h, w) * 0.1).astype(np.float32) for h, w in ((30, 50), (200, 170), (12, 9))]   # one larger than 160: cropped
+    infos = [("Q1", "R1"), ("Q2", "R7"), ("Q3", "R2")]
+    got = matching.match_classify(cls_models, feats, infos, batch_size=2, device=dev)
+    assert [(q, r) for q, r, _ in got] == infos
+    data = matching.MatchClassifyDataset(feats, infos, matching.MATCH_CLS_RESOLUTION)
+    x = torch.from_numpy(np.stack([data[i][0] for i in range(3)]))
+    with torch.no_grad():
+        want = cnn_oracle.match_classify_probability([{k[len("model."):]: v for k, v in sd.items()} for sd in cls_sds], x)
+    assert np.allclose([p for _, _, p in got], want.numpy(), atol=1e-4)
+
+    d = 64
+    meta = []
+    for qn, rn in ((20, 36), (7, 11)):
+        q = rng.randn(qn, d).astype(np.float32)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        r = rng.randn(rn, d).astype(np.float32)
+        r /= np.linalg.norm(r, axis=1, keepdims=True)
+        meta.append((f"Q{qn}", f"R{rn}", q, r))
+    res = matching.match_refine(refine_models, meta, batch_size=1, device=dev)
+    assert [(a, b) for a, b, _, _ in res] == [("Q20", "R36"), ("Q7", "R11")]
+    for (qid, rid, prob, sim), (_, _, q, r) in zip(res, meta):
+        assert prob.shape == sim.shape == (len(q), len(r))
+        canvas = np.zeros((224, 224), np.float32)
+        canvas[:len(q), :len(r)] = sim
+        with torch.no_grad():
+            want = cnn_oracle.match_refine_probability(ref_sds, torch.from_numpy(np.stack([canvas] * 3)[None]))[0, 1, :len(q), :len(r)]
+        assert np.abs(prob - want.numpy()).max() < 1e-4
+        assert np.abs(sim - q @ r.T).max() < 1e-5
+    out = matching.generate_matching_result([["Qx", "Ry", np.eye(40, dtype=np.float32) * 0.9, None]])
+    assert len(out) == 1 and out[0][:2] == ["Qx", "Ry"]

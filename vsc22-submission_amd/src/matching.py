@@ -10,6 +10,8 @@ candidate search and the classifier / refinement networks:
   * ``transform_features``                    utils.py:12-16
   * ``search_candidate_pairs``                infer_matching.py:229-262   candidate (query video, reference video) search
   * ``MatchRefineDataset``                    src/dataset.py:127-144      padded maps fed to the refinement networks
+  * ``match_classify`` / ``match_refine``     infer_matching.py:158-204   the MobileNetV3 pair classifier and the HRNet
+                                              refinement net (vsc_hip/cnn.py: fp32 convolutions on the HIP path)
 
 The reference runs one ``np.matmul(qfeat, rfeat.T)`` per candidate on the host (twice: once to pick the query
 view, once for the map).  Here every candidate of a call goes through ONE ``vsc_pair_similarity_f32`` launch
@@ -222,6 +224,55 @@ class MatchRefineDataset:
         feat = np.zeros(self.resolution, dtype=np.float32)
         feat[:h, :w] = sim_mat[:h, :w]
         return np.stack([feat, feat, feat]), qid, rid, h, w
+
+
+# ---- the two networks between candidate search and localisation (infer_matching.py:158-204) -------------------
+MATCH_CLS_RESOLUTION, MATCH_REFINE_RESOLUTION = (160, 160), (224, 224)   # infer_matching.py:159,178
+MATCH_CLS_BATCH, MATCH_REFINE_BATCH = 2048, 16                           # infer_matching.py:160,179
+
+
+def load_match_models(cls_state_dicts, refine_state_dicts, device="cuda"):
+    """State dicts of the reference's ClassifyModel / HRnet modules (train/models.py; timm parameter names; a
+    torch.jit.load(...).state_dict() of the shipped submit_cls_model*.pt / submit_match_model*.pt has them) ->
+    (classifier models, refinement models) on the HIP path."""
+    from vsc_hip import cnn
+    return ([cnn.MobileNetV3SmallHip(sd, device) for sd in cls_state_dicts],
+            [cnn.HRNetRefineHip(sd, device) for sd in refine_state_dicts])
+
+
+def match_classify(cls_models, match_cls_feature, match_cls_info, batch_size: int = MATCH_CLS_BATCH, device="cuda"):
+    """Main.match_classify (infer_matching.py:158-175): probability of "this candidate pair holds a copy" per candidate,
+    averaged over the classifier models.  -> list of (query_id, ref_id, prob) in candidate order (the reference builds a
+    DataFrame with these three columns)."""
+    import torch
+
+    from vsc_hip import cnn
+    data = MatchClassifyDataset(match_cls_feature, match_cls_info, MATCH_CLS_RESOLUTION)
+    out = []
+    for lo in range(0, len(data), batch_size):
+        items = [data[i] for i in range(lo, min(lo + batch_size, len(data)))]
+        feature = torch.from_numpy(np.stack([it[0] for it in items])).to(device)
+        prob = cnn.match_classify_probability(cls_models, feature).cpu().numpy()
+        out.extend((it[1], it[2], float(p)) for it, p in zip(items, prob))
+    return out
+
+
+def match_refine(refine_models, match_meta, batch_size: int = MATCH_REFINE_BATCH, device="cuda", pair_similarity=None):
+    """Main.match_refine (infer_matching.py:177-204): per candidate the copy-probability map over (query frame, ref frame),
+    averaged over the refinement models and over each model's transposed pass, cropped to the valid h x w.
+    -> [[qid, rid, probability map [h, w], similarity map [h, w]], ...], the input of generate_matching_result."""
+    import torch
+
+    from vsc_hip import cnn
+    data = MatchRefineDataset(match_meta, MATCH_REFINE_RESOLUTION, pair_similarity)
+    res_list = []
+    for lo in range(0, len(data), batch_size):
+        items = [data[i] for i in range(lo, min(lo + batch_size, len(data)))]
+        feature = torch.from_numpy(np.stack([it[0] for it in items]))
+        pred = cnn.match_refine_probability(refine_models, feature.to(device)).cpu().numpy()
+        for i, (fea, qid, rid, h, w) in enumerate(items):
+            res_list.append([qid, rid, pred[i][1][:h, :w], fea[0][:h, :w]])
+    return res_list
 
 
 # ---- localisation from the refinement maps (host code, utils.py:80-116) ---------------------------------------
