@@ -284,7 +284,7 @@ def bench_search_sharded(dev, args, dist, rank, world):
 
 def bench_swin(dev, args):
     """Secondary: the reference's other backbone family (swinv2_v1xx), same contract as the ViT step."""
-    from src import synth
+    from tools import synth
     from vsc_hip.swin_config import get_swin_config
     from vsc_hip.swin_encoder import SwinHipEncoder
     cfg = get_swin_config("swinv2_base_256")
@@ -328,7 +328,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
 
-    from src import synth
+    from tools import synth
     from vsc_hip import _lib
     from vsc_hip.config import get_config
     from vsc_hip.encoder import HipEncoder

@@ -24,7 +24,7 @@ Plain PyTorch fp32 restatement of the encoder the reference runs per frame:
 Pinning: tests/golden/vit_*.npz were produced by tests/golden/gen_vit_golden.py,
 which runs ``transformers.ViTModel`` / ``transformers.CLIPVisionModel`` (the
 reference's own third-party backbone implementation) in this container on the
-deterministic weights and frames of src/synth.py; tests/test_oracle_vit.py checks this
+deterministic weights and frames of tools/synth.py; tests/test_oracle_vit.py checks this
 restatement against those vectors.
 """
 from __future__ import annotations

@@ -3,7 +3,7 @@
     python tests/golden/gen_swin_golden.py
 
 transformers.Swinv2Model (third-party port of the Microsoft Swin-V2 code the reference inlines in
-train/train_v115/torch2scripts.py) is loaded with the deterministic weights of src/synth.py --
+train/train_v115/torch2scripts.py) is loaded with the deterministic weights of tools/synth.py --
 translated from the reference's parameter names to HF's -- and run on deterministic frames.  The
 reference head (norm -> gem -> output_proj, torch2scripts.py:628-630) is applied on HF's
 last_hidden_state (HF applies the final LayerNorm itself).
@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
 
-from src import synth  # noqa: E402
+from tools import synth  # noqa: E402
 from vsc_hip.swin_config import get_swin_config  # noqa: E402
 
 WEIGHT_SEED, FRAME_SEED = 5, 13

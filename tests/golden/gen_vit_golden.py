@@ -7,7 +7,7 @@ The frame -> token backbone of the reference is a third-party module
 VSC22-Descriptor-Track-1st/train/train_v115/vsc/baseline/model_factory/backbones/vit.py:27-30;
 its CLIP tower follows OpenAI CLIP, video/clip.py).  ``transformers`` is installed
 in this container, so the vectors below are outputs of that implementation on the
-deterministic weights/frames of src/synth.py.  The reference wrapper itself
+deterministic weights/frames of tools/synth.py.  The reference wrapper itself
 (``VIT``) cannot be imported here (its package imports mmcv), so its three
 head lines -- gem (vit.py:52-54) and output_proj (vit.py:47-48) -- are applied
 verbatim in ``_vit_head`` below.
@@ -30,7 +30,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
 
-from src import synth  # noqa: E402
+from tools import synth  # noqa: E402
 from vsc_hip.config import get_config  # noqa: E402
 
 WEIGHT_SEED = 7

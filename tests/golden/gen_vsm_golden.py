@@ -6,7 +6,7 @@ The reference's ``MS`` (train/train_vid_score/video/model.py:63-99) wraps transf
 module that is installed here; MS itself imports only torch + transformers, but instantiates the encoder with
 ``AutoModel.from_pretrained(bert_path)`` -- a checkpoint directory that is not available -- so the encoder is built
 from a BertConfig of the same architecture and MS.forward's own lines (:79-99) are applied verbatim below.
-Weights and inputs are the deterministic tensors of src/synth.py.
+Weights and inputs are the deterministic tensors of tools/synth.py.
 
 Output (small, committed): tests/golden/vsm_tiny_vsm.npz with weights_seed, feats_seed, n_valid [cases],
 logits [cases], states_cls [cases, H] (last hidden state of [CLS])."""
@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
 
-from src import synth  # noqa: E402
+from tools import synth  # noqa: E402
 from vsc_hip.vsm_config import get_vsm_config  # noqa: E402
 
 WEIGHT_SEED, FEAT_SEED = 17, 23

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from src import synth
+from tools import synth
 from vsc_hip import distributed as vdist
 
 

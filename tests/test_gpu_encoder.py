@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from src import synth
+from tools import synth
 from vsc_hip.config import get_config
 
 pytestmark = pytest.mark.gpu

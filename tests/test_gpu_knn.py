@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from src import synth
+from tools import synth
 
 pytestmark = pytest.mark.gpu
 

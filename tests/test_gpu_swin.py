@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import swin_oracle
-from src import synth
+from tools import synth
 from vsc_hip.swin_config import get_swin_config
 
 pytestmark = pytest.mark.gpu

@@ -16,7 +16,7 @@ LOGIT_ATOL = 3e-2   # bf16 operands through 2-12 post-LN layers; the gate compar
 
 
 def _head(preset, seed):
-    from src import synth
+    from tools import synth
     from vsc_hip.video_score import VideoScoreHead
     from vsc_hip.vsm_config import get_vsm_config
     cfg = get_vsm_config(preset)
@@ -26,7 +26,7 @@ def _head(preset, seed):
 
 def test_tiny_head_matches_golden_and_oracle():
     from oracle import vsm_oracle
-    from src import synth
+    from tools import synth
     g = np.load(os.path.join(ROOT, "tests", "golden", "vsm_tiny_vsm.npz"))
     cfg, w, head = _head("tiny_vsm", int(g["weights_seed"]))
     for i, n in enumerate(g["n_valid"].tolist()):
@@ -39,7 +39,7 @@ def test_tiny_head_matches_golden_and_oracle():
 @pytest.mark.parametrize("n", [3, 200, 256, 300])
 def test_full_size_head_vs_oracle(n):
     from oracle import vsm_oracle
-    from src import synth
+    from tools import synth
     cfg, w, head = _head("vsm_roberta_base", 41)
     f = torch.from_numpy(synth.normalish(100 + n, (n, cfg.feat_dim)))
     fo = torch.zeros(cfg.max_frames, cfg.feat_dim)

@@ -97,7 +97,7 @@ def test_micro_ap():
 
 
 def test_weight_name_translation_round_trip():
-    from src import synth
+    from tools import synth
     from vsc_hip import weights as W
     from vsc_hip.config import get_config
     cfg = get_config("tiny")
@@ -162,7 +162,7 @@ def test_weight_name_translation_round_trip():
 
 @no_gpu
 def test_product_path_fails_loudly_without_gpu():
-    from src import synth
+    from tools import synth
     from vsc_hip import _lib, ops
     from vsc_hip.config import get_config
     from vsc_hip.encoder import HipEncoder
@@ -202,7 +202,7 @@ class _NumpyOps:
 
 
 def test_hip_pca_mirrors_sklearn_transform():
-    from src import synth
+    from tools import synth
     """HipPCA.transform == sklearn PCA.transform (plain and whitened) on the fitted attributes the reference pickles."""
     from sklearn.decomposition import PCA
     from src.query_postprocess import HipPCA

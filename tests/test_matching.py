@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import knn_oracle  # noqa: E402
 
-from src import matching, synth  # noqa: E402
+from src import matching  # noqa: E402
+from tools import synth  # noqa: E402
 
 
 def _oracle_pairs(q_bank, r_bank, pairs):

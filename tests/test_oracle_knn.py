@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import knn_oracle
-from src import synth
+from tools import synth
 
 
 @pytest.mark.parametrize("nq,nr,d,k", [(17, 300, 512, 10), (5, 40, 31, 40), (3, 7, 8, 12)])

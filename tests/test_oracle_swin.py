@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import swin_oracle
-from src import synth
+from tools import synth
 from vsc_hip.swin_config import get_swin_config
 
 

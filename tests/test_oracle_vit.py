@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import vit_oracle
-from src import synth
+from tools import synth
 from vsc_hip.config import get_config
 
 

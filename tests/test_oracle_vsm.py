@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import vsm_oracle  # noqa: E402
 
-from src import synth  # noqa: E402
+from tools import synth  # noqa: E402
 from vsc_hip.vsm_config import get_vsm_config  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden", "vsm_tiny_vsm.npz")

@@ -10,7 +10,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from src import synth  # noqa: E402
+from tools import synth  # noqa: E402
 from src.model_zoo import load_encoder, parse_model_spec  # noqa: E402
 from src.query_pipeline import run_query_videos  # noqa: E402
 from src.query_postprocess import HipPCA, process_query_video  # noqa: E402

@@ -8,10 +8,11 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
+sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from src import synth
+from tools import synth
 from src.query_pipeline import VideoScorer, run_query_videos
 from src.query_postprocess import HipPCA
 from vsc_hip.config import aligned_batch, get_config

@@ -3,8 +3,9 @@
 GPU is the limit and a hipGraph would not shorten the call."""
 import os, sys, time
 sys.path.insert(0, "/root/repo/vsc22-submission_amd")
+sys.path.insert(0, "/root/repo")
 import torch
-from src import synth
+from tools import synth
 from vsc_hip.config import get_config
 from vsc_hip.encoder import HipEncoder
 cfg = get_config("vit_b16_224")

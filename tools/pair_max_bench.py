@@ -9,7 +9,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
-from src import synth  # noqa: E402
+sys.path.insert(0, ROOT)
+from tools import synth  # noqa: E402
 from vsc_hip import ops  # noqa: E402
 
 

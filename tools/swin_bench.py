@@ -5,9 +5,10 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
+sys.path.insert(0, ROOT)
 import torch
 
-from src import synth
+from tools import synth
 from vsc_hip.swin_config import get_swin_config
 from vsc_hip.swin_encoder import SwinHipEncoder
 
