@@ -292,7 +292,7 @@ int vsc_debug_spin_ticks(uint64_t ticks, uint64_t *out_dev, void *stream);
  *   train/models.py:6-40 (ClassifyModel, HRnet).
  * Activations are NHWC float32; BatchNorm is folded into weight / bias by the host (vsc_hip/cnn.py).
  * ------------------------------------------------------------------------ */
-enum { VSC_ACT_NONE = 0, VSC_ACT_RELU = 1, VSC_ACT_HARDSWISH = 2, VSC_ACT_HARDSIGMOID = 3 };
+enum { VSC_ACT_NONE = 0, VSC_ACT_RELU = 1, VSC_ACT_HARDSWISH = 2, VSC_ACT_HARDSIGMOID = 3, VSC_ACT_GELU = 4 };
 
 /* floats per packed weight row: cin * kh * kw rounded up to a multiple of 32 */
 int vsc_conv_packed_k(int32_t cin, int32_t kh, int32_t kw);
@@ -316,6 +316,11 @@ int vsc_channel_scale_f32(float *x_dev, const float *scale_dev, int64_t n, int32
  * nn.Upsample(scale_factor, 'nearest') fused with the sum of an HRNet fuse layer or with torch.cat along channels. */
 int vsc_upsample_add_f32(const float *src_dev, int64_t n, int32_t h, int32_t w, int32_t c, int32_t factor, float *out_dev,
                          int32_t ldo, int32_t coff, int32_t accumulate, int32_t act, void *stream);
+
+/* fp32 multi-head self-attention for short sequences: out[t, h*dh:(h+1)*dh] = softmax(q k^T / sqrt(dh)) v per head, qkv
+ * [tokens, 3 * heads * head_dim] float32 as q | k | v column blocks.  Used by the video-score head (BERT encoder over <= 258
+ * tokens, infer/extract_query_feats.py:165-173), whose sigmoid gate is compared with 1e-3 and therefore runs in fp32. */
+int vsc_attention_f32(const float *qkv_dev, float *out_dev, int32_t tokens, int32_t heads, int32_t head_dim, void *stream);
 
 #ifdef __cplusplus
 }

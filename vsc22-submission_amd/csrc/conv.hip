@@ -29,6 +29,7 @@ __device__ __forceinline__ float activate(float v, int act) {
         case VSC_ACT_RELU: return fmaxf(v, 0.f);
         case VSC_ACT_HARDSWISH: return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.0f / 6.0f);
         case VSC_ACT_HARDSIGMOID: return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.0f / 6.0f);
+        case VSC_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));   // exact (erf) GELU, torch's default
         default: return v;
     }
 }
@@ -185,6 +186,54 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restri
     }
 }
 
+// softmax(q k^T / sqrt(dh)) v for one (head, query) pair per workgroup, all in fp32 (the video-score head: <= 258 tokens,
+// one video at a time -- 0.1 GFLOP per layer, latency- not throughput-bound).  qkv [tokens, 3 * heads * dh] as q | k | v.
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restrict__ qkv, float *__restrict__ out, int tokens,
+                                                            int heads, int dh) {
+    extern __shared__ float sm[];            // [tokens] probabilities, then [4][dh] partial outputs, [dh] query
+    float *prob = sm, *part = sm + tokens, *qs = part + 4 * dh;
+    __shared__ float red[8];
+    const int q = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int width = heads * dh, ld = 3 * width;
+    for (int d = tid; d < dh; d += 256) qs[d] = qkv[(int64_t)q * ld + hd * dh + d];
+    __syncthreads();
+    const float scale = rsqrtf((float)dh);
+    float mx = -INFINITY;
+    for (int t = tid; t < tokens; t += 256) {
+        const float *kr = qkv + (int64_t)t * ld + width + hd * dh;
+        float a = 0.f;
+        for (int d = 0; d < dh; ++d) a = fmaf(qs[d], kr[d], a);
+        a *= scale;
+        prob[t] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int t = tid; t < tokens; t += 256) {
+        const float e = expf(prob[t] - mx);
+        prob[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wv] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    // out[d] = sum_t prob[t] v[t][d]: wave wv takes keys wv, wv + 4, ...; lane = head-dim column (dh <= 64 per pass)
+    for (int d0 = 0; d0 < dh; d0 += 64) {
+        const int d = d0 + lane;
+        float a = 0.f;
+        if (d < dh)
+            for (int t = wv; t < tokens; t += 4) a = fmaf(prob[t], qkv[(int64_t)t * ld + 2 * width + hd * dh + d], a);
+        if (d < dh) part[wv * dh + d] = a;
+    }
+    __syncthreads();
+    for (int d = tid; d < dh; d += 256)
+        out[(int64_t)q * width + hd * dh + d] = ((part[d] + part[dh + d]) + (part[2 * dh + d] + part[3 * dh + d])) * inv;
+}
+
 struct Scratch {
     void *ptr = nullptr;
     size_t bytes = 0;
@@ -217,7 +266,7 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     VSC_REQUIRE(x_dev && w_packed_dev && out_dev, "conv2d: null operand");
     VSC_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "conv2d: bad shape");
     VSC_REQUIRE(ldx >= cin && ldo >= cout && (!res_dev || ldr >= cout), "conv2d: leading dimensions smaller than the channel counts");
-    VSC_REQUIRE(act >= VSC_ACT_NONE && act <= VSC_ACT_HARDSIGMOID, "conv2d: unknown activation %d", act);
+    VSC_REQUIRE(act >= VSC_ACT_NONE && act <= VSC_ACT_GELU, "conv2d: unknown activation %d", act);
     const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
     VSC_REQUIRE(ho > 0 && wo > 0, "conv2d: empty output");
     const int64_t rows = n * ho * wo;
@@ -259,7 +308,7 @@ extern "C" int vsc_dwconv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_
                                 float *out_dev, void *stream_) {
     VSC_REQUIRE(x_dev && w_dev && out_dev, "dwconv2d: null operand");
     VSC_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "dwconv2d: bad shape");
-    VSC_REQUIRE(act >= VSC_ACT_NONE && act <= VSC_ACT_HARDSIGMOID, "dwconv2d: unknown activation %d", act);
+    VSC_REQUIRE(act >= VSC_ACT_NONE && act <= VSC_ACT_GELU, "dwconv2d: unknown activation %d", act);
     const int ho = (h + 2 * pad - kh) / stride + 1, wo = (w + 2 * pad - kw) / stride + 1;
     VSC_REQUIRE(ho > 0 && wo > 0, "dwconv2d: empty output");
     const int64_t total = n * ho * wo * c;
@@ -289,10 +338,21 @@ extern "C" int vsc_upsample_add_f32(const float *src_dev, int64_t n, int32_t h, 
     VSC_REQUIRE(src_dev && out_dev && n > 0 && h > 0 && w > 0 && c > 0 && factor >= 1, "upsample_add: bad arguments");
     VSC_REQUIRE(h % factor == 0 && w % factor == 0, "upsample_add: %d x %d is not a multiple of the factor %d", h, w, factor);
     VSC_REQUIRE(ldo >= coff + c && coff >= 0, "upsample_add: channel window outside the output row");
-    VSC_REQUIRE(act >= VSC_ACT_NONE && act <= VSC_ACT_HARDSIGMOID, "upsample_add: unknown activation %d", act);
+    VSC_REQUIRE(act >= VSC_ACT_NONE && act <= VSC_ACT_GELU, "upsample_add: unknown activation %d", act);
     const int64_t total = n * h * w * c;
     hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream_, src_dev, out_dev, total, h,
                        w, c, factor, ldo, coff, accumulate, act);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+extern "C" int vsc_attention_f32(const float *qkv_dev, float *out_dev, int32_t tokens, int32_t heads, int32_t head_dim, void *stream_) {
+    VSC_REQUIRE(qkv_dev && out_dev && tokens > 0 && heads > 0 && head_dim > 0, "attention_f32: bad arguments");
+    VSC_REQUIRE(tokens <= 8192 && heads < 65536, "attention_f32: %d tokens / %d heads unsupported", tokens, heads);
+    const size_t smem = (size_t)(tokens + 5 * head_dim) * 4;
+    VSC_REQUIRE(smem <= 48 * 1024, "attention_f32: %d tokens x head_dim %d exceeds the kernel's LDS budget", tokens, head_dim);
+    hipLaunchKernelGGL(attention_f32_kernel, dim3(tokens, heads), dim3(256), smem, (hipStream_t)stream_, qkv_dev, out_dev, tokens, heads,
+                       head_dim);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }

@@ -92,6 +92,7 @@ SIGNATURES = {
     "vsc_channel_scale_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "vsc_upsample_add_f32": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32,
                                        c_int32, c_int32, c_void_p]),
+    "vsc_attention_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "vsc_knn_last_path": (c_int32, []),
     "vsc_knn_set_profiling": (None, [c_int32]),
     "vsc_knn_last_profile": (c_int32, [c_void_p]),

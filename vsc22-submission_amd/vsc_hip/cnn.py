@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import check, current_stream, ptr
 
-ACT = {None: 0, "none": 0, "relu": 1, "hard_swish": 2, "hard_sigmoid": 3}
+ACT = {None: 0, "none": 0, "relu": 1, "hard_swish": 2, "hard_sigmoid": 3, "gelu": 4}
 BN_EPS = 1e-5
 
 # timm `mobilenetv3_small_100`: per stage, per block (kind, stride, activation); channel counts, kernel sizes and

@@ -6,9 +6,12 @@ never enters the pooling, so only the visible tokens are run: [CLS, frame_1 .. f
 positions 0..n+1 (the reference's mask is ``cat([ones(2), frame_mask])`` against [CLS, frames..., SEP], so the slot after
 the last real frame is visible and SEP is hidden), or all 258 tokens when the video fills every frame.
 
-Per layer (BERT post-LN): qkv GEMM -> fused MHSA -> proj GEMM (+x, fp32) -> LayerNorm -> fc1 GEMM (+erf GELU) ->
-fc2 GEMM (+x, fp32) -> LayerNorm, i.e. vsc_gemm_bf16 / vsc_attention_bf16 / vsc_ln_residual_f32; bf16 operands,
-fp32 accumulation, fp32 residual stream, like the frame encoders.  No CPU fallback."""
+Per layer (BERT post-LN): qkv Linear -> MHSA -> proj Linear (+x) -> LayerNorm -> fc1 Linear (+erf GELU) -> fc2 Linear (+x)
+-> LayerNorm.  The head runs in FLOAT32 end to end: its sigmoid is compared with SCORE_THRESHOLD = 0.001
+(extract_query_feats.py:53,172-174) and a bf16 pipeline through 12 post-LN layers moved the logit by up to 3e-2 (round 1) --
+enough to flip a video that sits near the gate.  It is one video of <= 258 tokens at a time (44 GFLOP), so precision is
+free: every Linear is vsc_conv2d_f32 as a 1x1 convolution (exact fp32 MFMA chains, bias / residual / GELU fused), attention
+is vsc_attention_f32, LayerNorm is vsc_layernorm_f32 / vsc_ln_residual_f32.  No CPU fallback."""
 from __future__ import annotations
 
 from typing import Dict, Tuple
@@ -16,7 +19,7 @@ from typing import Dict, Tuple
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, cnn, ops
 from .vsm_config import VsmConfig, get_vsm_config
 
 
@@ -40,17 +43,18 @@ class VideoScoreHead:
     def __init__(self, cfg: VsmConfig | str, weights: Dict[str, np.ndarray]):
         _lib.require_device()
         self.cfg = cfg = get_vsm_config(cfg) if isinstance(cfg, str) else cfg
-        if cfg.hidden != cfg.heads * 64:
-            raise ValueError(f"head_dim {cfg.hidden // cfg.heads} unsupported: the attention kernel takes 64")
+        if cfg.hidden % cfg.heads:
+            raise ValueError(f"hidden {cfg.hidden} is not a multiple of {cfg.heads} heads")
         dev = torch.device("cuda", torch.cuda.current_device())
 
         def f32(name):
             return torch.from_numpy(np.ascontiguousarray(weights[name], np.float32)).to(dev)
 
-        def bf16(name):
-            return f32(name).to(torch.bfloat16).contiguous()
+        def linear(w, b):
+            """nn.Linear weight [out, in] + bias -> a packed 1x1 convolution on the fp32 MFMA tiles"""
+            return cnn.Conv({"l.weight": np.asarray(w, np.float32)[:, :, None, None], "l.bias": np.asarray(b, np.float32)}, "l", None, 1, dev)
 
-        self.proj_w, self.proj_b = bf16("frame_proj.0.weight"), f32("frame_proj.0.bias")
+        self.proj = linear(weights["frame_proj.0.weight"], weights["frame_proj.0.bias"])
         self.proj_g, self.proj_beta = f32("frame_proj.1.weight"), f32("frame_proj.1.bias")
         e = "bert.embeddings."
         words = weights[e + "word_embeddings.weight"]
@@ -64,15 +68,21 @@ class VideoScoreHead:
             qkv_w = np.concatenate([weights[p + f"attention.self.{n}.weight"] for n in ("query", "key", "value")], axis=0)
             qkv_b = np.concatenate([weights[p + f"attention.self.{n}.bias"] for n in ("query", "key", "value")], axis=0)
             self.layers.append({
-                "qkv_w": torch.from_numpy(np.ascontiguousarray(qkv_w, np.float32)).to(dev).to(torch.bfloat16),
-                "qkv_b": torch.from_numpy(np.ascontiguousarray(qkv_b, np.float32)).to(dev),
-                "o_w": bf16(p + "attention.output.dense.weight"), "o_b": f32(p + "attention.output.dense.bias"),
+                "qkv": linear(qkv_w, qkv_b),
+                "o": linear(weights[p + "attention.output.dense.weight"], weights[p + "attention.output.dense.bias"]),
                 "ln1_g": f32(p + "attention.output.LayerNorm.weight"), "ln1_b": f32(p + "attention.output.LayerNorm.bias"),
-                "fc1_w": bf16(p + "intermediate.dense.weight"), "fc1_b": f32(p + "intermediate.dense.bias"),
-                "fc2_w": bf16(p + "output.dense.weight"), "fc2_b": f32(p + "output.dense.bias"),
+                "fc1": linear(weights[p + "intermediate.dense.weight"], weights[p + "intermediate.dense.bias"]),
+                "fc2": linear(weights[p + "output.dense.weight"], weights[p + "output.dense.bias"]),
                 "ln2_g": f32(p + "output.LayerNorm.weight"), "ln2_b": f32(p + "output.LayerNorm.bias"),
             })
         self.out_w, self.out_b = f32("output_proj.weight"), f32("output_proj.bias")
+
+    def _attention(self, qkv: torch.Tensor, tokens: int) -> torch.Tensor:
+        lib = _lib.require_device()
+        out = torch.empty((tokens, self.cfg.hidden), dtype=torch.float32, device=qkv.device)
+        _lib.check(lib.vsc_attention_f32(_lib.ptr(qkv), _lib.ptr(out), tokens, self.cfg.heads, self.cfg.hidden // self.cfg.heads,
+                                         _lib.current_stream()))
+        return out
 
     def logit(self, clip_cls: torch.Tensor) -> torch.Tensor:
         """clip_cls [n, feat_dim] (device): the CLIP [CLS] feature of each frame of ONE video -> 0-d logit tensor."""
@@ -85,20 +95,21 @@ class VideoScoreHead:
         f = clip_cls[: cfg.max_frames].float()
         if rows > f.shape[0]:
             f = torch.cat([f, torch.zeros(rows - f.shape[0], cfg.feat_dim, device=f.device)])
-        t = ops.gemm_bf16(f.to(torch.bfloat16), self.proj_w, self.proj_b, epilogue=_lib.EPI_F32)
-        vision = ops.layernorm(t, self.proj_g, self.proj_beta, cfg.proj_ln_eps, out_f32=True)
+
+        def lin(layer, x, act=None, residual=None):   # [T, in] -> [T, out] through the NHWC convolution entry point
+            r = None if residual is None else residual.reshape(1, x.shape[0], 1, -1)
+            return layer(x.contiguous().reshape(1, x.shape[0], 1, x.shape[1]), act=act, residual=r).reshape(x.shape[0], -1)
+
+        vision = ops.layernorm(lin(self.proj, f), self.proj_g, self.proj_beta, cfg.proj_ln_eps, out_f32=True)
         toks = [self.cls_emb[None], vision] + ([self.sep_emb[None]] if with_sep else [])
         emb = torch.cat(toks) + self.pos_type[: rows + 1 + int(with_sep)]
         T = emb.shape[0]
-        x, xb = ops.ln_residual(emb, self.emb_g, self.emb_b, cfg.ln_eps)
+        x, _ = ops.ln_residual(emb, self.emb_g, self.emb_b, cfg.ln_eps)
         for L in self.layers:
-            qkv = ops.gemm_bf16(xb, L["qkv_w"], L["qkv_b"])
-            att = ops.attention_bf16(qkv, 1, T, cfg.heads)
-            t = ops.gemm_bf16(att, L["o_w"], L["o_b"], epilogue=_lib.EPI_RESADD_F32, aux=x)
-            x, xb = ops.ln_residual(t, L["ln1_g"], L["ln1_b"], cfg.ln_eps)
-            h = ops.gemm_bf16(xb, L["fc1_w"], L["fc1_b"], epilogue=_lib.EPI_GELU_BF16)
-            t = ops.gemm_bf16(h, L["fc2_w"], L["fc2_b"], epilogue=_lib.EPI_RESADD_F32, aux=x)
-            x, xb = ops.ln_residual(t, L["ln2_g"], L["ln2_b"], cfg.ln_eps)
+            att = self._attention(lin(L["qkv"], x), T)
+            x, _ = ops.ln_residual(lin(L["o"], att, residual=x), L["ln1_g"], L["ln1_b"], cfg.ln_eps)
+            h = lin(L["fc1"], x, act="gelu")
+            x, _ = ops.ln_residual(lin(L["fc2"], h, residual=x), L["ln2_g"], L["ln2_b"], cfg.ln_eps)
         pooled = torch.cat([x[0], x.sum(dim=0) / (T + 1e-5)])
         return (self.out_w[0] * pooled).sum() + self.out_b[0]
 
