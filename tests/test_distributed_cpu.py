@@ -47,6 +47,52 @@ def _worker(rank, world_size, port, out_dir):
         dist.destroy_process_group()
 
 
+def _worker8(rank, world_size, port, out_dir):
+    """8 ranks, 5-row and 1003-row banks: empty shards, ragged shards, and the result gather of the sharded search."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        for n in (5, 1003):
+            refs = torch.from_numpy(synth.descriptor_bank(3, n, 32))
+            lo, hi = vdist.shard_bounds(n, rank, world_size)
+            bank, offsets = vdist.all_gather_rows(refs[lo:hi])
+            assert torch.equal(bank, refs)
+            assert offsets.tolist() == [vdist.shard_bounds(n, r, world_size)[0] for r in range(world_size)] + [n]
+        qs = torch.from_numpy(synth.descriptor_bank(4, 11, 32))          # 11 queries over 8 ranks: 2, 2, 2, 1, 1, 1, 1, 1
+        qlo, qhi = vdist.shard_bounds(11, rank, world_size)
+        D, I = vdist.sharded_knn(qs[qlo:qhi], refs[lo:hi], 7, knn=_oracle_knn)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "res8.npz"), D=D.numpy(), I=I.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_world8_ragged_and_empty_shards(tmp_path):
+    """BASELINE.json configs[3]'s host logic at the node's rank count: the bank all_gather with ragged and EMPTY shards
+    (fewer videos than ranks) and the sharded search, on gloo."""
+    port = _free_port()
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    got = np.load(tmp_path / "res8.npz")
+    from oracle import knn_oracle
+    D, I = knn_oracle.knn_ip(synth.descriptor_bank(4, 11, 32), synth.descriptor_bank(3, 1003, 32), 7)
+    assert np.array_equal(got["I"], I) and np.array_equal(got["D"], D)
+
+
+def test_ref_feature_merge_skips_empty_rank_parts(tmp_path):
+    """extract_ref_feats.py's rank-0 merge when a rank had nothing to encode (its part holds a (0, 0) block)."""
+    from src.extractor import extract_vsc_feat
+    ids, feats, stamps = extract_vsc_feat(lambda x: x, [], torch.device("cpu"))
+    assert ids == [] and feats.shape[0] == 0 and stamps.shape == (0,)
+    np.savez(tmp_path / "p_0.npz", video_ids=np.array(["R1", "R1"]), features=np.ones((2, 4), np.float32), timestamps=np.arange(2))
+    np.savez(tmp_path / "p_1.npz", video_ids=ids, features=feats, timestamps=stamps)
+    parts = [np.load(tmp_path / f"p_{i}.npz") for i in range(2)]
+    parts = [p for p in parts if len(p["features"])] or parts[:1]         # the merge rule of extract_ref_feats.py
+    merged = np.concatenate([p["features"] for p in parts])
+    assert merged.shape == (2, 4) and np.concatenate([p["video_ids"] for p in parts]).tolist() == ["R1", "R1"]
+
+
 def test_shard_bounds_cover_everything():
     for n in (0, 1, 7, 8, 1000):
         for ws in (1, 2, 3, 8):

@@ -43,3 +43,6 @@ def test_bench_stdout_is_one_line_with_a_process_group():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["search"]["value"] > 0
+    # the N > 1 search leg ran on a real RCCL communicator: bank all_gather (all_gather_into_tensor) + local sweep
+    assert d["search"]["n_gpus"] == 1 and d["search"]["scaling"] == "weak" and d["search"]["all_gather_bytes_per_rank"] == 0
+    assert "all_gather" in d["search"]["metric"] and d["search"]["nr_total"] == 50000

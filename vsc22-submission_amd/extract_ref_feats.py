@@ -42,6 +42,9 @@ def main(args):
         dist.barrier()
     if rank == 0:
         parts = [np.load(f"{args.save_file}_{i}.npz") for i in range(world_size)]
+        # a rank whose shard held no video (more ranks than videos, or all of its zips missing) wrote a (0, 0) feature
+        # block and an empty float id array: leave such parts out of the merge
+        parts = [p for p in parts if len(p["features"])] or parts[:1]
         np.savez(args.save_file + ".npz", video_ids=np.concatenate([p["video_ids"] for p in parts]),
                  features=np.concatenate([p["features"] for p in parts]),
                  timestamps=np.concatenate([p["timestamps"] for p in parts]))

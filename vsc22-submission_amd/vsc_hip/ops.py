@@ -172,6 +172,11 @@ def video_pair_max(q, q_video, n_q_videos: int, r, r_video, n_r_videos: int, thr
     assert q.dim() == 2 and r.dim() == 2 and q.shape[1] == r.shape[1], "query / reference dimension mismatch"
     q_video, r_video = _dev(q_video, torch.int32), _dev(r_video, torch.int32)
     assert q_video.shape == (q.shape[0],) and r_video.shape == (r.shape[0],)
+    # the sweep indexes a dense [n_q_videos, n_r_videos] table with these ids (atomic max): reject ids outside it here
+    if q.shape[0] and (int(q_video.min()) < 0 or int(q_video.max()) >= n_q_videos):
+        raise ValueError(f"q_video ids outside [0, {n_q_videos})")
+    if r.shape[0] and (int(r_video.min()) < 0 or int(r_video.max()) >= n_r_videos):
+        raise ValueError(f"r_video ids outside [0, {n_r_videos})")
     lims = torch.zeros(n_q_videos + 1, dtype=torch.int64, device=q.device)
     if q.shape[0] == 0 or r.shape[0] == 0 or n_q_videos == 0 or n_r_videos == 0:
         return (lims, torch.empty(0, dtype=torch.int32, device=q.device),
