@@ -49,4 +49,5 @@ for name, m, n, k, epi in shapes:
     tot_f += fl * mult
     tot_t += us * mult
     print(f"{name:6s} M={m} N={n} K={k}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s")
-print(f"weighted (12 layers): {tot_t / 1e3:.2f} ms per step, {tot_f / tot_t / 1e6:.1f} TF/s")
+if tot_t:
+    print(f"weighted (12 layers): {tot_t / 1e3:.2f} ms per step, {tot_f / tot_t / 1e6:.1f} TF/s")
