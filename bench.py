@@ -95,6 +95,7 @@ def parse():
     ap.add_argument("--lanes", type=int, default=1,
                     help="internal streams the chunks of a step alternate over (2: +1.9 %% frames/s, but the "
                          "per-kernel event times then overlap; the roofline line is quoted at 1)")
+    ap.add_argument("--fuse-ln", action="store_true", help="LayerNorm folded into the neighbouring GEMM epilogues (DESIGN 4.1b)")
     ap.add_argument("--preset", default="vit_b16_224")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search", action="store_true")
@@ -343,7 +344,7 @@ def main():
 
     cfg = get_config(args.preset)
     weights = synth.encoder_weights(7, cfg)
-    enc = HipEncoder(cfg, weights, max_batch=args.max_batch, l2_normalize=True, lanes=args.lanes)
+    enc = HipEncoder(cfg, weights, max_batch=args.max_batch, l2_normalize=True, lanes=args.lanes, fuse_ln=args.fuse_ln)
     # every rank encodes its own shard of the (synthetic) frame set
     base = synth.frames(1000 + rank, 32, cfg)
     frames = torch.from_numpy(base).to(dev).repeat((args.batch + 31) // 32, 1, 1, 1)[: args.batch]

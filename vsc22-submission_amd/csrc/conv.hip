@@ -120,6 +120,96 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p) {
     }
 }
 
+// Narrow variant for the thin layers (HRNet's 18- / 36- / 72-wide branches, the SE and head convolutions): 32 output
+// channels x 256 pixels per workgroup, wave w owns pixels [64 w, 64 w + 64) as two 32 x 32 accumulators.  An 18-channel
+// layer fills 56 % of this tile against 14 % of the 128-row one.  Same packed operands, same ascending-k chains.
+constexpr int NARROW_C = 32, NARROW_P = 256;
+constexpr int NARROW_W_BYTES = 4096;                         // 32 weight rows x 32 floats
+constexpr int NARROW_STAGE = NARROW_W_BYTES + 2 * TILE_BYTES;   // W | P0 | P1 = 36 KiB: two workgroups per CU
+
+__global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * NARROW_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int64_t tile = blockIdx.x;
+    const int tc = (int)(tile % p.tiles_c);
+    const int64_t tp = tile / p.tiles_c;
+    const int64_t c0 = (int64_t)tc * NARROW_C, p0 = tp * NARROW_P;
+    f32x16_t acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    auto stage = [&](int ks, char *st) {
+        // weights: pieces 0..3 (8 rows each) of a 128-row tile image, one per wave
+        {
+            const int r = wave * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int64_t gr = c0 + r;
+            gr = gr > p.cout - 1 ? p.cout - 1 : gr;
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.wp + gr * p.kpad + ks * KS + c * 4), (lptr_t)(st + wave * 1024), 16, 0, 0);
+        }
+        stage_tile(p.ap, p.kpad, p0, p.rows - 1, ks * KS, st + NARROW_W_BYTES, wave, lane);
+        stage_tile(p.ap, p.kpad, p0 + 128, p.rows - 1, ks * KS, st + NARROW_W_BYTES + TILE_BYTES, wave, lane);
+    };
+    const int nks = p.kpad / KS;
+    stage(0, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < nks; ++ks) {
+        if (ks + 1 < nks) stage(ks + 1, lds + (cur ^ 1) * NARROW_STAGE);
+        const char *wt = lds + cur * NARROW_STAGE;
+        const char *pt = wt + NARROW_W_BYTES + (wave >> 1) * TILE_BYTES;   // waves 0,1 -> P0, waves 2,3 -> P1
+        const int prow = (wave & 1) * 64;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const f32x4_t af = lds_frag(wt, l31, 2 * pr + hi);
+            f32x4_t bf[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = lds_frag(pt, prow + b * 32 + l31, 2 * pr + hi);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[b][t], acc[b], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    // acc[b][reg] = <w[c0 + 8*(reg>>2) + 4*hi + (reg&3)], patch[p0 + wave*64 + b*32 + l31]>
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t pix = p0 + wave * 64 + b * 32 + l31;
+        if (pix >= p.rows) continue;
+        float *orow = p.out + pix * p.ldo;
+        const float *rrow = p.res ? p.res + pix * p.ldr : nullptr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = (int)c0 + 8 * g + 4 * hi;
+            if (co >= p.cout) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[b][4 * g + r];
+                if (co + r < p.cout) {
+                    if (p.bias) v[r] += p.bias[co + r];
+                    if (rrow) v[r] += rrow[co + r];
+                    v[r] = activate(v[r], p.act);
+                }
+            }
+            if (co + 3 < p.cout && ((p.ldo | co) & 3) == 0) {
+                *(float4 *)(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < p.cout) orow[co + r] = v[r];
+            }
+        }
+    }
+}
+
 // depthwise: one thread per (pixel, channel); w [c, kh * kw]
 __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
                                                      const float *__restrict__ bias, float *__restrict__ out, int64_t total,
@@ -294,11 +384,16 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     hipLaunchKernelGGL(im2col_pack_kernel, dim3(blocks_for(rows * (kpad / 4))), dim3(256), 0, stream, x_dev, (float *)s.ptr, rows,
                        h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k, kpad);
     VSC_CHECK_LAUNCH();
-    const int tiles_c = (cout + TR - 1) / TR;
-    const int64_t tiles_p = (rows + TQ - 1) / TQ;
+    const bool narrow = cout <= 80;   // <= 3 channel tiles of 32: the thin layers (see conv_gemm_narrow_kernel)
+    const int tiles_c = narrow ? (cout + NARROW_C - 1) / NARROW_C : (cout + TR - 1) / TR;
+    const int64_t tiles_p = narrow ? (rows + NARROW_P - 1) / NARROW_P : (rows + TQ - 1) / TQ;
     VSC_REQUIRE(tiles_p * tiles_c < (1ll << 31), "conv2d: grid too large");
     ConvGemmArgs a{w_packed_dev, (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c};
-    hipLaunchKernelGGL(conv_gemm_kernel, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
+    if (narrow) {
+        hipLaunchKernelGGL(conv_gemm_narrow_kernel, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(conv_gemm_kernel, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
+    }
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }

@@ -1132,10 +1132,10 @@ int launch_gemm_bf16_ex(const uint16_t *a, const uint16_t *w, const float *bias,
             case VSC_EPI_RESADD_F32: return launch_v2_pick<VSC_EPI_RESADD_F32>(p, stream);
             case VSC_EPI_PATCH_F32: return launch_v2_pick<VSC_EPI_PATCH_F32>(p, stream);
             case VSC_EPI_F32: return launch_v2_pick<VSC_EPI_F32>(p, stream);
-            case VSC_EPI_LNF_BF16: return launch_v2<VSC_EPI_LNF_BF16, 2, 4, 8, 4, 4>(p, stream);
-            case VSC_EPI_LNF_GELU_BF16: return launch_v2<VSC_EPI_LNF_GELU_BF16, 2, 4, 8, 4, 4>(p, stream);
-            case VSC_EPI_LNF_QGELU_BF16: return launch_v2<VSC_EPI_LNF_QGELU_BF16, 2, 4, 8, 4, 4>(p, stream);
-            case VSC_EPI_RESADD_STATS_F32: return launch_v2<VSC_EPI_RESADD_STATS_F32, 2, 4, 8, 4, 4>(p, stream);
+            case VSC_EPI_LNF_BF16: return p.k % 64 == 0 ? launch_v3<VSC_EPI_LNF_BF16>(p, stream) : launch_v2<VSC_EPI_LNF_BF16, 2, 4, 8, 4, 4>(p, stream);
+            case VSC_EPI_LNF_GELU_BF16: return p.k % 64 == 0 ? launch_v3<VSC_EPI_LNF_GELU_BF16>(p, stream) : launch_v2<VSC_EPI_LNF_GELU_BF16, 2, 4, 8, 4, 4>(p, stream);
+            case VSC_EPI_LNF_QGELU_BF16: return p.k % 64 == 0 ? launch_v3<VSC_EPI_LNF_QGELU_BF16>(p, stream) : launch_v2<VSC_EPI_LNF_QGELU_BF16, 2, 4, 8, 4, 4>(p, stream);
+            case VSC_EPI_RESADD_STATS_F32: return p.k % 64 == 0 ? launch_v3<VSC_EPI_RESADD_STATS_F32>(p, stream) : launch_v2<VSC_EPI_RESADD_STATS_F32, 2, 4, 8, 4, 4>(p, stream);
             default: VSC_REQUIRE(false, "gemm: unknown epilogue %d", epilogue);
         }
     }
