@@ -648,8 +648,11 @@ __global__ __launch_bounds__(256) void knn_pack_bf16_kernel(const float *__restr
         if (lane == 0) {
             if (stats) *(float4 *)(stats + row * 4) = make_float4(sqrtf(ss), sqrtf(sh), sqrtf(sd), 0.f);
             if (max_bits) {   // norms are >= 0, so their float bits order like unsigned ints (NaN sorts above everything)
-                atomicMax(max_bits, __float_as_uint(sqrtf(ss)));
-                atomicMax(max_bits + 1, __float_as_uint(sqrtf(sd)));
+                // a million same-address atomics serialise (23 ms per 1M rows): look first, update only when this row raises
+                // the maximum -- a stale read can only cause a redundant atomic, never a missed one
+                const unsigned bn = __float_as_uint(sqrtf(ss)), bd = __float_as_uint(sqrtf(sd));
+                if (bn > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, bn);
+                if (bd > __hip_atomic_load(max_bits + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits + 1, bd);
             }
         }
     }
