@@ -247,3 +247,97 @@ def test_query_postprocess_matches_reference_statement():
     np.random.seed(5)
     assert idx == 5 and low.feature.shape == (1, 512)
     np.testing.assert_array_equal(low.feature[0], np.random.uniform(-1e-5, 1e-5, size=512).astype(np.float32))
+
+
+class _NumpySweep:
+    """Stand-in for vsc_hip.ops on CPU tensors: the same three calls on the oracle's chains.  Exercises the HOST logic of
+    vsc.index (metric augmentation, probe / radius search, sorting); the HIP sweeps themselves are tested with -m gpu."""
+
+    @staticmethod
+    def knn_ip(q, r, k, ref_id_offset=0):
+        import torch
+        from oracle import knn_oracle
+        D, I = knn_oracle.knn_ip(q.numpy(), r.numpy(), k)
+        return torch.from_numpy(D), torch.from_numpy(I + ref_id_offset * (I >= 0))
+
+    @staticmethod
+    def range_search_ip(q, r, radius, ref_id_offset=0, capacity=0):
+        import torch
+        from oracle import knn_oracle
+        lims, D, I = knn_oracle.range_search_ip(q.numpy(), r.numpy(), float(radius))
+        return torch.from_numpy(lims), torch.from_numpy(D), torch.from_numpy(I)
+
+    @staticmethod
+    def range_count_ip(q, r, radius):
+        from oracle import knn_oracle
+        return int(knn_oracle.range_search_ip(q.numpy(), r.numpy(), float(radius))[0][-1])
+
+
+@pytest.fixture
+def cpu_sweep(monkeypatch):
+    import torch
+    import vsc.index as vi
+    from vsc_hip import ops
+    monkeypatch.setattr(vi.FlatIPBank, "_to_device", staticmethod(lambda host: torch.from_numpy(np.ascontiguousarray(host))))
+    for name in ("knn_ip", "range_search_ip", "range_count_ip"):
+        monkeypatch.setattr(ops, name, getattr(_NumpySweep, name))
+    return vi
+
+
+def test_global_threshold_search_host_logic(cpu_sweep):
+    """_global_threshold_knn_search == the min(global_k, nq * nr) best pairs of the full score matrix in all three regimes:
+    probe sufficient; one row owns more winners than the probe (threshold range sweep); probe smaller than global_k
+    (radius found by counting) -- index.py:145-165 of the reference returns exactly that set."""
+    vi = cpu_sweep
+    from oracle import knn_oracle
+    rng = np.random.RandomState(0)
+    r = rng.randn(400, 16).astype(np.float32)
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    for nq, gk, probe in ((6, 30, 1024), (6, 300, 16), (1, 250, 64), (2, 799, 32), (2, 5000, 32)):
+        q = rng.randn(nq, 16).astype(np.float32)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        if probe == 16:
+            r[50:200] = q[2] + 0.01 * rng.randn(150, 16).astype(np.float32)
+        idx = vi.VideoIndex(16)
+        idx.add([vi.VideoFeature("R1", np.arange(400.0), r)])
+        S = knn_oracle.ip_matrix(q, r)
+        old, vi.MAX_K = vi.MAX_K, probe
+        try:
+            hits = idx._global_threshold_knn_search(q, gk)
+        finally:
+            vi.MAX_K = old
+        n = min(gk, nq * 400)
+        flat = np.argsort(-S.ravel().astype(np.float64), kind="stable")[:n]
+        assert len(hits) == n
+        assert sorted((i, j) for i, j, _ in hits) == sorted((int(f // 400), int(f % 400)) for f in flat)
+        assert all(s == S[i, j] for i, j, s in hits) and all(a[2] >= b[2] for a, b in zip(hits, hits[1:]))
+
+
+def test_flat_l2_index_host_logic(cpu_sweep):
+    """METRIC_L2 through the inner-product sweep (rows [r, |r|^2, 1] against [2q, -1, -|q|^2]): exact squared distances,
+    brute-force ids, and the reference's own tests/test_index.py vectors through both VideoIndex search modes."""
+    vi = cpu_sweep
+    rng = np.random.RandomState(3)
+    r = (rng.randn(300, 12) * 3).astype(np.float32)
+    q = (rng.randn(9, 12) * 3).astype(np.float32)
+    q[5] = r[77]
+    bank = vi.FlatIPBank(12, vi.METRIC_L2)
+    bank.add(r[:100])
+    bank.add(r[100:])
+    D, I = bank.search(q, 7)
+    d64 = ((q[:, None, :].astype(np.float64) - r[None].astype(np.float64)) ** 2).sum(-1)
+    want = np.argsort(d64, axis=1, kind="stable")[:, :7]
+    assert np.array_equal(I, want) and D[5, 0] == 0.0 and (np.diff(D, axis=1) >= 0).all()
+    assert np.allclose(D, np.take_along_axis(d64, want, 1), rtol=1e-5, atol=1e-5)
+    rows, ids, dist = bank.range_search(q, 60.0)
+    assert sorted(zip(rows.tolist(), ids.tolist())) == sorted(map(tuple, np.argwhere(d64 < 60.0).tolist()))
+    assert bank.range_count(q, 60.0) == len(rows)
+    feats = np.array([[[1, 2, 3], [4, 5, 6], [7, 8, 9]], [[11, 12, 13], [14, 15, 16], [17, 18, 19]],
+                      [[111, 112, 113], [114, 115, 116], [117, 118, 119]]], np.float32)
+    mk = lambda pre: [vi.VideoFeature(video_id=f"{pre}{i:06d}", feature=f, timestamps=np.arange(3, dtype=np.float32))
+                      for i, f in enumerate(feats)]
+    for gk in (1, -1, 4):
+        idx = vi.VideoIndex(3, "Flat", vi.METRIC_L2)
+        idx.add(mk("R"))
+        res = idx.search(mk("Q"), gk)
+        assert res and all(x.query_id[1:] == x.ref_id[1:] for x in res)

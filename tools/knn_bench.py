@@ -27,4 +27,4 @@ for _ in range(steps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / steps
-print(f"nq={nq} nr={nr} k={k}: {ms:.2f} ms/sweep, {nq * nr / ms / 1e3:.0f} Mpairs/s, {2 * nq * nr * 512 / ms / 1e9:.1f} TFLOP/s fp32")
+print(f"nq={nq} nr={nr} k={k}: {ms:.2f} ms/sweep, {nq * nr / ms / 1e3:.0f} Mpairs/s, {2 * nq * nr * 512 / ms / 1e9:.1f} TFLOP/s-equivalent (2 nq nr d / call time)")

@@ -104,25 +104,29 @@ class FlatIPBank:
             self._chunks = [np.concatenate(self._chunks)]
         return self._chunks[0] if self._chunks else np.zeros((0, self.d), np.float32)
 
-    def device_bank(self):
+    @staticmethod
+    def _to_device(host: np.ndarray):
+        """float32 rows -> a GPU tensor for the C ABI (there is no CPU search path: this raises without an MI355X)."""
         import torch
         from vsc_hip import _lib
         _lib.require_device()
+        return torch.from_numpy(host).cuda()
+
+    def device_bank(self):
         if self._bank is None:
             host = self._host_rows()
             if not self.is_similarity:
                 sq = np.einsum("ij,ij->i", host, host, dtype=np.float32)[:, None]
                 host = np.concatenate([host, sq, np.ones_like(sq)], axis=1)
-            self._bank = torch.from_numpy(host).cuda()
+            self._bank = self._to_device(host)
         return self._bank
 
     def _device_queries(self, x: np.ndarray):
-        import torch
         x = np.ascontiguousarray(x, dtype=np.float32)
         if not self.is_similarity:
             sq = np.einsum("ij,ij->i", x, x, dtype=np.float32)[:, None]
             x = np.concatenate([2.0 * x, -np.ones_like(sq), -sq], axis=1)
-        return torch.from_numpy(x).cuda()
+        return self._to_device(np.ascontiguousarray(x))
 
     def _exact_l2(self, x: np.ndarray, rows: np.ndarray, ids: np.ndarray) -> np.ndarray:
         """float32 sum((x[rows] - bank[ids])^2); ids < 0 (padding) -> FLT_MAX as faiss does."""
