@@ -318,7 +318,8 @@ __device__ __forceinline__ void epilogue_frag(const GemmArgs &p, f32x4_t v, int6
 template <int EPI, int TM, int TN>
 __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&acc)[TM][TN], char *lds2,
                                                  int wave, int lane, int wm, int wn, int64_t m0,
-                                                 int n0, const float2 (&rs)[TM], const f32x4_t (&bzp)[TN]) {
+                                                 int n0, const float2 (&rs)[TM], const f32x4_t (&bzp)[TN],
+                                                 const f32x4_t (&csp)[TN]) {
     const int fr = lane & 15, fq = lane >> 4;
     // ---- epilogue through LDS.  A lane's accumulators are 4 columns of 16 different rows
     // per fragment: stored directly that is 32-byte pieces of 16 rows per instruction, and the
@@ -344,8 +345,8 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
         for (int j = 0; j < TN; ++j) {
             const int n = ncol0 + j * 16 + fq * 4;
             const f32x4_t bz = bzp[j];
-            f32x4_t cs = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            if (epi_lnf(EPI) && n < p.n) cs = *(const f32x4_t *)(p.ex.colsum + n);
+            (void)n;
+            const f32x4_t cs = csp[j];   // LayerNorm folding: column sums of W' (zeros otherwise)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 f32x4_t v;
@@ -620,7 +621,14 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
     if (NW == 8 && group == 0) __builtin_amdgcn_s_barrier();
     if (NW == 4) __builtin_amdgcn_s_barrier();  // every wave is past its last fragment read
 
-    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0, rs, bzp);
+    f32x4_t csp[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + wn * TN * 16 + j * 16 + (lane >> 4) * 4;
+        csp[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (epi_lnf(EPI) && nb < p.n) csp[j] = *(const f32x4_t *)(p.ex.colsum + nb);
+    }
+    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0, rs, bzp, csp);
 #ifdef VSC_GEMM_TIMING
     if (blockIdx.x == 300 % gridDim.x && lane == 0 && p.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -665,21 +673,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    float2 rs[TM];
-    if (epi_lnf(EPI)) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            int64_t m = m0 + wm * TM * 16 + i * 16 + (lane & 15);
-            m = m < p.m ? m : p.m - 1;
-            rs[i] = *(const float2 *)(p.ex.rowstats + 2 * m);
+    // Per-tile epilogue constants -- the bias, and for LayerNorm folding the column sums and the rows' (mean, rstd) -- go to
+    // the 4 KiB of LDS behind the ring by LDS-DMA before the first operand unit is requested: they are older than every
+    // counted unit, so they have landed by the first barrier, and the epilogue reads them with ds_reads.  Held in registers
+    // across the K loop instead (v2) they cost 16-32 VGPRs of a 254-VGPR kernel (spilled in the folding variants), fetched
+    // at the end they cost an exposed global round trip per tile.
+    char *ext = lds2 + ml64::RING_BYTES;   // [0, 1 KiB) bias | [1, 2 KiB) colsum | [2, 4 KiB) rowstats of the tile's 256 rows
+    {
+        typedef __attribute__((address_space(3))) void *lptr_t;
+        const int piece = wave & 3;
+        const float *vec = wave < 4 ? p.bias : (epi_lnf(EPI) ? p.ex.colsum : nullptr);
+        if (vec) {
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)vec, 0, p.n * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)(ext + (wave < 4 ? 0 : 1024) + piece * 256), 4,
+                                                     (n0 + piece * 64 + lane) * 4, 0, 0, 0);
+        } else {
+            *(float *)(ext + (wave < 4 ? 0 : 1024) + piece * 256 + lane * 4) = 0.f;
         }
-    }
-    f32x4_t bzp[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + wn * TN * 16 + j * 16 + (lane >> 4) * 4;
-        bzp[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (p.bias && nb < p.n) bzp[j] = *(const f32x4_t *)(p.bias + nb);
+        if (epi_lnf(EPI)) {
+            const int64_t rows_left = p.m - m0;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)(p.ex.rowstats + 2 * m0), 0,
+                                                                              (int)(rows_left < 256 ? rows_left : 256) * 8, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)(ext + 2048 + wave * 256), 4, (wave * 64 + lane) * 4, 0, 0, 0);
+        }
     }
     ml64::Ctx c;
     const int64_t a_rows = p.m - m0;
@@ -687,12 +703,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs p) {
     ml64::init(c, p.a + m0 * p.k, p.k, (int)(a_rows < 256 ? a_rows : 256), p.w + (int64_t)n0 * p.k, p.k,
                w_rows < 256 ? w_rows : 256, lds2, wave, lane);
     ml64::run(c, acc, p.k / 64);
-    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0, rs, bzp);
+    float2 rs[TM];
+    f32x4_t bzp[TN], csp[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+        rs[i] = epi_lnf(EPI) ? *(const float2 *)(ext + 2048 + (wm * 128 + i * 16 + (lane & 15)) * 8) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn * 64 + j * 16 + (lane >> 4) * 4;
+        bzp[j] = *(const f32x4_t *)(ext + col * 4);
+        csp[j] = *(const f32x4_t *)(ext + 1024 + col * 4);
+    }
+    epilogue_via_lds<EPI, TM, TN>(p, acc, lds2, wave, lane, wm, wn, m0, n0, rs, bzp, csp);
 }
 
 template <int EPI>
 int launch_v3(GemmArgs p, hipStream_t stream) {
-    constexpr int smem = ml64::RING_BYTES;   // == 8 waves x 16 KiB of write-out staging
+    constexpr int smem = ml64::RING_BYTES + 4096;   // ring (== 8 waves x 16 KiB of write-out staging) + the epilogue constants
     auto kern = gemm_bf16_v3_kernel<EPI>;
     static bool attr_set[16] = {};
     int dev = 0;
