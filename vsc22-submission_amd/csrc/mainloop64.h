@@ -5,11 +5,14 @@
 // from L2, where the BK = 32 loop of v2 fetched every line in two halves), and a K-tile is worked off in
 // FOUR phases of 16 MFMAs -- one quadrant (64 x 32) of the wave tile each:
 //
-//     phase  fragment reads (ds_read_b128)        LDS-DMA issued (2 x 1 KiB per wave)   MFMAs
-//       0    W-sub0 (4), A-sub0 (8)               unit (t+1, W-h1)                      A0 x W0
-//       1    W-sub1 (4)                           unit (t+1, A-h1)                      A0 x W1
-//       2    A-sub1 (8)                           unit (t+2, W-h0)                      A1 x W1
-//       3    --                                   unit (t+2, A-h0)                      A1 x W0
+//     phase  fragment reads (ds_read_b128)              LDS-DMA issued (2 x 1 KiB per wave)   MFMAs
+//       0    A-sub0 (8)                                 unit (t+1, W-h1)                      A0 x W0
+//       1    W-sub1 (4)                                 unit (t+1, A-h1)                      A0 x W1
+//       2    A-sub1 (8)                                 unit (t+2, W-h0)                      A1 x W1
+//       3    W-sub0 of tile t+1 (4), a phase early      unit (t+2, A-h0)                      A1 x W0
+// (W-sub0 is kept in registers from phase 0 to phase 3; reading the next tile's W-sub0 in phase 3 into a second register
+//  set balances the L segments at 8 / 4 / 8 / 4 reads where 12 / 4 / 8 / 0 left phase 0 the longest: 8192^3 1561 -> 1609
+//  TF/s, the K = 768 shapes within noise.)
 //
 // Every phase is an L segment (reads + DMA issue + counted vmcnt) and a C segment (16 MFMAs under s_setprio),
 // each closed by a raw s_barrier; waves 4-7 (the M-half wm = 1, the second wave of every SIMD) run one
@@ -102,13 +105,16 @@ __device__ __forceinline__ bf16x8_t frag(const Ctx &c, int slot, uint32_t rd, in
     return *(const bf16x8_t *)(c.lds + slot * UNIT_BYTES + ((rd + f * 2048) ^ (kh * 64)));
 }
 
-// fragments of one K-tile: af[i][kh] (i = 0..3: the A sub-tile in use), wf[j][kh] (j = 0..3: both W sub-tiles)
+// fragments: af[i][kh] (i = 0..3: the A sub-tile in use), w1[j][kh] (W sub-tile 1 of the K-tile at hand) and, by tile parity,
+// w0[B][j][kh]: W sub-tile 0 of the tile at hand lives in w0[t & 1] -- it is read one phase EARLY, in the otherwise read-free
+// phase 3 of the tile before, into the other parity's registers (fragment reads per phase 8 / 4 / 8 / 4 instead of 12 / 4 / 8 / 0)
 struct Frags {
     bf16x8_t af[4][2];
-    bf16x8_t wf[4][2];
+    bf16x8_t w1[2][2];
+    bf16x8_t w0[2][2][2];
 };
 
-template <int ASUB, int WSUB>
+template <int B, int ASUB, int WSUB>
 __device__ __forceinline__ void mfma_quadrant(f32x4_t (&acc)[8][4], const Frags &f) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -117,8 +123,8 @@ __device__ __forceinline__ void mfma_quadrant(f32x4_t (&acc)[8][4], const Frags 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                acc[ASUB * 4 + i][WSUB * 2 + j] =
-                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wf[WSUB * 2 + j][kh], f.af[i][kh], acc[ASUB * 4 + i][WSUB * 2 + j], 0, 0, 0);
+                acc[ASUB * 4 + i][WSUB * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    WSUB == 0 ? f.w0[B][j][kh] : f.w1[j][kh], f.af[i][kh], acc[ASUB * 4 + i][WSUB * 2 + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
 }
 
@@ -142,28 +148,25 @@ __device__ __forceinline__ void end_c() {
 template <int B, bool STEADY>
 __device__ __forceinline__ void ktile(const Ctx &c, f32x4_t (&acc)[8][4], Frags &f, int t, int rem) {
     constexpr int S_W0 = 4 * B + 0, S_A0 = 4 * B + 1, S_W1 = 4 * B + 2, S_A1 = 4 * B + 3;   // this tile's slots
-    constexpr int N_W1 = 4 * (B ^ 1) + 2, N_A1 = 4 * (B ^ 1) + 3;                          // tile t+1, j = 2, 3
-    // ---- phase 0
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) f.wf[j][kh] = frag(c, S_W0, c.rd_w, j, kh);
+    constexpr int N_W0 = 4 * (B ^ 1) + 0, N_W1 = 4 * (B ^ 1) + 2, N_A1 = 4 * (B ^ 1) + 3;  // tile t+1, j = 0, 2, 3
+    (void)S_W0;
+    // ---- phase 0 (W sub-tile 0 is already in f.w0[B]: read in phase 3 of the previous tile, or by tiles() for tile 0)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) f.af[i][kh] = frag(c, S_A0, c.rd_a, i, kh);
     if (STEADY || rem > 1) stage_unit<1, 1>(c, N_W1, t + 1);
     end_l<STEADY, 8, 2>(rem);
-    mfma_quadrant<0, 0>(acc, f);
+    mfma_quadrant<B, 0, 0>(acc, f);
     end_c();
     // ---- phase 1
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) f.wf[2 + j][kh] = frag(c, S_W1, c.rd_w, j, kh);
+        for (int kh = 0; kh < 2; ++kh) f.w1[j][kh] = frag(c, S_W1, c.rd_w, j, kh);
     if (STEADY || rem > 1) stage_unit<0, 1>(c, N_A1, t + 1);
     end_l<STEADY, 8, 0>(rem);
-    mfma_quadrant<0, 1>(acc, f);
+    mfma_quadrant<B, 0, 1>(acc, f);
     end_c();
     // ---- phase 2
 #pragma unroll
@@ -172,12 +175,18 @@ __device__ __forceinline__ void ktile(const Ctx &c, f32x4_t (&acc)[8][4], Frags 
         for (int kh = 0; kh < 2; ++kh) f.af[i][kh] = frag(c, S_A1, c.rd_a, i, kh);
     if (STEADY || rem > 2) stage_unit<1, 0>(c, S_W0, t + 2);
     end_l<STEADY, 6, 0>(rem);
-    mfma_quadrant<1, 1>(acc, f);
+    mfma_quadrant<B, 1, 1>(acc, f);
     end_c();
-    // ---- phase 3
+    // ---- phase 3: unit (t+1, W-h0) landed with the wait of phase 2 (units <= g + 2) and the barriers since
+    if (STEADY || rem > 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) f.w0[B ^ 1][j][kh] = frag(c, N_W0, c.rd_w, j, kh);
+    }
     if (STEADY || rem > 2) stage_unit<0, 0>(c, S_A0, t + 2);
     end_l<STEADY, 4, 0>(rem);
-    mfma_quadrant<1, 0>(acc, f);
+    mfma_quadrant<B, 1, 0>(acc, f);
     end_c();
 }
 
@@ -204,6 +213,12 @@ __device__ __forceinline__ void tiles(const Ctx &c, f32x4_t (&acc)[8][4], Frags 
     const int group = c.wave >> 2;
     if (group == 1) __builtin_amdgcn_s_barrier();   // stagger: waves 4-7 run one segment behind
     __builtin_amdgcn_sched_barrier(0);
+    if (t0 == 0) {   // W sub-tile 0 of the very first K-tile (every later one is read a phase early by its predecessor)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) f.w0[0][j][kh] = frag(c, 0, c.rd_w, j, kh);
+    }
     int t = t0;
     const int end = t0 + n;
     for (; t + 2 <= end && t + 4 <= total; t += 2) {   // both tiles have at least two more behind them
