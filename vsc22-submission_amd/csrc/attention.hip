@@ -61,11 +61,18 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
         qf[i][0] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8);
         qf[i][1] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8 + 32);
     }
-    // ---- stage K (row-major, swizzled); pad rows are zero.  All of a thread's rows are requested before the first
-    //      LDS write (as a plain loop each 16-B load was waited for before the next one was issued).
+    // ---- stage K (row-major, swizzled; pad rows are zero) and V (transposed): ALL of a thread's K and V rows are requested
+    //      before the first LDS write, so the workgroup pays one memory round trip for its 50 KB instead of two (K, then V);
+    //      the kernel runs at the rate its workgroups can keep loads in flight (2.7-3.0 TB/s at every token count and
+    //      occupancy, tools/micro/attn_occupancy.py), not at a compute limit.
+    //      V task = (4 keys) x (8 head-dim columns); 16 consecutive lanes take 16 consecutive key groups of one column
+    //      block, so every ds_write_b64 of a 16-lane group lands on 128 contiguous bytes (conflict-free).
     {
         constexpr int KIT = (TP * 8 + 511) / 512;
+        constexpr int VTASKS = ((TP / 4 + 15) / 16) * 128;   // 16 key groups x 8 column blocks per 128 tasks
+        constexpr int VIT = (VTASKS + 511) / 512;
         uint4 kv[KIT];
+        bf16x8_t vr[VIT][4];
 #pragma unroll
         for (int i = 0; i < KIT; ++i) {
             const int e = tid + i * 512, row = e >> 3, c = e & 7;
@@ -73,32 +80,33 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
             if (e < TP * 8 && row < tokens) kv[i] = *(const uint4 *)(kptr + row * ld + c * 8);
         }
 #pragma unroll
+        for (int it = 0; it < VIT; ++it) {
+            const int e = tid + it * 512;
+            const int blk = e >> 7, c8 = (e >> 4) & 7, kg = blk * 16 + (e & 15);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = kg * 4 + i;
+                vr[it][i] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+                if (e < VTASKS && kg < TP / 4 && row < tokens) vr[it][i] = *(const bf16x8_t *)(vptr + row * ld + c8 * 8);
+            }
+        }
+#pragma unroll
         for (int i = 0; i < KIT; ++i) {
             const int e = tid + i * 512, row = e >> 3, c = e & 7;
             if (e < TP * 8) *(uint4 *)(klds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kv[i];
         }
-    }
-    // ---- stage V transposed: task = (4 keys) x (8 head-dim columns).  16 consecutive lanes
-    //      take 16 consecutive key groups of one column block, so every ds_write_b64 of a
-    //      16-lane group lands on 128 contiguous bytes (conflict-free).
-    for (int e = tid; e < ((TP / 4 + 15) / 16) * 128; e += 512) {  // 16 key groups x 8 column blocks per 128 tasks
-        const int blk = e >> 7, c8 = (e >> 4) & 7, kg = blk * 16 + (e & 15);
-        if (kg >= TP / 4) continue;
-        bf16x8_t r[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = kg * 4 + i;
-            if (row < tokens)
-                r[i] = *(const bf16x8_t *)(vptr + row * ld + c8 * 8);
-            else
-                r[i] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-        }
+        for (int it = 0; it < VIT; ++it) {
+            const int e = tid + it * 512;
+            const int blk = e >> 7, c8 = (e >> 4) & 7, kg = blk * 16 + (e & 15);
+            if (e >= VTASKS || kg >= TP / 4) continue;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            uint2 pk;
-            pk.x = (uint32_t)(uint16_t)r[0][j] | ((uint32_t)(uint16_t)r[1][j] << 16);
-            pk.y = (uint32_t)(uint16_t)r[2][j] | ((uint32_t)(uint16_t)r[3][j] << 16);
-            *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + kg * 8) = pk;
+            for (int j = 0; j < 8; ++j) {
+                uint2 pk;
+                pk.x = (uint32_t)(uint16_t)vr[it][0][j] | ((uint32_t)(uint16_t)vr[it][1][j] << 16);
+                pk.y = (uint32_t)(uint16_t)vr[it][2][j] | ((uint32_t)(uint16_t)vr[it][3][j] << 16);
+                *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + kg * 8) = pk;
+            }
         }
     }
     __syncthreads();
