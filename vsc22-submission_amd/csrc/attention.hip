@@ -21,6 +21,9 @@
 //     side by side): 139 us per launch against 121 with these 8 waves, and a runtime tile loop with fewer waves is slower
 //     too (tools/micro/attn_bench.py).  The launch moves 392 MB (qkv in, context out): ~71 us at HBM speed, so the kernel
 //     sits at 1.7 x its memory floor; what is left is the K / V staging of the second resident workgroup.
+//     Also measured and dropped: persistent workgroups that request the NEXT (frame, head)'s Q / K / V into registers
+//     while the current one is computed -- 173 VGPRs halve the residency (159 vs 148 us), capped at 128 VGPRs it spills
+//     (239 us).
 //   * softmax runs in fp32 with exp2 and a folded scale (1/8 * log2 e); probabilities are
 //     rounded to bf16 for the PV MFMA, the row sum is kept in fp32 from the unrounded values.
 #include "common.h"
