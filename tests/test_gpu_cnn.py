@@ -147,3 +147,65 @@ def test_match_classify_and_refine_entry_points(dev):
         assert np.abs(sim - q @ r.T).max() < 1e-5
     out = matching.generate_matching_result([["Qx", "Ry", np.eye(40, dtype=np.float32) * 0.9, None]])
     assert len(out) == 1 and out[0][:2] == ["Qx", "Ry"]
+
+
+def test_infer_matching_entry_point_end_to_end(dev, tmp_path):
+    """infer_matching.py (Main.run() of the reference from the query descriptors on): score normalisation -> candidate
+    retrieval -> classifier -> refinement -> localisation, on synthetic descriptor files with a planted copy and
+    random-weight networks.  Checks the plumbing the reference's run() has: candidate csv = brute-force statement of
+    :229-262, every stage consumes the previous one's output, output columns / ordering."""
+    import csv
+    import importlib
+    import subprocess
+    from src import matching
+    from vsc.baseline.score_normalization import normalize, query_score_normalize, ref_score_normalize
+    from vsc.index import VideoFeature
+    from vsc.storage import store_features
+    rng = np.random.RandomState(7)
+    d = 512
+    mk = lambda pre, i, n: VideoFeature(video_id=f"{pre}{i:06d}", timestamps=np.arange(n, dtype=np.float32),
+                                        feature=rng.randn(n, d).astype(np.float32))
+    refs = [mk("R", 200000 + i, n) for i, n in enumerate((30, 44, 25))]
+    norm = [mk("R", 100000 + i, 20) for i in range(4)]
+    queries = [mk("Q", 300000 + i, n) for i, n in enumerate((18, 27))]
+    queries[0].feature[3:15] = refs[1].feature[10:22] + 0.05 * rng.randn(12, d).astype(np.float32)   # planted copy
+    sn_refs = ref_score_normalize(refs, norm, beta=1.5, nk=10)
+    paths = {}
+    for name, feats in (("q", queries), ("norm", norm), ("refs", refs), ("sn", sn_refs)):
+        paths[name] = str(tmp_path / f"{name}.npz")
+        store_features(paths[name], feats)
+    cls_paths, ref_paths = [], []
+    for i in range(2):
+        p = str(tmp_path / f"cls{i}.pt")
+        torch.save(cnn_synth.mobilenetv3_small_state(40 + i), p)
+        cls_paths.append(p)
+    p = str(tmp_path / "refine0.pt")
+    torch.save(cnn_synth.hrnet_refine_state(50), p)
+    ref_paths.append(p)
+    out_csv, cand_csv = str(tmp_path / "out" / "matches.csv"), str(tmp_path / "cands.csv")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "vsc22-submission_amd") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    res = subprocess.run([sys.executable, os.path.join(root, "vsc22-submission_amd", "infer_matching.py"), "--query_features", paths["q"],
+                          "--norm_refs", paths["norm"], "--refs", paths["refs"], "--sn_refs", paths["sn"], "--cls_models", *cls_paths,
+                          "--refine_models", *ref_paths, "--candidates_csv", cand_csv, "--output", out_csv],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    # candidate retrieval == the reference's dict of best frame scores above SEARCH_THRESHOLD (float64 brute force)
+    import collections
+    low = matching.calclualte_low_var_dim(norm)
+    snq = query_score_normalize(queries, norm, collections.defaultdict(lambda: 1.0), low_var_dim=low, beta=1.5, nk=10)
+    want = {}
+    for q in snq:
+        for r in sn_refs:
+            s = (q.feature.astype(np.float64) @ r.feature.astype(np.float64).T).max()
+            if s > matching.SEARCH_THRESHOLD:
+                want[q.video_id, r.video_id] = s
+    with open(cand_csv) as f:
+        got = [(r[0], r[1], float(r[2])) for r in list(csv.reader(f))[1:]]
+    assert {(q, r) for q, r, _ in got} == set(want) and all(abs(s - want[q, r]) < 1e-4 for q, r, s in got)
+    assert all(a[2] >= b[2] for a, b in zip(got, got[1:])) and got[0][:2] == ("Q300000", "R200001")   # the planted pair ranks first
+    with open(out_csv) as f:
+        rows = list(csv.reader(f))
+    assert rows[0] == ["query_id", "ref_id", "query_start", "query_end", "ref_start", "ref_end", "score"]
+    for r in rows[1:]:
+        assert (r[0], r[1]) in want and float(r[2]) <= float(r[3]) and float(r[4]) <= float(r[5])
