@@ -11,13 +11,15 @@ Frames shard across ranks with no data-path collective ("weak" scaling: per-GPU 
 fixed); value = frames of all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel = the bf16 GEMM (gemm_bf16_kernel, all five call sites);
-                achieved = algorithmic FLOPs of those launches / their HIP-event time
-                measured inside the timed steps; peak = 2500 TFLOP/s dense bf16 MFMA.
+  roofline      dominant kernel = the bf16 GEMM (gemm_bf16_v3_kernel, all five call sites);
+                achieved = algorithmic FLOPs of those launches / their HIP-event time (events on the launch
+                stream, in a separate loop of --profile-steps steps right after the timed region: the headline
+                loop carries no events); peak = 2500 TFLOP/s dense bf16 MFMA.
   cpu_baseline  the fp32 oracle (oracle/vit_oracle.py, a port) on the host cores, on a
                 bounded sample of the same frames.
-  search        secondary metric: exact 512-d inner-product top-100 sweep
-                (vsc_knn_ip_f32), Mpairs/s, with its own fp32-MFMA roofline.  With N > 1 ranks: the sharded form
+  search        secondary metric (BASELINE.json configs[2]): exact 512-d inner-product top-100 over 1M x 1M pairs
+                (vsc_knn_ip_f32: bf16 pre-filter sweep + exact fp32 re-scoring), Mpairs/s, with the sweep kernel's
+                own roofline (HIP events around the phases of the call) and its PMC traffic.  With N > 1 ranks: the sharded form
                 (each rank holds nr / N references, one RCCL all_gather assembles the bank, every rank sweeps its
                 own nq queries; weak scaling, all_gather inside the timed region).
   swin          secondary metric: Swin-V2-B 256 encode (vsc_swin_forward), frames/s.
@@ -127,7 +129,7 @@ def gemm_flops_per_frame(cfg):
 def gemm_traffic(cfg, chunk):
     """(measured HBM bytes per GEMM launch from the committed PMC profile, algorithmic bytes per launch).
 
-    PMC counters need rocprofv3, so they are not collected live: profiles/r01_pmc_per_launch_v2.json holds
+    PMC counters need rocprofv3, so they are not collected live: profiles/r02_pmc_per_launch.json (v3 loop; r01_pmc_per_launch_v2.json for v2) holds
     FETCH_SIZE / WRITE_SIZE per launch of this same configuration (separate --pmc passes).  Correction as
     /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes for gfx950: FETCH_SIZE reports half of a 16-byte-per-lane
     stream, so reads = 2 x FETCH_SIZE -- confirmed in the same run on kernels with known byte counts (layernorm:
