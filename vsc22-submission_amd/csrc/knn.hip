@@ -622,6 +622,7 @@ struct SweepArgs {
     int *fallback;               // [1 + nqb]: [0] any, [1 + qb] this query block must be redone on the exact sweep
     int abl;                     // diagnostic (VSC_KNN_ABL): 1 = skip the filter, 2 = skip the appends (timing only; results invalid), 8 = count
     unsigned long long *dbg;     // [4] appends, compaction rounds, lists compacted, filter bodies entered (abl & 8)
+    int trig;
 };
 
 // stats (queries): [n][4] = (|x|, |bf16 x|, |x - bf16 x|, 0); max_bits (refs): [0] max |x|, [1] max |x - bf16 x| as float bits
@@ -707,7 +708,8 @@ __device__ __forceinline__ int compact_band(const unsigned long long *list, int 
 
 template <int EPL, bool STREAM>
 __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
-    constexpr int CAP = 64 * EPL, KEEP = CAP / 2, TRIG = CAP - 2 * SR;
+    constexpr int CAP = 64 * EPL, KEEP = CAP / 2;
+    const int TRIG = p.trig;   // list length that asks for a compaction round (<= CAP - 2 * SR: flags are read one tile late)
     extern __shared__ __attribute__((aligned(16))) char lds[];   // ONE shared array: ring, then the per-query slots
     int *cnt_s = (int *)(lds + ml64::RING_BYTES);
     float *thr_s = (float *)(lds + ml64::RING_BYTES + 1024);
@@ -818,21 +820,22 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                     for (int i = 0; i < 8; ++i) {
                         const int ql = wm * 128 + i * 16 + l15;
                         const float thr = thr_s[ql];
-                        float best = acc[i][0][0];
+                        float bj[4];   // maxima of the four 4-score sub-groups: the wave descends only into sub-groups with a hit
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int x = 0; x < 4; ++x) best = fmaxf(best, acc[i][j][x]);
+                        for (int j = 0; j < 4; ++j) bj[j] = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3]));
+                        const float best = fmaxf(fmaxf(bj[0], bj[1]), fmaxf(bj[2], bj[3]));
                         mask[i] = 0;
                         if (__any(best >= thr && ql < q_rows)) {
                             unsigned m = 0;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                            for (int j = 0; j < 4; ++j) {
+                                if (!__any(bj[j] >= thr)) continue;
 #pragma unroll
                                 for (int x = 0; x < 4; ++x) {
                                     const int rl = wn * 64 + j * 16 + (int)lq * 4 + x;
                                     m |= (acc[i][j][x] >= thr && rl < r_rows) ? 1u << (j * 4 + x) : 0u;
                                 }
+                            }
                             mask[i] = ql < q_rows ? m : 0u;
                             any_hit = true;
                         }
@@ -868,7 +871,8 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                             if ((p.abl & 8) && mask[i]) atomicAdd(p.dbg, (unsigned long long)cntm);
                             const unsigned slot0 = (unsigned)ql * CAP + (unsigned)base[i];   // 32-bit offset from the uniform list base
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                            for (int j = 0; j < 4; ++j) {
+                                if (!__any((mask[i] >> (4 * j) & 15u) != 0)) continue;
 #pragma unroll
                                 for (int x = 0; x < 4; ++x) {
                                     const int bit = j * 4 + x;
@@ -876,6 +880,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                                     if ((mask[i] >> bit & 1u) && base[i] + (int)rank < CAP && !(p.abl & 4))
                                         mylists[slot0 + rank] = make_key(acc[i][j][x], ref0 + j * 16 + x);
                                 }
+                            }
                         }
                     }
                 }
@@ -1203,7 +1208,8 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     const float cd = (float)d * (2.384185791015625e-7f + 5.9604644775390625e-8f);   // d (2^-22 + 2^-24)
     SweepArgs a{(const uint16_t *)qb, (const uint16_t *)rb, (const float *)qstats, (const unsigned *)flags, nq, nr, dp, k, nqb,
                 splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
-                (int *)ncand, fb_dev, 0, nullptr};
+                (int *)ncand, fb_dev, 0, nullptr, cap - 2 * SR};
+    if (const char *e = getenv("VSC_KNN_TRIG")) { const int t = atoi(e); if (t >= k && t <= cap - 2 * SR) a.trig = t; }
     a.dbg = (unsigned long long *)(((uintptr_t)(fb_dev + 1 + nqb) + 7) & ~(uintptr_t)7);
     if (const char *e = getenv("VSC_KNN_ABL")) a.abl = atoi(e);
     if ((rc = epl == 16 ? launch_sweep<16>(a, grid, stream) : launch_sweep<32>(a, grid, stream))) return rc;
