@@ -64,6 +64,45 @@ __global__ __launch_bounds__(256) void im2col_pack_kernel(const float *__restric
     }
 }
 
+// The same pass without integer divisions in the inner loop (they were most of its time: 35 % of an HRNet pass): one
+// workgroup row per output image row (blockIdx.y = img * ho + oy), the (kh, kw, ci) decomposition of every k in an LDS
+// table built once per workgroup, threads over (ox, 16-byte chunk).
+constexpr int IM2COL_TABLE = 4096;   // k values the table holds (16 KiB); larger K takes the generic kernel
+__global__ __launch_bounds__(256) void im2col_pack_rows_kernel(const float *__restrict__ x, float *__restrict__ dst, int h, int w,
+                                                               int c, int ldx, int kh, int kw, int stride, int pad, int ho,
+                                                               int wo, int k, int kpad) {
+    __shared__ unsigned tab[IM2COL_TABLE];   // (i << 28) | (j << 24) | ci, 0xFFFFFFFF past k
+    for (int kk = threadIdx.x; kk < kpad; kk += 256) {
+        unsigned v = 0xFFFFFFFFu;
+        if (kk < k) {
+            const int ci = kk % c, ij = kk / c;
+            v = ((unsigned)(ij / kw) << 28) | ((unsigned)(ij % kw) << 24) | (unsigned)ci;
+        }
+        tab[kk] = v;
+    }
+    __syncthreads();
+    const int oy = blockIdx.y % ho;
+    const int64_t img = blockIdx.y / ho;
+    const int chunks = kpad >> 2;
+    const int64_t row0 = (int64_t)blockIdx.y * wo;
+    const float *ximg = x + img * h * w * ldx;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < wo * chunks; e += gridDim.x * 256) {
+        const int ox = e / chunks, c4 = e - ox * chunks;   // one division per 16 bytes written (chunks is small)
+        const int base = (c4 >> 1) * 8, half = c4 & 1;
+        const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned t = tab[base + 2 * u + half];
+            const int iy = iy0 + (int)(t >> 28), ix = ix0 + (int)((t >> 24) & 15u);
+            float val = 0.f;
+            if (t != 0xFFFFFFFFu && iy >= 0 && iy < h && ix >= 0 && ix < w) val = ximg[((int64_t)iy * w + ix) * ldx + (t & 0xFFFFFFu)];
+            v[u] = val;
+        }
+        *(float4 *)(dst + (row0 + ox) * kpad + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 struct ConvGemmArgs {
     const float *wp;     // packed weights [cout, kpad]
     const float *ap;     // packed patches [rows, kpad]
@@ -381,8 +420,16 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
         }
         s.bytes = need;
     }
-    hipLaunchKernelGGL(im2col_pack_kernel, dim3(blocks_for(rows * (kpad / 4))), dim3(256), 0, stream, x_dev, (float *)s.ptr, rows,
-                       h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k, kpad);
+    if (kpad <= IM2COL_TABLE && kh < 16 && kw < 16 && n * ho < 65536) {
+        const int per_row = wo * (kpad / 4);
+        int bx = (per_row + 255) / 256;
+        bx = bx > 64 ? 64 : bx;
+        hipLaunchKernelGGL(im2col_pack_rows_kernel, dim3(bx, (unsigned)(n * ho)), dim3(256), 0, stream, x_dev, (float *)s.ptr, h, w, cin,
+                           ldx, kh, kw, stride, pad, ho, wo, k, kpad);
+    } else {
+        hipLaunchKernelGGL(im2col_pack_kernel, dim3(blocks_for(rows * (kpad / 4))), dim3(256), 0, stream, x_dev, (float *)s.ptr, rows,
+                           h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k, kpad);
+    }
     VSC_CHECK_LAUNCH();
     const bool narrow = cout <= 80;   // <= 3 channel tiles of 32: the thin layers (see conv_gemm_narrow_kernel)
     const int tiles_c = narrow ? (cout + NARROW_C - 1) / NARROW_C : (cout + TR - 1) / TR;
