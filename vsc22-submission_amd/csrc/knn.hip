@@ -1215,6 +1215,8 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     if ((rc = epl == 16 ? launch_sweep<16>(a, grid, stream) : launch_sweep<32>(a, grid, stream))) return rc;
     knn_mark(2, stream);
     const unsigned rgrid = (unsigned)((nlists + 3) / 4);
+    VSC_CHECK_HIP(hipFuncSetAttribute((const void *)knn_rescore_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 36 * 4));
+    VSC_CHECK_HIP(hipFuncSetAttribute((const void *)knn_rescore_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 36 * 4));
     if (epl == 16)
         hipLaunchKernelGGL(knn_rescore_kernel<8>, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d, splits,
                            k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part);
