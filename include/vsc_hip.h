@@ -297,7 +297,7 @@ enum { VSC_ACT_NONE = 0, VSC_ACT_RELU = 1, VSC_ACT_HARDSWISH = 2, VSC_ACT_HARDSI
 /* floats per packed weight row: cin * kh * kw rounded up to a multiple of 32 */
 int vsc_conv_packed_k(int32_t cin, int32_t kh, int32_t kw);
 /* w_dev [cout, k] float32 with k = (kh, kw, cin) order (torch's [cout, cin, kh, kw] permuted to [cout, kh, kw, cin]) ->
- * packed_dev [cout, vsc_conv_packed_k] in the operand layout of the fp32 MFMA tiles; done once per layer. */
+ * packed_dev [cout, vsc_conv_packed_k]: rows zero-padded to a multiple of 32 floats for the fp32 MFMA tiles; done once per layer. */
 int vsc_conv_pack_weight_f32(const float *w_dev, float *packed_dev, int32_t cout, int32_t k, void *stream);
 /* out[n, ho, wo, 0:cout] (row stride ldo) = act(conv2d(x[n, h, w, 0:cin] (row stride ldx), W) + bias [+ res[.., 0:cout]
  * (row stride ldr)]) -- torch.nn.functional.conv2d(stride, padding) + the fused tail of a BN/ReLU/residual block. */

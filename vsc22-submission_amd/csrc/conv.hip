@@ -11,8 +11,11 @@
 // Activations are NHWC float32 (a pixel's channels are contiguous: a convolution is a GEMM whose rows are pixels).
 //
 // CDNA4 mapping of the dense convolution: implicit GEMM on the EXACT fp32 matrix pipe.  out[pixel, co] = sum_k
-// patch[pixel, k] w[co, k], k = (kh, kw, ci).  An im2col pass writes the patches straight into the packed operand layout
-// of f32_tile.h (rows padded to 32 floats, k-interleaved) and the product runs on the 128 x 128 v_mfma_f32_32x32x2_f32
+// patch[pixel, k] w[co, k], k = (kh, kw, ci).  An im2col pass writes the patches as rows padded to 32 floats -- in plain k
+// order: the k-interleave of f32_tile.h only fixes the ORDER of the fmaf chain (bit-exactness against the search oracle),
+// which a convolution does not need, and plain order lets a 16-byte chunk of a patch be one 16-byte load of 4 channels, and
+// lets a 1 x 1 / stride-1 layer whose channel count is a multiple of 32 read its input in place, with no patch matrix at
+// all -- and the product runs on the 128 x 128 v_mfma_f32_32x32x2_f32
 // tiles of the similarity sweep (157 TF/s peak, ascending-k fmaf chains: results match a float32 reference to rounding
 // of the summation order, ~1e-6, where a bf16 pipeline through ~60 layers would not hold the 1e-3 of the probability maps).
 // The weights are the MFMA row operand and the pixels the column operand, so a lane owns one pixel and 4 consecutive
@@ -42,7 +45,6 @@ __global__ __launch_bounds__(256) void im2col_pack_kernel(const float *__restric
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t row = e / (kpad >> 2);
         const int c4 = (int)(e - row * (kpad >> 2));
-        const int base = (c4 >> 1) * 8, half = c4 & 1;
         const int ox = (int)(row % wo);
         const int64_t t = row / wo;
         const int oy = (int)(t % ho);
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void im2col_pack_kernel(const float *__restric
         float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int kk = base + 2 * u + half;
+            const int kk = c4 * 4 + u;
             float val = 0.f;
             if (kk < k) {
                 const int ci = kk % c, ij = kk / c;
@@ -86,20 +88,40 @@ __global__ __launch_bounds__(256) void im2col_pack_rows_kernel(const float *__re
     const int chunks = kpad >> 2;
     const int64_t row0 = (int64_t)blockIdx.y * wo;
     const float *ximg = x + img * h * w * ldx;
+    const bool vec = (c & 3) == 0 && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0;   // a chunk = 4 channels of one tap: one 16-byte load
     for (int e = blockIdx.x * 256 + threadIdx.x; e < wo * chunks; e += gridDim.x * 256) {
         const int ox = e / chunks, c4 = e - ox * chunks;   // one division per 16 bytes written (chunks is small)
-        const int base = (c4 >> 1) * 8, half = c4 & 1;
         const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned t = tab[base + 2 * u + half];
+        float4 out4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec) {
+            const unsigned t = tab[c4 * 4];
             const int iy = iy0 + (int)(t >> 28), ix = ix0 + (int)((t >> 24) & 15u);
-            float val = 0.f;
-            if (t != 0xFFFFFFFFu && iy >= 0 && iy < h && ix >= 0 && ix < w) val = ximg[((int64_t)iy * w + ix) * ldx + (t & 0xFFFFFFu)];
-            v[u] = val;
+            if (t != 0xFFFFFFFFu && iy >= 0 && iy < h && ix >= 0 && ix < w)
+                out4 = *(const float4 *)(ximg + ((int64_t)iy * w + ix) * ldx + (t & 0xFFFFFFu));
+        } else {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned t = tab[c4 * 4 + u];
+                const int iy = iy0 + (int)(t >> 28), ix = ix0 + (int)((t >> 24) & 15u);
+                float val = 0.f;
+                if (t != 0xFFFFFFFFu && iy >= 0 && iy < h && ix >= 0 && ix < w) val = ximg[((int64_t)iy * w + ix) * ldx + (t & 0xFFFFFFu)];
+                v[u] = val;
+            }
+            out4 = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *(float4 *)(dst + (row0 + ox) * kpad + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4 *)(dst + (row0 + ox) * kpad + c4 * 4) = out4;
+    }
+}
+
+// w [rows, k] -> [rows, kpad], zero padded (plain k order)
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t rows, int k,
+                                                       int kpad) {
+    const int64_t total = rows * kpad;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / kpad;
+        const int kk = (int)(e - r * kpad);
+        dst[e] = kk < k ? src[r * k + kk] : 0.f;
     }
 }
 
@@ -381,8 +403,8 @@ extern "C" int vsc_conv_packed_k(int32_t cin, int32_t kh, int32_t kw) { return (
 extern "C" int vsc_conv_pack_weight_f32(const float *w_dev, float *packed_dev, int32_t cout, int32_t k, void *stream_) {
     VSC_REQUIRE(w_dev && packed_dev && cout > 0 && k > 0, "conv_pack_weight: bad arguments");
     const int kpad = (k + KS - 1) / KS * KS;
-    hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for((int64_t)cout * (kpad / 4))), dim3(256), 0, (hipStream_t)stream_, w_dev,
-                       packed_dev, (int64_t)cout, k, kpad);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(blocks_for((int64_t)cout * kpad)), dim3(256), 0, (hipStream_t)stream_, w_dev, packed_dev,
+                       (int64_t)cout, k, kpad);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }
@@ -403,8 +425,10 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     int dev = 0;
     VSC_CHECK_HIP(hipGetDevice(&dev));
     VSC_REQUIRE(dev >= 0 && dev < 16, "conv2d: device %d out of range", dev);
+    // 1 x 1, stride 1, dense rows of a multiple of 32 channels: the input IS the patch matrix
+    const bool in_place = kh == 1 && kw == 1 && stride == 1 && pad == 0 && ldx == cin && (cin % KS) == 0 && (((uintptr_t)x_dev) & 15) == 0;
     Scratch &s = g_patch[dev];
-    const size_t need = (size_t)rows * kpad * 4;
+    const size_t need = in_place ? 0 : (size_t)rows * kpad * 4;
     if (s.bytes < need) {
         if (s.ptr) {
             VSC_CHECK_HIP(hipDeviceSynchronize());
@@ -420,7 +444,9 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
         }
         s.bytes = need;
     }
-    if (kpad <= IM2COL_TABLE && kh < 16 && kw < 16 && n * ho < 65536) {
+    if (in_place) {
+        // nothing to gather
+    } else if (kpad <= IM2COL_TABLE && kh < 16 && kw < 16 && n * ho < 65536) {
         const int per_row = wo * (kpad / 4);
         int bx = (per_row + 255) / 256;
         bx = bx > 64 ? 64 : bx;
@@ -435,7 +461,7 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     const int tiles_c = narrow ? (cout + NARROW_C - 1) / NARROW_C : (cout + TR - 1) / TR;
     const int64_t tiles_p = narrow ? (rows + NARROW_P - 1) / NARROW_P : (rows + TQ - 1) / TQ;
     VSC_REQUIRE(tiles_p * tiles_c < (1ll << 31), "conv2d: grid too large");
-    ConvGemmArgs a{w_packed_dev, (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c};
+    ConvGemmArgs a{w_packed_dev, in_place ? x_dev : (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c};
     if (narrow) {
         hipLaunchKernelGGL(conv_gemm_narrow_kernel, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
     } else {

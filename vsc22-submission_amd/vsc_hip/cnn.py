@@ -51,9 +51,20 @@ def _fold(sd: dict, conv: str, bn: str | None):
 class Conv:
     """One dense convolution: packed weight + bias on the device."""
 
-    def __init__(self, sd, conv, bn, stride=1, device="cuda"):
+    def __init__(self, sd, conv, bn, stride=1, device="cuda", pad4=False, cin_map=None):
+        """pad4: zero-pad output AND input channels to multiples of 4 (the layer then consumes / produces 16-byte aligned
+        pixels: the patch gather runs on float4 loads; padded output channels are exactly 0 after ReLU / hardswish / none).
+        cin_map: positions of the real input channels inside a wider, zero-padded input (concatenated padded features)."""
         lib = _lib.require_device()
         w, b = _fold(sd, conv, bn)
+        if cin_map is not None:
+            wide = np.zeros((w.shape[0], cin_map[1]) + w.shape[2:], np.float32)
+            wide[:, cin_map[0]] = w
+            w = wide
+        if pad4:
+            co, ci = -w.shape[0] % 4, -w.shape[1] % 4
+            w = np.pad(w, ((0, co), (0, ci), (0, 0), (0, 0)))
+            b = np.pad(b, (0, co))
         self.cout, self.cin, self.kh, self.kw = w.shape
         self.stride, self.pad = stride, self.kh // 2
         k = self.cin * self.kh * self.kw
@@ -186,8 +197,8 @@ class MobileNetV3SmallHip:
 
 class _Basic:
     def __init__(self, sd, p, device):
-        self.c1 = Conv(sd, p + ".conv1", p + ".bn1", 1, device)
-        self.c2 = Conv(sd, p + ".conv2", p + ".bn2", 1, device)
+        self.c1 = Conv(sd, p + ".conv1", p + ".bn1", 1, device, pad4=True)
+        self.c2 = Conv(sd, p + ".conv2", p + ".bn2", 1, device, pad4=True)
 
     def __call__(self, x):
         return self.c2(self.c1(x, act="relu"), act="relu", residual=x)
@@ -216,9 +227,9 @@ class _HrModule:
         for i in range(nbr):
             for j in range(nbr):
                 if j > i:
-                    self.fuse[i, j] = Conv(sd, f"{p}.fuse_layers.{i}.{j}.0", f"{p}.fuse_layers.{i}.{j}.1", 1, device)
+                    self.fuse[i, j] = Conv(sd, f"{p}.fuse_layers.{i}.{j}.0", f"{p}.fuse_layers.{i}.{j}.1", 1, device, pad4=True)
                 elif j < i:
-                    self.fuse[i, j] = [Conv(sd, f"{p}.fuse_layers.{i}.{j}.{k}.0", f"{p}.fuse_layers.{i}.{j}.{k}.1", 2, device)
+                    self.fuse[i, j] = [Conv(sd, f"{p}.fuse_layers.{i}.{j}.{k}.0", f"{p}.fuse_layers.{i}.{j}.{k}.1", 2, device, pad4=True)
                                        for k in range(i - j)]
 
     def __call__(self, xs):
@@ -263,13 +274,23 @@ class HRNetRefineHip:
         self.conv1 = Conv(sd, "conv1", "bn1", 1, device)   # stride 2 in timm, set to 1 by the reference (models.py:25-26)
         self.conv2 = Conv(sd, "conv2", "bn2", 1, device)
         self.layer1 = [_Bottleneck(sd, f"layer1.{k}", device) for k in range(4)]
-        self.t1 = [Conv(sd, "transition1.0.0", "transition1.0.1", 1, device), Conv(sd, "transition1.1.0.0", "transition1.1.0.1", 2, device)]
+        # branch widths 18 / 36 / 72 / 144: the 18-wide branch is carried as 20 channels (two zero channels), so that every
+        # pixel is 16-byte aligned and the 3 x 3 patch gathers of its 64 full-resolution convolutions are float4 loads
+        self.t1 = [Conv(sd, "transition1.0.0", "transition1.0.1", 1, device, pad4=True),
+                   Conv(sd, "transition1.1.0.0", "transition1.1.0.1", 2, device, pad4=True)]
         self.stages = []
         for stage, nmod, nbr in HRNET_STAGES:
-            grow = Conv(sd, f"transition{stage - 1}.{nbr - 1}.0.0", f"transition{stage - 1}.{nbr - 1}.0.1", 2, device) if stage > 2 else None
+            grow = Conv(sd, f"transition{stage - 1}.{nbr - 1}.0.0", f"transition{stage - 1}.{nbr - 1}.0.1", 2, device, pad4=True) if stage > 2 else None
             self.stages.append((grow, [_HrModule(sd, f"stage{stage}.{m}", nbr, device) for m in range(nmod)]))
-        self.fuse0 = Conv(state_dict, "fuse.0", None, 1, device)
-        self.fuse2 = Conv(state_dict, "fuse.2", None, 1, device)
+        # torch.cat([stem 64, 18, 36, 72, 144]) -> fuse.0: here the concatenated pixel is [64 | 18 + 2 zeros | 36 | 72 | 144]
+        widths = [64, 18, 36, 72, 144]
+        real, off = [], 0
+        for wd in widths:
+            real += list(range(off, off + wd))
+            off += wd + (-wd % 4)
+        self.fuse0 = Conv(state_dict, "fuse.0", None, 1, device, pad4=True, cin_map=(real, off))
+        self.fuse2 = Conv(state_dict, "fuse.2", None, 1, device, pad4=True)
+        self.classes = int(_np(state_dict["fuse.2.weight"]).shape[0])
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
         x = _nhwc(x)
@@ -291,7 +312,7 @@ class HRNetRefineHip:
         for i, y in enumerate([stem] + xs):
             upsample_into(y, cat, 1 if i < 2 else 2 ** (i - 1), off, False, None)
             off += widths[i]
-        y = self.fuse2(self.fuse0(cat, act="relu"))
+        y = self.fuse2(self.fuse0(cat, act="relu"))[..., : self.classes]
         return y.permute(0, 3, 1, 2).contiguous()
 
 
