@@ -84,6 +84,45 @@ def test_gemm_residual_epilogue_in_place(dev, m, n, k):
     torch.testing.assert_close(x.cpu(), ref, rtol=1e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "qgelu", "resadd"])
+@pytest.mark.parametrize("m,n,k", [(23040 + 77, 768, 256),      # 273 tiles on 256 CUs: some workgroups take two, ragged M
+                                   (30001, 1000, 384),           # ragged N tile (n % 256 = 232), 6 K-tiles
+                                   (18000, 2304, 1152),          # 639 tiles, several N-groups, 18 K-tiles
+                                   (65404, 768, 768)])           # the encoder's proj shape at B = 332: 3 whole rounds
+def test_gemm_persistent_kernel_equals_one_tile_per_workgroup(dev, epi, m, n, k):
+    """v4 (persistent: the operand ring streams across output tiles, write-out through 4 KiB per wave) runs the same
+    MFMA chain and the same epilogue arithmetic as v3 -> identical bits; v3 itself is checked against fp32 above."""
+    import os
+    from vsc_hip import ops, _lib
+    kind = {"bf16": _lib.EPI_BF16, "gelu": _lib.EPI_GELU_BF16, "qgelu": _lib.EPI_QGELU_BF16, "resadd": _lib.EPI_RESADD_F32}[epi]
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    b = torch.randn(n, generator=g).to(dev)
+    x = torch.randn(m, n, generator=g).to(dev) if epi == "resadd" else None
+    outs = {}
+    for v4 in ("0", "1", "1"):      # twice through v4: the second launch finds the ring / bias rows of the first in LDS
+        os.environ["VSC_GEMM_V4"] = v4
+        try:
+            xx = None if x is None else x.clone()
+            outs[v4] = ops.gemm_bf16(a, w, b, epilogue=kind, aux=xx, out=xx).clone()
+        finally:
+            os.environ.pop("VSC_GEMM_V4", None)
+        torch.cuda.synchronize()
+        if v4 == "1":
+            assert torch.equal(outs["0"].view(torch.int16 if x is None else torch.int32), outs["1"].view(torch.int16 if x is None else torch.int32))
+    # and against fp32 on a slice (rows that straddle tile boundaries, the last row)
+    rows = torch.tensor([0, 255, 256, 257, m // 2, m - 1], device=dev)
+    ref = a[rows].float() @ w.float().t() + b
+    if epi == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    elif epi == "qgelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    elif epi == "resadd":
+        ref = ref + x[rows]
+    torch.testing.assert_close(outs["1"][rows].float(), ref, rtol=2 ** -7, atol=3e-3)
+
+
 def test_gemm_patch_epilogue(dev):
     from vsc_hip import ops, _lib
     frames, tokens, n, k = 3, 17, 128, 768

@@ -1,6 +1,6 @@
-"""A/B of the GEMM main loops on the encoder's shapes in ONE process, rounds interleaved (guide rule 24):
-v2 (BK = 32 ring), v3 (BK = 64 four-phase) and the library (torch.matmul -> hipBLASLt) with the plain bf16 epilogue,
-then the fused epilogues v2 vs v3.  (run on the GPU box)"""
+"""A/B of the GEMM kernels on the encoder's shapes in ONE process, rounds interleaved (guide rule 24):
+v3 (BK = 64 four-phase loop, one tile per workgroup), v4 (the same loop in a persistent kernel) and the library
+(torch.matmul -> hipBLASLt) with the plain bf16 epilogue, then the fused epilogues v3 vs v4.  (run on the GPU box)"""
 import os
 import sys
 
@@ -31,14 +31,14 @@ def timeit(fn, it=10):
     return e0.elapsed_time(e1) * 1e3 / it
 
 
-def own(v3, a, w, b, epi, aux):
+def own(v4, a, w, b, epi, aux):
     def f():
-        os.environ["VSC_GEMM_V3"] = "1" if v3 else "0"
+        os.environ["VSC_GEMM_V4"] = "1" if v4 else "0"
         ops.gemm_bf16(a, w, b, epilogue=epi, aux=aux, out=aux)
     return f
 
 
-tot = {"v2": 0.0, "v3": 0.0, "lib": 0.0, "v2e": 0.0, "v3e": 0.0}
+tot = {"v3": 0.0, "v4": 0.0, "lib": 0.0, "v3e": 0.0, "v4e": 0.0}
 totf = 0.0
 for name, m, n, k, epi in shapes:
     a = torch.randn(m, k, device=dev).to(torch.bfloat16)
@@ -46,9 +46,9 @@ for name, m, n, k, epi in shapes:
     wt = w.t().contiguous()
     b = torch.randn(n, device=dev)
     aux = torch.randn(m, n, device=dev) if epi == _lib.EPI_RESADD_F32 else None
-    variants = {"v2": own(False, a, w, None, _lib.EPI_BF16, None), "v3": own(True, a, w, None, _lib.EPI_BF16, None),
+    variants = {"v3": own(False, a, w, None, _lib.EPI_BF16, None), "v4": own(True, a, w, None, _lib.EPI_BF16, None),
                 "lib": lambda: torch.matmul(a, w.t()), "libT": lambda: torch.matmul(a, wt),
-                "v2e": own(False, a, w, b, epi, aux), "v3e": own(True, a, w, b, epi, aux)}
+                "v3e": own(False, a, w, b, epi, aux), "v4e": own(True, a, w, b, epi, aux)}
     best = {key: [] for key in variants}
     for _ in range(ROUNDS):
         for key, fn in variants.items():
@@ -60,5 +60,5 @@ for name, m, n, k, epi in shapes:
     totf += fl * mult
     for key in tot:
         tot[key] += med[key] * mult
-    print(f"{name:5s} M={m} N={n} K={k}: " + "  ".join(f"{key} {med[key]:7.1f} us {fl / med[key] / 1e6:6.0f} TF" for key in ("v2", "v3", "lib", "v2e", "v3e")), flush=True)
+    print(f"{name:5s} M={m} N={n} K={k}: " + "  ".join(f"{key} {med[key]:7.1f} us {fl / med[key] / 1e6:6.0f} TF" for key in ("v3", "v4", "lib", "v3e", "v4e")), flush=True)
 print("weighted ViT-B/16 (12 layers): " + "  ".join(f"{key} {tot[key] / 1e3:.2f} ms {totf / tot[key] / 1e6:.0f} TF" for key in tot))

@@ -43,11 +43,12 @@ struct GemmArgs {
     void *out;
     int64_t m;
     int n, k, tokens, tiles_n, tiles_m, group_n;
-    int skew;  // first-round start skew in shader cycles (see phase_skew)
+    int skew;  // first-round start skew in shader cycles (see phase_skew); v4: cycles per skew group
+    int skew_groups;  // v4: workgroups of an XCD start in this many groups, `skew` cycles apart (launch_v4)
 #ifdef VSC_GEMM_TIMING
     unsigned long long *dbg;  // [8 waves][8] cycle sums of workgroup 0 (build with -DVSC_GEMM_TIMING)
 #endif
-    int abl;  // diagnostic ablation bits (VSC_GEMM_ABL): 1 no loop DMA, 2 no MFMA, 4 no epilogue stores, 8 no frag reads
+    int abl;  // diagnostic ablation bits (VSC_GEMM_ABL): 1 no loop DMA, 2 no MFMA, 8 no frag reads
     GemmExtra ex;  // LayerNorm-folding operands (common.h)
 };
 
@@ -93,21 +94,31 @@ __device__ __forceinline__ bf16x8_t lds_frag(const char *tile, int row, int chun
     return *(const bf16x8_t *)(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-// exact (erf) GELU.  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16
-// rounding of the stored result): one v_rcp_f32 + one v_exp_f32 instead of libm's erff.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));  // v_rcp_f32 (1 ulp)
-    float poly = 0.5f * 1.061405429f;  // 0.5 folded into the A&S coefficients
-    poly = fmaf(poly, t, 0.5f * -1.453152027f);
-    poly = fmaf(poly, t, 0.5f * 1.421413741f);
-    poly = fmaf(poly, t, 0.5f * -0.284496736f);
-    poly = fmaf(poly, t, 0.5f * 0.254829592f);
-    // exp(-z^2) = exp2(-(x^2/2) * log2 e): one multiply feeding v_exp_f32
-    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
-    const float half_erfc = poly * t * e;  // 0.5 * (1 - erf(|x| / sqrt 2))
-    // x * Phi(x) with Phi = 1 - half_erfc (x > 0) | half_erfc (x <= 0)  ==  max(x, 0) - |x| * half_erfc
-    return fmaf(-ax, half_erfc, fmaxf(x, 0.f));
+// GELU(x) = x Phi(x) without transcendentals, on packed fp32 (v_pk_fma_f32: two elements per instruction):
+//     Phi(x) = 1/2 + t Q(z),   t = clamp(x, -5, 5),   z = 0.08 t^2 - 1 in [-1, 1],
+// Q = the degree-11 polynomial fitted (Chebyshev nodes, weights t^2, then converted to powers of z -- the powers of t^2
+// itself cancel badly in fp32) to (Phi(t) - 1/2) / t by tools/micro/gelu_poly_fit.py.  Error of the fp32 evaluation against
+// erf in float64: |GELU error| <= 2.2e-6 + 6.6e-7 |x| (tests/test_gelu_poly.py) -- under half a bf16 ulp of the stored
+// value wherever |GELU| > 2e-3.  17 packed/scalar instructions per TWO elements against ~19 per ONE (two of them
+// quarter-rate: v_rcp_f32, v_exp_f32) for the Abramowitz-Stegun 7.1.26 form used before: the fc1 write-out was
+// VALU-bound on it (18 k of the 48 k cycles a tile took).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu2(f32x2_t x) {
+    f32x2_t t;
+    t[0] = __builtin_amdgcn_fmed3f(x[0], -5.0f, 5.0f);
+    t[1] = __builtin_amdgcn_fmed3f(x[1], -5.0f, 5.0f);
+    const f32x2_t z = __builtin_elementwise_fma(t * t, (f32x2_t){0.08f, 0.08f}, (f32x2_t){-1.0f, -1.0f});
+    constexpr float C[12] = {1.413637698e-01f, -7.029826939e-02f, 5.152343214e-02f, -4.038983583e-02f, 3.137785569e-02f,
+                             -2.364724688e-02f, 1.683344319e-02f, -1.008572429e-02f, 5.223751534e-03f, -4.000799730e-03f,
+                             3.139984794e-03f, -1.040469273e-03f};
+    f32x2_t q = (f32x2_t){C[11], C[11]};
+#pragma unroll
+    for (int i = 10; i >= 0; --i) q = __builtin_elementwise_fma(q, z, (f32x2_t){C[i], C[i]});
+    return x * __builtin_elementwise_fma(t, q, (f32x2_t){0.5f, 0.5f});
+}
+__device__ __forceinline__ void gelu4(f32x4_t &v) {
+    const f32x2_t lo = gelu2((f32x2_t){v[0], v[1]}), hi = gelu2((f32x2_t){v[2], v[3]});
+    v = (f32x4_t){lo[0], lo[1], hi[0], hi[1]};
 }
 __device__ __forceinline__ float quick_gelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.45546696f));  // 1.702 * log2 e
@@ -208,8 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
             if (p.bias) v += *(const f32x4_t *)(p.bias + n);
             if (EPI == VSC_EPI_BF16 || EPI == VSC_EPI_GELU_BF16 || EPI == VSC_EPI_QGELU_BF16) {
                 if (EPI == VSC_EPI_GELU_BF16) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+gelu4(v);
                 } else if (EPI == VSC_EPI_QGELU_BF16) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
@@ -297,8 +307,7 @@ __device__ __forceinline__ void epilogue_frag(const GemmArgs &p, f32x4_t v, int6
     if (p.bias) v += *(const f32x4_t *)(p.bias + n);
     if (EPI == VSC_EPI_BF16 || EPI == VSC_EPI_GELU_BF16 || EPI == VSC_EPI_QGELU_BF16) {
         if (EPI == VSC_EPI_GELU_BF16) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+gelu4(v);
         } else if (EPI == VSC_EPI_QGELU_BF16) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
@@ -357,8 +366,7 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
                     v = acc[i][j] + bz;
                 }
                 if (epi_gelu(EPI)) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+gelu4(v);
                 } else if (epi_qgelu(EPI)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
@@ -382,7 +390,7 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
             uint4 d = *(const uint4 *)(reg + row * 128 + ((c ^ (row & 7)) << 4));
             if (it & 1) d = make_uint4(d.z, d.w, d.x, d.y);  // (row >> 3) & 1 == it & 1: halves were swapped
             const int64_t m = m0 + wm * TM * 16 + row;
-            if (m < p.m && n < p.n && !((p.abl & 4) && d.x != 0x12345678u))
+            if (m < p.m && n < p.n)
                 *(uint4 *)((uint16_t *)p.out + m * p.n + n) = d;
         }
     } else {
@@ -438,7 +446,7 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmArgs &p, f32x4_t (&ac
                     if (EPI != VSC_EPI_F32) v += ax[it];
                     if (m < p.m && n < p.n) {
                         const int64_t orow = EPI == VSC_EPI_PATCH_F32 ? (int64_t)orow8[it] : m;
-                        if (!((p.abl & 4) && v[0] != 12345.678f)) *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
+                        *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
                         if (EPI == VSC_EPI_RESADD_STATS_F32) {
                             uint2 pk;
                             pk.x = pack_bf16x2(v[0], v[1]);
@@ -744,6 +752,278 @@ int launch_v3(GemmArgs p, hipStream_t stream) {
     return VSC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// v4: v3's K loop in a PERSISTENT kernel.  One workgroup per CU walks the tile order with stride gridDim (same XCD ranges
+// and N-groups as v3); ml64::tile_p keeps the operand ring streaming across output tiles, so what a tile boundary costs is
+// the write-out alone -- not a workgroup launch, a prologue round trip, a pipeline ramp and a drain (v3: ~7 us per tile
+// against 17 us of K loop at K = 768).  The write-out stages through the two ring slots that are free at a tile boundary
+// (slots 6, 7: 4 KiB per wave) in passes of 32 (bf16) / 16 (fp32) rows, with the next tile's first six units in flight;
+// the per-tile bias sits in a double-buffered 1-KiB row behind the ring, fetched during the previous write-out.
+// Serves the plain, GELU and residual epilogues; K % 128 == 0 (an even number of K-tiles), K >= 256.
+constexpr bool epi_v4(int e) {
+    return e == VSC_EPI_BF16 || e == VSC_EPI_GELU_BF16 || e == VSC_EPI_QGELU_BF16 || e == VSC_EPI_RESADD_F32;
+}
+
+#ifdef VSC_GEMM_TIMING
+static __device__ unsigned long long g_v4_t_mid[16];   // (per-wave scratch of the instrumented build; racy by design, read by the same wave)
+#endif
+// write-out of one wave's 128 x 64 tile through its 4 KiB of staging; bias: this tile's 256 floats in LDS
+template <int EPI>
+__device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)[8][4], char *reg, const char *bias_lds,
+                                               int lane, int wm, int wn, int64_t m0, int n0) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int ncol0 = n0 + wn * 64;
+    const int64_t mrow0 = m0 + wm * 128;
+    f32x4_t bz[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bz[j] = *(const f32x4_t *)(bias_lds + (wn * 64 + j * 16 + fq * 4) * 4);
+    if (epi_bf16_out(EPI)) {
+        // four passes of 32 rows: bias + activation + pack -> staging -> whole 128-byte row segments.  The activation of a
+        // pass is VALU work between the store bursts of its neighbours (GELU: ~2 k cycles per pass), so the 128 KiB of a
+        // workgroup's tile leave spread over the write-out instead of in one burst behind it.
+        const int c = lane & 7;
+        const int n = ncol0 + c * 8;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4_t v = acc[pass * 2 + ii][j] + bz[j];
+                    if (epi_gelu(EPI)) gelu4(v);
+                    else if (epi_qgelu(EPI)) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+                    }
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    const int row = ii * 16 + fr, chunk = 2 * j + (fq >> 1);
+                    // rows r and r+8 share (r & 7): opposite 8-byte halves of the chunk (see epilogue_via_lds)
+                    *(uint2 *)(reg + row * 128 + ((chunk ^ (row & 7)) << 4) + ((fq ^ (row >> 3)) & 1) * 8) = pk;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (pass == 0) {
+                ml64::wait_vmcnt<0>();   // this wave's pieces of the next tile's units 0..5 (tile_p: `first` contract)
+#ifdef VSC_GEMM_TIMING
+                if (blockIdx.x == 37) g_v4_t_mid[wm * 4 + wn] = __builtin_amdgcn_s_memtime();
+#endif
+            }
+            uint4 d[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                d[it] = *(const uint4 *)(reg + row * 128 + ((c ^ (row & 7)) << 4));
+                if (it & 1) d[it] = make_uint4(d[it].z, d[it].w, d[it].x, d[it].y);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int64_t m = mrow0 + pass * 32 + it * 8 + (lane >> 3);
+                if (m < p.m && n < p.n) *(uint4 *)((uint16_t *)p.out + m * p.n + n) = d[it];
+            }
+        }
+    } else {
+        const int c = lane & 15, rq = lane >> 4;
+        const int n = ncol0 + c * 4;
+        const int nc = n < p.n ? n : 0;
+        f32x4_t ax[2][4];   // residual rows of this pass and the next (requested a pass ahead)
+        auto load_aux = [&](int i, f32x4_t (&dst)[4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                int64_t m = mrow0 + i * 16 + it * 4 + rq;
+                m = m < p.m ? m : p.m - 1;
+                dst[it] = *(const f32x4_t *)(p.aux + m * p.n + nc);
+            }
+        };
+        load_aux(0, ax[0]);   // queued behind the next tile's DMA: waiting for it covers tile_p's `first` contract
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i + 1 < 8) load_aux(i + 1, ax[(i + 1) & 1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(f32x4_t *)(reg + fr * 256 + (((4 * j + fq) ^ fr) << 4)) = acc[i][j] + bz[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 4 + rq;
+                f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ row) << 4));
+                v += ax[i & 1][it];
+                const int64_t m = mrow0 + i * 16 + row;
+                if (m < p.m && n < p.n) *(f32x4_t *)((float *)p.out + m * p.n + n) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs p) {
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    extern __shared__ __attribute__((aligned(16))) char lds2[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int total = p.tiles_m * p.tiles_n;
+    const int nk = p.k / 64;
+    auto tile_of = [&](int vt, int &tm, int &tn) {
+        const int t = xcd_remap(vt, total);
+        const int G = p.group_n;
+        const int per_group = G * p.tiles_m;
+        const int grp = t / per_group;
+        const int first = grp * G;
+        const int width = (p.tiles_n - first) < G ? (p.tiles_n - first) : G;
+        const int rem = t - grp * per_group;
+        tm = rem / width;
+        tn = first + (rem - tm * width);
+    };
+    char *ext = lds2 + ml64::RING_BYTES;   // 2 x 1 KiB: the bias of this tile / of the next one
+    const __amdgpu_buffer_rsrc_t bias_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, p.bias ? p.n * 4 : 0, 0x00020000);
+    auto stage_bias = [&](int buf, int n0) {   // waves 0-3, one 256-byte piece each (zeros without a bias / past n)
+        if (wave < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(bias_rsrc, (lptr_t)(ext + buf * 1024 + wave * 256), 4,
+                                                     (n0 + wave * 64 + lane) * 4, 0, 0, 0);
+    };
+    int vt = blockIdx.x, tm, tn;
+    tile_of(vt, tm, tn);
+    stage_bias(0, tn * 256);
+    ml64::Ctx c;
+    ml64::init_whole(c, p.a, p.k, p.m, p.w, p.k, p.n, (int64_t)tm * 256, (int64_t)tn * 256, lds2, wave, lane);
+    // Start skew.  All workgroups of a persistent launch run in lockstep (same start, same tile times), so the 32 CUs of an
+    // XCD would hit their write-outs together: 4 MiB of stores against the XCD's L2 / fabric write rate (~13 B/clk per CU
+    // when everyone stores: tools/micro/atomic_add_bw) -- measured 5-7 k cycles per plain bf16 tile where the CU's own
+    // store path needs 2 k.  The workgroups of an XCD therefore start in `skew_groups` groups `skew` cycles apart (slot =
+    // blockIdx / 8 is the workgroup's index inside its XCD) and keep that distance to the end, so only one group is in its
+    // write-out at a time.  The delay sits between the issue of the first operand units and their first use.
+    const int skew_wait = p.skew * ((int)(blockIdx.x >> 3) % p.skew_groups);
+    const unsigned long long t_launch = __builtin_amdgcn_s_memtime();
+    ml64::prologue(c, nk);
+    if (skew_wait > 0)
+        while (__builtin_amdgcn_s_memtime() - t_launch < (unsigned long long)skew_wait) __builtin_amdgcn_s_sleep(4);
+    ml64::Frags f;
+    char *reg = lds2 + 6 * ml64::UNIT_BYTES + wave * 4096;
+#ifdef VSC_GEMM_TIMING
+    const bool rec = blockIdx.x == 37 && lane == 0 && (wave == 0 || wave == 4) && p.dbg;
+    unsigned long long *tb = p.dbg + (wave >> 2) * 32;
+    if (rec) tb[0] = __builtin_amdgcn_s_memtime();
+#endif
+    for (int i = 0;; ++i) {
+        const int vnext = vt + (int)gridDim.x;
+        const bool last = vnext >= total;
+        int tm2 = tm, tn2 = tn;
+        if (!last) tile_of(vnext, tm2, tn2);
+        const uint32_t da = (uint32_t)((int64_t)(tm2 - tm) * 256 * p.k * 2), dw = (uint32_t)((int64_t)(tn2 - tn) * 256 * p.k * 2);
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ii][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (!last) stage_bias((i + 1) & 1, tn2 * 256);   // a tile ahead: landed long before the write-out that reads it
+#ifdef VSC_GEMM_TIMING
+        if (rec && i < 6) tb[1 + i * 5] = __builtin_amdgcn_s_memtime();
+#endif
+        ml64::tile_p(c, acc, f, nk, i == 0, last, da, dw, (p.abl & 32) != 0);
+#ifdef VSC_GEMM_TIMING
+        if (rec && i < 6) tb[2 + i * 5] = __builtin_amdgcn_s_memtime();
+#endif
+        // the write-out's per-lane addresses hang off a lane id the compiler cannot see through: computed here, per tile,
+        // instead of hoisted out of the tile loop and carried (spilled) across the K loop
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        epilogue_small<EPI>(p, acc, reg, ext + (i & 1) * 1024, lane_e, wm, wn, (int64_t)tm * 256, tn * 256);
+#ifdef VSC_GEMM_TIMING
+        if (rec && i < 6) {
+            tb[3 + i * 5] = g_v4_t_mid[wave];
+            tb[4 + i * 5] = __builtin_amdgcn_s_memtime();
+        }
+#endif
+        if (last) break;
+        __builtin_amdgcn_s_barrier();   // every wave is done with slots 6, 7 and has waited for its DMA pieces
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef VSC_GEMM_TIMING
+        if (rec && i < 6) tb[5 + i * 5] = __builtin_amdgcn_s_memtime();
+#endif
+        vt = vnext;
+        tm = tm2;
+        tn = tn2;
+    }
+}
+
+template <int EPI>
+int launch_v4(GemmArgs p, int cus, hipStream_t stream) {
+    constexpr int smem = ml64::RING_BYTES + 2048;
+    auto kern = gemm_bf16_v4_kernel<EPI>;
+    static bool attr_set[16] = {};
+    int dev = 0;
+    VSC_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 16 || !attr_set[dev]) {
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        if (dev < 16) attr_set[dev] = true;
+    }
+    int g = 4;
+    if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
+    p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
+    p.skew = 0;
+    p.skew_groups = 1;
+    if (const char *e = getenv("VSC_GEMM_V4_SKEW")) {   // "cycles,groups" (diagnostic sweep)
+        int cyc = 0, grp = 1;
+        if (sscanf(e, "%d,%d", &cyc, &grp) == 2 && cyc >= 0 && grp >= 1) {
+            p.skew = cyc;
+            p.skew_groups = grp;
+        }
+    }
+#ifdef VSC_GEMM_TIMING
+    static unsigned long long *dbg = nullptr;
+    if (!dbg) VSC_CHECK_HIP(hipMalloc(&dbg, 64 * 8));
+    VSC_CHECK_HIP(hipMemsetAsync(dbg, 0, 64 * 8, stream));
+    p.dbg = dbg;
+#endif
+    hipLaunchKernelGGL(kern, dim3(cus), dim3(512), smem, stream, p);
+    VSC_CHECK_LAUNCH();
+#ifdef VSC_GEMM_TIMING
+    if (getenv("VSC_GEMM_TIMING_PRINT")) {
+        unsigned long long h[64];
+        VSC_CHECK_HIP(hipStreamSynchronize(stream));
+        VSC_CHECK_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+        for (int g = 0; g < 2; ++g) {
+            const unsigned long long *t = h + g * 32;
+            fprintf(stderr, "v4 timing m=%lld n=%d k=%d epi=%d wave %d (10 ns ticks from kernel start):", (long long)p.m, p.n, p.k, EPI, g * 4);
+            for (int i = 0; i < 6 && t[1 + i * 5]; ++i)
+                fprintf(stderr, "  | tile %d: K loop %llu..%llu, DMA wait until %llu, write-out until %llu, barrier %llu", i, t[1 + i * 5] - t[0],
+                        t[2 + i * 5] - t[0], t[3 + i * 5] - t[0], t[4 + i * 5] - t[0], t[5 + i * 5] ? t[5 + i * 5] - t[0] : 0ull);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
+    return VSC_OK;
+}
+
+// v3 or its persistent form: v4 wherever a workgroup gets more than one tile and the 32-bit source offsets hold
+template <int EPI>
+int launch_v34(GemmArgs p, hipStream_t stream) {
+    p.tiles_m = (int)((p.m + 255) / 256);
+    p.tiles_n = (p.n + 255) / 256;
+    if constexpr (epi_v4(EPI)) {
+        const char *v4e = getenv("VSC_GEMM_V4");   // diagnostic A/B switch, read per launch
+        const bool off = v4e && v4e[0] == '0';
+        static int cus_of[16] = {};
+        int dev = 0;
+        VSC_CHECK_HIP(hipGetDevice(&dev));
+        int cus = dev < 16 ? cus_of[dev] : 0;
+        if (!cus) {
+            VSC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            if (dev < 16) cus_of[dev] = cus;
+        }
+        const int64_t a_span = (int64_t)p.tiles_m * 256 * p.k * 2, w_span = (int64_t)p.tiles_n * 256 * p.k * 2;
+        if (!off && p.k % 128 == 0 && p.k >= 256 && cus % 8 == 0 && (int64_t)p.tiles_m * p.tiles_n > cus &&
+            a_span < (1ll << 32) && w_span < (1ll << 32) && (EPI != VSC_EPI_RESADD_F32 || p.aux))
+            return launch_v4<EPI>(p, cus, stream);
+    }
+    return launch_v3<EPI>(p, stream);
+}
+
 // first-round start skew (diagnostic, off by default): VSC_GEMM_SKEW_NS_PER_K * K / 10 shader cycles spread over the
 // first 256 workgroups.  Re-measured in the ViT step with skews from 0.6 us to a whole tile time: 0 is as fast as any
 // (19.7 k frames/s), a tile time costs 6 % -- the start-up delay is never recovered.
@@ -816,7 +1096,7 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
     // stages fly during the write-out (+-1 %: launch, fill and drain were already hidden; 3 stages are as fast
     // as 4).  tools/micro/fill_bench.hip: LDS-DMA alone delivers 21.6 B/clk/CU with 64-B row pieces (34-40 with
     // full 128-B lines), VGPR staging no more; the K loop is issue/phase-bound, not delivery-bound.
-    static const char *force = getenv("VSC_GEMM_CFG");
+    const char *force = getenv("VSC_GEMM_CFG");   // diagnostic, read per launch
     // measured: A wins on every ViT shape (K >= 768).  With K <= 512 (Swin) the K loop is only 4-16 stages long and
     // the epilogue is a large share of a tile: the 4-wave tiles run two workgroups per CU, so one's write-out
     // overlaps the other's K loop (stage-3 qkv 765 -> 875 TF/s); D when N is a multiple of 128 but not of 256.
@@ -825,7 +1105,7 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
     if (force) cfg = force[0];
     const char *v3e = getenv("VSC_GEMM_V3");   // diagnostic A/B switch, read per launch
     const bool no_v3 = v3e && v3e[0] == '0';
-    if (cfg == 'A' && p.k % 64 == 0 && !no_v3) return launch_v3<EPI>(p, stream);
+    if (cfg == 'A' && p.k % 64 == 0 && !no_v3) return launch_v34<EPI>(p, stream);
     switch (cfg) {
         case 'A': return launch_v2<EPI, 2, 4, 8, 4, 4>(p, stream);
         case 'B': return launch_v2<EPI, 4, 2, 4, 4, 4>(p, stream);
@@ -1129,7 +1409,7 @@ int launch_gemm_bf16_ex(const uint16_t *a, const uint16_t *w, const float *bias,
     p.ex = ex;
     if (const char *e = getenv("VSC_GEMM_ABL")) p.abl = atoi(e);
     static const bool force_v1 = getenv("VSC_GEMM_V1") != nullptr;
-    static const bool force_v2 = getenv("VSC_GEMM_CFG") != nullptr;
+    const bool force_v2 = getenv("VSC_GEMM_CFG") != nullptr;
     // A launch that cannot put a 256-row tile on at least half the CUs runs the 128 x 128 kernel instead (four times
     // the workgroups, two per CU): at 8 frames (M = 1576) fc2 takes 44 instead of 74 us and proj 16 instead of 27,
     // at 32 frames the N = 768 GEMMs 26 / 57 instead of 35 / 77 us; from ~130 tiles up the big tile wins.

@@ -131,8 +131,10 @@ __device__ __forceinline__ void mfma_quadrant(f32x4_t (&acc)[8][4], const Frags 
 // closes an L segment: counted wait for this wave's DMA pieces (steady state: the four newest units stay in flight;
 // the last two tiles drain: `tail_vm` instructions may stay), then the workgroup barrier
 template <bool STEADY, int TAIL1, int TAIL2>
-__device__ __forceinline__ void end_l(int rem) {
-    if (STEADY || rem > 2) wait_vmcnt<8>();
+__device__ __forceinline__ void end_l(int rem, bool nowait = false) {
+    if (STEADY) {
+        if (!nowait) wait_vmcnt<8>();
+    } else if (rem > 2) wait_vmcnt<8>();
     else if (rem == 2) wait_vmcnt<TAIL1>();
     else wait_vmcnt<TAIL2>();
     __builtin_amdgcn_s_barrier();
@@ -143,10 +145,13 @@ __device__ __forceinline__ void end_c() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// One K-tile (four phases).  B = t & 1 (slot parity); rem = nk - t (K-tiles left including this one); STEADY: rem > 2
-// is known (no tail branches in the body).
+// One K-tile (four phases).  B = slot parity of the tile; kt1 / kt2: K-tile indices (source offsets) of the units staged
+// for the next tile (j = 2, 3) and the one after (j = 0, 1) -- t + 1 and t + 2 inside one operand pair, something else where
+// a persistent sequence moves on to its next output tile; rem = K-tiles left including this one; STEADY: rem > 2 is known (no
+// tail branches in the body); nowait (STEADY only): every unit this tile and the next one read has landed already (the first
+// K-tile behind a write-out), so the L segments close without their vmcnt.
 template <int B, bool STEADY>
-__device__ __forceinline__ void ktile(const Ctx &c, f32x4_t (&acc)[8][4], Frags &f, int t, int rem) {
+__device__ __forceinline__ void ktile_g(const Ctx &c, f32x4_t (&acc)[8][4], Frags &f, int kt1, int kt2, int rem, bool nowait) {
     constexpr int S_W0 = 4 * B + 0, S_A0 = 4 * B + 1, S_W1 = 4 * B + 2, S_A1 = 4 * B + 3;   // this tile's slots
     constexpr int N_W0 = 4 * (B ^ 1) + 0, N_W1 = 4 * (B ^ 1) + 2, N_A1 = 4 * (B ^ 1) + 3;  // tile t+1, j = 0, 2, 3
     (void)S_W0;
@@ -155,8 +160,8 @@ __device__ __forceinline__ void ktile(const Ctx &c, f32x4_t (&acc)[8][4], Frags 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) f.af[i][kh] = frag(c, S_A0, c.rd_a, i, kh);
-    if (STEADY || rem > 1) stage_unit<1, 1>(c, N_W1, t + 1);
-    end_l<STEADY, 8, 2>(rem);
+    if (STEADY || rem > 1) stage_unit<1, 1>(c, N_W1, kt1);
+    end_l<STEADY, 8, 2>(rem, nowait);
     mfma_quadrant<B, 0, 0>(acc, f);
     end_c();
     // ---- phase 1
@@ -164,8 +169,8 @@ __device__ __forceinline__ void ktile(const Ctx &c, f32x4_t (&acc)[8][4], Frags 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) f.w1[j][kh] = frag(c, S_W1, c.rd_w, j, kh);
-    if (STEADY || rem > 1) stage_unit<0, 1>(c, N_A1, t + 1);
-    end_l<STEADY, 8, 0>(rem);
+    if (STEADY || rem > 1) stage_unit<0, 1>(c, N_A1, kt1);
+    end_l<STEADY, 8, 0>(rem, nowait);
     mfma_quadrant<B, 0, 1>(acc, f);
     end_c();
     // ---- phase 2
@@ -173,8 +178,8 @@ __device__ __forceinline__ void ktile(const Ctx &c, f32x4_t (&acc)[8][4], Frags 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) f.af[i][kh] = frag(c, S_A1, c.rd_a, i, kh);
-    if (STEADY || rem > 2) stage_unit<1, 0>(c, S_W0, t + 2);
-    end_l<STEADY, 6, 0>(rem);
+    if (STEADY || rem > 2) stage_unit<1, 0>(c, S_W0, kt2);
+    end_l<STEADY, 6, 0>(rem, nowait);
     mfma_quadrant<B, 1, 1>(acc, f);
     end_c();
     // ---- phase 3: unit (t+1, W-h0) landed with the wait of phase 2 (units <= g + 2) and the barriers since
@@ -184,10 +189,14 @@ __device__ __forceinline__ void ktile(const Ctx &c, f32x4_t (&acc)[8][4], Frags 
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) f.w0[B ^ 1][j][kh] = frag(c, N_W0, c.rd_w, j, kh);
     }
-    if (STEADY || rem > 2) stage_unit<0, 0>(c, S_A0, t + 2);
-    end_l<STEADY, 4, 0>(rem);
+    if (STEADY || rem > 2) stage_unit<0, 0>(c, S_A0, kt2);
+    end_l<STEADY, 4, 0>(rem, nowait);
     mfma_quadrant<B, 1, 0>(acc, f);
     end_c();
+}
+template <int B, bool STEADY>
+__device__ __forceinline__ void ktile(const Ctx &c, f32x4_t (&acc)[8][4], Frags &f, int t, int rem) {
+    ktile_g<B, STEADY>(c, acc, f, t + 1, t + 2, rem, false);
 }
 
 // staging of units 0..5 (tile 0 whole, tile 1 j = 0, 1), wait for the first two, workgroup barrier
@@ -238,6 +247,75 @@ __device__ __forceinline__ void run(const Ctx &c, f32x4_t (&acc)[8][4], int nk) 
     prologue(c, nk);
     Frags f;
     tiles(c, acc, f, 0, nk, nk);
+}
+
+// ---- persistent sequences of output tiles (gemm_bf16.hip, v4) -------------------------------------------------------
+// One workgroup works off several output tiles back to back.  The ring never drains between them: the last two K-tiles of
+// an output tile stage units 0..5 of the NEXT one (kt1 / kt2 of ktile_g wrap to 0 / 1 and the per-lane source offsets are
+// moved to the next tile's origin), so the next K loop starts on landed data -- no prologue round trip, no ramp -- and the
+// write-out in between runs with that DMA in flight.  Both operands use ONE descriptor each for the whole matrix (the
+// lane offsets carry the tile origin; rows past the matrix edge are past the descriptor's extent and read as zeros), so a
+// tile change is four v_add per half.
+
+// as init(), with whole-matrix descriptors: a [m, lda], w [n, ldw], this workgroup's first tile at rows m0 / n0.
+// (tiles_m * 256) * lda * 2 and (tiles_n * 256) * ldw * 2 must fit 32 bits (checked by the launcher).
+__device__ __forceinline__ void init_whole(Ctx &c, const uint16_t *a, int64_t lda, int64_t m, const uint16_t *w, int64_t ldw,
+                                           int64_t n, int64_t m0, int64_t n0, char *lds, int wave, int lane) {
+    init(c, a, lda, 1, w, ldw, 1, lds, wave, lane);
+    c.a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a, 0, (int)(uint32_t)(m * lda * 2), 0x00020000);
+    c.w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, (int)(uint32_t)(n * ldw * 2), 0x00020000);
+    const uint32_t ba = (uint32_t)(m0 * lda * 2), bw = (uint32_t)(n0 * ldw * 2);
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            c.a_off[half][jj] += ba;
+            c.w_off[half][jj] += bw;
+        }
+}
+
+template <int HALF>
+__device__ __forceinline__ void bump(Ctx &c, uint32_t da, uint32_t dw) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        c.a_off[HALF][jj] += da;
+        c.w_off[HALF][jj] += dw;
+    }
+}
+
+// One output tile of a persistent sequence: nk K-tiles (even, >= 4).
+//   first  the ring holds units 0..5 from prologue(); otherwise the previous tile_p staged them, every wave has waited for
+//          its own pieces (vmcnt(0) in the write-out) and a workgroup barrier has passed since
+//   last   nothing follows: staging stops and the waits drain as in tiles()
+//   da/dw  byte distance from this tile's A / W origin to the next tile's (wrapping 32-bit adds)
+// On return every wave is past its last fragment read; unless `last`, units 0..5 of the next tile are in flight or landed
+// in slots 0..5 and slots 6, 7 are free until the next tile_p (the write-out stages through them).
+__device__ __forceinline__ void tile_p(Ctx &c, f32x4_t (&acc)[8][4], Frags &f, int nk, bool first, bool last, uint32_t da,
+                                       uint32_t dw, bool unsafe_nowait2 = false) {
+    const int group = c.wave >> 2;
+    if (group == 1) __builtin_amdgcn_s_barrier();   // stagger: waves 4-7 run one segment behind
+    __builtin_amdgcn_sched_barrier(0);
+    if (first) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) f.w0[0][j][kh] = frag(c, 0, c.rd_w, j, kh);
+    }
+    const int steady_end = last ? nk - 2 : nk;
+#pragma nounroll   // (also keeps the t == 0 iteration from being peeled into a third copy of the two bodies)
+    for (int t = 0; t < steady_end; t += 2) {
+        const bool wrap = t + 2 == nk;               // the two K-tiles that stage the next output tile
+        const uint32_t ba = wrap ? da : 0u, bw = wrap ? dw : 0u;
+        bump<0>(c, ba, bw);                          // half-0 units (j = 0, 1) are staged for kt2: next tile from here on
+        ktile_g<0, true>(c, acc, f, t + 1, wrap ? 0 : t + 2, 0, !first && t == 0);
+        bump<1>(c, ba, bw);                          // half-1 units (j = 2, 3) are staged for kt1
+        ktile_g<1, true>(c, acc, f, wrap ? 0 : t + 2, wrap ? 1 : t + 3, 0, unsafe_nowait2 && !first && t == 0);
+    }
+    if (last) {
+        ktile<0, false>(c, acc, f, nk - 2, 2);
+        ktile<1, false>(c, acc, f, nk - 1, 1);
+    }
+    if (group == 0) __builtin_amdgcn_s_barrier();
 }
 
 }  // namespace ml64
