@@ -11,7 +11,7 @@ Frames shard across ranks with no data-path collective ("weak" scaling: per-GPU 
 fixed); value = frames of all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel = the bf16 GEMM (gemm_bf16_v3_kernel, all five call sites);
+  roofline      dominant kernel = the bf16 GEMM (gemm_bf16_v4_kernel: qkv/proj/fc1/fc2; _v3_ for the patch GEMM);
                 achieved = algorithmic FLOPs of those launches / their HIP-event time (events on the launch
                 stream, in a separate loop of --profile-steps steps right after the timed region: the headline
                 loop carries no events); peak = 2500 TFLOP/s dense bf16 MFMA.
@@ -129,7 +129,7 @@ def gemm_flops_per_frame(cfg):
 def gemm_traffic(cfg, chunk):
     """(measured HBM bytes per GEMM launch from the committed PMC profile, algorithmic bytes per launch).
 
-    PMC counters need rocprofv3, so they are not collected live: profiles/r02_pmc_per_launch.json (v3 loop; r01_pmc_per_launch_v2.json for v2) holds
+    PMC counters need rocprofv3, so they are not collected live: profiles/r02_pmc_per_launch.json (v4 / v3 kernels; r01_pmc_per_launch_v2.json for v2) holds
     FETCH_SIZE / WRITE_SIZE per launch of this same configuration (separate --pmc passes).  Correction as
     /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes for gfx950: FETCH_SIZE reports half of a 16-byte-per-lane
     stream, so reads = 2 x FETCH_SIZE -- confirmed in the same run on kernels with known byte counts (layernorm:
@@ -144,13 +144,14 @@ def gemm_traffic(cfg, chunk):
             "4": chunk * (t - 1) * cfg.patch_dim * 2 + cfg.patch_dim * d * 2 + chunk * (t - 1) * d * 4}
     n = sum(launches.values())
     algorithmic = sum(launches[k] * algo[k] for k in launches) / n
-    for name, prefix in (("r02_pmc_per_launch.json", "gemm_bf16_v3_kernel<"), ("r01_pmc_per_launch_v2.json", "gemm_bf16_v2_kernel<")):
+    for name, prefix in (("r02_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")),
+                         ("r01_pmc_per_launch_v2.json", ("gemm_bf16_v2_kernel<",))):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))["per_launch"]
             meas = 0.0
             seen = 0
             for key, v in prof.items():
-                if prefix in key:
+                if any(pf in key for pf in prefix):
                     epi = key.split("<")[1].split(",")[0].split(">")[0]
                     meas += launches.get(epi, 0) * (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
                     seen += launches.get(epi, 0)
@@ -309,7 +310,7 @@ def bench_swin(dev, args):
             "value": round(b / dt, 1), "unit": "frames/s", "frames_per_step": b, "ms_per_step": round(dt * 1e3, 3),
             "dtype": "bf16", "gflop_per_frame": round(cfg.flops_per_frame() / 1e9, 2),
             "model_tflops": round(cfg.flops_per_frame() * b / dt / 1e12, 1),
-            "roofline": {"bound": "mfma", "kernel": "whole Swin-V2-B step (GEMMs 77 % of it: gemm_bf16_v3 / v2 / gemm_ln kernels)",
+            "roofline": {"bound": "mfma", "kernel": "whole Swin-V2-B step (GEMMs 77 % of it: gemm_bf16_v4 / v3 / v2 / gemm_ln kernels)",
                          "achieved": round(cfg.flops_per_frame() * b / dt / 1e12, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(cfg.flops_per_frame() * b / dt / 1e12 / BF16_PEAK_TFLOPS, 4), "traffic": None,
                          "note": "model FLOPs / wall time of the step (no per-launch events in the Swin encoder)"}}
@@ -435,7 +436,7 @@ def main():
                        "gflop_per_frame": round(cfg.flops_per_frame() / 1e9, 2),
                        "parallelism": f"frames sharded over {world} rank(s), no data-path collective"},
             "model_tflops": round(cfg.flops_per_frame() * total_frames / dt / 1e12 / world, 1),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_v3_kernel (patch/qkv/proj/fc1/fc2 launches)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_v4_kernel (qkv/proj/fc1/fc2; the patch GEMM runs gemm_bf16_v3_kernel: same K loop, one tile per workgroup)",
                          "achieved": round(achieved, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / BF16_PEAK_TFLOPS, 4),
                          "traffic": None if traffic is None else round(traffic),

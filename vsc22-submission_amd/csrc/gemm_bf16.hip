@@ -827,7 +827,12 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
         const int c = lane & 15, rq = lane >> 4;
         const int n = ncol0 + c * 4;
         const int nc = n < p.n ? n : 0;
-        f32x4_t ax[2][4];   // residual rows of this pass and the next (requested a pass ahead)
+        // Residual rows are requested two passes ahead.  (Loads and stores share one in-order counter on gfx9 and the
+        // compiler's waits count only the loads issued since, so with the stores of this read-modify-write loop in between
+        // its vmcnt(n) forces more than the row it needs.  Hand-counted waits around untracked inline-asm loads were
+        // measured: proj 114.6 -> 111.1 us, fc2 unchanged -- the write-out is bound by the fabric's read + write rate, not
+        // by this latency -- and they need unconditional stores to keep the count exact on ragged tiles.  Not kept.)
+        f32x4_t ax[3][4];
         auto load_aux = [&](int i, f32x4_t (&dst)[4]) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -836,10 +841,11 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
                 dst[it] = *(const f32x4_t *)(p.aux + m * p.n + nc);
             }
         };
-        load_aux(0, ax[0]);   // queued behind the next tile's DMA: waiting for it covers tile_p's `first` contract
+        load_aux(0, ax[0]);   // queued behind the next tile's DMA: waiting for these covers tile_p's `first` contract
+        load_aux(1, ax[1]);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (i + 1 < 8) load_aux(i + 1, ax[(i + 1) & 1]);
+            if (i + 2 < 8) load_aux(i + 2, ax[(i + 2) % 3]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *(f32x4_t *)(reg + fr * 256 + (((4 * j + fq) ^ fr) << 4)) = acc[i][j] + bz[j];
@@ -849,7 +855,7 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 4 + rq;
                 f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ row) << 4));
-                v += ax[i & 1][it];
+                v += ax[i % 3][it];
                 const int64_t m = mrow0 + i * 16 + row;
                 if (m < p.m && n < p.n) *(f32x4_t *)((float *)p.out + m * p.n + n) = v;
             }
@@ -919,12 +925,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs p) {
 #pragma unroll
         for (int ii = 0; ii < 8; ++ii)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ii][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) {
+                acc[ii][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                asm volatile("" : "+v"(acc[ii][j]));   // real zeros in real registers: folded into the first MFMAs' C operand, the
+                                                       // first K-tile gets a register assignment of its own and the kernel spills
+            }
         if (!last) stage_bias((i + 1) & 1, tn2 * 256);   // a tile ahead: landed long before the write-out that reads it
 #ifdef VSC_GEMM_TIMING
         if (rec && i < 6) tb[1 + i * 5] = __builtin_amdgcn_s_memtime();
 #endif
-        ml64::tile_p(c, acc, f, nk, i == 0, last, da, dw, (p.abl & 32) != 0);
+        ml64::tile_p(c, acc, f, nk, i == 0, da, dw);
 #ifdef VSC_GEMM_TIMING
         if (rec && i < 6) tb[2 + i * 5] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1017,7 +1027,8 @@ int launch_v34(GemmArgs p, hipStream_t stream) {
             if (dev < 16) cus_of[dev] = cus;
         }
         const int64_t a_span = (int64_t)p.tiles_m * 256 * p.k * 2, w_span = (int64_t)p.tiles_n * 256 * p.k * 2;
-        if (!off && p.k % 128 == 0 && p.k >= 256 && cus % 8 == 0 && (int64_t)p.tiles_m * p.tiles_n > cus &&
+        // (K > 3072: the per-tile costs v4 removes are < 1 % of a tile and its lockstep costs ~3 % -- 8192^3 680 vs 701 us)
+        if (!off && p.k % 128 == 0 && p.k >= 256 && p.k <= 3072 && cus % 8 == 0 && (int64_t)p.tiles_m * p.tiles_n > cus &&
             a_span < (1ll << 32) && w_span < (1ll << 32) && (EPI != VSC_EPI_RESADD_F32 || p.aux))
             return launch_v4<EPI>(p, cus, stream);
     }
@@ -1101,7 +1112,12 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
     // the epilogue is a large share of a tile: the 4-wave tiles run two workgroups per CU, so one's write-out
     // overlaps the other's K loop (stage-3 qkv 765 -> 875 TF/s); D when N is a multiple of 128 but not of 256.
     char cfg = p.n > 128 ? 'A' : 'B';
-    if (p.k <= 512 && p.n > 128) cfg = (p.n % 256 != 0 && p.n % 128 == 0) ? 'D' : 'C';
+    if (p.k <= 512 && p.n > 128) {
+        cfg = (p.n % 256 != 0 && p.n % 128 == 0) ? 'D' : 'C';
+        // ... unless the persistent kernel takes it (v4: K = 256 / 384 / 512, more 256 x 256 tiles than CUs): without the per-tile
+        // launch / prologue / drain the big tile wins here too (Swin-V2-B batch 256: 12.15 k -> 12.95 k frames/s)
+        if (epi_v4(EPI) && p.k % 128 == 0 && p.k >= 256 && p.n % 256 == 0 && ((p.m + 255) / 256) * (p.n / 256) > 256) cfg = 'A';
+    }
     if (force) cfg = force[0];
     const char *v3e = getenv("VSC_GEMM_V3");   // diagnostic A/B switch, read per launch
     const bool no_v3 = v3e && v3e[0] == '0';

@@ -34,6 +34,9 @@
 #include "common.h"
 
 namespace ml64 {
+#ifndef NOWAIT_TEST
+#define NOWAIT_TEST true
+#endif
 
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -286,12 +289,14 @@ __device__ __forceinline__ void bump(Ctx &c, uint32_t da, uint32_t dw) {
 // One output tile of a persistent sequence: nk K-tiles (even, >= 4).
 //   first  the ring holds units 0..5 from prologue(); otherwise the previous tile_p staged them, every wave has waited for
 //          its own pieces (vmcnt(0) in the write-out) and a workgroup barrier has passed since
-//   last   nothing follows: staging stops and the waits drain as in tiles()
-//   da/dw  byte distance from this tile's A / W origin to the next tile's (wrapping 32-bit adds)
-// On return every wave is past its last fragment read; unless `last`, units 0..5 of the next tile are in flight or landed
-// in slots 0..5 and slots 6, 7 are free until the next tile_p (the write-out stages through them).
-__device__ __forceinline__ void tile_p(Ctx &c, f32x4_t (&acc)[8][4], Frags &f, int nk, bool first, bool last, uint32_t da,
-                                       uint32_t dw, bool unsafe_nowait2 = false) {
+//   da/dw  byte distance from this tile's A / W origin to the next tile's (wrapping 32-bit adds); 0 / 0 behind the last
+//          tile of the sequence: its last two K-tiles then stage units 0..5 of the SAME tile once more (96 KiB of reads per
+//          workgroup and launch that nobody uses) -- cheaper than a draining copy of the two K-tile bodies, which cost
+//          registers (spills) in every tile
+// On return every wave is past its last fragment read; units 0..5 of the next tile are in flight or landed in slots 0..5
+// and slots 6, 7 are free until the next tile_p (the write-out stages through them).  The caller waits for its DMA
+// (vmcnt(0)) in the write-out in any case, so nothing is in flight when the kernel ends.
+__device__ __forceinline__ void tile_p(Ctx &c, f32x4_t (&acc)[8][4], Frags &f, int nk, bool first, uint32_t da, uint32_t dw) {
     const int group = c.wave >> 2;
     if (group == 1) __builtin_amdgcn_s_barrier();   // stagger: waves 4-7 run one segment behind
     __builtin_amdgcn_sched_barrier(0);
@@ -301,19 +306,14 @@ __device__ __forceinline__ void tile_p(Ctx &c, f32x4_t (&acc)[8][4], Frags &f, i
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) f.w0[0][j][kh] = frag(c, 0, c.rd_w, j, kh);
     }
-    const int steady_end = last ? nk - 2 : nk;
-#pragma nounroll   // (also keeps the t == 0 iteration from being peeled into a third copy of the two bodies)
-    for (int t = 0; t < steady_end; t += 2) {
+#pragma nounroll   // (also keeps the t == 0 iteration from being peeled into a third copy of the two bodies: that spills)
+    for (int t = 0; t < nk; t += 2) {
         const bool wrap = t + 2 == nk;               // the two K-tiles that stage the next output tile
         const uint32_t ba = wrap ? da : 0u, bw = wrap ? dw : 0u;
         bump<0>(c, ba, bw);                          // half-0 units (j = 0, 1) are staged for kt2: next tile from here on
-        ktile_g<0, true>(c, acc, f, t + 1, wrap ? 0 : t + 2, 0, !first && t == 0);
+        ktile_g<0, true>(c, acc, f, t + 1, wrap ? 0 : t + 2, 0, NOWAIT_TEST && !first && t == 0);
         bump<1>(c, ba, bw);                          // half-1 units (j = 2, 3) are staged for kt1
-        ktile_g<1, true>(c, acc, f, wrap ? 0 : t + 2, wrap ? 1 : t + 3, 0, unsafe_nowait2 && !first && t == 0);
-    }
-    if (last) {
-        ktile<0, false>(c, acc, f, nk - 2, 2);
-        ktile<1, false>(c, acc, f, nk - 1, 1);
+        ktile_g<1, true>(c, acc, f, wrap ? 0 : t + 2, wrap ? 1 : t + 3, 0, false);
     }
     if (group == 0) __builtin_amdgcn_s_barrier();
 }
