@@ -228,7 +228,7 @@ int vsc_l2_normalize_f32(float *x_dev, int64_t n, int32_t d, void *stream);
  * ------------------------------------------------------------------------ */
 typedef enum vsc_epilogue {
     VSC_EPI_BF16 = 0,        /* out bf16 = acc + bias */
-    VSC_EPI_GELU_BF16 = 1,   /* out bf16 = gelu(acc + bias) */
+    VSC_EPI_GELU_BF16 = 1,   /* out bf16 = gelu(acc + bias): erf GELU to 2.2e-6 + 6.6e-7 |x| absolute (polynomial) */
     VSC_EPI_QGELU_BF16 = 2,  /* out bf16 = quick_gelu(acc + bias) */
     VSC_EPI_RESADD_F32 = 3,  /* out f32  = residual + acc + bias (out may alias residual) */
     VSC_EPI_PATCH_F32 = 4,   /* out f32 row n*T+1+p = acc + bias + pos[1+p] (row = n*(T-1)+p) */
