@@ -94,9 +94,11 @@ def parse():
     ap.add_argument("--max-batch", type=int, default=332,
                     help="frames per internal encoder chunk (332 x 197 tokens = 255.5 -> 256 GEMM row "
                          "tiles: every GEMM grid is then a whole number of 256-CU rounds)")
-    ap.add_argument("--lanes", type=int, default=1,
-                    help="internal streams the chunks of a step alternate over (2: +1.9 %% frames/s, but the "
-                         "per-kernel event times then overlap; the roofline line is quoted at 1)")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="internal streams the chunks of a step alternate over (the encoder's default: 2 -- the two 332-frame "
+                         "chunks of a step are independent, and on two HIP streams the tail of one chunk's kernel overlaps the "
+                         "head of the other's: +5 %% frames/s over 1; the per-launch event loop behind kernels{} / roofline "
+                         "always runs the chunks back to back on one stream)")
     ap.add_argument("--fuse-ln", action="store_true", help="LayerNorm folded into the neighbouring GEMM epilogues (DESIGN 4.1b)")
     ap.add_argument("--preset", default="vit_b16_224")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -446,8 +448,9 @@ def main():
                          "gemm_ms_per_step": round(gemm_ms / psteps, 3),
                          "profiled_steps": psteps,
                          "note": "per-launch HIP-event time on the launch stream, taken in a separate loop of profiled_steps steps right "
-                                 "after the timed region (the headline loop carries no events); with lanes=2 launches of the two "
-                                 "chunks overlap, so the sum of kernel times exceeds ms_per_step"},
+                                 "after the timed region (the headline loop carries no events).  The headline loop runs the two chunks of a "
+                                 "step on two streams (config.lanes); the event loop runs them back to back on one, so its kernel times "
+                                 "are per kernel alone and their sum exceeds ms_per_step"},
             "kernels": per_class,
         }
         clk = sampler.summary() if sampler else None

@@ -353,7 +353,9 @@ static int encoder_forward_impl(vsc_encoder *e, const float *frames, const uint8
     }
     hipStream_t user = (hipStream_t)stream_;
     const vsc_encoder_config &c = e->cfg;
-    const bool fork = e->lanes == 2 && n > c.max_batch;  // >= 2 chunks: alternate them over the two lanes
+    // >= 2 chunks: alternate them over the two lanes.  Not while profiling: the per-launch events are meant to time one kernel
+    // at a time (bench.py's kernels{} / roofline loop), so the chunks then run back to back on the caller's stream.
+    const bool fork = e->lanes == 2 && n > c.max_batch && !e->profile;
     if (fork) {
         VSC_CHECK_HIP(hipEventRecord(e->ev_fork, user));
         for (int l = 0; l < 2; ++l) VSC_CHECK_HIP(hipStreamWaitEvent(e->lane_stream[l], e->ev_fork, 0));

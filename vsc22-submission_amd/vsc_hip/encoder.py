@@ -18,7 +18,7 @@ from .config import EncoderConfig, aligned_batch, get_config
 
 class HipEncoder:
     def __init__(self, cfg: EncoderConfig | str, weights: dict, *, max_batch: int = 128,
-                 l2_normalize: bool = False, lanes: int = 1, fuse_ln: int = 0,
+                 l2_normalize: bool = False, lanes: int = 2, fuse_ln: int = 0,
                  u8_mean=(0.5, 0.5, 0.5), u8_std=(0.5, 0.5, 0.5)):
         if isinstance(cfg, str):
             cfg = get_config(cfg)
