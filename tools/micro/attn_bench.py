@@ -31,3 +31,15 @@ def timeit(it=10, flush=True):
 
 ops.attention_bf16(qkv, frames, tokens, heads)
 print(f"cold (Infinity Cache flushed) {timeit():.1f} us   warm {timeit(flush=False):.1f} us", flush=True)
+
+for skew in (0, 4000, 8000, 12000, 16000, 24000, 32000):
+    os.environ["VSC_ATTN_SKEW"] = str(skew)
+    print(f"skew {skew}: cold {timeit():.1f} us   warm {timeit(flush=False):.1f} us", flush=True)
+os.environ.pop("VSC_ATTN_SKEW")
+
+# ablations (library built with -DVSC_ATTN_ABLATION): what each part of the kernel costs
+for abl, what in ((1, "no exp2"), (2, "no PV MFMA"), (4, "no QK MFMA"), (6, "no MFMA"), (7, "no MFMA, no exp2"), (8, "no K/V loads"), (16, "no stores"),
+                  (24, "no K/V loads, no stores"), (31, "nothing but Q loads + LDS + VALU")):
+    os.environ["VSC_ATTN_ABL"] = str(abl)
+    print(f"abl {abl:2d} ({what}): cold {timeit():.1f} us   warm {timeit(flush=False):.1f} us", flush=True)
+os.environ.pop("VSC_ATTN_ABL")

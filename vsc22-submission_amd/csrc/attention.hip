@@ -19,11 +19,17 @@
 //   * O^T puts 4 consecutive head-dim columns of one query in a lane: 8-byte bf16 stores.
 //   * waves per workgroup: measured again in round 2 with one wave per query tile (13 waves for 197 tokens, all chains
 //     side by side): 139 us per launch against 121 with these 8 waves, and a runtime tile loop with fewer waves is slower
-//     too (tools/micro/attn_bench.py).  The launch moves 392 MB (qkv in, context out): ~71 us at HBM speed, so the kernel
-//     sits at 1.7 x its memory floor; what is left is the K / V staging of the second resident workgroup.
+//     too (tools/micro/attn_bench.py).  The launch moves 392 MB (qkv in, context out): ~71 us at HBM speed.
 //     Also measured and dropped: persistent workgroups that request the NEXT (frame, head)'s Q / K / V into registers
 //     while the current one is computed -- 173 VGPRs halve the residency (159 vs 148 us), capped at 128 VGPRs it spills
 //     (239 us).
+//   * where the time goes (ablations, -DVSC_ATTN_ABLATION + tools/micro/attn_bench.py, standalone launch, warm): whole
+//     kernel 135 us; without MFMAs and exp2 109; without the K / V loads 78; without the stores 92; with neither 64 -- the
+//     launch is bound by its memory phases, not by compute, although it moves only 3 TB/s.  Two things followed:
+//     the context is written out through 2 KiB of wave-private LDS as whole 128-byte rows (the fragment layout stores
+//     32-byte pieces of 16 rows: 135 -> 126 us), and the second resident workgroup of every CU starts half a lifetime late
+//     (all workgroups last equally long, so the two residents of a CU otherwise load together and compute together for
+//     the whole launch: 126 -> 104 us warm, 149 -> 122 cold).  In the encoder step: 124 -> 107 us per launch.
 //   * softmax runs in fp32 with exp2 and a folded scale (1/8 * log2 e); probabilities are
 //     rounded to bf16 for the PV MFMA, the row sum is kept in fp32 from the unrounded values.
 #include "common.h"
@@ -32,16 +38,23 @@ namespace {
 
 constexpr int DH = 64;
 
-template <int KT>  // key tiles of 32 -> padded token count 32*KT
+template <int KT, int ABL = 0>  // key tiles of 32 -> padded token count 32*KT; ABL: diagnostic ablation bits (VSC_ATTN_ABL, KT = 7 only)
 __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__restrict__ qkv,
                                                            uint16_t *__restrict__ out, int tokens,
-                                                           int heads) {
+                                                           int heads, int skew) {
     constexpr int TP = KT * 32;
+    // Start skew of the SECOND workgroup of every CU (the first 512 workgroups start together, two per CU; all have the same
+    // duration, so without it the two residents of a CU load together and compute together for the whole launch).
+    if (skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)skew) __builtin_amdgcn_s_sleep(8);
+    }
     constexpr int VSTRIDE = TP * 2 + 8;  // bytes per head-dim row of V^T (8-B aligned, odd multiple of 8)
     constexpr int QT_MAX = (2 * KT + 7) / 8;  // 16-query tiles per wave (8 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *klds = smem;             // [TP][64] bf16, 128-B rows, chunk ^= (row >> 1) & 7
     char *vt = smem + TP * 128;    // [64][VSTRIDE]
+    char *ost = vt + 64 * VSTRIDE; // 8 waves x 2 KiB: write-out transposition
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
         for (int i = 0; i < KIT; ++i) {
             const int e = tid + i * 512, row = e >> 3, c = e & 7;
             kv[i] = make_uint4(0, 0, 0, 0);
-            if (e < TP * 8 && row < tokens) kv[i] = *(const uint4 *)(kptr + row * ld + c * 8);
+            if (e < TP * 8 && row < tokens && !(ABL & 8)) kv[i] = *(const uint4 *)(kptr + row * ld + c * 8);
         }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
@@ -90,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
             for (int i = 0; i < 4; ++i) {
                 const int row = kg * 4 + i;
                 vr[it][i] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-                if (e < VTASKS && kg < TP / 4 && row < tokens) vr[it][i] = *(const bf16x8_t *)(vptr + row * ld + c8 * 8);
+                if (e < VTASKS && kg < TP / 4 && row < tokens && !(ABL & 8)) vr[it][i] = *(const bf16x8_t *)(vptr + row * ld + c8 * 8);
             }
         }
 #pragma unroll
@@ -121,8 +134,6 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
     for (int qi = 0; qi < QT_MAX; ++qi) {
         const int qt = wave + 8 * qi;
         if (qt >= qtiles) break;
-        const int qrow = qt * 16 + fr;
-        const bool qvalid = qrow < tokens;
 
         // scores: s[t][r] = <q[query = fr], k[key = 16 t + 4 g + r]>
         f32x4_t s[2 * KT];
@@ -134,7 +145,8 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
             for (int kk = 0; kk < 2; ++kk) {
                 const bf16x8_t kf =
                     *(const bf16x8_t *)(klds + krow * 128 + (((g + 4 * kk) ^ ((krow >> 1) & 7)) << 4));
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][kk], s[t], 0, 0, 0);
+                if (ABL & 4) s[t][kk] += (float)kf[0] + (float)qf[qi][kk][1];
+                else s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][kk], s[t], 0, 0, 0);
             }
             // keep the scheduler from hoisting every tile's K fragments (register blow-up)
             if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -160,8 +172,8 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
             float e[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                e[r] = __builtin_amdgcn_exp2f(fmaf(s[2 * u][r], scale, -mxs));
-                e[4 + r] = __builtin_amdgcn_exp2f(fmaf(s[2 * u + 1][r], scale, -mxs));
+                e[r] = (ABL & 1) ? fmaf(s[2 * u][r], scale, -mxs) : __builtin_amdgcn_exp2f(fmaf(s[2 * u][r], scale, -mxs));
+                e[4 + r] = (ABL & 1) ? fmaf(s[2 * u + 1][r], scale, -mxs) : __builtin_amdgcn_exp2f(fmaf(s[2 * u + 1][r], scale, -mxs));
             }
             sum += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
             union { uint32_t w[4]; bf16x8_t v; } pk;
@@ -185,19 +197,38 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
                 union { uint2 h[2]; bf16x8_t v; } vf;
                 vf.h[0] = *(const uint2 *)(vrow);
                 vf.h[1] = *(const uint2 *)(vrow + 32);
-                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
+                if (ABL & 2) o[ct][u & 3] += (float)vf.v[0] + (float)pb[u][ct];
+                else o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
             }
             if (u & 1) __builtin_amdgcn_sched_barrier(0);
         }
-        if (qvalid) {
-            uint16_t *orow = out + ((int64_t)frame * tokens + qrow) * width + head * DH + g * 4;
+        // write-out through 2 KiB of wave-private LDS: a lane's accumulators are 4 head-dim columns of 16 different queries,
+        // stored directly that is 32-byte pieces of 16 rows per instruction (four instructions per 128-byte row: 4 x the
+        // store requests -- the stores cost 43 of the launch's 135 us).  Transposed, eight lanes write one whole 128-byte
+        // (token, head) row with 16-byte stores.  Same swizzle as the GEMM write-out (gemm_bf16.hip, epilogue_via_lds).
+        {
+            char *reg = ost + wave * 2048;
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 uint2 pk;
                 pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
                 pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
-                *(uint2 *)(orow + ct * 16) = pk;
+                const int chunk = 2 * ct + (g >> 1);
+                *(uint2 *)(reg + fr * 128 + ((chunk ^ (fr & 7)) << 4) + ((g ^ (fr >> 3)) & 1) * 8) = pk;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int c = lane & 7;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                uint4 d = *(const uint4 *)(reg + row * 128 + ((c ^ (row & 7)) << 4));
+                if (it & 1) d = make_uint4(d.z, d.w, d.x, d.y);
+                const int q = qt * 16 + row;
+                if (q < tokens && !(ABL & 16)) *(uint4 *)(out + ((int64_t)frame * tokens + q) * width + head * DH + c * 8) = d;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -206,7 +237,7 @@ template <int KT>
 int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int heads,
               hipStream_t stream) {
     constexpr int TP = KT * 32;
-    constexpr int smem = TP * 128 + 64 * (TP * 2 + 8);
+    constexpr int smem = TP * 128 + 64 * (TP * 2 + 8) + 8 * 2048;
     static bool attr_set[16] = {};   // per device (one process may drive several)
     int dev = 0;
     VSC_CHECK_HIP(hipGetDevice(&dev));
@@ -215,8 +246,23 @@ int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int he
                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         if (dev < 16) attr_set[dev] = true;
     }
+    // start skew of each CU's second resident (see the kernel): half a workgroup lifetime.  Measured at 197 tokens (lifetime
+    // ~32 k cycles): 0 / 4 / 8 / 12 / 16 / 24 / 32 k cycles -> 148.6 / 140.3 / 137.6 / 132.4 / 121.8 / 136.4 / 139.4 us cold,
+    // 116.9 / 114.1 / 107.6 / 104.9 / 104.2 / 116.9 / 114.7 us warm (tools/micro/attn_bench.py).  Two workgroups are resident
+    // from 5 key tiles up (LDS); the lifetime goes with the square of the token count.
+    int skew = KT >= 5 && frames * heads > 512 ? 16000 * KT * KT / 49 : 0;
+    if (const char *e = getenv("VSC_ATTN_SKEW")) skew = atoi(e);
+#ifdef VSC_ATTN_ABLATION
+    if (KT == 7)
+        if (const char *e = getenv("VSC_ATTN_ABL")) {
+            const int abl = atoi(e);
+#define VSC_ABL_CASE(A) case A: { auto k = attention_kernel<7, A>; VSC_CHECK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); \
+            hipLaunchKernelGGL(k, dim3(frames * heads), dim3(512), smem, stream, qkv, out, tokens, heads, skew); VSC_CHECK_LAUNCH(); return VSC_OK; }
+            switch (abl) { VSC_ABL_CASE(1) VSC_ABL_CASE(2) VSC_ABL_CASE(4) VSC_ABL_CASE(6) VSC_ABL_CASE(7) VSC_ABL_CASE(8) VSC_ABL_CASE(16) VSC_ABL_CASE(24) VSC_ABL_CASE(31) default: break; }
+        }
+#endif
     hipLaunchKernelGGL(attention_kernel<KT>, dim3(frames * heads), dim3(512), smem, stream, qkv, out,
-                       tokens, heads);
+                       tokens, heads, skew);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }
