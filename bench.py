@@ -295,7 +295,7 @@ def bench_swin(dev, args):
     from vsc_hip.swin_encoder import SwinHipEncoder
     cfg = get_swin_config("swinv2_base_256")
     enc = SwinHipEncoder(cfg, synth.swin_weights(5, cfg), max_batch=args.swin_batch, l2_normalize=True)
-    b = args.swin_batch
+    b = 2 * args.swin_batch   # two encoder chunks per step: they run on the Swin encoder's two lanes, as the ViT step's do
     x = torch.from_numpy(synth.swin_frames(1, 8, cfg)).to(dev).repeat((b + 7) // 8, 1, 1, 1)[:b].contiguous()
     for _ in range(2):
         enc(x)
@@ -309,7 +309,8 @@ def bench_swin(dev, args):
     assert torch.isfinite(out).all()
     enc.close()
     return {"metric": "frames/s (Swin-V2-B 256x256 window-16 encode -> L2-normalised 512-d descriptors)",
-            "value": round(b / dt, 1), "unit": "frames/s", "frames_per_step": b, "ms_per_step": round(dt * 1e3, 3),
+            "value": round(b / dt, 1), "unit": "frames/s", "frames_per_step": b, "encoder_chunk": args.swin_batch, "lanes": 2,
+            "ms_per_step": round(dt * 1e3, 3),
             "dtype": "bf16", "gflop_per_frame": round(cfg.flops_per_frame() / 1e9, 2),
             "model_tflops": round(cfg.flops_per_frame() * b / dt / 1e12, 1),
             "roofline": {"bound": "mfma", "kernel": "whole Swin-V2-B step (GEMMs 77 % of it: gemm_bf16_v4 / v3 / v2 / gemm_ln kernels)",

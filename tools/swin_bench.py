@@ -1,4 +1,5 @@
-"""Throughput of the Swin-V2 encoder (run on the GPU box): python tools/swin_bench.py [batch] [steps]"""
+"""Throughput of the Swin-V2 encoder (run on the GPU box): python tools/swin_bench.py [batch] [steps] [max_batch]
+(batch > max_batch: the chunks alternate over the encoder's two lanes)"""
 import os
 import sys
 import time
@@ -14,8 +15,9 @@ from vsc_hip.swin_encoder import SwinHipEncoder
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+MB = int(sys.argv[3]) if len(sys.argv) > 3 else B
 cfg = get_swin_config("swinv2_base_256")
-enc = SwinHipEncoder(cfg, synth.swin_weights(5, cfg), max_batch=B, l2_normalize=True)
+enc = SwinHipEncoder(cfg, synth.swin_weights(5, cfg), max_batch=MB, l2_normalize=True)
 x = torch.from_numpy(synth.swin_frames(1, 8, cfg)).cuda().repeat((B + 7) // 8, 1, 1, 1)[:B].contiguous()
 for _ in range(2):
     enc(x)
