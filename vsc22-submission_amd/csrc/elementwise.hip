@@ -147,13 +147,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 // same columns for every token, GeM's per-column sum of clamp(y,1e-6)^p accumulates in
 // registers; the 4 waves combine through LDS.  pool = 1 (CLS): token 0 only.
 // tokens_out (optional) receives the normalised tokens (parity tests).
-__global__ __launch_bounds__(256) void ln_pool_kernel(const float *__restrict__ x,
+template <int NW>   // waves per frame: 16 (width <= 1024) or 8 -- one frame's 197 tokens on 4 waves left the launch latency-bound (146 us for 201 MB)
+__global__ __launch_bounds__(NW * 64) void ln_pool_kernel(const float *__restrict__ x,
                                                       const float *__restrict__ gamma,
                                                       const float *__restrict__ beta,
                                                       float *__restrict__ pooled,
                                                       float *__restrict__ tokens_out, int tokens,
                                                       int width, float eps, int pool, float gem_p) {
-    __shared__ float comb[4][2048];
+    extern __shared__ float comb[];   // [NW][width]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t f = blockIdx.x;
     const int nv = width >> 8, tail = width & 255;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void ln_pool_kernel(const float *__restrict__ 
     for (int i = 0; i < MAXV; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool cube = gem_p == 3.0f;
     const int tend = (pool == 1 && tokens_out == nullptr) ? 1 : tokens;
-    for (int t = wave; t < tend; t += 4) {
+    for (int t = wave; t < tend; t += NW) {
         const float *xr = x + (f * tokens + t) * width;
         float4 v[MAXV];
         float sum = 0.f;
@@ -208,11 +209,14 @@ __global__ __launch_bounds__(256) void ln_pool_kernel(const float *__restrict__ 
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int col = i * 256 + lane * 4;
-        if (col < width) *(float4 *)(&comb[wave][col]) = acc[i];
+        if (col < width) *(float4 *)(&comb[wave * width + col]) = acc[i];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < width; c += 256) {
-        const float s = (comb[0][c] + comb[1][c]) + (comb[2][c] + comb[3][c]);
+    for (int c = threadIdx.x; c < width; c += NW * 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4)
+            s += (comb[w * width + c] + comb[(w + 1) * width + c]) + (comb[(w + 2) * width + c] + comb[(w + 3) * width + c]);
         float r;
         if (pool == 1) r = s;  // only wave 0 / token 0 contributed
         else {
@@ -251,57 +255,53 @@ __global__ __launch_bounds__(256) void gem_pool_bf16_kernel(const uint16_t *__re
 }
 
 // ------------------------------------------------------------------ descriptor head
-// desc[f,:] = pooled[f,:] . W^T + b (fp32), optionally L2-normalised (zero rows untouched).
-// One workgroup per frame; a wave computes outputs w, w+4, ... with coalesced weight rows.
+// desc[f,:] = pooled[f,:] . W^T + b (fp32); the L2 normalisation, when asked for, is l2_normalize_kernel behind it.
+// One workgroup per (HF = 4 frames, quarter of the outputs).  With one workgroup per frame every frame streamed the
+// whole weight matrix (1.5 MiB for 768 -> 512) through four waves: 87 us for 332 frames, the time ONE workgroup needs
+// for that stream; now a workgroup reads a quarter of it once for four frames.  A wave computes outputs o0 .. o0+7 of
+// the four frames from one pass over the coalesced weight rows; every (frame, output) is one explicit fmaf chain, so
+// the bits do not depend on how the frames are grouped (tests/test_gpu_encoder.py::test_encoder_batching_is_invisible).
+constexpr int HF = 4, HSPLIT = 4;
 __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ pooled,
                                                    const float *__restrict__ w,
                                                    const float *__restrict__ bias,
-                                                   float *__restrict__ desc, int width, int out_dim,
-                                                   int l2) {
-    __shared__ __attribute__((aligned(16))) float xs[2048];
-    __shared__ float ys[2048];
-    __shared__ float red[4];
+                                                   float *__restrict__ desc, int64_t frames, int width, int out_dim) {
+    __shared__ __attribute__((aligned(16))) float xs[HF][2048];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t f = blockIdx.x;
-    for (int c = threadIdx.x; c < width; c += 256) xs[c] = pooled[f * width + c];
+    const int64_t f0 = (int64_t)blockIdx.x * HF;
+    const int nf = frames - f0 < HF ? (int)(frames - f0) : HF;
+    const int per = ((out_dim + HSPLIT - 1) / HSPLIT + 31) / 32 * 32;   // outputs per workgroup, whole wave rounds
+    const int o_begin = blockIdx.y * per, o_end = o_begin + per < out_dim ? o_begin + per : out_dim;
+    for (int q = 0; q < HF; ++q)
+        for (int c = threadIdx.x; c < width; c += 256) xs[q][c] = q < nf ? pooled[(f0 + q) * width + c] : 0.f;
     __syncthreads();
-    const int n_out = w ? out_dim : width;
-    if (w) {
-        // 8 outputs per wave iteration: 8 independent load streams / accumulators, so the weight
-        // rows' latency overlaps instead of serialising one dot product after another
-        for (int o0 = wave * 8; o0 < out_dim; o0 += 32) {
-            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int c = lane * 4; c < width; c += 256) {
-                const float4 xv = *(const float4 *)(xs + c);
+    for (int o0 = o_begin + wave * 8; o0 < o_end; o0 += 32) {
+        float a[8][HF];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int o = o0 + j < out_dim ? o0 + j : out_dim - 1;
-                    const float4 wv = *(const float4 *)(w + (int64_t)o * width + c);
-                    a[j] += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
-                }
-            }
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int q = 0; q < HF; ++q) a[j][q] = 0.f;
+        for (int c = lane * 4; c < width; c += 256) {
+            float4 xv[HF];
+#pragma unroll
+            for (int q = 0; q < HF; ++q) xv[q] = *(const float4 *)(&xs[q][c]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float r = wave_sum(a[j]);
-                if (lane == 0 && o0 + j < out_dim) ys[o0 + j] = r + (bias ? bias[o0 + j] : 0.f);
+                const int o = o0 + j < out_dim ? o0 + j : out_dim - 1;
+                const float4 wv = *(const float4 *)(w + (int64_t)o * width + c);
+#pragma unroll
+                for (int q = 0; q < HF; ++q)
+                    a[j][q] = fmaf(wv.w, xv[q].w, fmaf(wv.z, xv[q].z, fmaf(wv.y, xv[q].y, fmaf(wv.x, xv[q].x, a[j][q]))));
             }
         }
-    } else {
-        for (int c = threadIdx.x; c < width; c += 256) ys[c] = xs[c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int q = 0; q < HF; ++q) {
+                const float r = wave_sum(a[j][q]);
+                if (lane == 0 && o0 + j < o_end && q < nf) desc[(f0 + q) * out_dim + o0 + j] = r + (bias ? bias[o0 + j] : 0.f);
+            }
     }
-    __syncthreads();
-    float scale = 1.f;
-    if (l2) {
-        float ss = 0.f;
-        for (int c = threadIdx.x; c < n_out; c += 256) ss += ys[c] * ys[c];
-        ss = wave_sum(ss);
-        if (lane == 0) red[wave] = ss;
-        __syncthreads();
-        const float nrm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-        scale = nrm == 0.f ? 1.f : 1.0f / nrm;
-    }
-    for (int c = threadIdx.x; c < n_out; c += 256)
-        desc[f * n_out + c] = l2 ? ys[c] * scale : ys[c];
 }
 
 // ------------------------------------------------------------------ L2 normalise rows in place
@@ -437,8 +437,20 @@ int launch_ln_pool(const float *x, const float *g, const float *b, float *pooled
                    int64_t frames, int tokens, int width, float eps, int pool, float gem_p,
                    hipStream_t stream) {
     VSC_REQUIRE(width % 4 == 0 && width <= 2048, "ln_pool: width %d unsupported", width);
-    hipLaunchKernelGGL(ln_pool_kernel, dim3((unsigned)frames), dim3(256), 0, stream, x, g, b, pooled,
-                       tokens_out, tokens, width, eps, pool, gem_p);
+    static bool attr_set[16] = {};
+    int dev = 0;
+    VSC_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 16 || !attr_set[dev]) {
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)ln_pool_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024 * 4));
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)ln_pool_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4));
+        if (dev < 16) attr_set[dev] = true;
+    }
+    if (width <= 1024)
+        hipLaunchKernelGGL(ln_pool_kernel<16>, dim3((unsigned)frames), dim3(1024), 16 * width * 4, stream, x, g, b, pooled, tokens_out,
+                           tokens, width, eps, pool, gem_p);
+    else
+        hipLaunchKernelGGL(ln_pool_kernel<8>, dim3((unsigned)frames), dim3(512), 8 * width * 4, stream, x, g, b, pooled, tokens_out,
+                           tokens, width, eps, pool, gem_p);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }
@@ -455,10 +467,14 @@ int launch_gem_pool_bf16(const uint16_t *x, float *pooled, int64_t frames, int t
 int launch_head(const float *pooled, const float *w, const float *bias, float *desc, int64_t frames,
                 int width, int out_dim, int l2, hipStream_t stream) {
     VSC_REQUIRE(width <= 2048 && out_dim <= 2048 && width % 4 == 0, "head: dims unsupported");
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)frames), dim3(256), 0, stream, pooled, w, bias, desc,
-                       width, out_dim, l2);
-    VSC_CHECK_LAUNCH();
-    return VSC_OK;
+    if (w) {
+        hipLaunchKernelGGL(head_kernel, dim3((unsigned)((frames + HF - 1) / HF), HSPLIT), dim3(256), 0, stream, pooled, w, bias,
+                           desc, frames, width, out_dim);
+        VSC_CHECK_LAUNCH();
+    } else {   // no projection: the pooled vector is the descriptor
+        VSC_CHECK_HIP(hipMemcpyAsync(desc, pooled, (size_t)frames * width * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    return l2 ? launch_l2_normalize(desc, frames, w ? out_dim : width, stream) : VSC_OK;
 }
 
 int launch_l2_normalize(float *x, int64_t n, int d, hipStream_t stream) {
