@@ -38,10 +38,11 @@ namespace {
 
 constexpr int DH = 64;
 
-template <int KT, int ABL = 0>  // key tiles of 32 -> padded token count 32*KT; ABL: diagnostic ablation bits (VSC_ATTN_ABL, KT = 7 only)
+template <int KT, int NI, int ABL = 0>  // key tiles of 32 -> padded token count 32*KT; NI: (frame, head) items per workgroup;
+                                         // ABL: diagnostic ablation bits (VSC_ATTN_ABL, KT = 7 only)
 __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__restrict__ qkv,
                                                            uint16_t *__restrict__ out, int tokens,
-                                                           int heads, int skew) {
+                                                           int heads, int total, int skew) {
     constexpr int TP = KT * 32;
     // Start skew of the SECOND workgroup of every CU (the first 512 workgroups start together, two per CU; all have the same
     // duration, so without it the two residents of a CU load together and compute together for the whole launch).
@@ -58,42 +59,45 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int frame = blockIdx.x / heads, head = blockIdx.x - frame * heads;
     const int width = heads * DH;
     const int64_t ld = 3 * (int64_t)width;
-    const uint16_t *qptr = qkv + (int64_t)frame * tokens * ld + head * DH;
-    const uint16_t *kptr = qptr + width;
-    const uint16_t *vptr = qptr + 2 * width;
     const int fr = lane & 15, g = lane >> 4;
     const int qtiles = (tokens + 15) >> 4;
+    const float scale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
+    const int full_tiles = tokens >> 4;                    // 16-key tiles without padding
+
+    constexpr int KIT = (TP * 8 + 511) / 512;
+    constexpr int VTASKS = ((TP / 4 + 15) / 16) * 128;   // 16 key groups x 8 column blocks per 128 tasks
+    constexpr int VIT = (VTASKS + 511) / 512;
+    struct KV {
+        uint4 kv[KIT];
+        bf16x8_t vr[VIT][4];
+    };
+    auto q_of = [&](int item) { return qkv + (int64_t)(item / heads) * tokens * ld + (item % heads) * DH; };
 
     // ---- Q fragments of every query tile this wave owns, issued first: their HBM latency
     //      hides behind the K/V staging instead of stalling each tile.
-    bf16x8_t qf[QT_MAX][2];
+    auto load_q = [&](int item, bf16x8_t (&qf)[QT_MAX][2]) {
+        const uint16_t *qptr = q_of(item);
 #pragma unroll
-    for (int i = 0; i < QT_MAX; ++i) {
-        int qrow = (wave + 8 * i) * 16 + fr;
-        qrow = qrow < tokens ? qrow : tokens - 1;
-        qf[i][0] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8);
-        qf[i][1] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8 + 32);
-    }
-    // ---- stage K (row-major, swizzled; pad rows are zero) and V (transposed): ALL of a thread's K and V rows are requested
-    //      before the first LDS write, so the workgroup pays one memory round trip for its 50 KB instead of two (K, then V);
-    //      the kernel runs at the rate its workgroups can keep loads in flight (2.7-3.0 TB/s at every token count and
-    //      occupancy, tools/micro/attn_occupancy.py), not at a compute limit.
+        for (int i = 0; i < QT_MAX; ++i) {
+            int qrow = (wave + 8 * i) * 16 + fr;
+            qrow = qrow < tokens ? qrow : tokens - 1;
+            qf[i][0] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8);
+            qf[i][1] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8 + 32);
+        }
+    };
+    // ---- K (row-major, swizzled; pad rows are zero) and V (transposed): ALL of a thread's K and V rows are requested
+    //      before the first LDS write, so the workgroup pays one memory round trip for its 50 KB instead of two (K, then V).
     //      V task = (4 keys) x (8 head-dim columns); 16 consecutive lanes take 16 consecutive key groups of one column
     //      block, so every ds_write_b64 of a 16-lane group lands on 128 contiguous bytes (conflict-free).
-    {
-        constexpr int KIT = (TP * 8 + 511) / 512;
-        constexpr int VTASKS = ((TP / 4 + 15) / 16) * 128;   // 16 key groups x 8 column blocks per 128 tasks
-        constexpr int VIT = (VTASKS + 511) / 512;
-        uint4 kv[KIT];
-        bf16x8_t vr[VIT][4];
+    auto load_kv = [&](int item, KV &r) {
+        const uint16_t *kptr = q_of(item) + width, *vptr = q_of(item) + 2 * width;
 #pragma unroll
         for (int i = 0; i < KIT; ++i) {
             const int e = tid + i * 512, row = e >> 3, c = e & 7;
-            kv[i] = make_uint4(0, 0, 0, 0);
-            if (e < TP * 8 && row < tokens && !(ABL & 8)) kv[i] = *(const uint4 *)(kptr + row * ld + c * 8);
+            r.kv[i] = make_uint4(0, 0, 0, 0);
+            if (e < TP * 8 && row < tokens && !(ABL & 8)) r.kv[i] = *(const uint4 *)(kptr + row * ld + c * 8);
         }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
@@ -102,14 +106,16 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = kg * 4 + i;
-                vr[it][i] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
-                if (e < VTASKS && kg < TP / 4 && row < tokens && !(ABL & 8)) vr[it][i] = *(const bf16x8_t *)(vptr + row * ld + c8 * 8);
+                r.vr[it][i] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+                if (e < VTASKS && kg < TP / 4 && row < tokens && !(ABL & 8)) r.vr[it][i] = *(const bf16x8_t *)(vptr + row * ld + c8 * 8);
             }
         }
+    };
+    auto store_kv = [&](const KV &r) {
 #pragma unroll
         for (int i = 0; i < KIT; ++i) {
             const int e = tid + i * 512, row = e >> 3, c = e & 7;
-            if (e < TP * 8) *(uint4 *)(klds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kv[i];
+            if (e < TP * 8) *(uint4 *)(klds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = r.kv[i];
         }
 #pragma unroll
         for (int it = 0; it < VIT; ++it) {
@@ -119,117 +125,140 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 uint2 pk;
-                pk.x = (uint32_t)(uint16_t)vr[it][0][j] | ((uint32_t)(uint16_t)vr[it][1][j] << 16);
-                pk.y = (uint32_t)(uint16_t)vr[it][2][j] | ((uint32_t)(uint16_t)vr[it][3][j] << 16);
+                pk.x = (uint32_t)(uint16_t)r.vr[it][0][j] | ((uint32_t)(uint16_t)r.vr[it][1][j] << 16);
+                pk.y = (uint32_t)(uint16_t)r.vr[it][2][j] | ((uint32_t)(uint16_t)r.vr[it][3][j] << 16);
                 *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + kg * 8) = pk;
             }
         }
+    };
+    auto compute = [&](int item, const bf16x8_t (&qf)[QT_MAX][2]) {
+        const int frame = item / heads, head = item - frame * heads;
+#pragma unroll
+        for (int qi = 0; qi < QT_MAX; ++qi) {
+            const int qt = wave + 8 * qi;
+            if (qt >= qtiles) break;
+
+            // scores: s[t][r] = <q[query = fr], k[key = 16 t + 4 g + r]>
+            f32x4_t s[2 * KT];
+#pragma unroll
+            for (int t = 0; t < 2 * KT; ++t) {
+                s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                const int krow = t * 16 + fr;
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bf16x8_t kf =
+                        *(const bf16x8_t *)(klds + krow * 128 + (((g + 4 * kk) ^ ((krow >> 1) & 7)) << 4));
+                    if (ABL & 4) s[t][kk] += (float)kf[0] + (float)qf[qi][kk][1];
+                    else s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][kk], s[t], 0, 0, 0);
+                }
+                // keep the scheduler from hoisting every tile's K fragments (register blow-up)
+                if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            // row max on the raw scores (scale > 0); only the ragged tail tile needs masking
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2 * KT; ++t) {
+                if (t >= full_tiles) {  // wave-uniform
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * 16 + g * 4 + r >= tokens) s[t][r] = -INFINITY;
+                }
+                mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mxs = mx * scale;
+            float sum = 0.f;
+            bf16x8_t pb[KT];
+#pragma unroll
+            for (int u = 0; u < KT; ++u) {
+                float e[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = (ABL & 1) ? fmaf(s[2 * u][r], scale, -mxs) : __builtin_amdgcn_exp2f(fmaf(s[2 * u][r], scale, -mxs));
+                    e[4 + r] = (ABL & 1) ? fmaf(s[2 * u + 1][r], scale, -mxs) : __builtin_amdgcn_exp2f(fmaf(s[2 * u + 1][r], scale, -mxs));
+                }
+                sum += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+                union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk.w[r] = pack_bf16x2(e[2 * r], e[2 * r + 1]);
+                pb[u] = pk.v;
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = __builtin_amdgcn_rcpf(sum);
+
+            // O^T[dh][query] += V^T[dh][key] . P^T[key][query]
+            f32x4_t o[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) o[ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < KT; ++u) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const char *vrow = vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 4 * g) * 2;
+                    union { uint2 h[2]; bf16x8_t v; } vf;
+                    vf.h[0] = *(const uint2 *)(vrow);
+                    vf.h[1] = *(const uint2 *)(vrow + 32);
+                    if (ABL & 2) o[ct][u & 3] += (float)vf.v[0] + (float)pb[u][ct];
+                    else o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
+                }
+                if (u & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            // write-out through 2 KiB of wave-private LDS: a lane's accumulators are 4 head-dim columns of 16 different queries,
+            // stored directly that is 32-byte pieces of 16 rows per instruction (four instructions per 128-byte row: 4 x the
+            // store requests -- the stores cost 43 of the launch's 135 us).  Transposed, eight lanes write one whole 128-byte
+            // (token, head) row with 16-byte stores.  Same swizzle as the GEMM write-out (gemm_bf16.hip, epilogue_via_lds).
+            {
+                char *reg = ost + wave * 2048;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
+                    pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
+                    const int chunk = 2 * ct + (g >> 1);
+                    *(uint2 *)(reg + fr * 128 + ((chunk ^ (fr & 7)) << 4) + ((g ^ (fr >> 3)) & 1) * 8) = pk;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int c = lane & 7;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int row = it * 8 + (lane >> 3);
+                    uint4 d = *(const uint4 *)(reg + row * 128 + ((c ^ (row & 7)) << 4));
+                    if (it & 1) d = make_uint4(d.z, d.w, d.x, d.y);
+                    const int q = qt * 16 + row;
+                    if (q < tokens && !(ABL & 16)) *(uint4 *)(out + ((int64_t)frame * tokens + q) * width + head * DH + c * 8) = d;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    };
+
+    // ---- NI items per workgroup: the K / V rows of item i+1 are requested (into registers) before item i is computed and
+    //      staged behind it, so only the first item's load latency is exposed.
+    const int item0 = blockIdx.x * NI;
+    bf16x8_t qf[QT_MAX][2];
+    {
+        KV cur;
+        load_q(item0, qf);
+        load_kv(item0, cur);
+        store_kv(cur);
     }
     __syncthreads();
-
-    const float scale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
-    const int full_tiles = tokens >> 4;                    // 16-key tiles without padding
-
 #pragma unroll
-    for (int qi = 0; qi < QT_MAX; ++qi) {
-        const int qt = wave + 8 * qi;
-        if (qt >= qtiles) break;
-
-        // scores: s[t][r] = <q[query = fr], k[key = 16 t + 4 g + r]>
-        f32x4_t s[2 * KT];
-#pragma unroll
-        for (int t = 0; t < 2 * KT; ++t) {
-            s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            const int krow = t * 16 + fr;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const bf16x8_t kf =
-                    *(const bf16x8_t *)(klds + krow * 128 + (((g + 4 * kk) ^ ((krow >> 1) & 7)) << 4));
-                if (ABL & 4) s[t][kk] += (float)kf[0] + (float)qf[qi][kk][1];
-                else s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][kk], s[t], 0, 0, 0);
-            }
-            // keep the scheduler from hoisting every tile's K fragments (register blow-up)
-            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-        // row max on the raw scores (scale > 0); only the ragged tail tile needs masking
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 2 * KT; ++t) {
-            if (t >= full_tiles) {  // wave-uniform
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (t * 16 + g * 4 + r >= tokens) s[t][r] = -INFINITY;
-            }
-            mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mxs = mx * scale;
-        float sum = 0.f;
-        bf16x8_t pb[KT];
-#pragma unroll
-        for (int u = 0; u < KT; ++u) {
-            float e[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                e[r] = (ABL & 1) ? fmaf(s[2 * u][r], scale, -mxs) : __builtin_amdgcn_exp2f(fmaf(s[2 * u][r], scale, -mxs));
-                e[4 + r] = (ABL & 1) ? fmaf(s[2 * u + 1][r], scale, -mxs) : __builtin_amdgcn_exp2f(fmaf(s[2 * u + 1][r], scale, -mxs));
-            }
-            sum += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
-            union { uint32_t w[4]; bf16x8_t v; } pk;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pk.w[r] = pack_bf16x2(e[2 * r], e[2 * r + 1]);
-            pb[u] = pk.v;
-        }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = __builtin_amdgcn_rcpf(sum);
-
-        // O^T[dh][query] += V^T[dh][key] . P^T[key][query]
-        f32x4_t o[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) o[ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < KT; ++u) {
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                const char *vrow = vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 4 * g) * 2;
-                union { uint2 h[2]; bf16x8_t v; } vf;
-                vf.h[0] = *(const uint2 *)(vrow);
-                vf.h[1] = *(const uint2 *)(vrow + 32);
-                if (ABL & 2) o[ct][u & 3] += (float)vf.v[0] + (float)pb[u][ct];
-                else o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
-            }
-            if (u & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        // write-out through 2 KiB of wave-private LDS: a lane's accumulators are 4 head-dim columns of 16 different queries,
-        // stored directly that is 32-byte pieces of 16 rows per instruction (four instructions per 128-byte row: 4 x the
-        // store requests -- the stores cost 43 of the launch's 135 us).  Transposed, eight lanes write one whole 128-byte
-        // (token, head) row with 16-byte stores.  Same swizzle as the GEMM write-out (gemm_bf16.hip, epilogue_via_lds).
-        {
-            char *reg = ost + wave * 2048;
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-                uint2 pk;
-                pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
-                pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
-                const int chunk = 2 * ct + (g >> 1);
-                *(uint2 *)(reg + fr * 128 + ((chunk ^ (fr & 7)) << 4) + ((g ^ (fr >> 3)) & 1) * 8) = pk;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int c = lane & 7;
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int row = it * 8 + (lane >> 3);
-                uint4 d = *(const uint4 *)(reg + row * 128 + ((c ^ (row & 7)) << 4));
-                if (it & 1) d = make_uint4(d.z, d.w, d.x, d.y);
-                const int q = qt * 16 + row;
-                if (q < tokens && !(ABL & 16)) *(uint4 *)(out + ((int64_t)frame * tokens + q) * width + head * DH + c * 8) = d;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
+    for (int it = 0; it < NI; ++it) {
+        const int item = item0 + it;
+        const bool more = it + 1 < NI && item + 1 < total;   // workgroup-uniform
+        KV nxt;
+        if (more) load_kv(item + 1, nxt);
+        compute(item, qf);
+        if (!more) break;
+        __syncthreads();   // every wave is done with this item's K / V
+        load_q(item + 1, qf);
+        store_kv(nxt);
+        __syncthreads();
     }
 }
 
@@ -242,7 +271,9 @@ int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int he
     int dev = 0;
     VSC_CHECK_HIP(hipGetDevice(&dev));
     if (dev >= 16 || !attr_set[dev]) {
-        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel<KT>,
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel<KT, 1>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel<KT, 2>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         if (dev < 16) attr_set[dev] = true;
     }
@@ -256,13 +287,22 @@ int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int he
     if (KT == 7)
         if (const char *e = getenv("VSC_ATTN_ABL")) {
             const int abl = atoi(e);
-#define VSC_ABL_CASE(A) case A: { auto k = attention_kernel<7, A>; VSC_CHECK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); \
-            hipLaunchKernelGGL(k, dim3(frames * heads), dim3(512), smem, stream, qkv, out, tokens, heads, skew); VSC_CHECK_LAUNCH(); return VSC_OK; }
+#define VSC_ABL_CASE(A) case A: { auto k = attention_kernel<7, 1, A>; VSC_CHECK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); \
+            hipLaunchKernelGGL(k, dim3(frames * heads), dim3(512), smem, stream, qkv, out, tokens, heads, frames * heads, skew); VSC_CHECK_LAUNCH(); return VSC_OK; }
             switch (abl) { VSC_ABL_CASE(1) VSC_ABL_CASE(2) VSC_ABL_CASE(4) VSC_ABL_CASE(6) VSC_ABL_CASE(7) VSC_ABL_CASE(8) VSC_ABL_CASE(16) VSC_ABL_CASE(24) VSC_ABL_CASE(31) default: break; }
         }
 #endif
-    hipLaunchKernelGGL(attention_kernel<KT>, dim3(frames * heads), dim3(512), smem, stream, qkv, out,
-                       tokens, heads, skew);
+    const int total = frames * heads;
+    // items per workgroup: 1.  Two (the second one's K / V rows requested into registers before the first is computed) were
+    // measured again on this kernel (tools/micro/attn_ni.py): 166 VGPRs, i.e. one resident workgroup per CU, or capped at
+    // 128 VGPRs 120 bytes of scratch -- 160 us per launch against 110-119.  VSC_ATTN_NI=2 keeps the variant reachable.
+    int ni = 1;
+    if (const char *e = getenv("VSC_ATTN_NI")) ni = atoi(e) == 2 ? 2 : 1;
+    if (ni == 2)
+        hipLaunchKernelGGL((attention_kernel<KT, 2>), dim3((total + 1) / 2), dim3(512), smem, stream, qkv, out, tokens, heads,
+                           total, 2 * skew);
+    else
+        hipLaunchKernelGGL((attention_kernel<KT, 1>), dim3(total), dim3(512), smem, stream, qkv, out, tokens, heads, total, skew);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }
