@@ -84,7 +84,7 @@ def test_gemm_residual_epilogue_in_place(dev, m, n, k):
     torch.testing.assert_close(x.cpu(), ref, rtol=1e-5, atol=2e-4)
 
 
-@pytest.mark.parametrize("epi", ["bf16", "gelu", "qgelu", "resadd"])
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "qgelu", "resadd", "f32"])
 @pytest.mark.parametrize("m,n,k", [(23040 + 77, 768, 256),      # 273 tiles on 256 CUs: some workgroups take two, ragged M
                                    (30001, 1000, 384),           # ragged N tile (n % 256 = 232), 6 K-tiles
                                    (18000, 2304, 1152),          # 639 tiles, several N-groups, 18 K-tiles
@@ -94,7 +94,8 @@ def test_gemm_persistent_kernel_equals_one_tile_per_workgroup(dev, epi, m, n, k)
     MFMA chain and the same epilogue arithmetic as v3 -> identical bits; v3 itself is checked against fp32 above."""
     import os
     from vsc_hip import ops, _lib
-    kind = {"bf16": _lib.EPI_BF16, "gelu": _lib.EPI_GELU_BF16, "qgelu": _lib.EPI_QGELU_BF16, "resadd": _lib.EPI_RESADD_F32}[epi]
+    kind = {"bf16": _lib.EPI_BF16, "gelu": _lib.EPI_GELU_BF16, "qgelu": _lib.EPI_QGELU_BF16, "resadd": _lib.EPI_RESADD_F32,
+            "f32": _lib.EPI_F32}[epi]
     g = torch.Generator(device="cpu").manual_seed(m + n + k)
     a = torch.randn(m, k, generator=g).to(torch.bfloat16).to(dev)
     w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
@@ -110,7 +111,8 @@ def test_gemm_persistent_kernel_equals_one_tile_per_workgroup(dev, epi, m, n, k)
             os.environ.pop("VSC_GEMM_V4", None)
         torch.cuda.synchronize()
         if v4 == "1":
-            assert torch.equal(outs["0"].view(torch.int16 if x is None else torch.int32), outs["1"].view(torch.int16 if x is None else torch.int32))
+            bits = torch.int32 if outs["0"].dtype == torch.float32 else torch.int16
+            assert torch.equal(outs["0"].view(bits), outs["1"].view(bits))
     # and against fp32 on a slice (rows that straddle tile boundaries, the last row)
     rows = torch.tensor([0, 255, 256, 257, m // 2, m - 1], device=dev)
     ref = a[rows].float() @ w.float().t() + b

@@ -761,7 +761,7 @@ int launch_v3(GemmArgs p, hipStream_t stream) {
 // the per-tile bias sits in a double-buffered 1-KiB row behind the ring, fetched during the previous write-out.
 // Serves the plain, GELU and residual epilogues; K % 128 == 0 (an even number of K-tiles), K >= 256.
 constexpr bool epi_v4(int e) {
-    return e == VSC_EPI_BF16 || e == VSC_EPI_GELU_BF16 || e == VSC_EPI_QGELU_BF16 || e == VSC_EPI_RESADD_F32;
+    return e == VSC_EPI_BF16 || e == VSC_EPI_GELU_BF16 || e == VSC_EPI_QGELU_BF16 || e == VSC_EPI_RESADD_F32 || e == VSC_EPI_F32;
 }
 
 #ifdef VSC_GEMM_TIMING
@@ -841,11 +841,15 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
                 dst[it] = *(const f32x4_t *)(p.aux + m * p.n + nc);
             }
         };
-        load_aux(0, ax[0]);   // queued behind the next tile's DMA: waiting for these covers tile_p's `first` contract
-        load_aux(1, ax[1]);
+        if (EPI == VSC_EPI_F32) {
+            ml64::wait_vmcnt<0>();   // plain fp32 out: no residual loads to wait for (tile_p's `first` contract)
+        } else {
+            load_aux(0, ax[0]);   // queued behind the next tile's DMA: waiting for these covers tile_p's `first` contract
+            load_aux(1, ax[1]);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (i + 2 < 8) load_aux(i + 2, ax[(i + 2) % 3]);
+            if (EPI != VSC_EPI_F32 && i + 2 < 8) load_aux(i + 2, ax[(i + 2) % 3]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 *(f32x4_t *)(reg + fr * 256 + (((4 * j + fq) ^ fr) << 4)) = acc[i][j] + bz[j];
@@ -855,7 +859,7 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 4 + rq;
                 f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ row) << 4));
-                v += ax[i % 3][it];
+                if (EPI != VSC_EPI_F32) v += ax[i % 3][it];
                 const int64_t m = mrow0 + i * 16 + row;
                 if (m < p.m && n < p.n) *(f32x4_t *)((float *)p.out + m * p.n + n) = v;
             }

@@ -309,7 +309,8 @@ extern "C" int64_t vsc_swin_workspace_bytes(const vsc_swin *e) { return e ? e->w
 static int gemm_ln(vsc_swin *e, vsc_swin::Workspace &ws, const uint16_t *a, const uint16_t *w, const float *bias, const float *g, const float *b,
                    const float *x_in, int64_t m, int n, int k, hipStream_t st) {
     static const bool split = getenv("VSC_SWIN_SPLIT_LN") != nullptr;
-    if (!split && gemm_ln_supported(n, k))
+    static const int split_k = [] { const char *e = getenv("VSC_SWIN_SPLIT_K"); return e ? atoi(e) : 1 << 30; }();
+    if (!split && k < split_k && gemm_ln_supported(n, k))
         return launch_gemm_ln_bf16(a, w, bias, g, b, x_in, ws.x, ws.xb, m, n, k, e->cfg.ln_eps, st);
     int rc = launch_gemm_bf16(a, w, bias, nullptr, ws.t, m, n, k, VSC_EPI_F32, 0, st);
     if (rc) return rc;
