@@ -54,6 +54,36 @@ def test_conv2d_matches_torch(dev, n, h, w, cin, cout, k, stride, act, res):
     assert torch.equal(wide[..., 3:3 + cout], got) and (wide[..., :3] == 7).all() and (wide[..., 3 + cout:] == 7).all()
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,k,stride", [
+    (2, 16, 16, 20, 18, 3, 1),      # HRNet's high-resolution branch (18 channels carried as 20), 3 x 3, borders on all sides
+    (3, 13, 11, 36, 72, 3, 2),      # a downsampling step: odd sizes, stride 2
+    (1, 7, 9, 24, 8, 5, 1),         # 5 x 5, K = 600 (19 K-steps, the last one past K)
+    (2, 33, 17, 64, 64, 3, 1),      # several pixel tiles, the last one ragged
+    (5, 6, 6, 40, 80, 1, 2),        # 1 x 1 with a stride: not the in-place case
+])
+def test_conv2d_implicit_gather_equals_materialised_patches(dev, n, h, w, cin, cout, k, stride):
+    """The narrow convolution kernel gathers its patch operand from the feature map while staging it (no im2col matrix);
+    it must put the same values into the same LDS image as the packed path -> identical bits.  The packed path is checked
+    against torch above."""
+    import os
+    from vsc_hip import cnn
+    rng = np.random.RandomState(cin * 7 + k)
+    sd = {"c.weight": torch.from_numpy((rng.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)),
+          "c.bias": torch.from_numpy(rng.randn(cout).astype(np.float32) * 0.1)}
+    x = torch.from_numpy(rng.randn(n, h, w, cin).astype(np.float32)).to(dev)
+    conv = cnn.Conv(sd, "c", None, stride, dev)
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["VSC_CONV_IMPLICIT"] = flag
+        try:
+            outs.append(conv(x, act="relu").clone())
+        finally:
+            os.environ.pop("VSC_CONV_IMPLICIT", None)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    want = F.relu(F.conv2d(x.cpu().permute(0, 3, 1, 2), sd["c.weight"], sd["c.bias"], stride=stride, padding=k // 2))
+    assert torch.allclose(outs[1].cpu().permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)
+
+
 def test_depthwise_pool_scale_upsample(dev):
     from vsc_hip import cnn
     rng = np.random.RandomState(0)

@@ -133,6 +133,10 @@ struct ConvGemmArgs {
     float *out;          // [rows, ldo]
     int64_t rows;
     int cout, kpad, ldo, ldr, act, tiles_c;
+    // implicit patch gathering (conv_gemm_narrow_kernel<true>): the convolution's own geometry instead of `ap`
+    const float *x;      // input [n, h, w, ldx]
+    const float *zeros;  // >= 16 bytes of zeros: where padding taps and k >= K point
+    int h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k;
 };
 
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p) {
@@ -188,8 +192,16 @@ constexpr int NARROW_C = 32, NARROW_P = 256;
 constexpr int NARROW_W_BYTES = 4096;                         // 32 weight rows x 32 floats
 constexpr int NARROW_STAGE = NARROW_W_BYTES + 2 * TILE_BYTES;   // W | P0 | P1 = 36 KiB: two workgroups per CU
 
+// IMPLICIT: the patch operand is gathered from the input feature map while it is staged (no materialised im2col matrix:
+// the pack pass and the GEMM's read of its output were 616 MB each way for one 3 x 3 layer of HRNet's 224 x 224 branch, and
+// 37 % of a refinement pass).  A 16-byte chunk of a patch row is 4 consecutive channels of one tap (cin % 4 == 0, plain
+// k = (i * kw + j) * cin + ci), so every lane of the LDS-DMA points at x[img, iy0 + i, ix0 + j, ci .. ci+3] -- or at a
+// zero line when the tap falls into the padding or k >= K.  The pixel part of the address is decoded once per tile
+// (divisions), the tap part comes from a per-workgroup LDS table indexed by the chunk.  Same values in the same LDS image as
+// the packed path: results are bit-identical.
+template <bool IMPLICIT>
 __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * NARROW_STAGE];
+    __shared__ __attribute__((aligned(16))) char lds[2 * NARROW_STAGE + (IMPLICIT ? IM2COL_TABLE : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -197,6 +209,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
     const int tc = (int)(tile % p.tiles_c);
     const int64_t tp = tile / p.tiles_c;
     const int64_t c0 = (int64_t)tc * NARROW_C, p0 = tp * NARROW_P;
+    unsigned *tab = (unsigned *)(lds + 2 * NARROW_STAGE);   // per 16-byte chunk of k: (i << 28) | (j << 24) | ci, ~0u past K
+    int64_t pbase[2][4];   // this lane's 8 patch rows (2 pixel tiles x 4 pieces): element offset of x[img, iy0, ix0, 0]
+    int pyx[2][4];         // (iy0 << 16) | (ix0 & 0xffff)
+    if (IMPLICIT) {
+        for (int ch = tid; ch < p.kpad / 4; ch += 256) {
+            const int kk = ch * 4;
+            unsigned v = 0xFFFFFFFFu;
+            if (kk < p.k) {
+                const int ci = kk % p.cin, ij = kk / p.cin;
+                v = ((unsigned)(ij / p.kw) << 28) | ((unsigned)(ij % p.kw) << 24) | (unsigned)ci;
+            }
+            tab[ch] = v;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = (j * 4 + wave) * 8 + (lane >> 3);
+                int64_t pix = p0 + t * 128 + r;
+                pix = pix > p.rows - 1 ? p.rows - 1 : pix;
+                const int64_t img = pix / ((int64_t)p.ho * p.wo);
+                const int rem = (int)(pix - img * p.ho * p.wo);
+                const int oy = rem / p.wo, ox = rem - oy * p.wo;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                pbase[t][j] = ((img * p.h + iy0) * p.w + ix0) * (int64_t)p.ldx;
+                pyx[t][j] = (iy0 << 16) | (ix0 & 0xffff);
+            }
+        __syncthreads();
+    }
     f32x16_t acc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -211,8 +252,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
             gr = gr > p.cout - 1 ? p.cout - 1 : gr;
             __builtin_amdgcn_global_load_lds((gptr_t)(p.wp + gr * p.kpad + ks * KS + c * 4), (lptr_t)(st + wave * 1024), 16, 0, 0);
         }
-        stage_tile(p.ap, p.kpad, p0, p.rows - 1, ks * KS, st + NARROW_W_BYTES, wave, lane);
-        stage_tile(p.ap, p.kpad, p0 + 128, p.rows - 1, ks * KS, st + NARROW_W_BYTES + TILE_BYTES, wave, lane);
+        if (!IMPLICIT) {
+            stage_tile(p.ap, p.kpad, p0, p.rows - 1, ks * KS, st + NARROW_W_BYTES, wave, lane);
+            stage_tile(p.ap, p.kpad, p0 + 128, p.rows - 1, ks * KS, st + NARROW_W_BYTES + TILE_BYTES, wave, lane);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int piece = j * 4 + wave;
+                    const int r = piece * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ ((r >> 1) & 7);
+                    const unsigned tv = tab[ks * (KS / 4) + c];
+                    const int i = (int)(tv >> 28), jj = (int)((tv >> 24) & 15u), ci = (int)(tv & 0xFFFFFFu);
+                    const int iy = (pyx[t][j] >> 16) + i, ix = (int)(short)(pyx[t][j] & 0xffff) + jj;
+                    const bool ok = tv != 0xFFFFFFFFu && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+                    const float *g = ok ? p.x + pbase[t][j] + ((int64_t)i * p.w + jj) * p.ldx + ci : p.zeros;
+                    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(st + NARROW_W_BYTES + t * TILE_BYTES + piece * 1024), 16, 0, 0);
+                }
+        }
     };
     const int nks = p.kpad / KS;
     stage(0, lds);
@@ -390,6 +448,7 @@ struct Scratch {
     size_t bytes = 0;
 };
 Scratch g_patch[16];   // per device, grow-only: the packed patch matrix of the convolution in flight
+float *g_zero_line[16] = {};   // per device: 256 bytes of zeros (implicit gathering points padding taps at it)
 
 inline int blocks_for(int64_t items) {
     int64_t b = (items + 255) / 256;
@@ -427,8 +486,18 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     VSC_REQUIRE(dev >= 0 && dev < 16, "conv2d: device %d out of range", dev);
     // 1 x 1, stride 1, dense rows of a multiple of 32 channels: the input IS the patch matrix
     const bool in_place = kh == 1 && kw == 1 && stride == 1 && pad == 0 && ldx == cin && (cin % KS) == 0 && (((uintptr_t)x_dev) & 15) == 0;
+    const bool narrow = cout <= 80;   // <= 3 channel tiles of 32: the thin layers (see conv_gemm_narrow_kernel)
+    // patches gathered inside the GEMM's staging (narrow kernel): 4-channel chunks, table-sized K, 16-bit image coordinates
+    const char *imp_env = getenv("VSC_CONV_IMPLICIT");   // diagnostic / test switch, read per call
+    const bool no_implicit = imp_env && imp_env[0] == '0';
+    const bool implicit = !in_place && narrow && !no_implicit && (cin & 3) == 0 && (ldx & 3) == 0 && (((uintptr_t)x_dev) & 15) == 0 &&
+                          kpad <= IM2COL_TABLE && kh < 16 && kw < 16 && h < 32000 && w < 32000 && pad < 1000;
+    if (implicit && !g_zero_line[dev]) {
+        VSC_CHECK_HIP(hipMalloc((void **)&g_zero_line[dev], 256));
+        VSC_CHECK_HIP(hipMemset(g_zero_line[dev], 0, 256));
+    }
     Scratch &s = g_patch[dev];
-    const size_t need = in_place ? 0 : (size_t)rows * kpad * 4;
+    const size_t need = in_place || implicit ? 0 : (size_t)rows * kpad * 4;
     if (s.bytes < need) {
         if (s.ptr) {
             VSC_CHECK_HIP(hipDeviceSynchronize());
@@ -444,8 +513,8 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
         }
         s.bytes = need;
     }
-    if (in_place) {
-        // nothing to gather
+    if (in_place || implicit) {
+        // nothing to materialise
     } else if (kpad <= IM2COL_TABLE && kh < 16 && kw < 16 && n * ho < 65536) {
         const int per_row = wo * (kpad / 4);
         int bx = (per_row + 255) / 256;
@@ -457,13 +526,15 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
                            h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k, kpad);
     }
     VSC_CHECK_LAUNCH();
-    const bool narrow = cout <= 80;   // <= 3 channel tiles of 32: the thin layers (see conv_gemm_narrow_kernel)
     const int tiles_c = narrow ? (cout + NARROW_C - 1) / NARROW_C : (cout + TR - 1) / TR;
     const int64_t tiles_p = narrow ? (rows + NARROW_P - 1) / NARROW_P : (rows + TQ - 1) / TQ;
     VSC_REQUIRE(tiles_p * tiles_c < (1ll << 31), "conv2d: grid too large");
-    ConvGemmArgs a{w_packed_dev, in_place ? x_dev : (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c};
-    if (narrow) {
-        hipLaunchKernelGGL(conv_gemm_narrow_kernel, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
+    ConvGemmArgs a{w_packed_dev, in_place ? x_dev : (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c,
+                   x_dev, g_zero_line[dev], h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k};
+    if (implicit) {
+        hipLaunchKernelGGL(conv_gemm_narrow_kernel<true>, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
+    } else if (narrow) {
+        hipLaunchKernelGGL(conv_gemm_narrow_kernel<false>, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
     } else {
         hipLaunchKernelGGL(conv_gemm_kernel, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
     }
