@@ -217,6 +217,11 @@ int vsc_video_pair_max_f32(const float *q_dev, int64_t nq, const int32_t *q_vide
                            const float *r_dev, int64_t nr, const int32_t *r_video_dev, int32_t n_r_videos,
                            int32_t d, float threshold, int64_t *lims_dev, int32_t *out_rvideo_dev,
                            float *out_score_dev, int64_t capacity, int64_t *total_out, void *stream);
+/* Which sweep the last vsc_video_pair_max_f32 call ran: 1 = exact fp32 sweep, 2 = bf16 pre-filter (fixed-threshold variant of the
+ * top-k pre-filter: survivors of s~ >= threshold - eps are re-scored with the exact fp32 chain before they reach the table, so
+ * the result is the same table), 3 = pre-filter with some blocks of 256 queries redone on the exact sweep (a (query, reference
+ * split) list held more than 1024 survivors).  Chosen like vsc_knn_ip_f32's path; VSC_PAIRMAX_PATH=exact|bf16 forces one. */
+int vsc_video_pair_max_last_path(void);
 
 /* sklearn.preprocessing.normalize(x) in place (l2, axis=1; zero rows untouched):
  * infer/extract_query_feats.py:178, infer/vsc/baseline/score_normalization.py:84-88. */

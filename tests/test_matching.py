@@ -236,6 +236,40 @@ def test_video_pair_max_bit_exact(d, frac):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nr,frac,expect_path", [(40000, 0.0005, 2), (300000, 0.4, 3)])
+def test_video_pair_max_prefilter_path_equals_exact(nr, frac, expect_path):
+    """The bf16 pre-filter path (fixed-threshold sweep + exact re-scoring) must produce the table of the exact fp32 sweep bit
+    for bit -- including scores a hair above / below the threshold -- and fall back per query block when lists overflow
+    (300 k references, 40 % of the pairs above the threshold: ~1.4 k survivors per (query, 3.6 k-reference split) list > 1024)."""
+    import os
+    import torch
+    from vsc_hip import ops, _lib
+    g = torch.Generator(device="cpu").manual_seed(5)
+    nq, d, nqv, nrv = 700, 512, 9, 1300
+    q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1)
+    r = torch.nn.functional.normalize(torch.randn(nr, d, generator=g), dim=1)
+    r[1234] = q[17]                                    # a planted copy (score 1) and a near copy
+    r[30000] = torch.nn.functional.normalize(q[650] + 0.05 * torch.randn(d, generator=g), dim=0)
+    qv = torch.sort(torch.randint(0, nqv, (nq,), generator=g)).values.to(torch.int32)
+    rv = torch.sort(torch.randint(0, nrv, (nr,), generator=g)).values.to(torch.int32)
+    s = (q[:64] @ r.t()).flatten()
+    thr = float(torch.quantile(s[torch.randperm(s.numel(), generator=g)[:200000]], 1.0 - frac))
+    thr = float((q[3] * r[77]).sum()) if frac < 0.01 else thr    # sparse case: sit the threshold exactly on one pair's score
+    outs = {}
+    for path in ("exact", "bf16"):
+        os.environ["VSC_PAIRMAX_PATH"] = path
+        try:
+            outs[path] = [t.cpu() for t in ops.video_pair_max(q.cuda(), qv.cuda(), nqv, r.cuda(), rv.cuda(), nrv, thr)]
+            ran = _lib.require_device().vsc_video_pair_max_last_path()
+        finally:
+            os.environ.pop("VSC_PAIRMAX_PATH", None)
+        assert ran == (1 if path == "exact" else expect_path)
+    for a, b in zip(outs["exact"], outs["bf16"]):
+        assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)
+    assert outs["exact"][0][-1] > 0
+
+
+@pytest.mark.gpu
 def test_video_pair_max_every_pair_and_none():
     """threshold below every score: the dense table is full (negative maxima included); above: empty."""
     import torch

@@ -623,6 +623,8 @@ struct SweepArgs {
     int abl;                     // diagnostic (VSC_KNN_ABL): 1 = skip the filter, 2 = skip the appends (timing only; results invalid), 8 = count
     unsigned long long *dbg;     // [4] appends, compaction rounds, lists compacted, filter bodies entered (abl & 8)
     int trig;
+    int thr_mode = 0;            // 1: fixed-threshold sweep (video pair maxima): a pair survives when s~ >= thr0 - eps_q; lists never compact
+    float thr0 = 0.f;
 };
 
 // stats (queries): [n][4] = (|x|, |bf16 x|, |x - bf16 x|, 0); max_bits (refs): [0] max |x|, [1] max |x - bf16 x| as float bits
@@ -730,7 +732,6 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
         t_end = t_end > p.total_tiles ? p.total_tiles : t_end;
         if (tid < SQ) {
             cnt_s[tid] = 0;
-            thr_s[tid] = -INFINITY;
             float e2 = 0.f;
             if (q0 + tid < p.nq) {
                 const float4 st = *(const float4 *)(p.qstats + (q0 + tid) * 4);
@@ -738,6 +739,8 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                 if (!(e2 < INFINITY)) p.fallback[0] = p.fallback[1 + qb] = 1;   // NaN / Inf operands: no bound, the exact sweep decides
             }
             eps_s[tid] = e2;
+            // fixed threshold: exact s <= s~ + eps, so s~ + eps <= thr0 rules a pair out; everything else is re-scored exactly
+            thr_s[tid] = p.thr_mode ? p.thr0 - 0.5f * e2 : -INFINITY;
         }
         if (tid < 3) flag_s[tid] = 0;
         __syncthreads();
@@ -908,12 +911,20 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
 
 // Exact scores of the survivors of one (query, split) list and their best k, one wave per list.  The chain is the
 // oracle's: acc = fmaf(q[k], r[k], acc) for k = 0 .. d-1 from acc = 0 (oracle/knn_oracle.c), one lane per candidate.
-template <int EPL>
+// PAIRMAX: instead of ranking, every survivor whose exact score clears `thr` (strictly) is folded into the video-pair table
+// (vsc_video_pair_max_f32 on the pre-filter path).
+struct PairMaxOut {
+    const int32_t *qvid, *rvid;
+    unsigned *table;
+    int64_t n_rvid;
+    float thr;
+};
+template <int EPL, bool PAIRMAX = false>
 __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restrict__ q, const float *__restrict__ r,
                                                           int64_t nlists, int d, int splits, int k,
                                                           const unsigned long long *__restrict__ cand,
                                                           const int *__restrict__ ncand,
-                                                          unsigned long long *__restrict__ part) {
+                                                          unsigned long long *__restrict__ part, PairMaxOut pm) {
     constexpr int KEEP = 64 * EPL;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -1000,6 +1011,13 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
             for (int i = 0; i < EPL; ++i)
                 if (i < live) acc[i] = fmaf(qv, rrow[i][kk], acc[i]);
         }
+    }
+    if (PAIRMAX) {
+        const int64_t trow = (int64_t)pm.qvid[qi] * pm.n_rvid;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+            if (lane + 64 * i < n && acc[i] > pm.thr) atomicMax(pm.table + trow + pm.rvid[ids[i]], ordered_bits(acc[i]));
+        return;
     }
     // rank on the exact keys (score, then lower id), best k out in order
     static_assert(KEEP * 8 <= 2 * 64 * 36 * 4, "rank scratch fits the wave's gather buffer");
@@ -1219,10 +1237,10 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     VSC_CHECK_HIP(hipFuncSetAttribute((const void *)knn_rescore_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 36 * 4));
     if (epl == 16)
         hipLaunchKernelGGL(knn_rescore_kernel<8>, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d, splits,
-                           k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part);
+                           k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part, PairMaxOut{});
     else
         hipLaunchKernelGGL(knn_rescore_kernel<16>, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d,
-                           splits, k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part);
+                           splits, k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part, PairMaxOut{});
     VSC_CHECK_LAUNCH();
     knn_mark(3, stream);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream,
@@ -1388,17 +1406,9 @@ extern "C" int vsc_pair_similarity_f32(const float *q_dev, int64_t nq, const flo
     return VSC_OK;
 }
 
-extern "C" int vsc_video_pair_max_f32(const float *q_dev, int64_t nq, const int32_t *q_video_dev, int32_t n_q_videos,
-                                      const float *r_dev, int64_t nr, const int32_t *r_video_dev, int32_t n_r_videos,
-                                      int32_t d, float threshold, int64_t *lims_dev, int32_t *out_rvideo_dev,
-                                      float *out_score_dev, int64_t capacity, int64_t *total_out, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    VSC_REQUIRE(q_dev && r_dev && q_video_dev && r_video_dev && lims_dev && total_out, "video_pair_max: null pointer");
-    VSC_REQUIRE(nq > 0 && nr > 0, "video_pair_max: empty query or reference set");
-    VSC_REQUIRE(n_q_videos > 0 && n_r_videos > 0, "video_pair_max: no videos (%d x %d)", n_q_videos, n_r_videos);
-    VSC_REQUIRE(d > 0 && d <= 4096, "video_pair_max: dimension %d unsupported", d);
-    VSC_REQUIRE(capacity >= 0 && (capacity == 0 || (out_rvideo_dev && out_score_dev)),
-                "video_pair_max: capacity %lld without output buffers", (long long)capacity);
+// The exact fp32 sweep of the pair table: queries [q_dev, q_dev + nq) (video ids qvid), all references.
+static int pair_max_exact(const float *q_dev, int64_t nq, const int32_t *qvid, const float *r_dev, int64_t nr, const int32_t *rvid,
+                          int32_t n_r_videos, int32_t d, float threshold, unsigned *table, hipStream_t stream) {
     const int dpad = (d + KS - 1) / KS * KS;
     const int nqb = (int)((nq + TQ - 1) / TQ);
     const int64_t total_tiles = (nr + TR - 1) / TR;
@@ -1410,25 +1420,130 @@ extern "C" int vsc_video_pair_max_f32(const float *q_dev, int64_t nq, const int3
     const int splits = (int)((total_tiles + tiles_per_split - 1) / tiles_per_split);
     const int64_t work = (int64_t)nqb * splits;
     const int grid = (int)(work < 512 ? work : 512);
-    const size_t table_bytes = (size_t)n_q_videos * n_r_videos * 4;
-
-    void *qp, *rp, *table, *counts;
+    void *qp, *rp;
     int rc;
     if ((rc = scratch_get(0, (size_t)nq * dpad * 4, &qp))) return rc;
     if ((rc = scratch_get(1, (size_t)nr * dpad * 4, &rp))) return rc;
-    if ((rc = scratch_get(6, table_bytes, &table))) return rc;
-    if ((rc = scratch_get(7, (size_t)n_q_videos * 8, &counts))) return rc;
     hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nq * (dpad / 4))), dim3(256), 0, stream, q_dev, (float *)qp, nq,
                        d, dpad);
     VSC_CHECK_LAUNCH();
     hipLaunchKernelGGL(knn_pack_kernel, dim3(blocks_for(nr * (dpad / 4))), dim3(256), 0, stream, r_dev, (float *)rp, nr,
                        d, dpad);
     VSC_CHECK_LAUNCH();
-    VSC_CHECK_HIP(hipMemsetAsync(table, 0, table_bytes, stream));
-    PairMaxArgs a{(const float *)qp, (const float *)rp, q_video_dev, r_video_dev, nq, nr, dpad, nqb, splits,
-                  total_tiles, tiles_per_split, threshold, (unsigned *)table, n_r_videos};
+    PairMaxArgs a{(const float *)qp, (const float *)rp, qvid, rvid, nq, nr, dpad, nqb, splits,
+                  total_tiles, tiles_per_split, threshold, table, n_r_videos};
     hipLaunchKernelGGL(pair_max_kernel, dim3(grid), dim3(256), 0, stream, a);
     VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+// The same table through the bf16 pre-filter: the similarity sweep of vsc_knn_ip_f32 (section "top-k on the bf16 pipe") with
+// a fixed threshold instead of a running k-th score -- a pair survives when s~ >= threshold - eps_q, i.e. unless the bound
+// proves its exact score <= threshold -- and the re-scoring kernel folds every survivor whose exact fmaf chain clears the
+// threshold into the table.  Lists never compact here, so a (query, split) list that outgrows its capacity (more than
+// 1024 survivors) sends its block of 256 queries to the exact sweep.  Identical table (atomicMax of identical scores).
+static int pair_max_prefilter(const float *q_dev, int64_t nq, const int32_t *qvid, const float *r_dev, int64_t nr,
+                              const int32_t *rvid, int32_t n_r_videos, int32_t d, float threshold, unsigned *table,
+                              hipStream_t stream, int *fell_back) {
+    constexpr int EPL = 32;
+    const int dp = (d + 63) / 64 * 64;
+    const int cap = 64 * EPL, keep = cap / 2;
+    const int nqb = (int)((nq + SQ - 1) / SQ);
+    const int64_t total_tiles = (nr + SR - 1) / SR;
+    int64_t want = (256 + nqb - 1) / nqb;
+    if (want > 256) want = 256;
+    if (want > total_tiles) want = total_tiles;
+    if (want < 1) want = 1;
+    int64_t tiles_per_split = (total_tiles + want - 1) / want;
+    const int64_t max_tiles = ((1ll << 31) - 1) / ((int64_t)SR * dp * 2);
+    if (tiles_per_split > max_tiles) tiles_per_split = max_tiles;
+    const int splits = (int)((total_tiles + tiles_per_split - 1) / tiles_per_split);
+    const int64_t work = (int64_t)nqb * splits;
+    const int grid = (int)(work < 256 ? work : 256);
+    const int64_t nlists = nq * splits;
+    void *qb, *rb, *qstats, *flags, *lists, *cand, *ncand;
+    int rc;
+    const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 32;
+    if ((rc = scratch_get(12, (size_t)nq * dp * 2, &qb))) return rc;
+    if ((rc = scratch_get(13, (size_t)nr * dp * 2, &rb))) return rc;
+    if ((rc = scratch_get(14, (size_t)nq * 16, &qstats))) return rc;
+    if ((rc = scratch_get(15, flag_bytes, &flags))) return rc;
+    if ((rc = scratch_get(16, (size_t)grid * SQ * cap * 8, &lists))) return rc;
+    if ((rc = scratch_get(17, (size_t)nlists * keep * 8, &cand))) return rc;
+    if ((rc = scratch_get(18, (size_t)nlists * 4, &ncand))) return rc;
+    int *fb_dev = (int *)flags + 4;
+    VSC_CHECK_HIP(hipMemsetAsync(flags, 0, flag_bytes, stream));
+    hipLaunchKernelGGL(knn_pack_bf16_kernel, dim3(blocks_for(nq * 64)), dim3(256), 0, stream, q_dev, (uint16_t *)qb,
+                       (float *)qstats, (unsigned *)nullptr, nq, d, dp);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(knn_pack_bf16_kernel, dim3(blocks_for(nr * 64)), dim3(256), 0, stream, r_dev, (uint16_t *)rb,
+                       (float *)nullptr, (unsigned *)flags, nr, d, dp);
+    VSC_CHECK_LAUNCH();
+    const float cd = (float)d * (2.384185791015625e-7f + 5.9604644775390625e-8f);
+    SweepArgs a{(const uint16_t *)qb, (const uint16_t *)rb, (const float *)qstats, (const unsigned *)flags, nq, nr, dp, /*k=*/cap, nqb,
+                splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
+                (int *)ncand, fb_dev, 0, nullptr, cap - 2 * SR};
+    a.thr_mode = 1;
+    a.thr0 = threshold;
+    a.dbg = (unsigned long long *)(((uintptr_t)(fb_dev + 1 + nqb) + 7) & ~(uintptr_t)7);
+    if ((rc = launch_sweep<EPL>(a, grid, stream))) return rc;
+    const unsigned rgrid = (unsigned)((nlists + 3) / 4);
+    auto rk = knn_rescore_kernel<EPL / 2, true>;
+    VSC_CHECK_HIP(hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 36 * 4));
+    hipLaunchKernelGGL(rk, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d, splits, cap,
+                       (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)nullptr,
+                       PairMaxOut{qvid, rvid, table, (int64_t)n_r_videos, threshold});
+    VSC_CHECK_LAUNCH();
+    std::vector<int> fb(1 + nqb);
+    VSC_CHECK_HIP(hipMemcpyAsync(fb.data(), fb_dev, fb.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+    VSC_CHECK_HIP(hipStreamSynchronize(stream));
+    *fell_back = 0;
+    if (!fb[0]) return VSC_OK;
+    for (int b = 0; b < nqb;) {   // flagged query blocks (overfull lists, non-finite bound): the exact sweep decides
+        if (!fb[1 + b]) { ++b; continue; }
+        int e = b;
+        while (e < nqb && fb[1 + e]) ++e;
+        const int64_t row0 = (int64_t)b * SQ, rows = ((int64_t)e * SQ < nq ? (int64_t)e * SQ : nq) - row0;
+        if ((rc = pair_max_exact(q_dev + row0 * d, rows, qvid + row0, r_dev, nr, rvid, n_r_videos, d, threshold, table, stream))) return rc;
+        *fell_back += e - b;
+        b = e;
+    }
+    return VSC_OK;
+}
+
+static int g_pair_max_last_path = 0;   // 1 exact, 2 pre-filter, 3 pre-filter with blocks redone
+extern "C" int vsc_video_pair_max_last_path(void) { return g_pair_max_last_path; }
+
+extern "C" int vsc_video_pair_max_f32(const float *q_dev, int64_t nq, const int32_t *q_video_dev, int32_t n_q_videos,
+                                      const float *r_dev, int64_t nr, const int32_t *r_video_dev, int32_t n_r_videos,
+                                      int32_t d, float threshold, int64_t *lims_dev, int32_t *out_rvideo_dev,
+                                      float *out_score_dev, int64_t capacity, int64_t *total_out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VSC_REQUIRE(q_dev && r_dev && q_video_dev && r_video_dev && lims_dev && total_out, "video_pair_max: null pointer");
+    VSC_REQUIRE(nq > 0 && nr > 0, "video_pair_max: empty query or reference set");
+    VSC_REQUIRE(n_q_videos > 0 && n_r_videos > 0, "video_pair_max: no videos (%d x %d)", n_q_videos, n_r_videos);
+    VSC_REQUIRE(d > 0 && d <= 4096, "video_pair_max: dimension %d unsupported", d);
+    VSC_REQUIRE(capacity >= 0 && (capacity == 0 || (out_rvideo_dev && out_score_dev)),
+                "video_pair_max: capacity %lld without output buffers", (long long)capacity);
+    const size_t table_bytes = (size_t)n_q_videos * n_r_videos * 4;
+    void *table, *counts;
+    int rc;
+    if ((rc = scratch_get(6, table_bytes, &table))) return rc;
+    if ((rc = scratch_get(7, (size_t)n_q_videos * 8, &counts))) return rc;
+    VSC_CHECK_HIP(hipMemsetAsync(table, 0, table_bytes, stream));
+    // path: as vsc_knn_ip_f32 -- the pre-filter pays from ~16 M pairs and a few thousand references on
+    bool prefilter = nr >= 4096 && nq * nr >= (1ll << 24);
+    if (const char *e = getenv("VSC_PAIRMAX_PATH")) prefilter = e[0] == 'b' ? true : (e[0] == 'e' ? false : prefilter);
+    if (prefilter) {
+        int fb = 0;
+        if ((rc = pair_max_prefilter(q_dev, nq, q_video_dev, r_dev, nr, r_video_dev, n_r_videos, d, threshold, (unsigned *)table,
+                                     stream, &fb))) return rc;
+        g_pair_max_last_path = fb ? 3 : 2;
+    } else {
+        if ((rc = pair_max_exact(q_dev, nq, q_video_dev, r_dev, nr, r_video_dev, n_r_videos, d, threshold, (unsigned *)table, stream)))
+            return rc;
+        g_pair_max_last_path = 1;
+    }
     const int rows_grid = n_q_videos < 4096 ? n_q_videos : 4096;
     hipLaunchKernelGGL(pair_max_count_kernel, dim3(rows_grid), dim3(256), 0, stream, (const unsigned *)table,
                        (int64_t)n_q_videos, (int64_t)n_r_videos, (long long *)counts);
