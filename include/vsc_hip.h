@@ -188,6 +188,11 @@ int vsc_range_search_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, 
                             int32_t d, float radius, int64_t ref_id_offset, int64_t *lims_dev,
                             float *out_scores_dev, int64_t *out_ids_dev, int64_t capacity,
                             int64_t *total_out, void *stream);
+/* Which path the last vsc_range_search_ip_f32 call took: 1 = exact (two fp32 sweeps: count, fill), 2 = bf16 pre-filter (one bf16
+ * sweep with the radius as a fixed threshold, survivors re-scored with the exact fp32 chain, scan, emit: same CSR output bit for
+ * bit), 3 = pre-filter abandoned because a (query, reference split) list held more than 1024 survivors, then exact.  Chosen like
+ * vsc_knn_ip_f32's path; VSC_RANGE_PATH=exact|bf16 forces one. */
+int vsc_range_search_last_path(void);
 
 /* Per-candidate-pair frame similarity matrices -- the temporal alignment input of the matching track
  * (VSC22-Matching-Track-1st/infer/src/utils.py:29-51,66: np.matmul(qfeat, rfeat.T) per candidate).

@@ -200,6 +200,35 @@ def test_range_search_bit_exact(dev, nq, nr, d, radius):
         assert lr[-1] == nq * nr     # everything matches: the dense limit
 
 
+@pytest.mark.parametrize("nq,nr,d,radius,expect", [
+    (130, 5000, 511, 0.08, 2),       # the bit-exact case above, pre-filter path forced: d not a multiple of 64, ragged tiles
+    (600, 70000, 512, 0.12, 2),      # several query blocks and reference splits
+    (300, 3000, 32, -2.0, 2),        # every pair matches, lists of 3000 / splits stay under the capacity
+    (64, 300000, 64, -0.2, 3),       # ~95 % of 64-d pairs above -0.2: 1.2 k survivors per 1280-reference list -> overflow, the exact path answers
+])
+def test_range_search_prefilter_path_equals_exact(dev, nq, nr, d, radius, expect):
+    """vsc_range_search_ip_f32 through the bf16 pre-filter (one fixed-threshold bf16 sweep + exact re-scoring + scan + emit)
+    returns the CSR of the exact two-sweep path bit for bit; when a list overflows it hands the call to the exact path."""
+    import os
+    from vsc_hip import ops, _lib
+    q, r = synth.descriptor_bank(300 + nq, nq, d), synth.descriptor_bank(400 + nr, nr, d)
+    qt, rt = torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev)
+    out = {}
+    for path in ("exact", "bf16"):
+        os.environ["VSC_RANGE_PATH"] = path
+        try:
+            out[path] = [t.cpu() for t in ops.range_search_ip(qt, rt, radius, ref_id_offset=7, capacity=16)]
+            ran = _lib.require_device().vsc_range_search_last_path()
+            count = ops.range_count_ip(qt, rt, radius)
+        finally:
+            os.environ.pop("VSC_RANGE_PATH", None)
+        assert ran == (1 if path == "exact" else expect)
+        assert count == int(out[path][0][-1])
+    assert torch.equal(out["exact"][0], out["bf16"][0]) and torch.equal(out["exact"][2], out["bf16"][2])
+    assert torch.equal(out["exact"][1].view(torch.int32), out["bf16"][1].view(torch.int32))
+    assert int(out["exact"][0][-1]) > 0
+
+
 def test_video_index_reference_vectors(dev):
     """The reference's own unit tests, run through VideoIndex / CandidateGeneration on the HIP path:
     tests/test_candidates.py (expected candidate list) and tests/test_index.py (self match)."""

@@ -918,12 +918,15 @@ struct PairMaxOut {
     unsigned *table;
     int64_t n_rvid;
     float thr;
+    long long *counts = nullptr;   // MODE 2: hits per list
 };
-template <int EPL, bool PAIRMAX = false>
+// MODE 2 (range search on the pre-filter path): the survivors whose exact score clears `thr` go back to the FRONT of their
+// list in ascending reference id (as exact (score, id) keys), their number to counts[list] and ncand[list]; a scan and
+// range_emit_kernel turn that into the CSR output.
+template <int EPL, int MODE = 0>
 __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restrict__ q, const float *__restrict__ r,
                                                           int64_t nlists, int d, int splits, int k,
-                                                          const unsigned long long *__restrict__ cand,
-                                                          const int *__restrict__ ncand,
+                                                          const unsigned long long *cand, const int *ncand,
                                                           unsigned long long *__restrict__ part, PairMaxOut pm) {
     constexpr int KEEP = 64 * EPL;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1012,11 +1015,43 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
                 if (i < live) acc[i] = fmaf(qv, rrow[i][kk], acc[i]);
         }
     }
-    if (PAIRMAX) {
+    if (MODE == 1) {
         const int64_t trow = (int64_t)pm.qvid[qi] * pm.n_rvid;
 #pragma unroll
         for (int i = 0; i < EPL; ++i)
             if (lane + 64 * i < n && acc[i] > pm.thr) atomicMax(pm.table + trow + pm.rvid[ids[i]], ordered_bits(acc[i]));
+        return;
+    }
+    if (MODE == 2) {
+        unsigned *sid = (unsigned *)(lds + (size_t)wave * (2 * 64 * 36 * 4));   // ids of the hits, 0xFFFFFFFF for the rest
+        bool hit[EPL];
+        int nhit = 0;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+            const int idx = lane + 64 * i;
+            hit[i] = idx < n && acc[i] > pm.thr;
+            if (idx < n) sid[idx] = hit[i] ? ids[i] : 0xFFFFFFFFu;
+            nhit += __popcll(__ballot(hit[i]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int rank[EPL];
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) rank[i] = 0;
+        if (nhit > 1)
+            for (int j = 0; j < n; ++j) {
+                const unsigned v = sid[j];
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) rank[i] += v < ids[i] ? 1 : 0;
+            }
+        unsigned long long *mine = const_cast<unsigned long long *>(cand) + list * KEEP;   // every entry of the list is in registers by now
+#pragma unroll
+        for (int i = 0; i < EPL; ++i)
+            if (hit[i]) mine[rank[i]] = make_key(acc[i], ids[i]);
+        if (lane == 0) {
+            pm.counts[list] = nhit;
+            const_cast<int *>(ncand)[list] = nhit;
+        }
         return;
     }
     // rank on the exact keys (score, then lower id), best k out in order
@@ -1305,6 +1340,100 @@ extern "C" int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev
     return knn_exact(q_dev, nq, r_dev, nr, d, k, ref_id_offset, out_scores_dev, out_ids_dev, stream);
 }
 
+// one wave per (query, split) list: its hits (exact keys, ascending reference id, left by knn_rescore_kernel<.., 2>) -> CSR rows
+__global__ __launch_bounds__(256) void range_emit_kernel(const unsigned long long *__restrict__ cand, const int *__restrict__ nhit,
+                                                         const long long *__restrict__ bases, int64_t nlists, int keep,
+                                                         int64_t id_offset, float *__restrict__ out_d, int64_t *__restrict__ out_i) {
+    const int lane = threadIdx.x & 63;
+    const int64_t list = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (list >= nlists) return;
+    const int n = nhit[list];
+    const long long base = bases[list];
+    for (int i = lane; i < n; i += 64) {
+        const unsigned long long key = cand[list * keep + i];
+        out_d[base + i] = key_score(key);
+        out_i[base + i] = (int64_t)key_index(key) + id_offset;
+    }
+}
+
+// Range search through the bf16 pre-filter: ONE bf16 sweep with the radius as a fixed threshold (the exact path sweeps twice,
+// to count and to fill), exact re-scoring of the survivors, scan, emit.  Returns 1 when a list overflowed or a bound was not
+// finite -- the caller then takes the exact path for the whole call (dense radii) -- 0 when the CSR output is complete.
+static int range_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d, float radius,
+                           int64_t ref_id_offset, int64_t *lims_dev, float *out_scores_dev, int64_t *out_ids_dev,
+                           int64_t capacity, int64_t *total_out, hipStream_t stream, int *overflow) {
+    constexpr int EPL = 32;
+    const int dp = (d + 63) / 64 * 64;
+    const int cap = 64 * EPL, keep = cap / 2;
+    const int nqb = (int)((nq + SQ - 1) / SQ);
+    const int64_t total_tiles = (nr + SR - 1) / SR;
+    int64_t want = (256 + nqb - 1) / nqb;
+    if (want > 256) want = 256;
+    if (want > total_tiles) want = total_tiles;
+    if (want < 1) want = 1;
+    int64_t tiles_per_split = (total_tiles + want - 1) / want;
+    const int64_t max_tiles = ((1ll << 31) - 1) / ((int64_t)SR * dp * 2);
+    if (tiles_per_split > max_tiles) tiles_per_split = max_tiles;
+    const int splits = (int)((total_tiles + tiles_per_split - 1) / tiles_per_split);
+    const int64_t work = (int64_t)nqb * splits;
+    const int grid = (int)(work < 256 ? work : 256);
+    const int64_t nlists = nq * splits;
+    void *qb, *rb, *qstats, *flags, *lists, *cand, *ncand, *counts;
+    int rc;
+    const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 32;
+    if ((rc = scratch_get(12, (size_t)nq * dp * 2, &qb))) return rc;
+    if ((rc = scratch_get(13, (size_t)nr * dp * 2, &rb))) return rc;
+    if ((rc = scratch_get(14, (size_t)nq * 16, &qstats))) return rc;
+    if ((rc = scratch_get(15, flag_bytes, &flags))) return rc;
+    if ((rc = scratch_get(16, (size_t)grid * SQ * cap * 8, &lists))) return rc;
+    if ((rc = scratch_get(17, (size_t)nlists * keep * 8, &cand))) return rc;
+    if ((rc = scratch_get(18, (size_t)nlists * 4, &ncand))) return rc;
+    if ((rc = scratch_get(4, (size_t)nlists * 8, &counts))) return rc;
+    int *fb_dev = (int *)flags + 4;
+    VSC_CHECK_HIP(hipMemsetAsync(flags, 0, flag_bytes, stream));
+    hipLaunchKernelGGL(knn_pack_bf16_kernel, dim3(blocks_for(nq * 64)), dim3(256), 0, stream, q_dev, (uint16_t *)qb,
+                       (float *)qstats, (unsigned *)nullptr, nq, d, dp);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(knn_pack_bf16_kernel, dim3(blocks_for(nr * 64)), dim3(256), 0, stream, r_dev, (uint16_t *)rb,
+                       (float *)nullptr, (unsigned *)flags, nr, d, dp);
+    VSC_CHECK_LAUNCH();
+    const float cd = (float)d * (2.384185791015625e-7f + 5.9604644775390625e-8f);
+    SweepArgs a{(const uint16_t *)qb, (const uint16_t *)rb, (const float *)qstats, (const unsigned *)flags, nq, nr, dp, /*k=*/cap, nqb,
+                splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
+                (int *)ncand, fb_dev, 0, nullptr, cap - 2 * SR};
+    a.thr_mode = 1;
+    a.thr0 = radius;
+    a.dbg = (unsigned long long *)(((uintptr_t)(fb_dev + 1 + nqb) + 7) & ~(uintptr_t)7);
+    if ((rc = launch_sweep<EPL>(a, grid, stream))) return rc;
+    const unsigned rgrid = (unsigned)((nlists + 3) / 4);
+    auto rk = knn_rescore_kernel<EPL / 2, 2>;
+    VSC_CHECK_HIP(hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 36 * 4));
+    PairMaxOut pm{};
+    pm.thr = radius;
+    pm.counts = (long long *)counts;
+    hipLaunchKernelGGL(rk, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d, splits, cap,
+                       (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)nullptr, pm);
+    VSC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(range_scan_kernel, dim3(1), dim3(1024), 0, stream, (long long *)counts, nlists, splits, nq, lims_dev);
+    VSC_CHECK_LAUNCH();
+    int64_t total = 0;
+    int fb0 = 0;
+    VSC_CHECK_HIP(hipMemcpyAsync(&total, lims_dev + nq, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    VSC_CHECK_HIP(hipMemcpyAsync(&fb0, fb_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+    VSC_CHECK_HIP(hipStreamSynchronize(stream));
+    *overflow = fb0 != 0;
+    if (fb0) return VSC_OK;
+    *total_out = total;
+    if (total > capacity || total == 0) return VSC_OK;
+    hipLaunchKernelGGL(range_emit_kernel, dim3(rgrid), dim3(256), 0, stream, (const unsigned long long *)cand, (const int *)ncand,
+                       (const long long *)counts, nlists, keep, ref_id_offset, out_scores_dev, out_ids_dev);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+static int g_range_last_path = 0;   // 1 exact (two fp32 sweeps), 2 bf16 pre-filter, 3 pre-filter abandoned (overflow) -> exact
+extern "C" int vsc_range_search_last_path(void) { return g_range_last_path; }
+
 extern "C" int vsc_range_search_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr,
                                        int32_t d, float radius, int64_t ref_id_offset,
                                        int64_t *lims_dev, float *out_scores_dev, int64_t *out_ids_dev,
@@ -1315,6 +1444,19 @@ extern "C" int vsc_range_search_ip_f32(const float *q_dev, int64_t nq, const flo
     VSC_REQUIRE(d > 0 && d <= 4096, "range_search: dimension %d unsupported", d);
     VSC_REQUIRE(capacity >= 0 && (capacity == 0 || (out_scores_dev && out_ids_dev)),
                 "range_search: capacity %lld without output buffers", (long long)capacity);
+    int rc;
+    {   // path: as vsc_knn_ip_f32 (VSC_RANGE_PATH=exact|bf16 forces one)
+        bool prefilter = nr >= 4096 && nq * nr >= (1ll << 24);
+        if (const char *e = getenv("VSC_RANGE_PATH")) prefilter = e[0] == 'b' ? true : (e[0] == 'e' ? false : prefilter);
+        g_range_last_path = 1;
+        if (prefilter) {
+            int overflow = 0;
+            if ((rc = range_prefilter(q_dev, nq, r_dev, nr, d, radius, ref_id_offset, lims_dev, out_scores_dev, out_ids_dev, capacity,
+                                      total_out, stream, &overflow))) return rc;
+            g_range_last_path = overflow ? 3 : 2;
+            if (!overflow) return VSC_OK;
+        }
+    }
     const int dpad = (d + KS - 1) / KS * KS;
     const int nqb = (int)((nq + TQ - 1) / TQ);
     const int64_t total_tiles = (nr + TR - 1) / TR;
@@ -1328,7 +1470,6 @@ extern "C" int vsc_range_search_ip_f32(const float *q_dev, int64_t nq, const flo
     const int grid = (int)(work < 512 ? work : 512);
 
     void *qp, *rp, *counts;
-    int rc;
     if ((rc = scratch_get(0, (size_t)nq * dpad * 4, &qp))) return rc;
     if ((rc = scratch_get(1, (size_t)nr * dpad * 4, &rp))) return rc;
     if ((rc = scratch_get(4, (size_t)nq * splits * 8, &counts))) return rc;
@@ -1488,7 +1629,7 @@ static int pair_max_prefilter(const float *q_dev, int64_t nq, const int32_t *qvi
     a.dbg = (unsigned long long *)(((uintptr_t)(fb_dev + 1 + nqb) + 7) & ~(uintptr_t)7);
     if ((rc = launch_sweep<EPL>(a, grid, stream))) return rc;
     const unsigned rgrid = (unsigned)((nlists + 3) / 4);
-    auto rk = knn_rescore_kernel<EPL / 2, true>;
+    auto rk = knn_rescore_kernel<EPL / 2, 1>;
     VSC_CHECK_HIP(hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 36 * 4));
     hipLaunchKernelGGL(rk, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d, splits, cap,
                        (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)nullptr,

@@ -95,6 +95,7 @@ SIGNATURES = {
     "vsc_attention_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "vsc_knn_last_path": (c_int32, []),
     "vsc_video_pair_max_last_path": (c_int32, []),
+    "vsc_range_search_last_path": (c_int32, []),
     "vsc_knn_set_profiling": (None, [c_int32]),
     "vsc_knn_last_profile": (c_int32, [c_void_p]),
     "vsc_range_search_ip_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_float, c_int64,
