@@ -26,10 +26,12 @@ def timeit(fn, it):
     return (time.perf_counter() - t0) / it
 
 
-cls = cnn.MobileNetV3SmallHip(cnn_synth.mobilenetv3_small_state(1), dev)
-x = cnn_synth.similarity_maps(2, 8, 160, 160).to(dev).repeat(256, 1, 1, 1)
-dt = timeit(lambda: cls(x), 3)
-print(f"mobilenetv3_small_100 classifier, batch {x.shape[0]} x 3 x 160 x 160: {dt * 1e3:.1f} ms, {x.shape[0] / dt:.0f} maps/s")
+only = sys.argv[1] if len(sys.argv) > 1 else ""   # "hrnet": the refinement net alone
+if only != "hrnet":
+    cls = cnn.MobileNetV3SmallHip(cnn_synth.mobilenetv3_small_state(1), dev)
+    x = cnn_synth.similarity_maps(2, 8, 160, 160).to(dev).repeat(256, 1, 1, 1)
+    dt = timeit(lambda: cls(x), 3)
+    print(f"mobilenetv3_small_100 classifier, batch {x.shape[0]} x 3 x 160 x 160: {dt * 1e3:.1f} ms, {x.shape[0] / dt:.0f} maps/s")
 ref = cnn.HRNetRefineHip(cnn_synth.hrnet_refine_state(3), dev)
 y = cnn_synth.similarity_maps(4, 16, 224, 224).to(dev)
 dt = timeit(lambda: ref(y), 3)

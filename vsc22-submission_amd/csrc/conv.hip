@@ -133,6 +133,7 @@ struct ConvGemmArgs {
     float *out;          // [rows, ldo]
     int64_t rows;
     int cout, kpad, ldo, ldr, act, tiles_c;
+    int64_t tiles_p;     // pixel tiles (the narrow kernel walks tiles_p * tiles_c tiles persistently)
     // implicit patch gathering (conv_gemm_narrow_kernel<true>): the convolution's own geometry instead of `ap`
     const float *x;      // input [n, h, w, ldx]
     const float *zeros;  // >= 16 bytes of zeros: where padding taps and k >= K point
@@ -205,13 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int64_t tile = blockIdx.x;
-    const int tc = (int)(tile % p.tiles_c);
-    const int64_t tp = tile / p.tiles_c;
-    const int64_t c0 = (int64_t)tc * NARROW_C, p0 = tp * NARROW_P;
     unsigned *tab = (unsigned *)(lds + 2 * NARROW_STAGE);   // per 16-byte chunk of k: (i << 28) | (j << 24) | ci, ~0u past K
-    int64_t pbase[2][4];   // this lane's 8 patch rows (2 pixel tiles x 4 pieces): element offset of x[img, iy0, ix0, 0]
-    int pyx[2][4];         // (iy0 << 16) | (ix0 & 0xffff)
     if (IMPLICIT) {
         for (int ch = tid; ch < p.kpad / 4; ch += 256) {
             const int kk = ch * 4;
@@ -222,6 +217,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
             }
             tab[ch] = v;
         }
+        __syncthreads();
+    }
+    // this lane's 8 patch rows of a tile (2 pixel halves x 4 pieces): element offset of x[img, iy0, ix0, 0] and (iy0 << 16) | ix0
+    struct Rows {
+        int64_t pbase[2][4];
+        int pyx[2][4];
+    };
+    auto decode = [&](int64_t p0, Rows &rw) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -233,17 +236,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
                 const int rem = (int)(pix - img * p.ho * p.wo);
                 const int oy = rem / p.wo, ox = rem - oy * p.wo;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-                pbase[t][j] = ((img * p.h + iy0) * p.w + ix0) * (int64_t)p.ldx;
-                pyx[t][j] = (iy0 << 16) | (ix0 & 0xffff);
+                rw.pbase[t][j] = ((img * p.h + iy0) * p.w + ix0) * (int64_t)p.ldx;
+                rw.pyx[t][j] = (iy0 << 16) | (ix0 & 0xffff);
             }
-        __syncthreads();
-    }
-    f32x16_t acc[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-    auto stage = [&](int ks, char *st) {
+    };
+    auto stage = [&](int ks, char *st, int64_t c0, int64_t p0, const Rows &rw) {
         // weights: pieces 0..3 (8 rows each) of a 128-row tile image, one per wave
         {
             const int r = wave * 8 + (lane >> 3);
@@ -265,67 +262,100 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
                     const int c = (lane & 7) ^ ((r >> 1) & 7);
                     const unsigned tv = tab[ks * (KS / 4) + c];
                     const int i = (int)(tv >> 28), jj = (int)((tv >> 24) & 15u), ci = (int)(tv & 0xFFFFFFu);
-                    const int iy = (pyx[t][j] >> 16) + i, ix = (int)(short)(pyx[t][j] & 0xffff) + jj;
+                    const int iy = (rw.pyx[t][j] >> 16) + i, ix = (int)(short)(rw.pyx[t][j] & 0xffff) + jj;
                     const bool ok = tv != 0xFFFFFFFFu && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-                    const float *g = ok ? p.x + pbase[t][j] + ((int64_t)i * p.w + jj) * p.ldx + ci : p.zeros;
+                    const float *g = ok ? p.x + rw.pbase[t][j] + ((int64_t)i * p.w + jj) * p.ldx + ci : p.zeros;
                     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(st + NARROW_W_BYTES + t * TILE_BYTES + piece * 1024), 16, 0, 0);
                 }
         }
     };
+    // Persistent over the tile list (the launcher starts at most two workgroups per CU): the last K-step of a tile stages the
+    // first K-step of the workgroup's next tile, so a tile does not open with the table / pixel decode and an exposed first
+    // stage.  Measured gain: 1 % on an HRNet pass (52.7 vs 53.3 ms, VSC_CONV_PERSIST=0) -- the kernel is bound inside its K loop
+    // (18 -> 18 at 224 x 224: 195 us against 63 us of MFMA issue; two LDS stages with vmcnt(0) + barrier per 32-float K-step).
     const int nks = p.kpad / KS;
-    stage(0, lds);
+    const int64_t ntiles = p.tiles_p * p.tiles_c;
+    int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int64_t c0 = (tile % p.tiles_c) * NARROW_C, p0 = (tile / p.tiles_c) * NARROW_P;
+    Rows rw;
+    if (IMPLICIT) decode(p0, rw);
+    stage(0, lds, c0, p0, rw);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
-    for (int ks = 0; ks < nks; ++ks) {
-        if (ks + 1 < nks) stage(ks + 1, lds + (cur ^ 1) * NARROW_STAGE);
-        const char *wt = lds + cur * NARROW_STAGE;
-        const char *pt = wt + NARROW_W_BYTES + (wave >> 1) * TILE_BYTES;   // waves 0,1 -> P0, waves 2,3 -> P1
-        const int prow = (wave & 1) * 64;
+    for (;;) {
+        const int64_t next = tile + gridDim.x;
+        const bool more = next < ntiles;
+        const int64_t nc0 = more ? (next % p.tiles_c) * NARROW_C : 0, np0 = more ? (next / p.tiles_c) * NARROW_P : 0;
+        f32x16_t acc[2];
 #pragma unroll
-        for (int pr = 0; pr < 4; ++pr) {
-            const f32x4_t af = lds_frag(wt, l31, 2 * pr + hi);
-            f32x4_t bf[2];
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bf[b] = lds_frag(pt, prow + b * 32 + l31, 2 * pr + hi);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[b][t], acc[b], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
-    }
-    // acc[b][reg] = <w[c0 + 8*(reg>>2) + 4*hi + (reg&3)], patch[p0 + wave*64 + b*32 + l31]>
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int64_t pix = p0 + wave * 64 + b * 32 + l31;
-        if (pix >= p.rows) continue;
-        float *orow = p.out + pix * p.ldo;
-        const float *rrow = p.res ? p.res + pix * p.ldr : nullptr;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = (int)c0 + 8 * g + 4 * hi;
-            if (co >= p.cout) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[b][4 * g + r];
-                if (co + r < p.cout) {
-                    if (p.bias) v[r] += p.bias[co + r];
-                    if (rrow) v[r] += rrow[co + r];
-                    v[r] = activate(v[r], p.act);
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        for (int ks = 0; ks < nks; ++ks) {
+            {
+                if (ks + 1 < nks) {
+                    stage(ks + 1, lds + (cur ^ 1) * NARROW_STAGE, c0, p0, rw);
+                } else if (more) {
+                    Rows nrw;
+                    if (IMPLICIT) decode(np0, nrw);
+                    stage(0, lds + (cur ^ 1) * NARROW_STAGE, nc0, np0, nrw);
+                    if (IMPLICIT) rw = nrw;   // this tile's rows are not staged again
                 }
             }
-            if (co + 3 < p.cout && ((p.ldo | co) & 3) == 0) {
-                *(float4 *)(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
+            const char *wt = lds + cur * NARROW_STAGE;
+            const char *pt = wt + NARROW_W_BYTES + (wave >> 1) * TILE_BYTES;   // waves 0,1 -> P0, waves 2,3 -> P1
+            const int prow = (wave & 1) * 64;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co + r < p.cout) orow[co + r] = v[r];
+            for (int pr = 0; pr < 4; ++pr) {
+                const f32x4_t af = lds_frag(wt, l31, 2 * pr + hi);
+                f32x4_t bf[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) bf[b] = lds_frag(pt, prow + b * 32 + l31, 2 * pr + hi);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[b][t], acc[b], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+        // acc[b][reg] = <w[c0 + 8*(reg>>2) + 4*hi + (reg&3)], patch[p0 + wave*64 + b*32 + l31]>
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t pix = p0 + wave * 64 + b * 32 + l31;
+            if (pix >= p.rows) continue;
+            float *orow = p.out + pix * p.ldo;
+            const float *rrow = p.res ? p.res + pix * p.ldr : nullptr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = (int)c0 + 8 * g + 4 * hi;
+                if (co >= p.cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[b][4 * g + r];
+                    if (co + r < p.cout) {
+                        if (p.bias) v[r] += p.bias[co + r];
+                        if (rrow) v[r] += rrow[co + r];
+                        v[r] = activate(v[r], p.act);
+                    }
+                }
+                if (co + 3 < p.cout && ((p.ldo | co) & 3) == 0) {
+                    *(float4 *)(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.cout) orow[co + r] = v[r];
+                }
             }
         }
+        if (!more) break;
+        tile = next;
+        c0 = nc0;
+        p0 = np0;
     }
 }
 
@@ -529,12 +559,17 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     const int tiles_c = narrow ? (cout + NARROW_C - 1) / NARROW_C : (cout + TR - 1) / TR;
     const int64_t tiles_p = narrow ? (rows + NARROW_P - 1) / NARROW_P : (rows + TQ - 1) / TQ;
     VSC_REQUIRE(tiles_p * tiles_c < (1ll << 31), "conv2d: grid too large");
-    ConvGemmArgs a{w_packed_dev, in_place ? x_dev : (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c,
+    ConvGemmArgs a{w_packed_dev, in_place ? x_dev : (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c, tiles_p,
                    x_dev, g_zero_line[dev], h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k};
+    static int cus_of[16] = {};
+    if (!cus_of[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t resident = 2ll * cus_of[dev];   // two workgroups of the narrow kernel per CU (LDS)
+    const char *pe = getenv("VSC_CONV_PERSIST");   // diagnostic: 0 = one tile per workgroup
+    const unsigned ngrid = (unsigned)((pe && pe[0] == '0') || tiles_p * tiles_c < resident ? tiles_p * tiles_c : resident);
     if (implicit) {
-        hipLaunchKernelGGL(conv_gemm_narrow_kernel<true>, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(conv_gemm_narrow_kernel<true>, dim3(ngrid), dim3(256), 0, stream, a);
     } else if (narrow) {
-        hipLaunchKernelGGL(conv_gemm_narrow_kernel<false>, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(conv_gemm_narrow_kernel<false>, dim3(ngrid), dim3(256), 0, stream, a);
     } else {
         hipLaunchKernelGGL(conv_gemm_kernel, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
     }
