@@ -198,9 +198,11 @@ def search_traffic():
     the profiled launch, or None."""
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_knn.json")))
-        v = prof["per_launch"][prof["sweep_kernel_key"]]
-        return (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024, prof["nq"], prof["nr"]
-    except (OSError, KeyError, ValueError):
+        key = prof.get("sweep_kernel_key") or next(k for k in prof["per_launch"] if k.startswith("knn_sweep_bf16_kernel"))
+        v = prof["per_launch"][key]
+        # tools/profile_round.sh profiles `tools/knn_bench.py 8192 1000000 100 1`
+        return (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024, prof.get("nq", 8192), prof.get("nr", 1000000)
+    except (OSError, KeyError, ValueError, StopIteration):
         return None
 
 

@@ -708,8 +708,9 @@ __device__ __forceinline__ int compact_band(const unsigned long long *list, int 
     return base;
 }
 
-template <int EPL, bool STREAM>
+template <int EPL, bool STREAM, bool DIAG = false>   // DIAG: the VSC_KNN_ABL switches / counters are compiled in (timing diagnostics)
 __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
+    const int abl = DIAG ? p.abl : 0;
     constexpr int CAP = 64 * EPL, KEEP = CAP / 2;
     const int TRIG = p.trig;   // list length that asks for a compaction round (<= CAP - 2 * SR: flags are read one tile late)
     extern __shared__ __attribute__((aligned(16))) char lds[];   // ONE shared array: ring, then the per-query slots
@@ -790,11 +791,11 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                     // A round stalls the whole workgroup, so it takes every list that is at least half-way to the
                     // trigger with it: the lists of a block fill at similar rates, and rounds become ~10 per split
                     // instead of one per list and compaction.
-                    if ((p.abl & 8) && tid == 0) atomicAdd(p.dbg + 1, 1ull);
+                    if ((abl & 8) && tid == 0) atomicAdd(p.dbg + 1, 1ull);
                     for (int ql = wave * 32; ql < wave * 32 + 32; ++ql) {
                         const int n = cnt_s[ql];
                         if (n >= TRIG / 2 && n >= p.k) {
-                            if ((p.abl & 8) && lane == 0) atomicAdd(p.dbg + 2, 1ull);
+                            if ((abl & 8) && lane == 0) atomicAdd(p.dbg + 2, 1ull);
                             unsigned long long *l = mylists + (size_t)ql * CAP;
                             float thr;
                             const int kept = compact_band<EPL>(l, n < CAP ? n : CAP, p.k, eps_s[ql], l, CAP, &thr, lane);
@@ -807,7 +808,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                     }
                     __syncthreads();
                 }
-                if (!(p.abl & 1)) {
+                if (!(abl & 1)) {
                     // Everything per-lane below derives from an opaque copy of the lane id: otherwise the compiler hoists
                     // the eight list pointers / counter addresses out of the tile loop, spills them around the K loop
                     // (256 VGPRs are in use there) and reloads them here -- and a scratch reload is a vmcnt(0) wait, i.e.
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                             any_hit = true;
                         }
                     }
-                    if (any_hit && !(p.abl & 2)) {
+                    if (any_hit && !(abl & 2)) {
                         // (2) ALL counter updates of the tile back to back (a lane without hits adds 0), one wait: an LDS
                         //     atomic round trip per query in sequence was most of the filter's time.  Inline asm: for the
                         //     builtin the compiler cannot tell these addresses from the ring the LDS-DMA is writing and
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                             const int ql = wm * 128 + i * 16 + l15;
                             const unsigned cntm = __popc(mask[i]);
                             if (mask[i] && base[i] + (int)cntm >= TRIG) flag_s[fcur] = 1;
-                            if ((p.abl & 8) && mask[i]) atomicAdd(p.dbg, (unsigned long long)cntm);
+                            if ((abl & 8) && mask[i]) atomicAdd(p.dbg, (unsigned long long)cntm);
                             const unsigned slot0 = (unsigned)ql * CAP + (unsigned)base[i];   // 32-bit offset from the uniform list base
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                                 for (int x = 0; x < 4; ++x) {
                                     const int bit = j * 4 + x;
                                     const unsigned rank = __popc(mask[i] & ((1u << bit) - 1u));
-                                    if ((mask[i] >> bit & 1u) && base[i] + (int)rank < CAP && !(p.abl & 4))
+                                    if ((mask[i] >> bit & 1u) && base[i] + (int)rank < CAP && !(abl & 4))
                                         mylists[slot0 + rank] = make_key(acc[i][j][x], ref0 + j * 16 + x);
                                 }
                             }
@@ -1201,9 +1202,15 @@ static int knn_exact(const float *q_dev, int64_t nq, const float *r_dev, int64_t
 template <int EPL, bool STREAM>
 static int launch_sweep_t(const SweepArgs &a, int grid, hipStream_t stream) {
     constexpr int smem = ml64::RING_BYTES + 4096;
-    auto kern = knn_sweep_bf16_kernel<EPL, STREAM>;
-    VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a);
+    if (a.abl) {   // diagnostics requested (VSC_KNN_ABL): the instrumented build of the kernel
+        auto kern = knn_sweep_bf16_kernel<EPL, STREAM, true>;
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a);
+    } else {
+        auto kern = knn_sweep_bf16_kernel<EPL, STREAM, false>;
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a);
+    }
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }
