@@ -42,11 +42,11 @@ template <int KT, int NI, int ABL = 0>  // key tiles of 32 -> padded token count
                                          // ABL: diagnostic ablation bits (VSC_ATTN_ABL, KT = 7 only)
 __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__restrict__ qkv,
                                                            uint16_t *__restrict__ out, int tokens,
-                                                           int heads, int total, int skew) {
+                                                           int heads, int total, int skew, int ncu) {
     constexpr int TP = KT * 32;
-    // Start skew of the SECOND workgroup of every CU (the first 512 workgroups start together, two per CU; all have the same
+    // Start skew of the SECOND workgroup of every CU (the first 2 x ncu workgroups start together, two per CU; all have the same
     // duration, so without it the two residents of a CU load together and compute together for the whole launch).
-    if (skew > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+    if (skew > 0 && (int)blockIdx.x >= ncu && (int)blockIdx.x < 2 * ncu) {
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)skew) __builtin_amdgcn_s_sleep(8);
     }
@@ -281,14 +281,17 @@ int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int he
     // ~32 k cycles): 0 / 4 / 8 / 12 / 16 / 24 / 32 k cycles -> 148.6 / 140.3 / 137.6 / 132.4 / 121.8 / 136.4 / 139.4 us cold,
     // 116.9 / 114.1 / 107.6 / 104.9 / 104.2 / 116.9 / 114.7 us warm (tools/micro/attn_bench.py).  Two workgroups are resident
     // from 5 key tiles up (LDS); the lifetime goes with the square of the token count.
-    int skew = KT >= 5 && frames * heads > 512 ? 16000 * KT * KT / 49 : 0;
+    static int cus_of[16] = {};
+    if (dev < 16 && !cus_of[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    const int ncu = dev < 16 && cus_of[dev] > 0 ? cus_of[dev] : 256;
+    int skew = KT >= 5 && frames * heads > 2 * ncu ? 16000 * KT * KT / 49 : 0;
     if (const char *e = getenv("VSC_ATTN_SKEW")) skew = atoi(e);
 #ifdef VSC_ATTN_ABLATION
     if (KT == 7)
         if (const char *e = getenv("VSC_ATTN_ABL")) {
             const int abl = atoi(e);
 #define VSC_ABL_CASE(A) case A: { auto k = attention_kernel<7, 1, A>; VSC_CHECK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); \
-            hipLaunchKernelGGL(k, dim3(frames * heads), dim3(512), smem, stream, qkv, out, tokens, heads, frames * heads, skew); VSC_CHECK_LAUNCH(); return VSC_OK; }
+            hipLaunchKernelGGL(k, dim3(frames * heads), dim3(512), smem, stream, qkv, out, tokens, heads, frames * heads, skew, ncu); VSC_CHECK_LAUNCH(); return VSC_OK; }
             switch (abl) { VSC_ABL_CASE(1) VSC_ABL_CASE(2) VSC_ABL_CASE(4) VSC_ABL_CASE(6) VSC_ABL_CASE(7) VSC_ABL_CASE(8) VSC_ABL_CASE(16) VSC_ABL_CASE(24) VSC_ABL_CASE(31) default: break; }
         }
 #endif
@@ -300,9 +303,9 @@ int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int he
     if (const char *e = getenv("VSC_ATTN_NI")) ni = atoi(e) == 2 ? 2 : 1;
     if (ni == 2)
         hipLaunchKernelGGL((attention_kernel<KT, 2>), dim3((total + 1) / 2), dim3(512), smem, stream, qkv, out, tokens, heads,
-                           total, 2 * skew);
+                           total, 2 * skew, ncu);
     else
-        hipLaunchKernelGGL((attention_kernel<KT, 1>), dim3(total), dim3(512), smem, stream, qkv, out, tokens, heads, total, skew);
+        hipLaunchKernelGGL((attention_kernel<KT, 1>), dim3(total), dim3(512), smem, stream, qkv, out, tokens, heads, total, skew, ncu);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }
