@@ -87,7 +87,7 @@ def test_conv2d_implicit_gather_equals_materialised_patches(dev, n, h, w, cin, c
 def test_depthwise_pool_scale_upsample(dev):
     from vsc_hip import cnn
     rng = np.random.RandomState(0)
-    for c, k, stride in ((16, 3, 2), (96, 5, 1), (240, 5, 2)):
+    for c, k, stride in ((16, 3, 2), (96, 5, 1), (240, 5, 2), (18, 3, 1), (7, 5, 2)):   # the last two: c % 4 != 0 -> the scalar kernel
         sd = {"d.weight": torch.from_numpy(rng.randn(c, 1, k, k).astype(np.float32) * 0.2)}
         x = torch.from_numpy(rng.randn(2, c, 11, 9).astype(np.float32))
         want = F.hardswish(F.conv2d(x, sd["d.weight"], None, stride=stride, padding=k // 2, groups=c))
