@@ -138,6 +138,7 @@ struct ConvGemmArgs {
     const float *x;      // input [n, h, w, ldx]
     const float *zeros;  // >= 16 bytes of zeros: where padding taps and k >= K point
     int h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k;
+    int no_remap;        // diagnostic (VSC_CONV_REMAP=0)
 };
 
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p) {
@@ -275,8 +276,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
     // (18 -> 18 at 224 x 224: 195 us against 63 us of MFMA issue; two LDS stages with vmcnt(0) + barrier per 32-float K-step).
     const int nks = p.kpad / KS;
     const int64_t ntiles = p.tiles_p * p.tiles_c;
-    int64_t tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    // XCD-aware order: virtual tile vt runs on XCD vt % 8 (gridDim is a multiple of 8 or the whole tile list); xcd_remap gives every
+    // XCD a contiguous range of pixel tiles, so the rows a 3 x 3 tile shares with its neighbours are fetched into ONE L2
+    int64_t vt = blockIdx.x;
+    if (vt >= ntiles) return;
+    const bool remap = ntiles < (1ll << 31) && !p.no_remap;
+    int64_t tile = remap ? xcd_remap((int)vt, (int)ntiles) : vt;
     int64_t c0 = (tile % p.tiles_c) * NARROW_C, p0 = (tile / p.tiles_c) * NARROW_P;
     Rows rw;
     if (IMPLICIT) decode(p0, rw);
@@ -285,8 +290,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
     __syncthreads();
     int cur = 0;
     for (;;) {
-        const int64_t next = tile + gridDim.x;
-        const bool more = next < ntiles;
+        const int64_t vnext = vt + gridDim.x;
+        const bool more = vnext < ntiles;
+        const int64_t next = more ? (remap ? (int64_t)xcd_remap((int)vnext, (int)ntiles) : vnext) : 0;
         const int64_t nc0 = more ? (next % p.tiles_c) * NARROW_C : 0, np0 = more ? (next / p.tiles_c) * NARROW_P : 0;
         f32x16_t acc[2];
 #pragma unroll
@@ -353,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
             }
         }
         if (!more) break;
+        vt = vnext;
         tile = next;
         c0 = nc0;
         p0 = np0;
@@ -604,7 +611,8 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     const int64_t tiles_p = narrow ? (rows + NARROW_P - 1) / NARROW_P : (rows + TQ - 1) / TQ;
     VSC_REQUIRE(tiles_p * tiles_c < (1ll << 31), "conv2d: grid too large");
     ConvGemmArgs a{w_packed_dev, in_place ? x_dev : (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c, tiles_p,
-                   x_dev, g_zero_line[dev], h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k};
+                   x_dev, g_zero_line[dev], h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k, 0};
+    if (const char *e = getenv("VSC_CONV_REMAP")) a.no_remap = e[0] == '0';
     static int cus_of[16] = {};
     if (!cus_of[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t resident = 2ll * cus_of[dev];   // two workgroups of the narrow kernel per CU (LDS)
