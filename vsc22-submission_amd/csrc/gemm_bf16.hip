@@ -1034,7 +1034,16 @@ int launch_v34(GemmArgs p, hipStream_t stream) {
         // (K > 3072: the per-tile costs v4 removes are < 1 % of a tile and its lockstep costs ~3 % -- 8192^3 680 vs 701 us)
         if (!off && p.k % 128 == 0 && p.k >= 256 && p.k <= 3072 && cus % 8 == 0 && (int64_t)p.tiles_m * p.tiles_n > cus &&
             a_span < (1ll << 32) && w_span < (1ll << 32) && (EPI != VSC_EPI_RESADD_F32 || p.aux))
-            return launch_v4<EPI>(p, cus, stream);
+        {
+            int grid = cus;
+            // diagnostic: persistent workgroups per launch (a multiple of 8).  Measured with two lanes, so that the two chunks' GEMMs run
+            // side by side on half the chip each instead of one after the other: 128 -> 23.4 k, 192 -> 23.4 k, 256 -> 23.9 k frames/s
+            if (const char *e = getenv("VSC_GEMM_V4_GRID")) {
+                const int g = atoi(e);
+                if (g >= 8 && g <= cus && g % 8 == 0) grid = g;
+            }
+            return launch_v4<EPI>(p, grid, stream);
+        }
     }
     return launch_v3<EPI>(p, stream);
 }
