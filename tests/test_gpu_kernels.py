@@ -125,6 +125,21 @@ def test_gemm_persistent_kernel_equals_one_tile_per_workgroup(dev, epi, m, n, k)
     torch.testing.assert_close(outs["1"][rows].float(), ref, rtol=2 ** -7, atol=3e-3)
 
 
+def test_gemm_persistent_kernel_without_bias(dev):
+    """No bias vector: the persistent kernel's per-tile bias row comes from a zero-extent buffer descriptor (LDS-DMA zero fill)."""
+    from vsc_hip import ops, _lib
+    g = torch.Generator(device="cpu").manual_seed(3)
+    m, n, k = 25000, 1024, 384
+    a = torch.randn(m, k, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    out = ops.gemm_bf16(a, w, None, epilogue=_lib.EPI_BF16)
+    rows = torch.tensor([0, 1, 255, 256, 12345, m - 1], device=dev)
+    torch.testing.assert_close(out[rows].float(), a[rows].float() @ w.float().t(), rtol=2 ** -7, atol=3e-3)
+    x = torch.randn(m, n, generator=g).to(dev)
+    y = ops.gemm_bf16(a, w, None, epilogue=_lib.EPI_RESADD_F32, aux=x.clone(), out=None)
+    torch.testing.assert_close(y[rows], x[rows] + a[rows].float() @ w.float().t(), rtol=1e-4, atol=2e-3)
+
+
 def test_gemm_patch_epilogue(dev):
     from vsc_hip import ops, _lib
     frames, tokens, n, k = 3, 17, 128, 768
