@@ -26,7 +26,13 @@ constexpr int HD = 32;  // head dim of every Swin-V2 stage (C / heads)
 //     dependent global loads per query tile): bias[i][j] = table[(yi - yj + w-1) * (2w-1) + (xi - xj + w-1)],
 //     so the head's compact (2w-1)^2 table (3.8 KiB) sits in LDS and is gathered with ds_read_b32.
 //   * P (bf16) is directly the B operand of the PV MFMA (k-slot permutation as attention.hip).
-template <int NT>  // 16-key tiles per window: 4 (8x8 window) or 16 (16x16 window)
+//   * where the time goes (ablations of the -DVSC_ATTN_ABLATION build, tools/micro/wattn_bench.py, stage-3 launch of 256 frames,
+//     warm): whole kernel 115 us; without MFMAs and exp2 86; without the K / V loads 95; without the stores 100; without loads
+//     and stores 87; with only the Q loads, the LDS traffic and the remaining VALU work (bias-table gathers, masks, K-hat
+//     normalisation, index math) 63 -- unlike the ViT kernel (attention.hip) this one IS bound by its VALU / LDS work; requesting
+//     V together with K (one memory round trip instead of two) changes nothing with four resident workgroups (116 us), and a
+//     start skew of the residents loses (4 generations per launch only).
+template <int NT, int ABL = 0>  // 16-key tiles per window: 4 (8x8 window) or 16 (16x16 window); ABL: ablation bits of the diagnostic build
 __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
     const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, const float *__restrict__ bias,
     const float *__restrict__ scale, int res, int ws, int shift, int heads) {
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
         const int e = tid + it * NTHREADS;
-        kraw[it] = *(const bf16x8_t *)(base + C + rowmap[e >> 2] * ld + (e & 3) * 8);
+        kraw[it] = (ABL & 8) ? (bf16x8_t){1, 2, 3, 4, 5, 6, 7, 8} : *(const bf16x8_t *)(base + C + rowmap[e >> 2] * ld + (e & 3) * 8);
     }
 #pragma unroll
     for (int it = 0; it < KIT; ++it) {
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
         const int blk = e >> 6, c8 = (e >> 4) & 3, kg = blk * 16 + (e & 15);
         bf16x8_t r[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = *(const bf16x8_t *)(base + 2 * C + rowmap[kg * 4 + i] * ld + c8 * 8);
+        for (int i = 0; i < 4; ++i) r[i] = (ABL & 8) ? (bf16x8_t){1, 2, 3, 4, 5, 6, 7, 8} : *(const bf16x8_t *)(base + 2 * C + rowmap[kg * 4 + i] * ld + c8 * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             uint2 pk;
@@ -162,7 +168,8 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                 const int krow = t * 16 + fr;
                 const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
                 f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi], z, 0, 0, 0);
+                if (ABL & 2) z[0] = (float)kf[0] + (float)qf[qi][1];
+                else z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi], z, 0, 0, 0);
                 float tb[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const f32x2_t d = s[2 * u + (h >> 1)][h & 1] + nmx;  // v_pk_add_f32
-                    e[h] = (f32x2_t){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                    e[h] = (ABL & 1) ? d : (f32x2_t){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
                 }
                 sum2 += (e[0] + e[1]) + (e[2] + e[3]);
                 union { uint32_t w[4]; bf16x8_t v; } pk;
@@ -215,7 +222,8 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                     union { uint2 h[2]; bf16x8_t v; } vf;
                     vf.h[0] = *(const uint2 *)(vrow);
                     vf.h[1] = *(const uint2 *)(vrow + 32);
-                    o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
+                    if (ABL & 2) o[ct][u & 3] += (float)vf.v[0] + (float)pb[u][ct];
+                    else o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
                 }
                 if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                 uint2 pk;
                 pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
                 pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
-                *(uint2 *)(orow + ct * 16) = pk;
+                if (!((ABL & 16) && inv != 12345.f)) *(uint2 *)(orow + ct * 16) = pk;
             }
         }
     };
@@ -318,6 +326,13 @@ int launch_window_attention(const uint16_t *qkv, uint16_t *out, const float *bia
     const int nw = (res / ws) * (res / ws);
     const int64_t grid = (int64_t)frames * nw * heads;
     VSC_REQUIRE(grid > 0 && grid < (1ll << 31), "window_attention: grid");
+#ifdef VSC_ATTN_ABLATION
+    if (ws == 16)
+        if (const char *e = getenv("VSC_WATTN_ABL")) {
+#define VSC_WABL_CASE(A) case A: hipLaunchKernelGGL((window_attention_kernel<16, A>), dim3((unsigned)grid), dim3(512), 0, stream, qkv, out, bias, scale, res, ws, shift, heads); VSC_CHECK_LAUNCH(); return VSC_OK;
+            switch (atoi(e)) { VSC_WABL_CASE(1) VSC_WABL_CASE(2) VSC_WABL_CASE(3) VSC_WABL_CASE(8) VSC_WABL_CASE(16) VSC_WABL_CASE(24) VSC_WABL_CASE(27) default: break; }
+        }
+#endif
     if (ws == 16)
         hipLaunchKernelGGL(window_attention_kernel<16>, dim3((unsigned)grid), dim3(512), 0, stream, qkv, out, bias,
                            scale, res, ws, shift, heads);
