@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void im2col_pack_kernel(const float *__restric
 }
 
 // The same pass without integer divisions in the inner loop (they were most of its time: 35 % of an HRNet pass): one
-// workgroup row per output image row (blockIdx.y = img * ho + oy), the (kh, kw, ci) decomposition of every k in an LDS
+// workgroup row per output image row (blockIdx.x = img * ho + oy), the (kh, kw, ci) decomposition of every k in an LDS
 // table built once per workgroup, threads over (ox, 16-byte chunk).
 constexpr int IM2COL_TABLE = 4096;   // k values the table holds (16 KiB); larger K takes the generic kernel
 __global__ __launch_bounds__(256) void im2col_pack_rows_kernel(const float *__restrict__ x, float *__restrict__ dst, int h, int w,
@@ -83,13 +83,13 @@ __global__ __launch_bounds__(256) void im2col_pack_rows_kernel(const float *__re
         tab[kk] = v;
     }
     __syncthreads();
-    const int oy = blockIdx.y % ho;
-    const int64_t img = blockIdx.y / ho;
+    const int oy = blockIdx.x % ho;
+    const int64_t img = blockIdx.x / ho;
     const int chunks = kpad >> 2;
-    const int64_t row0 = (int64_t)blockIdx.y * wo;
+    const int64_t row0 = (int64_t)blockIdx.x * wo;
     const float *ximg = x + img * h * w * ldx;
     const bool vec = (c & 3) == 0 && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0;   // a chunk = 4 channels of one tap: one 16-byte load
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < wo * chunks; e += gridDim.x * 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < wo * chunks; e += gridDim.y * 256) {
         const int ox = e / chunks, c4 = e - ox * chunks;   // one division per 16 bytes written (chunks is small)
         const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
         float4 out4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x
 
 // The same for c % 4 == 0 (every depthwise layer of the classifier): a thread owns 4 channels of one output pixel -- one float4
 // of x per tap instead of four scalar loads -- the weights sit transposed ([tap][c]) in LDS so a tap's 4 weights are one
-// ds_read_b128, and a workgroup row is one output image row (blockIdx.y = img * ho + oy), so the index math is one 32-bit
+// ds_read_b128, and a workgroup row is one output image row (blockIdx.x = img * ho + oy), so the index math is one 32-bit
 // division per output instead of three 64-bit ones per channel.  Same tap order and fmaf chain per channel: identical bits.
 // 2048 x 160 x 160 classifier maps: 16.2 -> 12.3 ms.
 __global__ __launch_bounds__(256) void dwconv_rows_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
@@ -408,13 +408,13 @@ __global__ __launch_bounds__(256) void dwconv_rows_kernel(const float *__restric
         wt[tp * c + ch] = wgt[e];
     }
     __syncthreads();
-    const int oy = blockIdx.y % ho;
-    const int64_t img = blockIdx.y / ho;
+    const int oy = blockIdx.x % ho;
+    const int64_t img = blockIdx.x / ho;
     const int c4n = c >> 2;
     const float *ximg = x + img * h * w * c;
-    float *orow = out + ((int64_t)blockIdx.y * wo) * c;
+    float *orow = out + ((int64_t)blockIdx.x * wo) * c;
     const int iy0 = oy * stride - pad;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < wo * c4n; e += gridDim.x * 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < wo * c4n; e += gridDim.y * 256) {
         const int ox = e / c4n, c4 = e - ox * c4n;
         const int ix0 = ox * stride - pad;
         f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -596,11 +596,11 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     }
     if (in_place || implicit) {
         // nothing to materialise
-    } else if (kpad <= IM2COL_TABLE && kh < 16 && kw < 16 && n * ho < 65536) {
+    } else if (kpad <= IM2COL_TABLE && kh < 16 && kw < 16 && n * ho < (1ll << 31)) {
         const int per_row = wo * (kpad / 4);
         int bx = (per_row + 255) / 256;
         bx = bx > 64 ? 64 : bx;
-        hipLaunchKernelGGL(im2col_pack_rows_kernel, dim3(bx, (unsigned)(n * ho)), dim3(256), 0, stream, x_dev, (float *)s.ptr, h, w, cin,
+        hipLaunchKernelGGL(im2col_pack_rows_kernel, dim3((unsigned)(n * ho), bx), dim3(256), 0, stream, x_dev, (float *)s.ptr, h, w, cin,
                            ldx, kh, kw, stride, pad, ho, wo, k, kpad);
     } else {
         hipLaunchKernelGGL(im2col_pack_kernel, dim3(blocks_for(rows * (kpad / 4))), dim3(256), 0, stream, x_dev, (float *)s.ptr, rows,
@@ -640,7 +640,7 @@ extern "C" int vsc_dwconv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_
     const int64_t total = n * ho * wo * c;
     const size_t wbytes = (size_t)kh * kw * c * 4;
     const bool aligned = ((((uintptr_t)x_dev) | ((uintptr_t)out_dev) | (bias_dev ? (uintptr_t)bias_dev : 0)) & 15) == 0;
-    if ((c & 3) == 0 && aligned && wbytes <= 64 * 1024 && n * ho < 65536) {
+    if ((c & 3) == 0 && aligned && wbytes <= 64 * 1024 && n * ho < (1ll << 31)) {
         static bool attr_set[16] = {};
         int dev = 0;
         VSC_CHECK_HIP(hipGetDevice(&dev));
@@ -650,7 +650,7 @@ extern "C" int vsc_dwconv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_
         }
         int bx = (wo * (c / 4) + 255) / 256;
         bx = bx > 64 ? 64 : bx;
-        hipLaunchKernelGGL(dwconv_rows_kernel, dim3(bx, (unsigned)(n * ho)), dim3(256), wbytes, (hipStream_t)stream_, x_dev, w_dev, bias_dev,
+        hipLaunchKernelGGL(dwconv_rows_kernel, dim3((unsigned)(n * ho), bx), dim3(256), wbytes, (hipStream_t)stream_, x_dev, w_dev, bias_dev,
                            out_dev, h, w, c, kh, kw, stride, pad, ho, wo, act);
     } else
     hipLaunchKernelGGL(dwconv_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream_, x_dev, w_dev, bias_dev, out_dev,
