@@ -201,15 +201,15 @@ constexpr int NARROW_STAGE = NARROW_W_BYTES + 2 * TILE_BYTES;   // W | P0 | P1 =
 // zero line when the tap falls into the padding or k >= K.  The pixel part of the address is decoded once per tile
 // (divisions), the tap part comes from a per-workgroup LDS table indexed by the chunk.  Same values in the same LDS image as
 // the packed path: results are bit-identical.
-template <bool IMPLICIT>
-__global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * NARROW_STAGE + (IMPLICIT ? IM2COL_TABLE : 0)];
+template <bool IMPLICIT, int STAGES, int NW>   // NW waves: 4 (wave = 64 pixels, two accumulators) or 8 (wave = 32 pixels, one)
+__global__ __launch_bounds__(NW * 64, 1) void conv_gemm_narrow_kernel(ConvGemmArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[STAGES * NARROW_STAGE + (IMPLICIT ? IM2COL_TABLE : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    unsigned *tab = (unsigned *)(lds + 2 * NARROW_STAGE);   // per 16-byte chunk of k: (i << 28) | (j << 24) | ci, ~0u past K
+    unsigned *tab = (unsigned *)(lds + STAGES * NARROW_STAGE);   // per 16-byte chunk of k: (i << 28) | (j << 24) | ci, ~0u past K
     if (IMPLICIT) {
-        for (int ch = tid; ch < p.kpad / 4; ch += 256) {
+        for (int ch = tid; ch < p.kpad / 4; ch += NW * 64) {
             const int kk = ch * 4;
             unsigned v = 0xFFFFFFFFu;
             if (kk < p.k) {
@@ -220,17 +220,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
         }
         __syncthreads();
     }
-    // this lane's 8 patch rows of a tile (2 pixel halves x 4 pieces): element offset of x[img, iy0, ix0, 0] and (iy0 << 16) | ix0
+    constexpr int PJ = 16 / NW;   // 1-KiB pieces of a 128-row pixel tile per wave
+    // this lane's patch rows of a tile (2 pixel halves x 4 pieces): element offset of x[img, iy0, ix0, 0] and (iy0 << 16) | ix0
     struct Rows {
-        int64_t pbase[2][4];
-        int pyx[2][4];
+        int64_t pbase[2][PJ];
+        int pyx[2][PJ];
     };
     auto decode = [&](int64_t p0, Rows &rw) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = (j * 4 + wave) * 8 + (lane >> 3);
+            for (int j = 0; j < PJ; ++j) {
+                const int r = (j * NW + wave) * 8 + (lane >> 3);
                 int64_t pix = p0 + t * 128 + r;
                 pix = pix > p.rows - 1 ? p.rows - 1 : pix;
                 const int64_t img = pix / ((int64_t)p.ho * p.wo);
@@ -242,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
             }
     };
     auto stage = [&](int ks, char *st, int64_t c0, int64_t p0, const Rows &rw) {
-        // weights: pieces 0..3 (8 rows each) of a 128-row tile image, one per wave
-        {
+        // weights: pieces 0..3 (8 rows each) of a 128-row tile image, one per wave (waves 0-3)
+        if (wave < 4) {
             const int r = wave * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((r >> 1) & 7);
             int64_t gr = c0 + r;
@@ -251,14 +252,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
             __builtin_amdgcn_global_load_lds((gptr_t)(p.wp + gr * p.kpad + ks * KS + c * 4), (lptr_t)(st + wave * 1024), 16, 0, 0);
         }
         if (!IMPLICIT) {
-            stage_tile(p.ap, p.kpad, p0, p.rows - 1, ks * KS, st + NARROW_W_BYTES, wave, lane);
-            stage_tile(p.ap, p.kpad, p0 + 128, p.rows - 1, ks * KS, st + NARROW_W_BYTES + TILE_BYTES, wave, lane);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < PJ; ++j) {
+                    const int piece = j * NW + wave;
+                    const int r = piece * 8 + (lane >> 3);
+                    const int c = (lane & 7) ^ ((r >> 1) & 7);
+                    int64_t gr = p0 + t * 128 + r;
+                    gr = gr > p.rows - 1 ? p.rows - 1 : gr;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(p.ap + gr * p.kpad + ks * KS + c * 4),
+                                                     (lptr_t)(st + NARROW_W_BYTES + t * TILE_BYTES + piece * 1024), 16, 0, 0);
+                }
         } else {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int piece = j * 4 + wave;
+                for (int j = 0; j < PJ; ++j) {
+                    const int piece = j * NW + wave;
                     const int r = piece * 8 + (lane >> 3);
                     const int c = (lane & 7) ^ ((r >> 1) & 7);
                     const unsigned tv = tab[ks * (KS / 4) + c];
@@ -270,68 +281,93 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
                 }
         }
     };
-    // Persistent over the tile list (the launcher starts at most two workgroups per CU): the last K-step of a tile stages the
-    // first K-step of the workgroup's next tile, so a tile does not open with the table / pixel decode and an exposed first
-    // stage.  Measured gain: 1 % on an HRNet pass (52.7 vs 53.3 ms, VSC_CONV_PERSIST=0) -- the kernel is bound inside its K loop
-    // (18 -> 18 at 224 x 224: 195 us against 63 us of MFMA issue; two LDS stages with vmcnt(0) + barrier per 32-float K-step).
+    // Persistent over the tile list, with the operand stream running STAGES - 1 K-steps AHEAD of the MFMAs and straight across
+    // tile boundaries (a staging cursor of its own): with two stages and a full vmcnt(0) + barrier per 32-float K-step a wave
+    // spent ~11 k cycles per K-step for 2 k cycles of MFMA issue (18 -> 18 at 224 x 224: 195 us against 63 us); three stages
+    // keep two K-steps of loads in flight behind the one being multiplied (counted vmcnt: one stage = 9 loads per wave).
     const int nks = p.kpad / KS;
     const int64_t ntiles = p.tiles_p * p.tiles_c;
     // XCD-aware order: virtual tile vt runs on XCD vt % 8 (gridDim is a multiple of 8 or the whole tile list); xcd_remap gives every
     // XCD a contiguous range of pixel tiles, so the rows a 3 x 3 tile shares with its neighbours are fetched into ONE L2
-    int64_t vt = blockIdx.x;
-    if (vt >= ntiles) return;
+    if ((int64_t)blockIdx.x >= ntiles) return;
     const bool remap = ntiles < (1ll << 31) && !p.no_remap;
-    int64_t tile = remap ? xcd_remap((int)vt, (int)ntiles) : vt;
-    int64_t c0 = (tile % p.tiles_c) * NARROW_C, p0 = (tile / p.tiles_c) * NARROW_P;
-    Rows rw;
-    if (IMPLICIT) decode(p0, rw);
-    stage(0, lds, c0, p0, rw);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto origin = [&](int64_t vt, int64_t &c0, int64_t &p0) {
+        const int64_t tile = remap ? (int64_t)xcd_remap((int)vt, (int)ntiles) : vt;
+        c0 = (tile % p.tiles_c) * NARROW_C;
+        p0 = (tile / p.tiles_c) * NARROW_P;
+    };
+    // staging cursor
+    int64_t s_vt = blockIdx.x, s_c0, s_p0;
+    int s_ks = 0, s_buf = 0;
+    bool s_valid = true;
+    Rows s_rw;
+    origin(s_vt, s_c0, s_p0);
+    if (IMPLICIT) decode(s_p0, s_rw);
+    auto stage_next = [&]() {   // workgroup-uniform
+        stage(s_ks, lds + s_buf * NARROW_STAGE, s_c0, s_p0, s_rw);
+        s_buf = s_buf + 1 == STAGES ? 0 : s_buf + 1;
+        if (++s_ks == nks) {
+            s_ks = 0;
+            s_vt += gridDim.x;
+            s_valid = s_vt < ntiles;
+            if (s_valid) {
+                origin(s_vt, s_c0, s_p0);
+                if (IMPLICIT) decode(s_p0, s_rw);
+            }
+        }
+    };
+    int beyond = -1;   // stages issued beyond the one being multiplied
+#pragma unroll
+    for (int i = 0; i < STAGES - 1; ++i)
+        if (s_valid) {
+            stage_next();
+            ++beyond;
+        }
+    if (STAGES == 3 && NW == 4 && beyond == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
-    for (;;) {
-        const int64_t vnext = vt + gridDim.x;
-        const bool more = vnext < ntiles;
-        const int64_t next = more ? (remap ? (int64_t)xcd_remap((int)vnext, (int)ntiles) : vnext) : 0;
-        const int64_t nc0 = more ? (next % p.tiles_c) * NARROW_C : 0, np0 = more ? (next / p.tiles_c) * NARROW_P : 0;
-        f32x16_t acc[2];
+    for (int64_t vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
+        int64_t c0, p0;
+        origin(vt, c0, p0);
+        f32x16_t acc[8 / NW];
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 8 / NW; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
         for (int ks = 0; ks < nks; ++ks) {
-            {
-                if (ks + 1 < nks) {
-                    stage(ks + 1, lds + (cur ^ 1) * NARROW_STAGE, c0, p0, rw);
-                } else if (more) {
-                    Rows nrw;
-                    if (IMPLICIT) decode(np0, nrw);
-                    stage(0, lds + (cur ^ 1) * NARROW_STAGE, nc0, np0, nrw);
-                    if (IMPLICIT) rw = nrw;   // this tile's rows are not staged again
-                }
+            if (s_valid) {
+                stage_next();
+                ++beyond;
             }
             const char *wt = lds + cur * NARROW_STAGE;
-            const char *pt = wt + NARROW_W_BYTES + (wave >> 1) * TILE_BYTES;   // waves 0,1 -> P0, waves 2,3 -> P1
-            const int prow = (wave & 1) * 64;
+            constexpr int NB = 8 / NW;                                   // 32-pixel accumulators per wave
+            constexpr int WPT = NW / 2;                                  // waves per 128-pixel tile
+            const char *pt = wt + NARROW_W_BYTES + (wave / WPT) * TILE_BYTES;
+            const int prow = (wave % WPT) * (32 * NB);
 #pragma unroll
             for (int pr = 0; pr < 4; ++pr) {
                 const f32x4_t af = lds_frag(wt, l31, 2 * pr + hi);
-                f32x4_t bf[2];
+                f32x4_t bf[NB];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) bf[b] = lds_frag(pt, prow + b * 32 + l31, 2 * pr + hi);
+                for (int b = 0; b < NB; ++b) bf[b] = lds_frag(pt, prow + b * 32 + l31, 2 * pr + hi);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[b][t], acc[b], 0, 0, 0);
+                    for (int b = 0; b < NB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[b][t], acc[b], 0, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the next stage must have landed; the ones behind it may stay in flight (loads complete in order, and the epilogue's
+            // stores, which sit in the same queue, only make the count more conservative)
+            if (STAGES == 3 && NW == 4 && beyond == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            cur ^= 1;
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
+            --beyond;
         }
-        // acc[b][reg] = <w[c0 + 8*(reg>>2) + 4*hi + (reg&3)], patch[p0 + wave*64 + b*32 + l31]>
+        // acc[b][reg] = <w[c0 + 8*(reg>>2) + 4*hi + (reg&3)], patch[p0 + wave*(256/NW) + b*32 + l31]>
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int64_t pix = p0 + wave * 64 + b * 32 + l31;
+        for (int b = 0; b < 8 / NW; ++b) {
+            const int64_t pix = p0 + wave * (256 / NW) + b * 32 + l31;
             if (pix >= p.rows) continue;
             float *orow = p.out + pix * p.ldo;
             const float *rrow = p.res ? p.res + pix * p.ldr : nullptr;
@@ -358,11 +394,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_narrow_kernel(ConvGemmArgs p
                 }
             }
         }
-        if (!more) break;
-        vt = vnext;
-        tile = next;
-        c0 = nc0;
-        p0 = np0;
     }
 }
 
@@ -615,13 +646,18 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     if (const char *e = getenv("VSC_CONV_REMAP")) a.no_remap = e[0] == '0';
     static int cus_of[16] = {};
     if (!cus_of[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev));
-    const int64_t resident = 2ll * cus_of[dev];   // two workgroups of the narrow kernel per CU (LDS)
     const char *pe = getenv("VSC_CONV_PERSIST");   // diagnostic: 0 = one tile per workgroup
+    const char *se = getenv("VSC_CONV_STAGES");    // diagnostic: 3 = three LDS stages, one workgroup per CU
+    const char *we = getenv("VSC_CONV_WAVES");     // diagnostic: 4 = four waves per workgroup
+    const int stages = se && se[0] == '3' ? 3 : 2;
+    const int nw = we && we[0] == '4' ? 4 : 8;
+    const int64_t resident = (stages == 2 ? 2ll : 1ll) * cus_of[dev];   // 76 KiB (2 stages) / 112 KiB (3 stages) of LDS per workgroup
     const unsigned ngrid = (unsigned)((pe && pe[0] == '0') || tiles_p * tiles_c < resident ? tiles_p * tiles_c : resident);
-    if (implicit) {
-        hipLaunchKernelGGL(conv_gemm_narrow_kernel<true>, dim3(ngrid), dim3(256), 0, stream, a);
-    } else if (narrow) {
-        hipLaunchKernelGGL(conv_gemm_narrow_kernel<false>, dim3(ngrid), dim3(256), 0, stream, a);
+    if (narrow) {
+#define VSC_NARROW(I, S, W) hipLaunchKernelGGL((conv_gemm_narrow_kernel<I, S, W>), dim3(ngrid), dim3(W * 64), 0, stream, a)
+        if (implicit) { if (stages == 3) VSC_NARROW(true, 3, 4); else if (nw == 4) VSC_NARROW(true, 2, 4); else VSC_NARROW(true, 2, 8); }
+        else { if (stages == 3) VSC_NARROW(false, 3, 4); else if (nw == 4) VSC_NARROW(false, 2, 4); else VSC_NARROW(false, 2, 8); }
+#undef VSC_NARROW
     } else {
         hipLaunchKernelGGL(conv_gemm_kernel, dim3((unsigned)(tiles_p * tiles_c)), dim3(256), 0, stream, a);
     }
