@@ -1,0 +1,28 @@
+"""N-group width of the persistent GEMM's tile order (VSC_GEMM_GROUP_N) on the encoder's four GEMMs, fused epilogues."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
+import torch
+from vsc_hip import _lib, ops
+dev = torch.device("cuda:0")
+M = 332 * 197
+def timeit(fn, it=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / it
+for name, m, n, k, epi in [("qkv", M, 2304, 768, _lib.EPI_BF16), ("proj", M, 768, 768, _lib.EPI_RESADD_F32),
+                           ("fc1", M, 3072, 768, _lib.EPI_GELU_BF16), ("fc2", M, 768, 3072, _lib.EPI_RESADD_F32)]:
+    a = torch.randn(m, k, device=dev).to(torch.bfloat16)
+    w = (torch.randn(n, k, device=dev) * 0.05).to(torch.bfloat16)
+    b = torch.randn(n, device=dev)
+    x = torch.randn(m, n, device=dev) if epi == _lib.EPI_RESADD_F32 else None
+    res = {}
+    for rnd in range(3):
+        for g in ("1", "2", "3", "4", "6", "12"):
+            os.environ["VSC_GEMM_GROUP_N"] = g
+            res.setdefault(g, []).append(timeit(lambda: ops.gemm_bf16(a, w, b, epilogue=epi, aux=x, out=x)))
+    os.environ.pop("VSC_GEMM_GROUP_N")
+    print(f"{name:5s}", "  ".join(f"[G={g}] {sorted(t)[1]:6.1f}" for g, t in res.items()), flush=True)

@@ -743,7 +743,9 @@ int launch_v3(GemmArgs p, hipStream_t stream) {
     // N-group width (tile order): groups of 4 N-tiles whatever K is.  Swept on the ViT shapes with this loop (G = 1..12,
     // gpurun_out/gemm_ab_groups.txt -> profiles/r02_gemm_ab_groups.txt): 4 is fastest for qkv / fc1, equal for the
     // N = 768 GEMMs (3 N-tiles: one group), and the L2-capacity rule of v2 picked 1 at K = 8192 (1186 vs 1561 TF/s).
-    int g = 4;
+    // groups of 4 N-tiles; of 3 where that divides the row of tiles and 4 does not (qkv: 9 = 3 + 3 + 3 instead of 4 + 4 + 1:
+    // 204 -> 199.5 us on the persistent kernel, tools/micro/gemm_v4_groups.py)
+    int g = (p.tiles_n % 4 != 0 && p.tiles_n % 3 == 0) ? 3 : 4;
     if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
     p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
     p.skew = 0;
@@ -976,7 +978,9 @@ int launch_v4(GemmArgs p, int cus, hipStream_t stream) {
         VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         if (dev < 16) attr_set[dev] = true;
     }
-    int g = 4;
+    // groups of 4 N-tiles; of 3 where that divides the row of tiles and 4 does not (qkv: 9 = 3 + 3 + 3 instead of 4 + 4 + 1:
+    // 204 -> 199.5 us on the persistent kernel, tools/micro/gemm_v4_groups.py)
+    int g = (p.tiles_n % 4 != 0 && p.tiles_n % 3 == 0) ? 3 : 4;
     if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
     p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
     p.skew = 0;
