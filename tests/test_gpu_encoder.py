@@ -78,6 +78,22 @@ def test_encoder_vs_oracle_fresh_inputs(dev):
     assert ((out * ref).sum(1) > 0.9999).all()
 
 
+def test_encoder_wide_model_vs_oracle(dev):
+    """Width 1280 (ViT-H-like, two layers): the final LayerNorm + GeM takes its 8-waves-per-frame variant (width > 1024), the
+    head reads 1280 inputs per output, K = 1280 / 5120 GEMMs run the one-tile kernel; 11 frames = three head groups, ragged."""
+    from dataclasses import replace
+    from oracle import vit_oracle
+    from vsc_hip.encoder import HipEncoder
+    cfg = replace(get_config("tiny"), name="wide", width=1280, heads=20, mlp_dim=5120, out_dim=512)
+    w = synth.encoder_weights(31, cfg)
+    enc = HipEncoder(cfg, w, max_batch=4, l2_normalize=True)
+    x = torch.from_numpy(synth.frames(32, 11, cfg))
+    with torch.no_grad():
+        ref = vit_oracle.descriptors({k: torch.from_numpy(v) for k, v in w.items()}, cfg, x).numpy()
+    out = enc(x.to(dev)).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=DESC_L2_ATOL)
+
+
 def test_encoder_rejects_wrong_input(dev):
     from vsc_hip import _lib
     cfg, w, enc = _encoder("tiny", 3, max_batch=2)
