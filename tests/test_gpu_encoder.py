@@ -187,3 +187,28 @@ def test_uint8_frames_give_bit_identical_descriptors(dev, preset, mean, std):
     assert np.array_equal(a, b)
     with pytest.raises(ValueError):
         enc(u8.permute(0, 3, 1, 2).contiguous().to(dev))   # uint8 must be HWC
+
+
+def test_encoder_in_the_benchmarked_configuration_vs_oracle(dev):
+    """The configuration bench.py times -- 332-frame chunks (256 row tiles of 256 -> persistent gemm_bf16_v4, skewed
+    attention residents), two lanes -- on 700 frames (332 + 332 + a ragged 36-frame chunk): sampled frames against the
+    fp32 oracle at the descriptor tolerance, and every frame against the max_batch = 8 path (one-tile kernels, one lane),
+    which the golden vectors hold.  infer/src/extractor.py:23 runs the same model whatever the batch."""
+    from oracle import vit_oracle
+    from vsc_hip.encoder import HipEncoder
+    cfg, w, big = _encoder("vit_b16_224", 21, max_batch=332, l2_normalize=True, lanes=2)
+    small = HipEncoder(cfg, w, max_batch=8, l2_normalize=True, lanes=1)
+    n = 700
+    x = torch.from_numpy(synth.frames(23, n, cfg))
+    xd = x.to(dev)
+    out_big = big(xd).cpu().numpy()
+    out_small = small(xd).cpu().numpy()
+    assert np.isfinite(out_big).all()
+    assert np.abs(out_big - out_small).max() < 2e-4
+    sample = [0, 1, 331, 332, 500, 663, 664, 699]        # first / last rows of each chunk, both lanes, the ragged chunk
+    with torch.no_grad():
+        ref = vit_oracle.descriptors({k: torch.from_numpy(v) for k, v in w.items()}, cfg, x[sample]).numpy()
+    np.testing.assert_allclose(out_big[sample], ref, rtol=0, atol=DESC_L2_ATOL)
+    assert ((out_big[sample] * ref).sum(1) > 0.9999).all()
+    # a second call on the same encoder (workspaces and lanes reused) returns the same bits
+    assert np.array_equal(big(xd).cpu().numpy(), out_big)

@@ -134,6 +134,107 @@ def test_knn_auto_path_and_full_size_properties(dev):
             assert sorted(back[row, tie]) == sorted(I[row, tie]) or col == k - 1
 
 
+def _device_bank(dev, seed, n, d=512):
+    """L2-normalised random bank made on the GPU (a 1M x 512 bank takes a minute through tools/synth.py on the host); the
+    oracle gets the same bits back through a device -> host copy."""
+    from vsc_hip import ops
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randn(n, d, generator=g, device=dev)
+    ops.l2_normalize_(x)
+    return x
+
+
+def test_knn_in_the_benchmarked_regime_single_split_many_items_per_workgroup(dev):
+    """The regime bench.py's 1M x 1M search runs in: nq >= 65536 -> one reference split, and each of the 256 persistent
+    workgroups walks several (query block) work items back to back (lists, thresholds and LDS counters re-initialised per
+    item).  262 221 queries = 1025 query blocks (the last one 77 rows): 64 queries spread over the first, middle and last
+    work items of several workgroups against knn_oracle, bit for bit.  Replaces faiss IndexFlat.search,
+    infer/vsc/index.py:167-175."""
+    from oracle import knn_oracle
+    from vsc_hip import ops
+    nr, nq, k = 1_000_000, 262_221, 100
+    rt = _device_bank(dev, 5, nr)
+    qt = _device_bank(dev, 6, nq)
+    D, I = ops.knn_ip(qt, rt, k)
+    assert _last_path() == 2
+    # workgroup b owns query blocks b, b + 256, ...: block 0 / 512 / 1024 = first / third / last item of workgroup 0
+    blocks = [0, 255, 256, 511, 512, 700, 1023, 1024]
+    rows = np.concatenate([np.minimum(b * 256 + np.array([0, 1, 37, 76, 100, 128, 200, 255]), nq - 1) for b in blocks])
+    rows = np.unique(np.r_[rows, nq - 1])
+    r = rt.cpu().numpy()
+    Dr, Ir = knn_oracle.knn_ip(qt[torch.from_numpy(rows).to(dev)].cpu().numpy(), r, k)
+    Dh, Ih = D.cpu().numpy(), I.cpu().numpy()
+    assert np.array_equal(Ih[rows], Ir), f"ids differ at rows {rows[np.argwhere(Ih[rows] != Ir)[:5, 0]]}"
+    assert np.array_equal(Dh[rows].view(np.uint32), Dr.view(np.uint32))
+    # whole result: sorted, ids in range, no duplicate id within a row
+    assert (Dh[:, :-1] >= Dh[:, 1:]).all() and Ih.min() >= 0 and Ih.max() < nr
+    srt = np.sort(Ih[::997], axis=1)
+    assert (srt[:, 1:] != srt[:, :-1]).all()
+
+
+def test_knn_bank_beyond_one_buffer_descriptor(dev):
+    """A split is addressed through one buffer descriptor (32-bit extent): 8191 tiles = 2 096 896 rows of 512-d bf16.  With
+    nq >= 65 281 (256 query blocks -> one split wanted) and 2.2 M references the cap forces two splits (knn.hip,
+    max_tiles) -- the regime of BASELINE configs[3]'s 8M-row bank.  32 queries against the oracle bit for bit, among them
+    queries whose best matches sit on both sides of the split boundary."""
+    from oracle import knn_oracle
+    from vsc_hip import ops
+    nr, nq, k = 2_200_000, 65_600, 100
+    rt = _device_bank(dev, 7, nr)
+    qt = _device_bank(dev, 8, nq)
+    # plant near-duplicates of 4 queries just before and just after row 2 096 896 (the split boundary)
+    edge = 8191 * 256
+    planted = torch.tensor([edge - 3, edge - 1, edge, edge + 2, nr - 1], device=dev)
+    qt[:4] = rt[planted[:4]]
+    qt[nq - 1] = rt[nr - 1]
+    D, I = ops.knn_ip(qt, rt, k)
+    assert _last_path() == 2
+    rows = np.unique(np.r_[0:8, 255:259, 32768:32772, 65279:65283, 65535:65539, nq - 8:nq])
+    r = rt.cpu().numpy()
+    Dr, Ir = knn_oracle.knn_ip(qt[torch.from_numpy(rows).to(dev)].cpu().numpy(), r, k)
+    Dh, Ih = D.cpu().numpy(), I.cpu().numpy()
+    assert np.array_equal(Ih[rows], Ir) and np.array_equal(Dh[rows].view(np.uint32), Dr.view(np.uint32))
+    assert (Ih[:4, 0] == planted[:4].cpu().numpy()).all() and Ih[nq - 1, 0] == nr - 1
+    assert (Dh[:, :-1] >= Dh[:, 1:]).all() and Ih.min() >= 0 and Ih.max() < nr
+
+
+@pytest.mark.parametrize("scaled", [False, True])
+def test_prefilter_error_bound_is_measured_not_assumed(dev, scaled):
+    """The exactness of the pre-filter rests on |s~ - s| <= eps_q for every pair (knn.hip, header of the sweep), which in
+    turn assumes that one v_mfma_f32_16x16x32_bf16 accumulation stays within d 2^-23 |q||r| of the real sum.  Measure it:
+    s~ = the bf16 MFMA scores of the same main loop (mainloop64.h: vsc_gemm_bf16 with the plain fp32 write-out on the RNE
+    bf16 copies the pack kernel makes), s = the exact fp32 chain (vsc_pair_similarity_f32), over all 4096 x 1M pairs;
+    eps_q as the kernel computes it (eps2 / 2).  The worst ratio is reported and must stay below 1."""
+    from vsc_hip import _lib, ops
+    nr, nq, d = 1_000_000, 4096, 512
+    r = _device_bank(dev, 11, nr)
+    q = _device_bank(dev, 12, nq)
+    if scaled:   # un-normalised rows, norms over three decades
+        g = torch.Generator(device=dev).manual_seed(13)
+        r *= torch.exp(torch.rand(nr, 1, generator=g, device=dev) * 6.9 - 3.45)
+        q *= torch.exp(torch.rand(nq, 1, generator=g, device=dev) * 6.9 - 3.45)
+    qb, rb = q.to(torch.bfloat16), r.to(torch.bfloat16)            # RNE, like pack_bf16x2
+    dq, dr = q - qb.float(), r - rb.float()
+    n64 = lambda t: t.double().norm(dim=1)
+    rmax, drmax = n64(r).max(), n64(dr).max()
+    eps = (1.02 * (n64(dq) * rmax + n64(qb.float()) * drmax) + d * (2.0 ** -22 + 2.0 ** -24) * n64(q) * rmax).float()
+    worst, worst_abs = 0.0, 0.0
+    chunk = 65536
+    for c0 in range(0, nr, chunk):
+        rows = min(chunk, nr - c0)
+        approx = ops.gemm_bf16(qb, rb[c0:c0 + rows], epilogue=_lib.EPI_F32)
+        exact, _ = ops.pair_similarity(q, r, [[0, nq, c0, rows]])
+        err = (approx - exact.view(nq, rows)).abs()
+        worst = max(worst, float((err / eps[:, None]).max()))
+        worst_abs = max(worst_abs, float(err.max()))
+        del approx, exact, err
+    print(f"pre-filter bound: max |s~ - s| / eps_q = {worst:.4f} (max |s~ - s| = {worst_abs:.3e}) over {nq} x {nr} pairs, scaled={scaled}")
+    assert 0.0 < worst < 1.0
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/prefilter_bound_{'scaled' if scaled else 'unit'}.txt", "w") as f:
+        f.write(f"max |s~ - s| / eps_q = {worst:.6f}; max |s~ - s| = {worst_abs:.6e}; nq={nq} nr={nr} d={d} scaled={scaled}\n")
+
+
 def test_knn_ties_rank_lower_index_first(dev):
     r = synth.descriptor_bank(7, 3000, 64)
     r[1500:1600] = r[10]          # 100 exact duplicates of row 10, far away in the bank

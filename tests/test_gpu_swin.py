@@ -152,3 +152,26 @@ def test_swin_uint8_frames_bit_identical(dev):
     u8 = torch.from_numpy((synth.uniform(19, (5, cfg.image_size, cfg.image_size, 3), 0.0, 256.0)).astype(np.uint8))
     x = (u8.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5
     assert np.array_equal(enc(u8.to(dev)).cpu().numpy(), enc(x.to(dev)).cpu().numpy())
+
+
+def test_swin_encoder_in_the_benchmarked_configuration_vs_oracle(dev):
+    """Swin-V2-B as bench.py runs it -- 256-frame chunks on two lanes (persistent GEMMs, full gemm_ln grids) -- on 520
+    frames (256 + 256 + a ragged 8-frame chunk): sampled frames against the fp32 oracle, every frame against the
+    max_batch = 4 path that the golden vectors hold."""
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    cfg = get_swin_config("swinv2_base_256")
+    w = synth.swin_weights(9, cfg)
+    n = 520
+    x = torch.from_numpy(synth.swin_frames(10, n, cfg))
+    xd = x.to(dev)
+    big = SwinHipEncoder(cfg, w, max_batch=256, l2_normalize=True)
+    small = SwinHipEncoder(cfg, w, max_batch=4, l2_normalize=True)
+    out_big = big(xd).cpu().numpy()
+    out_small = small(xd).cpu().numpy()
+    assert np.isfinite(out_big).all()
+    assert np.abs(out_big - out_small).max() < 2e-4
+    sample = [0, 255, 256, 400, 511, 512, 519]
+    with torch.no_grad():
+        ref = swin_oracle.descriptors({k: torch.from_numpy(v) for k, v in w.items()}, cfg, x[sample]).numpy()
+    np.testing.assert_allclose(out_big[sample], ref, rtol=0, atol=1e-3)
+    assert np.array_equal(big(xd).cpu().numpy(), out_big)
