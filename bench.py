@@ -22,7 +22,10 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 own roofline (HIP events around the phases of the call) and its PMC traffic.  With N > 1 ranks: the sharded form
                 (each rank holds nr / N references, one RCCL all_gather assembles the bank, every rank sweeps its
                 own nq queries; weak scaling, all_gather inside the timed region).
-  swin          secondary metric: Swin-V2-B 256 encode (vsc_swin_forward), frames/s.
+  swin          secondary metric: Swin-V2-B 256 encode (vsc_swin_forward), frames/s, with per-kernel-class HIP-event times
+                (kernels{}) and the roofline of its GEMM launches (gemm_ln_kernel + gemm_bf16_v4 / v3 / v2).
+  matching      secondary: the matching track's fp32 networks (pair classifier, HRNet refinement net), maps/s and the
+                fraction of the fp32 MFMA peak.
 """
 import argparse
 import json
@@ -111,6 +114,7 @@ def parse():
     ap.add_argument("--search-k", type=int, default=100)
     ap.add_argument("--search-steps", type=int, default=1)
     ap.add_argument("--no-swin", action="store_true")
+    ap.add_argument("--no-matching", action="store_true")
     ap.add_argument("--force-sharded-search", action="store_true",
                     help="run the N > 1 search leg (RCCL all_gather + sweep) even with one rank; needs torchrun's env")
     ap.add_argument("--swin-batch", type=int, default=256)
@@ -331,16 +335,94 @@ def bench_swin(dev, args):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     assert torch.isfinite(out).all()
+    # per-launch HIP events (vsc_swin_set_profiling): the chunks run back to back on one stream, every kernel alone
+    psteps = 2
+    enc.set_profiling(True)
+    for _ in range(psteps):
+        enc(x)
+    prof = enc.profile()
+    enc.set_profiling(False)
     enc.close()
+    kernels, gemm_ms, gemm_flop, all_ms = {}, 0.0, 0.0, 0.0
+    frames_prof = b * psteps
+    for name, (ms, cnt) in prof.items():
+        flop, is_gemm = 0.0, False
+        if name == "patch_embed":
+            flop, is_gemm = 2.0 * (cfg.image_size // cfg.patch_size) ** 2 * cfg.embed_dim * 64, True
+        elif name[0] == "s" and "." in name:
+            st, kind = int(name[1]), name.split(".")[1]
+            C, R = cfg.dim(st), cfg.resolution(st)
+            T, N = R * R, min(cfg.window_size, R) ** 2
+            per_block = {"qkv": 2.0 * T * 3 * C * C, "proj_ln": 2.0 * T * C * C, "fc1": 2.0 * T * 4 * C * C, "fc2_ln": 2.0 * T * 4 * C * C,
+                         "attention": 4.0 * T * N * C}.get(kind)
+            if kind == "merge":
+                flop = 2.0 * (T // 4) * (2 * C) * (4 * C)
+            else:
+                flop = per_block * cfg.depths[st]
+            is_gemm = kind != "attention"
+        tf = flop * frames_prof / (ms * 1e-3) / 1e12 if flop and ms else None
+        kernels[name] = {"ms_per_step": round(ms / psteps, 4), "launches_per_step": cnt // psteps, "avg_launch_us": round(ms / cnt * 1e3, 2)}
+        if tf:
+            kernels[name]["tflops"] = round(tf, 1)
+        all_ms += ms
+        if is_gemm:
+            gemm_ms += ms
+            gemm_flop += flop * frames_prof
+    gemm_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms else 0.0
     return {"metric": "frames/s (Swin-V2-B 256x256 window-16 encode -> L2-normalised 512-d descriptors)",
             "value": round(b / dt, 1), "unit": "frames/s", "frames_per_step": b, "encoder_chunk": args.swin_batch, "lanes": 2,
             "ms_per_step": round(dt * 1e3, 3),
             "dtype": "bf16", "gflop_per_frame": round(cfg.flops_per_frame() / 1e9, 2),
             "model_tflops": round(cfg.flops_per_frame() * b / dt / 1e12, 1),
-            "roofline": {"bound": "mfma", "kernel": "whole Swin-V2-B step (GEMMs 77 % of it: gemm_bf16_v4 / v3 / v2 / gemm_ln kernels)",
-                         "achieved": round(cfg.flops_per_frame() * b / dt / 1e12, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(cfg.flops_per_frame() * b / dt / 1e12 / BF16_PEAK_TFLOPS, 4), "traffic": None,
-                         "note": "model FLOPs / wall time of the step (no per-launch events in the Swin encoder)"}}
+            "roofline": {"bound": "mfma", "kernel": "all GEMM launches of the Swin-V2-B step (gemm_ln_kernel: proj / fc2 / merge / patch embedding with their "
+                                                    "LayerNorms; gemm_bf16_v4 / v3 / v2: qkv, fc1)",
+                         "achieved": round(gemm_tf, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(gemm_tf / BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "gemm_ms_per_step": round(gemm_ms / psteps, 3), "all_kernels_ms_per_step": round(all_ms / psteps, 3),
+                         "whole_model_frac": round(cfg.flops_per_frame() * b / dt / 1e12 / BF16_PEAK_TFLOPS, 4),
+                         "note": "achieved = sum 2 M N K of the GEMM launches / sum of their HIP-event durations, taken in a separate loop of "
+                                 f"{psteps} steps on one stream (vsc_swin_set_profiling); the headline loop runs the two chunks on two lanes"},
+            "kernels": kernels}
+
+
+def bench_matching(dev, args):
+    """Secondary: the matching track's two fp32 networks (infer_matching.py:158-204) at the reference's batch sizes --
+    mobilenetv3_small_100 pair classifier on 2048 x 3 x 160 x 160 similarity maps, hrnet_w18 refinement net on
+    16 x 3 x 224 x 224 -- synthetic timm-named weights (tests/cnn_synth.py).  fp32 MFMA roof: 157.3 TF/s."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cnn_synth
+    from vsc_hip import cnn
+
+    def run(model, x, iters):
+        cnn.FLOPS = [0.0]
+        model(x)
+        flop = cnn.FLOPS[0]
+        cnn.FLOPS = None
+        model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = model(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        assert torch.isfinite(out).all()
+        return dt, flop
+
+    cls = cnn.MobileNetV3SmallHip(cnn_synth.mobilenetv3_small_state(1), dev)
+    xc = cnn_synth.similarity_maps(2, 8, 160, 160).to(dev).repeat(256, 1, 1, 1)
+    dtc, fc = run(cls, xc, 5)
+    ref = cnn.HRNetRefineHip(cnn_synth.hrnet_refine_state(3), dev)
+    xr = cnn_synth.similarity_maps(4, 16, 224, 224).to(dev)
+    dtr, fr = run(ref, xr, 5)
+    return {"dtype": "f32", "peak_tflops": F32_MFMA_PEAK_TFLOPS,
+            "classifier": {"model": "mobilenetv3_small_100, 2 classes", "batch": list(xc.shape), "ms": round(dtc * 1e3, 2),
+                           "maps_per_s": round(xc.shape[0] / dtc, 0), "gflop_per_map": round(fc / xc.shape[0] / 1e9, 4),
+                           "tflops": round(fc / dtc / 1e12, 2), "frac_of_f32_mfma_peak": round(fc / dtc / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},
+            "refiner": {"model": "hrnet_w18 features + fuse head", "batch": list(xr.shape), "ms_per_pass": round(dtr * 1e3, 2),
+                        "maps_per_s": round(xr.shape[0] / dtr, 1), "gflop_per_map": round(fr / xr.shape[0] / 1e9, 3),
+                        "tflops": round(fr / dtr / 1e12, 2), "frac_of_f32_mfma_peak": round(fr / dtr / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},
+            "note": "whole-network wall time per batch, inputs resident in HBM; FLOPs = 2 x MACs of every convolution call "
+                    "(depthwise included); parity of these networks is unpinned (DESIGN.md section 3)"}
 
 
 def main():
@@ -499,6 +581,9 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_swin and secondary:
             line["swin"] = bench_swin(dev, args)
+            torch.cuda.empty_cache()
+        if not args.no_matching and secondary:
+            line["matching"] = bench_matching(dev, args)
             torch.cuda.empty_cache()
         if not args.no_search and secondary:
             line["search"] = bench_search(dev, args)

@@ -37,6 +37,12 @@ const char *vsc_last_error(void);
 /* Number of visible HIP devices whose arch is gfx950; <0 on runtime failure. */
 int vsc_device_count(void);
 const char *vsc_version(void);
+/* Diagnostic / test switches (path forcing for the parity tests, A/B knobs of tools/micro).  Each switch VSC_<NAME> takes
+ * its initial value from the environment variable of the same name, read ONCE per process; after that it changes only
+ * through this call (name with or without the VSC_ prefix; value NULL or "" clears it).  No entry point reads the
+ * environment on its launch path.  Unknown names return VSC_ERR_INVALID.  Not a reference interface: the reference has no
+ * counterpart. */
+int vsc_set_option(const char *name, const char *value);
 
 /* ------------------------------------------------------------------------ *
  * Frame encoder: replaces `flat_features = model(flat_frames)` on the
@@ -148,6 +154,20 @@ int vsc_swin_forward_debug(vsc_swin *enc, const float *frames_dev, int64_t n, fl
                            float *tokens_dev, void *stream);
 int64_t vsc_swin_workspace_bytes(const vsc_swin *enc);
 
+/* Per-kernel-class timing for bench.py's Swin roofline, as vsc_encoder_set_profiling: when on, every launch of
+ * vsc_swin_forward is bracketed by HIP events on the stream it runs on, and the chunks of a call run back to back on the
+ * caller's stream (no lanes), so every kernel is timed alone.  Classes: patchify, patch embedding (GEMM + LayerNorm), then
+ * per stage s (0..3) at VSC_SWIN_PROF_STAGE0 + s * VSC_SWIN_PROF_PER_STAGE: qkv GEMM, window attention, proj GEMM with the
+ * res-post-norm LayerNorm, fc1 GEMM (+GELU), fc2 GEMM with its LayerNorm, patch merging (gather + reduction GEMM +
+ * LayerNorm); last the final LayerNorm + GeM + head.  vsc_swin_get_profile synchronises the device. */
+enum {
+    VSC_SWIN_PROF_PATCHIFY = 0, VSC_SWIN_PROF_PATCH_EMBED = 1, VSC_SWIN_PROF_POOL_HEAD = 2, VSC_SWIN_PROF_STAGE0 = 3,
+    VSC_SWIN_PROF_QKV = 0, VSC_SWIN_PROF_ATTENTION = 1, VSC_SWIN_PROF_PROJ_LN = 2, VSC_SWIN_PROF_FC1 = 3,
+    VSC_SWIN_PROF_FC2_LN = 4, VSC_SWIN_PROF_MERGE = 5, VSC_SWIN_PROF_PER_STAGE = 6, VSC_SWIN_PROF_CLASSES = 27
+};
+int vsc_swin_set_profiling(vsc_swin *enc, int32_t on);
+int vsc_swin_get_profile(vsc_swin *enc, double ms_out[VSC_SWIN_PROF_CLASSES], int64_t launches_out[VSC_SWIN_PROF_CLASSES]);
+
 /* ------------------------------------------------------------------------ *
  * Flat inner-product search: replaces faiss.IndexFlat(d, METRIC_INNER_PRODUCT)
  *   .search(x, k)        infer/vsc/index.py:167-175, infer/vsc/baseline/score_normalization.py:95,141,
@@ -159,16 +179,24 @@ int64_t vsc_swin_workspace_bytes(const vsc_swin *enc);
 
 /* q_dev [nq,d], r_dev [nr,d] float32 row-major, 1 <= d <= 4096, 1 <= k <= 1024.  out_scores_dev [nq,k] float32 descending, out_ids_dev [nq,k]
  * int64; slots beyond nr hold (-FLT_MAX, -1).  ref_id_offset is added to every
- * reported id (a shard of a larger bank).  Workspace is allocated internally and
- * cached on the calling thread's device. */
+ * reported id (a shard of a larger bank).
+ * Workspace: allocated internally, grow-only, cached per device (bf16 copies of both banks, candidate lists, partial
+ * results: ~7 GB after a 1M x 1M call); vsc_search_release_scratch() returns it.  One search call per device at a time.
+ * Host synchronisation: on the bf16 pre-filter path (nq * nr >= 2^24, nr >= 4096, k <= 512) the call waits for `stream`
+ * once, after the merge, to read the per-block fallback flags -- on return the results are complete; on the exact path
+ * (everything smaller) the call only enqueues. */
 int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d,
                    int32_t k, int64_t ref_id_offset, float *out_scores_dev,
                    int64_t *out_ids_dev, void *stream);
 
+/* Frees the search scratch (top-k, range search, video-pair maxima) of the current device after waiting for the device;
+ * returns the bytes released.  The next search call allocates again. */
+int64_t vsc_search_release_scratch(void);
+
 /* Diagnostic: which sweep the last vsc_knn_ip_f32 call of this process took -- 1 the exact fp32 MFMA sweep, 2 the
  * bf16 pre-filter sweep + exact re-scoring (large problems, k <= 512; results are bit-identical to 1; synchronises
  * `stream` once to read its fallback flag), 3 the pre-filter ran, but some 256-query blocks (a candidate band did not fit,
- * or non-finite operands) were redone on the exact sweep.  VSC_KNN_PATH=exact|bf16 in the environment forces a path. */
+ * or non-finite operands) were redone on the exact sweep.  vsc_set_option("VSC_KNN_PATH", "exact"|"bf16") forces a path. */
 int vsc_knn_last_path(void);
 
 /* Diagnostic (bench.py): with profiling on, every vsc_knn_ip_f32 call records HIP events on its stream around its phases;
@@ -310,7 +338,10 @@ int vsc_conv_packed_k(int32_t cin, int32_t kh, int32_t kw);
  * packed_dev [cout, vsc_conv_packed_k]: rows zero-padded to a multiple of 32 floats for the fp32 MFMA tiles; done once per layer. */
 int vsc_conv_pack_weight_f32(const float *w_dev, float *packed_dev, int32_t cout, int32_t k, void *stream);
 /* out[n, ho, wo, 0:cout] (row stride ldo) = act(conv2d(x[n, h, w, 0:cin] (row stride ldx), W) + bias [+ res[.., 0:cout]
- * (row stride ldr)]) -- torch.nn.functional.conv2d(stride, padding) + the fused tail of a BN/ReLU/residual block. */
+ * (row stride ldr)]) -- torch.nn.functional.conv2d(stride, padding) + the fused tail of a BN/ReLU/residual block.
+ * Layers that materialise their patch matrix share ONE grow-only scratch buffer per device: issue the convolutions of a
+ * device from one stream at a time (calls from several host threads are serialised on an internal mutex, their kernels
+ * are not ordered against each other). */
 int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t w, int32_t cin, int32_t ldx, const float *w_packed_dev,
                    const float *bias_dev, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
                    const float *res_dev, int32_t ldr, int32_t act, float *out_dev, int32_t ldo, void *stream);

@@ -69,6 +69,37 @@ def _worker8(rank, world_size, port, out_dir):
         dist.destroy_process_group()
 
 
+def _worker8_one_owner(rank, world_size, port, out_dir):
+    """Every rank's reference shard is EMPTY except rank 5's (one process encoded every reference video); queries on ranks 0
+    and 7 only.  The padded all_gather, the id numbering (position in rank order) and the result gather must still hold."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        refs = torch.from_numpy(synth.descriptor_bank(5, 77, 32))
+        qs = torch.from_numpy(synth.descriptor_bank(6, 9, 32))
+        mine = refs if rank == 5 else refs[:0]
+        bank, offsets = vdist.all_gather_rows(mine)
+        assert torch.equal(bank, refs) and offsets.tolist() == [0] * 6 + [77, 77, 77]
+        q_mine = qs[:4] if rank == 0 else (qs[4:] if rank == 7 else qs[:0])
+        D, I = vdist.sharded_knn(q_mine, mine, 6, knn=lambda q, r, k: _oracle_knn(q, r, k) if len(q) else
+                                 (torch.empty((0, k)), torch.empty((0, k), dtype=torch.int64)))
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "res8b.npz"), D=D.numpy(), I=I.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_world8_single_owner_of_the_bank(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker8_one_owner, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    got = np.load(tmp_path / "res8b.npz")
+    from oracle import knn_oracle
+    D, I = knn_oracle.knn_ip(synth.descriptor_bank(6, 9, 32), synth.descriptor_bank(5, 77, 32), 6)
+    assert np.array_equal(got["I"], I) and np.array_equal(got["D"], D)
+
+
 def test_sharded_search_world8_ragged_and_empty_shards(tmp_path):
     """BASELINE.json configs[3]'s host logic at the node's rank count: the bank all_gather with ragged and EMPTY shards
     (fewer videos than ranks) and the sharded search, on gloo."""

@@ -28,6 +28,13 @@ def test_bench_json_contract():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["value"] > 0 and abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01
     assert d["swin"]["value"] > 0 and d["search"]["value"] > 0 and d["search"]["roofline"]["bound"] == "mfma"
+    # Swin: per-kernel-class HIP-event times and the roofline of its GEMM launches
+    sw = d["swin"]
+    assert sw["roofline"]["bound"] == "mfma" and sw["roofline"]["achieved"] > 0 and "s2.fc1" in sw["kernels"] and "s0.proj_ln" in sw["kernels"]
+    assert sw["kernels"]["s2.qkv"]["launches_per_step"] == 36 and sw["kernels"]["s2.qkv"]["tflops"] > 0
+    # matching-track networks
+    mt = d["matching"]
+    assert mt["classifier"]["maps_per_s"] > 0 and mt["refiner"]["maps_per_s"] > 0 and 0 < mt["refiner"]["frac_of_f32_mfma_peak"] < 1
 
 
 def test_bench_stdout_is_one_line_with_a_process_group():
@@ -36,7 +43,7 @@ def test_bench_stdout_is_one_line_with_a_process_group():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded-search", "--steps", "2", "--warmup", "1",
            "--batch", "64", "--max-batch", "64", "--search-nq", "1024", "--search-nr", "50000", "--search-steps", "1",
-           "--no-swin", "--no-cpu-baseline"]
+           "--no-swin", "--no-matching", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip()]

@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import cnn_synth  # noqa: E402
+from vsc_hip import _lib as _vsc_lib
 
 pytestmark = pytest.mark.gpu
 
@@ -74,11 +75,11 @@ def test_conv2d_implicit_gather_equals_materialised_patches(dev, n, h, w, cin, c
     conv = cnn.Conv(sd, "c", None, stride, dev)
     outs = []
     for flag in ("0", "1"):
-        os.environ["VSC_CONV_IMPLICIT"] = flag
+        _vsc_lib.set_option("VSC_CONV_IMPLICIT", flag)
         try:
             outs.append(conv(x, act="relu").clone())
         finally:
-            os.environ.pop("VSC_CONV_IMPLICIT", None)
+            _vsc_lib.set_option("VSC_CONV_IMPLICIT", None)
     assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
     want = F.relu(F.conv2d(x.cpu().permute(0, 3, 1, 2), sd["c.weight"], sd["c.bias"], stride=stride, padding=k // 2))
     assert torch.allclose(outs[1].cpu().permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from tools import synth
+from vsc_hip import _lib as _vsc_lib
 
 pytestmark = pytest.mark.gpu
 
@@ -103,12 +104,12 @@ def test_gemm_persistent_kernel_equals_one_tile_per_workgroup(dev, epi, m, n, k)
     x = torch.randn(m, n, generator=g).to(dev) if epi == "resadd" else None
     outs = {}
     for v4 in ("0", "1", "1"):      # twice through v4: the second launch finds the ring / bias rows of the first in LDS
-        os.environ["VSC_GEMM_V4"] = v4
+        _vsc_lib.set_option("VSC_GEMM_V4", v4)
         try:
             xx = None if x is None else x.clone()
             outs[v4] = ops.gemm_bf16(a, w, b, epilogue=kind, aux=xx, out=xx).clone()
         finally:
-            os.environ.pop("VSC_GEMM_V4", None)
+            _vsc_lib.set_option("VSC_GEMM_V4", None)
         torch.cuda.synchronize()
         if v4 == "1":
             bits = torch.int32 if outs["0"].dtype == torch.float32 else torch.int16

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from tools import synth
+from vsc_hip import _lib as _vsc_lib
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +48,14 @@ def test_knn_bit_exact(dev, nq, nr, d, k):
         assert (I[:, nr:] == -1).all() and (D[:, nr:] == np.finfo(np.float32).min).all()
 
 
+@pytest.fixture
+def force_prefilter():
+    """VSC_KNN_PATH=bf16 for one test (vsc_set_option: the library reads its environment only once per process)."""
+    _vsc_lib.set_option("VSC_KNN_PATH", "bf16")
+    yield
+    _vsc_lib.set_option("VSC_KNN_PATH", None)
+
+
 def _last_path():
     from vsc_hip import _lib
     return _lib.require_device().vsc_knn_last_path()
@@ -56,10 +65,9 @@ def _last_path():
     (3, 5, 3, 2), (64, 1000, 512, 10), (130, 1001, 511, 7), (1, 70000, 512, 1), (257, 20000, 512, 100),
     (5, 40, 16, 64), (300, 3000, 64, 500), (700, 9000, 100, 257), (513, 4097, 512, 33),
 ])
-def test_knn_prefilter_path_bit_exact(dev, monkeypatch, nq, nr, d, k):
+def test_knn_prefilter_path_bit_exact(dev, force_prefilter, nq, nr, d, k):
     """The bf16 pre-filter sweep + exact re-scoring (VSC_KNN_PATH=bf16 forces it at every size) returns the same bits
     as the oracle's fp32 chain: scores as uint32 patterns, ids, tie order, ragged tiles, k > nr padding."""
-    monkeypatch.setenv("VSC_KNN_PATH", "bf16")
     q = synth.descriptor_bank(100 + nq, nq, d)
     r = synth.descriptor_bank(200 + nr, nr, d)
     D, I = _check(dev, q, r, k)
@@ -68,11 +76,10 @@ def test_knn_prefilter_path_bit_exact(dev, monkeypatch, nq, nr, d, k):
         assert (I[:, nr:] == -1).all() and (D[:, nr:] == np.finfo(np.float32).min).all()
 
 
-def test_knn_prefilter_unnormalised_ties_and_fallback(dev, monkeypatch):
+def test_knn_prefilter_unnormalised_ties_and_fallback(dev, force_prefilter):
     """Pre-filter path on inputs that stress its error bound and its lists: rows of very different norms, exact
     duplicates across the bank (ties -> lower id first), and a bank with thousands of near-duplicates of a query, whose
     candidate band cannot fit: the device flag must send the call to the exact sweep (path 3), result still exact."""
-    monkeypatch.setenv("VSC_KNN_PATH", "bf16")
     rng = np.random.RandomState(5)
     r = synth.descriptor_bank(31, 6000, 96) * rng.uniform(0.01, 30.0, size=(6000, 1)).astype(np.float32)
     q = synth.descriptor_bank(32, 70, 96) * rng.uniform(0.1, 5.0, size=(70, 1)).astype(np.float32)
@@ -316,13 +323,13 @@ def test_range_search_prefilter_path_equals_exact(dev, nq, nr, d, radius, expect
     qt, rt = torch.from_numpy(q).to(dev), torch.from_numpy(r).to(dev)
     out = {}
     for path in ("exact", "bf16"):
-        os.environ["VSC_RANGE_PATH"] = path
+        _vsc_lib.set_option("VSC_RANGE_PATH", path)
         try:
             out[path] = [t.cpu() for t in ops.range_search_ip(qt, rt, radius, ref_id_offset=7, capacity=16)]
             ran = _lib.require_device().vsc_range_search_last_path()
             count = ops.range_count_ip(qt, rt, radius)
         finally:
-            os.environ.pop("VSC_RANGE_PATH", None)
+            _vsc_lib.set_option("VSC_RANGE_PATH", None)
         assert ran == (1 if path == "exact" else expect)
         assert count == int(out[path][0][-1])
     assert torch.equal(out["exact"][0], out["bf16"][0]) and torch.equal(out["exact"][2], out["bf16"][2])

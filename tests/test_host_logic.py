@@ -341,3 +341,19 @@ def test_flat_l2_index_host_logic(cpu_sweep):
         idx.add(mk("R"))
         res = idx.search(mk("Q"), gk)
         assert res and all(x.query_id[1:] == x.ref_id[1:] for x in res)
+
+
+def test_matching_entry_derives_frames_per_video_from_timestamps():
+    """infer_matching.py without --query_frames: a multi-view query file (views repeat the timestamps) must give the frame
+    count, not the descriptor count (reference: vid_feature_len_map from extraction, infer_matching.py:155)."""
+    import infer_matching
+    from vsc.index import VideoFeature
+    ts = np.arange(7, dtype=np.float32)
+    one = VideoFeature(video_id="Q1", feature=np.zeros((7, 4), np.float32), timestamps=ts)
+    three = VideoFeature(video_id="Q2", feature=np.zeros((21, 4), np.float32), timestamps=np.tile(ts, 3))
+    spans = VideoFeature(video_id="Q3", feature=np.zeros((10, 4), np.float32),
+                         timestamps=np.tile(np.stack([np.arange(5.0), np.arange(5.0) + 1], 1), (2, 1)))
+    assert [infer_matching.frames_per_video(v) for v in (one, three, spans)] == [7, 7, 5]
+    bad = VideoFeature(video_id="Q4", feature=np.zeros((5, 4), np.float32), timestamps=np.array([0, 1, 0, 1, 2], np.float32))
+    with pytest.raises(ValueError, match="query_frames"):
+        infer_matching.frames_per_video(bad)

@@ -12,6 +12,7 @@ from oracle import knn_oracle  # noqa: E402
 
 from src import matching  # noqa: E402
 from tools import synth  # noqa: E402
+from vsc_hip import _lib as _vsc_lib
 
 
 def _oracle_pairs(q_bank, r_bank, pairs):
@@ -257,12 +258,12 @@ def test_video_pair_max_prefilter_path_equals_exact(nr, frac, expect_path):
     thr = float((q[3] * r[77]).sum()) if frac < 0.01 else thr    # sparse case: sit the threshold exactly on one pair's score
     outs = {}
     for path in ("exact", "bf16"):
-        os.environ["VSC_PAIRMAX_PATH"] = path
+        _vsc_lib.set_option("VSC_PAIRMAX_PATH", path)
         try:
             outs[path] = [t.cpu() for t in ops.video_pair_max(q.cuda(), qv.cuda(), nqv, r.cuda(), rv.cuda(), nrv, thr)]
             ran = _lib.require_device().vsc_video_pair_max_last_path()
         finally:
-            os.environ.pop("VSC_PAIRMAX_PATH", None)
+            _vsc_lib.set_option("VSC_PAIRMAX_PATH", None)
         assert ran == (1 if path == "exact" else expect_path)
     for a, b in zip(outs["exact"], outs["bf16"]):
         assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, b.view(torch.int32) if b.dtype == torch.float32 else b)

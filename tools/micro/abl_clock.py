@@ -2,6 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "vsc22-submission_amd"))
 import torch
 from vsc_hip import _lib, ops
+from vsc_hip import _lib as _vsc_lib
 lib = _lib.require_device()
 dev = torch.device("cuda:0")
 out = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -27,10 +28,10 @@ a = torch.randn(8192, 4096, device=dev).to(torch.bfloat16)
 w = (torch.randn(8192, 4096, device=dev) * 0.05).to(torch.bfloat16)
 o = torch.empty(8192, 8192, device=dev, dtype=torch.bfloat16)
 for abl, label in ((0, "ours: full"), (1, "ours: no loop DMA"), (2, "ours: no MFMA"), (3, "ours: frag reads only"), (4, "ours: no epilogue stores"), (8, "ours: no frag reads (const ops)")):
-    os.environ["VSC_GEMM_ABL"] = str(abl)
+    _vsc_lib.set_option("VSC_GEMM_ABL", str(abl))
     clock(lambda: ops.gemm_bf16(a, w, None), label, 60)
-os.environ["VSC_GEMM_ABL"] = "0"
+_vsc_lib.set_option("VSC_GEMM_ABL", "0")
 clock(lambda: torch.matmul(a, w.t(), out=o), "hipBLASLt", 60)
 for cfg in "CB":
-    os.environ["VSC_GEMM_CFG"] = cfg
+    _vsc_lib.set_option("VSC_GEMM_CFG", cfg)
     clock(lambda: ops.gemm_bf16(a, w, None), f"ours cfg {cfg}", 60)

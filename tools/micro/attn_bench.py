@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
 import torch
 
 from vsc_hip import ops
+from vsc_hip import _lib as _vsc_lib
 
 dev = torch.device("cuda:0")
 frames, tokens, heads = 332, 197, 12
@@ -33,13 +34,13 @@ ops.attention_bf16(qkv, frames, tokens, heads)
 print(f"cold (Infinity Cache flushed) {timeit():.1f} us   warm {timeit(flush=False):.1f} us", flush=True)
 
 for skew in (0, 4000, 8000, 12000, 16000, 24000, 32000):
-    os.environ["VSC_ATTN_SKEW"] = str(skew)
+    _vsc_lib.set_option("VSC_ATTN_SKEW", str(skew))
     print(f"skew {skew}: cold {timeit():.1f} us   warm {timeit(flush=False):.1f} us", flush=True)
-os.environ.pop("VSC_ATTN_SKEW")
+_vsc_lib.set_option("VSC_ATTN_SKEW", None)
 
 # ablations (library built with -DVSC_ATTN_ABLATION): what each part of the kernel costs
 for abl, what in ((1, "no exp2"), (2, "no PV MFMA"), (4, "no QK MFMA"), (6, "no MFMA"), (7, "no MFMA, no exp2"), (8, "no K/V loads"), (16, "no stores"),
                   (24, "no K/V loads, no stores"), (31, "nothing but Q loads + LDS + VALU")):
-    os.environ["VSC_ATTN_ABL"] = str(abl)
+    _vsc_lib.set_option("VSC_ATTN_ABL", str(abl))
     print(f"abl {abl:2d} ({what}): cold {timeit():.1f} us   warm {timeit(flush=False):.1f} us", flush=True)
-os.environ.pop("VSC_ATTN_ABL")
+_vsc_lib.set_option("VSC_ATTN_ABL", None)

@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
 import torch
 from vsc_hip import ops
+from vsc_hip import _lib as _vsc_lib
 dev = torch.device("cuda:0")
 frames, tokens, heads = 332, 197, 12
 qkv = torch.randn(frames * tokens, 3 * heads * 64, device=dev).to(torch.bfloat16)
@@ -19,7 +20,7 @@ def timeit(it=10, flush=True):
 ref = None
 for ni in ("1", "2"):
     for skew in ("0", "8000", "16000", "24000"):
-        os.environ["VSC_ATTN_NI"] = ni; os.environ["VSC_ATTN_SKEW"] = skew
+        _vsc_lib.set_option("VSC_ATTN_NI", ni); _vsc_lib.set_option("VSC_ATTN_SKEW", skew)
         o = ops.attention_bf16(qkv, frames, tokens, heads)
         if ref is None: ref = o.clone()
         same = torch.equal(o, ref)

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
 import torch
 
 from vsc_hip import _lib, ops
+from vsc_hip import _lib as _vsc_lib
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 332
@@ -33,7 +34,7 @@ def timeit(fn, it=10):
 
 def own(v4, a, w, b, epi, aux):
     def f():
-        os.environ["VSC_GEMM_V4"] = "1" if v4 else "0"
+        _vsc_lib.set_option("VSC_GEMM_V4", "1" if v4 else "0")
         ops.gemm_bf16(a, w, b, epilogue=epi, aux=aux, out=aux)
     return f
 

@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
 import torch
 from vsc_hip import _lib, ops
+from vsc_hip import _lib as _vsc_lib
 dev = torch.device("cuda:0")
 M = 332 * 197
 
@@ -24,10 +25,10 @@ for name, m, n, k, epi in [("qkv", M, 2304, 768, _lib.EPI_BF16), ("proj", M, 768
     res = {}
     for rnd in range(3):
         for st in ["v4", "v3", "v2A", "v2D", "v2C", "v2B"]:
-            os.environ.pop("VSC_GEMM_CFG", None)
-            os.environ["VSC_GEMM_V4"] = "1" if st == "v4" else "0"
-            os.environ["VSC_GEMM_V3"] = "0" if st.startswith("v2") else "1"
+            _vsc_lib.set_option("VSC_GEMM_CFG", None)
+            _vsc_lib.set_option("VSC_GEMM_V4", "1" if st == "v4" else "0")
+            _vsc_lib.set_option("VSC_GEMM_V3", "0" if st.startswith("v2") else "1")
             if st.startswith("v2"):
-                os.environ["VSC_GEMM_CFG"] = st[2]
+                _vsc_lib.set_option("VSC_GEMM_CFG", st[2])
             res.setdefault(st, []).append(timeit(lambda: ops.gemm_bf16(a, w, b, epilogue=epi, aux=x, out=x)))
     print(f"{name:5s}", "  ".join(f"[{st}] {sorted(t)[1]:6.1f}" for st, t in res.items()), flush=True)

@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
 import torch
 from vsc_hip import _lib, ops
+from vsc_hip import _lib as _vsc_lib
 dev = torch.device("cuda:0")
 M = 332 * 197
 def timeit(fn, it=10):
@@ -22,7 +23,7 @@ for name, m, n, k, epi in [("qkv", M, 2304, 768, _lib.EPI_BF16), ("proj", M, 768
     res = {}
     for rnd in range(3):
         for g in ("1", "2", "3", "4", "6", "12"):
-            os.environ["VSC_GEMM_GROUP_N"] = g
+            _vsc_lib.set_option("VSC_GEMM_GROUP_N", g)
             res.setdefault(g, []).append(timeit(lambda: ops.gemm_bf16(a, w, b, epilogue=epi, aux=x, out=x)))
-    os.environ.pop("VSC_GEMM_GROUP_N")
+    _vsc_lib.set_option("VSC_GEMM_GROUP_N", None)
     print(f"{name:5s}", "  ".join(f"[G={g}] {sorted(t)[1]:6.1f}" for g, t in res.items()), flush=True)

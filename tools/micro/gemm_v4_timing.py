@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
 import torch
 from vsc_hip import _lib, ops
+from vsc_hip import _lib as _vsc_lib
 dev = torch.device("cuda:0")
 M = 332 * 197
 for name, m, n, k, epi in [("qkv", M, 2304, 768, _lib.EPI_BF16), ("fc2", M, 768, 3072, _lib.EPI_BF16), ("fc2r", M, 768, 3072, _lib.EPI_RESADD_F32),
@@ -14,7 +15,7 @@ for name, m, n, k, epi in [("qkv", M, 2304, 768, _lib.EPI_BF16), ("fc2", M, 768,
     for _ in range(3):
         ops.gemm_bf16(a, w, None, epilogue=epi, aux=x, out=x)
     torch.cuda.synchronize()
-    os.environ["VSC_GEMM_TIMING_PRINT"] = "1"
+    _vsc_lib.set_option("VSC_GEMM_TIMING_PRINT", "1")
     for _ in range(2):
         ops.gemm_bf16(a, w, None, epilogue=epi, aux=x, out=x)
-    os.environ.pop("VSC_GEMM_TIMING_PRINT")
+    _vsc_lib.set_option("VSC_GEMM_TIMING_PRINT", None)

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
 import torch
 from vsc_hip import ops
+from vsc_hip import _lib as _vsc_lib
 dev = torch.device("cuda:0")
 frames, res, window, heads = 256, 16, 16, 16
 qkv = torch.randn(frames * res * res, 3 * heads * 32, device=dev).to(torch.bfloat16)
@@ -22,9 +23,9 @@ def timeit(shift, it=10, flush=False):
 ops.window_attention_bf16(qkv, bias, scale, frames, res, window, 0, heads)
 print(f"stage 3 (res 16 = one window): warm {timeit(0):.1f} us  cold {timeit(0, flush=True):.1f} us", flush=True)
 for abl, what in ((1, "no exp2"), (2, "no MFMA"), (3, "no MFMA, no exp2"), (8, "no K/V loads"), (16, "no stores"), (24, "no K/V loads, no stores"), (27, "only Q loads + LDS + rest of VALU")):
-    os.environ["VSC_WATTN_ABL"] = str(abl)
+    _vsc_lib.set_option("VSC_WATTN_ABL", str(abl))
     print(f"abl {abl:2d} ({what}): warm {timeit(0):.1f} us  cold {timeit(0, flush=True):.1f} us", flush=True)
-os.environ.pop("VSC_WATTN_ABL", None)
+_vsc_lib.set_option("VSC_WATTN_ABL", None)
 # stage 1 / 2 shapes (shifted windows)
 for fr, rs, hd in ((64, 64, 4), (128, 32, 8)):
     q2 = torch.randn(fr * rs * rs, 3 * hd * 32, device=dev).to(torch.bfloat16)

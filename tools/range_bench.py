@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd"))
 import torch
 
 from vsc_hip import ops
+from vsc_hip import _lib as _vsc_lib
 
 nq, nr, d = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (8192, 1_000_000, 512)))
 frac = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-4
@@ -19,7 +20,7 @@ r = torch.nn.functional.normalize(torch.randn(nr, d, device="cuda", generator=g)
 radius = NormalDist().inv_cdf(1.0 - frac) / d ** 0.5
 ref = None
 for path in ("exact", "bf16"):
-    os.environ["VSC_RANGE_PATH"] = path
+    _vsc_lib.set_option("VSC_RANGE_PATH", path)
     out = ops.range_search_ip(q, r, radius, capacity=1 << 24)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

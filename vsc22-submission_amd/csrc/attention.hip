@@ -285,10 +285,10 @@ int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int he
     if (dev < 16 && !cus_of[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev));
     const int ncu = dev < 16 && cus_of[dev] > 0 ? cus_of[dev] : 256;
     int skew = KT >= 5 && frames * heads > 2 * ncu ? 16000 * KT * KT / 49 : 0;
-    if (const char *e = getenv("VSC_ATTN_SKEW")) skew = atoi(e);
+    if (const char *e = vsc_opt(OPT_ATTN_SKEW)) skew = atoi(e);
 #ifdef VSC_ATTN_ABLATION
     if (KT == 7)
-        if (const char *e = getenv("VSC_ATTN_ABL")) {
+        if (const char *e = vsc_opt(OPT_ATTN_ABL)) {
             const int abl = atoi(e);
 #define VSC_ABL_CASE(A) case A: { auto k = attention_kernel<7, 1, A>; VSC_CHECK_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); \
             hipLaunchKernelGGL(k, dim3(frames * heads), dim3(512), smem, stream, qkv, out, tokens, heads, frames * heads, skew, ncu); VSC_CHECK_LAUNCH(); return VSC_OK; }
@@ -300,7 +300,7 @@ int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int he
     // measured again on this kernel (tools/micro/attn_ni.py): 166 VGPRs, i.e. one resident workgroup per CU, or capped at
     // 128 VGPRs 120 bytes of scratch -- 160 us per launch against 110-119.  VSC_ATTN_NI=2 keeps the variant reachable.
     int ni = 1;
-    if (const char *e = getenv("VSC_ATTN_NI")) ni = atoi(e) == 2 ? 2 : 1;
+    if (const char *e = vsc_opt(OPT_ATTN_NI)) ni = atoi(e) == 2 ? 2 : 1;
     if (ni == 2)
         hipLaunchKernelGGL((attention_kernel<KT, 2>), dim3((total + 1) / 2), dim3(512), smem, stream, qkv, out, tokens, heads,
                            total, 2 * skew, ncu);

@@ -31,6 +31,41 @@ extern "C" int vsc_device_count(void) {
     return ok;
 }
 
+// ---- diagnostic / test switches (common.h: VSC_OPT_LIST) -------------------------------------------------------------
+#include <atomic>
+#include <mutex>
+#include <stdlib.h>
+static const char *const g_opt_names[OPT_COUNT] = {
+#define X(n) "VSC_" #n,
+    VSC_OPT_LIST(X)
+#undef X
+};
+static std::atomic<const char *> g_opt_values[OPT_COUNT];
+static std::once_flag g_opt_once;
+static void opt_load_env() {
+    for (int i = 0; i < OPT_COUNT; ++i) {
+        const char *e = getenv(g_opt_names[i]);   // the only getenv calls of the library: once per process
+        g_opt_values[i].store(e ? strdup(e) : nullptr, std::memory_order_relaxed);
+    }
+}
+const char *vsc_opt(VscOpt o) {
+    std::call_once(g_opt_once, opt_load_env);
+    return g_opt_values[o].load(std::memory_order_acquire);
+}
+// value == NULL (or "") clears the switch.  Superseded strings are not freed: a reader may still hold them, and switches
+// change a handful of times per process (tests, A/B tools).
+extern "C" int vsc_set_option(const char *name, const char *value) {
+    VSC_REQUIRE(name, "set_option: null name");
+    std::call_once(g_opt_once, opt_load_env);
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(name, g_opt_names[i]) || !strcmp(name, g_opt_names[i] + 4)) {
+            g_opt_values[i].store(value && value[0] ? strdup(value) : nullptr, std::memory_order_release);
+            return VSC_OK;
+        }
+    vsc_set_error("set_option: unknown switch '%s'", name);
+    return VSC_ERR_INVALID;
+}
+
 extern "C" int vsc_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux,
                              void *out, int64_t m, int32_t n, int32_t k, int32_t epilogue,
                              int32_t tokens, void *stream) {

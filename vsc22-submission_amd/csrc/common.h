@@ -37,6 +37,22 @@ void vsc_set_error(const char *fmt, ...);
 
 #define VSC_CHECK_LAUNCH() VSC_CHECK_HIP(hipGetLastError())
 
+// ---- diagnostic / test switches ------------------------------------------------------------------
+// Every switch that used to be a getenv() on the launch path.  The environment is read ONCE per process (first use of any
+// switch); afterwards a switch changes only through vsc_set_option() (include/vsc_hip.h).  vsc_opt() is an array read.
+#define VSC_OPT_LIST(X)                                                                                                  \
+    X(ATTN_SKEW) X(ATTN_ABL) X(ATTN_NI) X(CONV_IMPLICIT) X(CONV_REMAP) X(CONV_PERSIST) X(CONV_STAGES) X(CONV_WAVES)      \
+    X(GEMM_GROUP_N) X(GEMM_V4_SKEW) X(GEMM_TIMING_PRINT) X(GEMM_V4) X(GEMM_V4_GRID) X(GEMM_SKEW_NS_PER_K) X(GEMM_CFG)    \
+    X(GEMM_V3) X(GEMM_ABL) X(GEMM_V1) X(KNN_TRIG) X(KNN_ABL) X(KNN_PATH) X(RANGE_PATH) X(PAIRMAX_PATH) X(WATTN_ABL)      \
+    X(SWIN_SPLIT_LN) X(SWIN_SPLIT_K)
+enum VscOpt {
+#define X(n) OPT_##n,
+    VSC_OPT_LIST(X)
+#undef X
+    OPT_COUNT
+};
+const char *vsc_opt(VscOpt o);   // value of VSC_<name> (environment at first use, or the last vsc_set_option), nullptr when unset
+
 // ---- bf16 <-> f32 ------------------------------------------------------------
 __device__ __host__ inline float bf16_to_f32(uint16_t h) {
     union { uint32_t u; float f; } v;

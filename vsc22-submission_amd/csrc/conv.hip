@@ -20,6 +20,8 @@
 // of the summation order, ~1e-6, where a bf16 pipeline through ~60 layers would not hold the 1e-3 of the probability maps).
 // The weights are the MFMA row operand and the pixels the column operand, so a lane owns one pixel and 4 consecutive
 // output channels per register group: 16-byte stores along the channel axis.
+#include <mutex>
+
 #include "common.h"
 #include "f32_tile.h"
 
@@ -560,6 +562,7 @@ struct Scratch {
     size_t bytes = 0;
 };
 Scratch g_patch[16];   // per device, grow-only: the packed patch matrix of the convolution in flight
+std::mutex g_conv_mutex;
 float *g_zero_line[16] = {};   // per device: 256 bytes of zeros (implicit gathering points padding taps at it)
 
 inline int blocks_for(int64_t items) {
@@ -600,13 +603,18 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     const bool in_place = kh == 1 && kw == 1 && stride == 1 && pad == 0 && ldx == cin && (cin % KS) == 0 && (((uintptr_t)x_dev) & 15) == 0;
     const bool narrow = cout <= 80;   // <= 3 channel tiles of 32: the thin layers (see conv_gemm_narrow_kernel)
     // patches gathered inside the GEMM's staging (narrow kernel): 4-channel chunks, table-sized K, 16-bit image coordinates
-    const char *imp_env = getenv("VSC_CONV_IMPLICIT");   // diagnostic / test switch, read per call
+    const char *imp_env = vsc_opt(OPT_CONV_IMPLICIT);   // diagnostic / test switch, read per call
     const bool no_implicit = imp_env && imp_env[0] == '0';
     const bool implicit = !in_place && narrow && !no_implicit && (cin & 3) == 0 && (ldx & 3) == 0 && (((uintptr_t)x_dev) & 15) == 0 &&
                           kpad <= IM2COL_TABLE && kh < 16 && kw < 16 && h < 32000 && w < 32000 && pad < 1000;
+    // The per-device scratch (zero line, patch matrix, CU count) is guarded; the patch matrix itself is ONE buffer per
+    // device, so convolutions on one device must be issued from one stream at a time (documented in vsc_hip.h).
+    std::lock_guard<std::mutex> scratch_lock(g_conv_mutex);
     if (implicit && !g_zero_line[dev]) {
         VSC_CHECK_HIP(hipMalloc((void **)&g_zero_line[dev], 256));
+        // filled on the NULL stream; callers' streams may be non-blocking (PyTorch side streams), so wait here, once
         VSC_CHECK_HIP(hipMemset(g_zero_line[dev], 0, 256));
+        VSC_CHECK_HIP(hipDeviceSynchronize());
     }
     Scratch &s = g_patch[dev];
     const size_t need = in_place || implicit ? 0 : (size_t)rows * kpad * 4;
@@ -643,12 +651,12 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     VSC_REQUIRE(tiles_p * tiles_c < (1ll << 31), "conv2d: grid too large");
     ConvGemmArgs a{w_packed_dev, in_place ? x_dev : (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c, tiles_p,
                    x_dev, g_zero_line[dev], h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k, 0};
-    if (const char *e = getenv("VSC_CONV_REMAP")) a.no_remap = e[0] == '0';
+    if (const char *e = vsc_opt(OPT_CONV_REMAP)) a.no_remap = e[0] == '0';
     static int cus_of[16] = {};
     if (!cus_of[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev));
-    const char *pe = getenv("VSC_CONV_PERSIST");   // diagnostic: 0 = one tile per workgroup
-    const char *se = getenv("VSC_CONV_STAGES");    // diagnostic: 3 = three LDS stages, one workgroup per CU
-    const char *we = getenv("VSC_CONV_WAVES");     // diagnostic: 4 = four waves per workgroup
+    const char *pe = vsc_opt(OPT_CONV_PERSIST);   // diagnostic: 0 = one tile per workgroup
+    const char *se = vsc_opt(OPT_CONV_STAGES);    // diagnostic: 3 = three LDS stages, one workgroup per CU
+    const char *we = vsc_opt(OPT_CONV_WAVES);     // diagnostic: 4 = four waves per workgroup
     const int stages = se && se[0] == '3' ? 3 : 2;
     const int nw = we && we[0] == '4' ? 4 : 8;
     const int64_t resident = (stages == 2 ? 2ll : 1ll) * cus_of[dev];   // 76 KiB (2 stages) / 112 KiB (3 stages) of LDS per workgroup

@@ -746,7 +746,7 @@ int launch_v3(GemmArgs p, hipStream_t stream) {
     // groups of 4 N-tiles; of 3 where that divides the row of tiles and 4 does not (qkv: 9 = 3 + 3 + 3 instead of 4 + 4 + 1:
     // 204 -> 199.5 us on the persistent kernel, tools/micro/gemm_v4_groups.py)
     int g = (p.tiles_n % 4 != 0 && p.tiles_n % 3 == 0) ? 3 : 4;
-    if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
+    if (const char *e = vsc_opt(OPT_GEMM_GROUP_N)) g = atoi(e);
     p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
     p.skew = 0;
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, stream, p);
@@ -981,11 +981,11 @@ int launch_v4(GemmArgs p, int cus, hipStream_t stream) {
     // groups of 4 N-tiles; of 3 where that divides the row of tiles and 4 does not (qkv: 9 = 3 + 3 + 3 instead of 4 + 4 + 1:
     // 204 -> 199.5 us on the persistent kernel, tools/micro/gemm_v4_groups.py)
     int g = (p.tiles_n % 4 != 0 && p.tiles_n % 3 == 0) ? 3 : 4;
-    if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
+    if (const char *e = vsc_opt(OPT_GEMM_GROUP_N)) g = atoi(e);
     p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
     p.skew = 0;
     p.skew_groups = 1;
-    if (const char *e = getenv("VSC_GEMM_V4_SKEW")) {   // "cycles,groups" (diagnostic sweep)
+    if (const char *e = vsc_opt(OPT_GEMM_V4_SKEW)) {   // "cycles,groups" (diagnostic sweep)
         int cyc = 0, grp = 1;
         if (sscanf(e, "%d,%d", &cyc, &grp) == 2 && cyc >= 0 && grp >= 1) {
             p.skew = cyc;
@@ -1001,7 +1001,7 @@ int launch_v4(GemmArgs p, int cus, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(cus), dim3(512), smem, stream, p);
     VSC_CHECK_LAUNCH();
 #ifdef VSC_GEMM_TIMING
-    if (getenv("VSC_GEMM_TIMING_PRINT")) {
+    if (vsc_opt(OPT_GEMM_TIMING_PRINT)) {
         unsigned long long h[64];
         VSC_CHECK_HIP(hipStreamSynchronize(stream));
         VSC_CHECK_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
@@ -1024,7 +1024,7 @@ int launch_v34(GemmArgs p, hipStream_t stream) {
     p.tiles_m = (int)((p.m + 255) / 256);
     p.tiles_n = (p.n + 255) / 256;
     if constexpr (epi_v4(EPI)) {
-        const char *v4e = getenv("VSC_GEMM_V4");   // diagnostic A/B switch, read per launch
+        const char *v4e = vsc_opt(OPT_GEMM_V4);   // diagnostic A/B switch, read per launch
         const bool off = v4e && v4e[0] == '0';
         static int cus_of[16] = {};
         int dev = 0;
@@ -1042,7 +1042,7 @@ int launch_v34(GemmArgs p, hipStream_t stream) {
             int grid = cus;
             // diagnostic: persistent workgroups per launch (a multiple of 8).  Measured with two lanes, so that the two chunks' GEMMs run
             // side by side on half the chip each instead of one after the other: 128 -> 23.4 k, 192 -> 23.4 k, 256 -> 23.9 k frames/s
-            if (const char *e = getenv("VSC_GEMM_V4_GRID")) {
+            if (const char *e = vsc_opt(OPT_GEMM_V4_GRID)) {
                 const int g = atoi(e);
                 if (g >= 8 && g <= cus && g % 8 == 0) grid = g;
             }
@@ -1056,7 +1056,8 @@ int launch_v34(GemmArgs p, hipStream_t stream) {
 // first 256 workgroups.  Re-measured in the ViT step with skews from 0.6 us to a whole tile time: 0 is as fast as any
 // (19.7 k frames/s), a tile time costs 6 % -- the start-up delay is never recovered.
 inline int skew_cycles(int k) {
-    static const int ns_per_k = [] { const char *e = getenv("VSC_GEMM_SKEW_NS_PER_K"); return e ? atoi(e) : 0; }();
+    const char *e = vsc_opt(OPT_GEMM_SKEW_NS_PER_K);
+    const int ns_per_k = e ? atoi(e) : 0;
     return (int)((int64_t)ns_per_k * k / 10);
 }
 
@@ -1081,7 +1082,7 @@ int launch_v2(GemmArgs p, hipStream_t stream) {
     // 3 passes over its 402 MB A (larger than the Infinity Cache) under the L2 rule: 395 -> 330 us with one.
     int g = (int)((int64_t)(3 << 19) / ((int64_t)BN2 * p.k * 2));
     if (p.tiles_n <= 4) g = p.tiles_n;
-    if (const char *e = getenv("VSC_GEMM_GROUP_N")) g = atoi(e);
+    if (const char *e = vsc_opt(OPT_GEMM_GROUP_N)) g = atoi(e);
     p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
     p.skew = skew_cycles(p.k);
 #ifdef VSC_GEMM_TIMING
@@ -1093,7 +1094,7 @@ int launch_v2(GemmArgs p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), smem, stream, p);
     VSC_CHECK_LAUNCH();
 #ifdef VSC_GEMM_TIMING
-    if (getenv("VSC_GEMM_TIMING_PRINT")) {
+    if (vsc_opt(OPT_GEMM_TIMING_PRINT)) {
         unsigned long long h[64];
         VSC_CHECK_HIP(hipStreamSynchronize(stream));
         VSC_CHECK_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
@@ -1124,7 +1125,7 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
     // stages fly during the write-out (+-1 %: launch, fill and drain were already hidden; 3 stages are as fast
     // as 4).  tools/micro/fill_bench.hip: LDS-DMA alone delivers 21.6 B/clk/CU with 64-B row pieces (34-40 with
     // full 128-B lines), VGPR staging no more; the K loop is issue/phase-bound, not delivery-bound.
-    const char *force = getenv("VSC_GEMM_CFG");   // diagnostic, read per launch
+    const char *force = vsc_opt(OPT_GEMM_CFG);   // diagnostic, read per launch
     // measured: A wins on every ViT shape (K >= 768).  With K <= 512 (Swin) the K loop is only 4-16 stages long and
     // the epilogue is a large share of a tile: the 4-wave tiles run two workgroups per CU, so one's write-out
     // overlaps the other's K loop (stage-3 qkv 765 -> 875 TF/s); D when N is a multiple of 128 but not of 256.
@@ -1136,7 +1137,7 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
         if (epi_v4(EPI) && p.k % 128 == 0 && p.k >= 256 && p.n % 256 == 0 && ((p.m + 255) / 256) * (p.n / 256) > 256) cfg = 'A';
     }
     if (force) cfg = force[0];
-    const char *v3e = getenv("VSC_GEMM_V3");   // diagnostic A/B switch, read per launch
+    const char *v3e = vsc_opt(OPT_GEMM_V3);   // diagnostic A/B switch, read per launch
     const bool no_v3 = v3e && v3e[0] == '0';
     if (cfg == 'A' && p.k % 64 == 0 && !no_v3) return launch_v34<EPI>(p, stream);
     switch (cfg) {
@@ -1408,7 +1409,7 @@ int launch_ln_t(const GemmLnArgs &p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), smem, stream, p);
     VSC_CHECK_LAUNCH();
 #ifdef VSC_GEMM_TIMING
-    if (getenv("VSC_GEMM_TIMING_PRINT")) {
+    if (vsc_opt(OPT_GEMM_TIMING_PRINT)) {
         unsigned long long h[8];
         VSC_CHECK_HIP(hipStreamSynchronize(stream));
         VSC_CHECK_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ln_dbg), sizeof(h)));
@@ -1440,9 +1441,9 @@ int launch_gemm_bf16_ex(const uint16_t *a, const uint16_t *w, const float *bias,
     GemmArgs p{a, w, bias, aux, out, m, n, k, tokens, tiles_n, (int)tiles_m, 1, 0};
     p.abl = 0;
     p.ex = ex;
-    if (const char *e = getenv("VSC_GEMM_ABL")) p.abl = atoi(e);
-    static const bool force_v1 = getenv("VSC_GEMM_V1") != nullptr;
-    const bool force_v2 = getenv("VSC_GEMM_CFG") != nullptr;
+    if (const char *e = vsc_opt(OPT_GEMM_ABL)) p.abl = atoi(e);
+    const bool force_v1 = vsc_opt(OPT_GEMM_V1) != nullptr;
+    const bool force_v2 = vsc_opt(OPT_GEMM_CFG) != nullptr;
     // A launch that cannot put a 256-row tile on at least half the CUs runs the 128 x 128 kernel instead (four times
     // the workgroups, two per CU): at 8 frames (M = 1576) fc2 takes 44 instead of 74 us and proj 16 instead of 27,
     // at 32 frames the N = 768 GEMMs 26 / 57 instead of 35 / 77 us; from ~130 tiles up the big tile wins.

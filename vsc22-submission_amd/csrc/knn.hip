@@ -1118,12 +1118,31 @@ int scratch_get(int slot, size_t bytes, void **out) {
     return VSC_OK;
 }
 
+// frees every grow-only scratch buffer of the current device (waits for the device first); -> bytes released
+int64_t scratch_release() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 0;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    (void)hipDeviceSynchronize();
+    int64_t freed = 0;
+    for (Scratch &s : g_scratch[dev])
+        if (s.ptr) {
+            (void)hipFree(s.ptr);
+            freed += (int64_t)s.bytes;
+            s.ptr = nullptr;
+            s.bytes = 0;
+        }
+    return freed;
+}
+
 inline int blocks_for(int64_t items) {
     int64_t b = (items + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
 }
 
 }  // namespace
+
+extern "C" int64_t vsc_search_release_scratch(void) { return scratch_release(); }
 
 // ---- per-phase HIP events of the last top-k call (bench.py: duration of the dominant kernel, on the caller's stream)
 static bool g_knn_profiling = false;
@@ -1269,9 +1288,9 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     SweepArgs a{(const uint16_t *)qb, (const uint16_t *)rb, (const float *)qstats, (const unsigned *)flags, nq, nr, dp, k, nqb,
                 splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
                 (int *)ncand, fb_dev, 0, nullptr, cap - 2 * SR};
-    if (const char *e = getenv("VSC_KNN_TRIG")) { const int t = atoi(e); if (t >= k && t <= cap - 2 * SR) a.trig = t; }
+    if (const char *e = vsc_opt(OPT_KNN_TRIG)) { const int t = atoi(e); if (t >= k && t <= cap - 2 * SR) a.trig = t; }
     a.dbg = (unsigned long long *)(((uintptr_t)(fb_dev + 1 + nqb) + 7) & ~(uintptr_t)7);
-    if (const char *e = getenv("VSC_KNN_ABL")) a.abl = atoi(e);
+    if (const char *e = vsc_opt(OPT_KNN_ABL)) a.abl = atoi(e);
     if ((rc = epl == 16 ? launch_sweep<16>(a, grid, stream) : launch_sweep<32>(a, grid, stream))) return rc;
     knn_mark(2, stream);
     const unsigned rgrid = (unsigned)((nlists + 3) / 4);
@@ -1333,7 +1352,7 @@ extern "C" int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev
     // Path: the pre-filter pays once the sweep dominates (its fixed costs: two pack passes, the re-scoring launch and
     // one host synchronisation for the fallback flag).  VSC_KNN_PATH=exact|bf16 forces one (tests run both).
     bool prefilter = k <= 512 && nr >= 4096 && nq * nr >= (1ll << 24);
-    if (const char *e = getenv("VSC_KNN_PATH")) {
+    if (const char *e = vsc_opt(OPT_KNN_PATH)) {
         if (e[0] == 'e') prefilter = false;
         if (e[0] == 'b') prefilter = k <= 512;
     }
@@ -1454,7 +1473,7 @@ extern "C" int vsc_range_search_ip_f32(const float *q_dev, int64_t nq, const flo
     int rc;
     {   // path: as vsc_knn_ip_f32 (VSC_RANGE_PATH=exact|bf16 forces one)
         bool prefilter = nr >= 4096 && nq * nr >= (1ll << 24);
-        if (const char *e = getenv("VSC_RANGE_PATH")) prefilter = e[0] == 'b' ? true : (e[0] == 'e' ? false : prefilter);
+        if (const char *e = vsc_opt(OPT_RANGE_PATH)) prefilter = e[0] == 'b' ? true : (e[0] == 'e' ? false : prefilter);
         g_range_last_path = 1;
         if (prefilter) {
             int overflow = 0;
@@ -1681,7 +1700,7 @@ extern "C" int vsc_video_pair_max_f32(const float *q_dev, int64_t nq, const int3
     VSC_CHECK_HIP(hipMemsetAsync(table, 0, table_bytes, stream));
     // path: as vsc_knn_ip_f32 -- the pre-filter pays from ~16 M pairs and a few thousand references on
     bool prefilter = nr >= 4096 && nq * nr >= (1ll << 24);
-    if (const char *e = getenv("VSC_PAIRMAX_PATH")) prefilter = e[0] == 'b' ? true : (e[0] == 'e' ? false : prefilter);
+    if (const char *e = vsc_opt(OPT_PAIRMAX_PATH)) prefilter = e[0] == 'b' ? true : (e[0] == 'e' ? false : prefilter);
     if (prefilter) {
         int fb = 0;
         if ((rc = pair_max_prefilter(q_dev, nq, q_video_dev, r_dev, nr, r_video_dev, n_r_videos, d, threshold, (unsigned *)table,

@@ -328,7 +328,7 @@ int launch_window_attention(const uint16_t *qkv, uint16_t *out, const float *bia
     VSC_REQUIRE(grid > 0 && grid < (1ll << 31), "window_attention: grid");
 #ifdef VSC_ATTN_ABLATION
     if (ws == 16)
-        if (const char *e = getenv("VSC_WATTN_ABL")) {
+        if (const char *e = vsc_opt(OPT_WATTN_ABL)) {
 #define VSC_WABL_CASE(A) case A: hipLaunchKernelGGL((window_attention_kernel<16, A>), dim3((unsigned)grid), dim3(512), 0, stream, qkv, out, bias, scale, res, ws, shift, heads); VSC_CHECK_LAUNCH(); return VSC_OK;
             switch (atoi(e)) { VSC_WABL_CASE(1) VSC_WABL_CASE(2) VSC_WABL_CASE(3) VSC_WABL_CASE(8) VSC_WABL_CASE(16) VSC_WABL_CASE(24) VSC_WABL_CASE(27) default: break; }
         }

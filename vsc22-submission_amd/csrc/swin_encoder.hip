@@ -50,6 +50,16 @@ struct vsc_swin {
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     int64_t ws_bytes = 0;
+    size_t ws_sizes[9] = {0};
+    bool lanes_ready = false;   // second workspace + lane streams: made by the first call that has more than one chunk
+    // per-launch HIP events (vsc_swin_set_profiling), as in encoder.hip
+    bool profile = false;
+    struct Span { int cls; size_t e0, e1; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double prof_ms[VSC_SWIN_PROF_CLASSES] = {0};
+    int64_t prof_n[VSC_SWIN_PROF_CLASSES] = {0};
 
     int res(int s) const { return cfg.image_size / cfg.patch_size >> s; }
     int dim(int s) const { return cfg.embed_dim << s; }
@@ -205,6 +215,7 @@ extern "C" void vsc_swin_destroy(vsc_swin *e) {
         if (e->ev_join[l]) (void)hipEventDestroy(e->ev_join[l]);
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -220,6 +231,55 @@ extern "C" int vsc_swin_set_weight(vsc_swin *e, const char *name, const float *h
     e->host_w[name].assign(host, host + count);
     return VSC_OK;
 }
+
+// one lane's workspace (sizes fixed by finalize)
+static int swin_alloc_workspace(vsc_swin *e, int l) {
+    vsc_swin::Workspace &w = e->ws[l];
+    void **dst[] = {(void **)&w.patches, (void **)&w.x, (void **)&w.xb, (void **)&w.t, (void **)&w.qkv,
+                    (void **)&w.att, (void **)&w.h, (void **)&w.merged, (void **)&w.pooled};
+    for (int i = 0; i < 9; ++i) {
+        int rc = sw_alloc(e, e->ws_sizes[i], dst[i]);
+        if (rc) return rc;
+        e->ws_bytes += (int64_t)e->ws_sizes[i];
+    }
+    return VSC_OK;
+}
+// The two lanes (second workspace, two internal streams, fork / join events) exist from the first call with more than one
+// chunk on: callers that never exceed max_batch per call hold one workspace only.
+static int swin_make_lanes(vsc_swin *e) {
+    if (e->lanes_ready) return VSC_OK;
+    int rc = swin_alloc_workspace(e, 1);
+    if (rc) return rc;
+    for (int l = 0; l < 2; ++l) {
+        VSC_CHECK_HIP(hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking));
+        VSC_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join[l], hipEventDisableTiming));
+    }
+    VSC_CHECK_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    e->lanes_ready = true;
+    return VSC_OK;
+}
+
+struct SwinProfScope {
+    vsc_swin *e;
+    hipStream_t st;
+    size_t e0 = 0;
+    int cls;
+    SwinProfScope(vsc_swin *enc, int c, hipStream_t s) : e(enc), st(s), cls(c) {
+        if (e->profile) e0 = rec();
+    }
+    ~SwinProfScope() {
+        if (e->profile) e->spans.push_back({cls, e0, rec()});
+    }
+    size_t rec() {
+        if (e->ev_used == e->ev_pool.size()) {
+            hipEvent_t ev;
+            (void)hipEventCreate(&ev);
+            e->ev_pool.push_back(ev);
+        }
+        (void)hipEventRecord(e->ev_pool[e->ev_used], st);
+        return e->ev_used++;
+    }
+};
 
 extern "C" int vsc_swin_finalize(vsc_swin *e) {
     VSC_REQUIRE(e, "swin finalize: null");
@@ -284,18 +344,8 @@ extern "C" int vsc_swin_finalize(vsc_swin *e) {
     const size_t B = c.max_batch, M0 = B * e->res(0) * e->res(0), MC = M0 * c.embed_dim;
     const size_t sz[] = {M0 * (size_t)e->kpad * 2, MC * 4, MC * 2, MC * 4, MC * 3 * 2, MC * 2, MC * 4 * 2, MC * 2,
                          B * (size_t)e->dim(c.stages - 1) * 4};
-    for (int l = 0; l < 2; ++l) {
-        vsc_swin::Workspace &w = e->ws[l];
-        void **dst[] = {(void **)&w.patches, (void **)&w.x, (void **)&w.xb, (void **)&w.t, (void **)&w.qkv,
-                        (void **)&w.att, (void **)&w.h, (void **)&w.merged, (void **)&w.pooled};
-        for (int i = 0; i < 9; ++i) {
-            TRY(sw_alloc(e, sz[i], dst[i]));
-            e->ws_bytes += (int64_t)sz[i];
-        }
-        VSC_CHECK_HIP(hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking));
-        VSC_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join[l], hipEventDisableTiming));
-    }
-    VSC_CHECK_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 9; ++i) e->ws_sizes[i] = sz[i];
+    TRY(swin_alloc_workspace(e, 0));
 #undef TRY
     e->host_w.clear();
     e->finalized = true;
@@ -308,13 +358,71 @@ extern "C" int64_t vsc_swin_workspace_bytes(const vsc_swin *e) { return e ? e->w
 // (widths 128/256/512), otherwise GEMM to fp32 scratch + the row kernel (width 1024: the last stage).
 static int gemm_ln(vsc_swin *e, vsc_swin::Workspace &ws, const uint16_t *a, const uint16_t *w, const float *bias, const float *g, const float *b,
                    const float *x_in, int64_t m, int n, int k, hipStream_t st) {
-    static const bool split = getenv("VSC_SWIN_SPLIT_LN") != nullptr;
-    static const int split_k = [] { const char *e = getenv("VSC_SWIN_SPLIT_K"); return e ? atoi(e) : 1 << 30; }();
+    const bool split = vsc_opt(OPT_SWIN_SPLIT_LN) != nullptr;
+    const char *split_k_opt = vsc_opt(OPT_SWIN_SPLIT_K);
+    const int split_k = split_k_opt ? atoi(split_k_opt) : 1 << 30;
     if (!split && k < split_k && gemm_ln_supported(n, k))
         return launch_gemm_ln_bf16(a, w, bias, g, b, x_in, ws.x, ws.xb, m, n, k, e->cfg.ln_eps, st);
     int rc = launch_gemm_bf16(a, w, bias, nullptr, ws.t, m, n, k, VSC_EPI_F32, 0, st);
     if (rc) return rc;
     return launch_ln_residual(ws.t, g, b, x_in, ws.x, ws.xb, m, n, e->cfg.ln_eps, st);
+}
+
+// the chunks of one call; `fork`: alternate them over the two lanes.  Returns at the first failing launch (the caller joins
+// the lanes in every case).
+static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *frames_u8, const float *mean, const float *std,
+                           int64_t n, float *desc, float *tokens_out, hipStream_t user, bool fork) {
+    const vsc_swin_config &c = e->cfg;
+    const int64_t frame_elems = (int64_t)c.channels * c.image_size * c.image_size;
+    const int SL = c.stages - 1, TL = e->res(SL) * e->res(SL), CL = e->dim(SL);
+    int rc;
+#define TRY(x) do { if ((rc = (x))) return rc; } while (0)
+#define PROF(cls) SwinProfScope _ps(e, (cls), st)
+    int chunk = 0;
+    for (int64_t off = 0; off < n; off += c.max_batch, ++chunk) {
+        const int lane = fork ? (chunk & 1) : 0;
+        hipStream_t st = fork ? e->lane_stream[lane] : user;
+        vsc_swin::Workspace &w = e->ws[lane];
+        const int64_t B = (n - off) < c.max_batch ? (n - off) : c.max_batch;
+        int64_t M = B * e->res(0) * e->res(0);
+        {
+            PROF(VSC_SWIN_PROF_PATCHIFY);
+            if (frames)
+                TRY(launch_patchify(frames + off * frame_elems, w.patches, B, c.channels, c.image_size, c.patch_size, e->kpad, st));
+            else
+                TRY(launch_patchify_u8(frames_u8 + off * frame_elems, w.patches, B, c.channels, c.image_size, c.patch_size,
+                                       e->kpad, mean, std, st));
+        }
+        { PROF(VSC_SWIN_PROF_PATCH_EMBED); TRY(gemm_ln(e, w, w.patches, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, nullptr, M, c.embed_dim, e->kpad, st)); }
+        for (int s = 0; s < c.stages; ++s) {
+            const int C = e->dim(s), R = e->res(s), W = e->window(s), H = c.heads[s];
+            const int pc = VSC_SWIN_PROF_STAGE0 + (s < 4 ? s : 3) * VSC_SWIN_PROF_PER_STAGE;
+            M = B * R * R;
+            for (int b = 0; b < c.depths[s]; ++b) {
+                const SwinBlockW &K = e->stages[s].blocks[b];
+                { PROF(pc + VSC_SWIN_PROF_QKV); TRY(launch_gemm_bf16(w.xb, K.qkv_w, K.qkv_b, nullptr, w.qkv, M, 3 * C, C, VSC_EPI_BF16, 0, st)); }
+                { PROF(pc + VSC_SWIN_PROF_ATTENTION); TRY(launch_window_attention(w.qkv, w.att, K.bias, K.scale, (int)B, R, W, e->shift(s, b), H, st)); }
+                { PROF(pc + VSC_SWIN_PROF_PROJ_LN); TRY(gemm_ln(e, w, w.att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, w.x, M, C, C, st)); }
+                { PROF(pc + VSC_SWIN_PROF_FC1); TRY(launch_gemm_bf16(w.xb, K.fc1_w, K.fc1_b, nullptr, w.h, M, 4 * C, C, VSC_EPI_GELU_BF16, 0, st)); }
+                { PROF(pc + VSC_SWIN_PROF_FC2_LN); TRY(gemm_ln(e, w, w.h, K.fc2_w, K.fc2_b, K.n2_g, K.n2_b, w.x, M, C, 4 * C, st)); }
+            }
+            if (s + 1 < c.stages) {
+                PROF(pc + VSC_SWIN_PROF_MERGE);
+                TRY(launch_merge_gather(w.xb, w.merged, B, R, C, st));
+                TRY(gemm_ln(e, w, w.merged, e->stages[s].red_w, nullptr, e->stages[s].dn_g, e->stages[s].dn_b, nullptr,
+                            M / 4, 2 * C, 4 * C, st));
+            }
+        }
+        {
+            PROF(VSC_SWIN_PROF_POOL_HEAD);
+            TRY(launch_ln_pool(w.x, e->norm_g, e->norm_b, w.pooled, tokens_out ? tokens_out + off * TL * CL : nullptr, B,
+                               TL, CL, c.ln_eps, 0, c.gem_p, st));
+            TRY(launch_head(w.pooled, e->out_w, e->out_b, desc + off * c.out_dim, B, CL, c.out_dim, c.l2_normalize, st));
+        }
+    }
+#undef PROF
+#undef TRY
+    return VSC_OK;
 }
 
 static int swin_forward_impl(vsc_swin *e, const float *frames, const uint8_t *frames_u8, const float *mean, const float *std,
@@ -325,56 +433,57 @@ static int swin_forward_impl(vsc_swin *e, const float *frames, const uint8_t *fr
         return VSC_ERR_STATE;
     }
     hipStream_t user = (hipStream_t)stream_;
-    const vsc_swin_config &c = e->cfg;
-    const int64_t frame_elems = (int64_t)c.channels * c.image_size * c.image_size;
-    const int SL = c.stages - 1, TL = e->res(SL) * e->res(SL), CL = e->dim(SL);
-    int rc;
-#define TRY(x) do { if ((rc = (x))) return rc; } while (0)
-    const bool fork = n > c.max_batch;   // >= 2 chunks: alternate them over the two lanes
+    // >= 2 chunks: alternate them over the two lanes.  Not while profiling: per-launch events are meant to time one kernel alone.
+    const bool fork = n > e->cfg.max_batch && !e->profile;
     if (fork) {
+        int rc = swin_make_lanes(e);
+        if (rc) return rc;
         VSC_CHECK_HIP(hipEventRecord(e->ev_fork, user));
         for (int l = 0; l < 2; ++l) VSC_CHECK_HIP(hipStreamWaitEvent(e->lane_stream[l], e->ev_fork, 0));
     }
-    int chunk = 0;
-    for (int64_t off = 0; off < n; off += c.max_batch, ++chunk) {
-        const int lane = fork ? (chunk & 1) : 0;
-        hipStream_t st = fork ? e->lane_stream[lane] : user;
-        vsc_swin::Workspace &w = e->ws[lane];
-        const int64_t B = (n - off) < c.max_batch ? (n - off) : c.max_batch;
-        int64_t M = B * e->res(0) * e->res(0);
-        if (frames)
-            TRY(launch_patchify(frames + off * frame_elems, w.patches, B, c.channels, c.image_size, c.patch_size, e->kpad, st));
-        else
-            TRY(launch_patchify_u8(frames_u8 + off * frame_elems, w.patches, B, c.channels, c.image_size, c.patch_size,
-                                   e->kpad, mean, std, st));
-        TRY(gemm_ln(e, w, w.patches, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, nullptr, M, c.embed_dim, e->kpad, st));
-        for (int s = 0; s < c.stages; ++s) {
-            const int C = e->dim(s), R = e->res(s), W = e->window(s), H = c.heads[s];
-            M = B * R * R;
-            for (int b = 0; b < c.depths[s]; ++b) {
-                const SwinBlockW &K = e->stages[s].blocks[b];
-                TRY(launch_gemm_bf16(w.xb, K.qkv_w, K.qkv_b, nullptr, w.qkv, M, 3 * C, C, VSC_EPI_BF16, 0, st));
-                TRY(launch_window_attention(w.qkv, w.att, K.bias, K.scale, (int)B, R, W, e->shift(s, b), H, st));
-                TRY(gemm_ln(e, w, w.att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, w.x, M, C, C, st));
-                TRY(launch_gemm_bf16(w.xb, K.fc1_w, K.fc1_b, nullptr, w.h, M, 4 * C, C, VSC_EPI_GELU_BF16, 0, st));
-                TRY(gemm_ln(e, w, w.h, K.fc2_w, K.fc2_b, K.n2_g, K.n2_b, w.x, M, C, 4 * C, st));
-            }
-            if (s + 1 < c.stages) {
-                TRY(launch_merge_gather(w.xb, w.merged, B, R, C, st));
-                TRY(gemm_ln(e, w, w.merged, e->stages[s].red_w, nullptr, e->stages[s].dn_g, e->stages[s].dn_b, nullptr,
-                            M / 4, 2 * C, 4 * C, st));
-            }
-        }
-        TRY(launch_ln_pool(w.x, e->norm_g, e->norm_b, w.pooled, tokens_out ? tokens_out + off * TL * CL : nullptr, B,
-                           TL, CL, c.ln_eps, 0, c.gem_p, st));
-        TRY(launch_head(w.pooled, e->out_w, e->out_b, desc + off * c.out_dim, B, CL, c.out_dim, c.l2_normalize, st));
-    }
-    if (fork)
+    const int rc = swin_run_chunks(e, frames, frames_u8, mean, std, n, desc, tokens_out, user, fork);
+    if (fork) {
+        // also after a failed launch: whatever the lanes already hold is ordered before the caller's next work on `user`,
+        // so the caller may free or reuse frames / desc once its stream has drained
         for (int l = 0; l < 2; ++l) {
-            VSC_CHECK_HIP(hipEventRecord(e->ev_join[l], e->lane_stream[l]));
-            VSC_CHECK_HIP(hipStreamWaitEvent(user, e->ev_join[l], 0));
+            const hipError_t e1 = hipEventRecord(e->ev_join[l], e->lane_stream[l]);
+            const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(user, e->ev_join[l], 0) : e1;
+            if (e2 != hipSuccess && !rc) {
+                vsc_set_error("swin forward: joining lane %d failed: %s", l, hipGetErrorString(e2));
+                return VSC_ERR_HIP;
+            }
         }
-#undef TRY
+    }
+    return rc;
+}
+
+extern "C" int vsc_swin_set_profiling(vsc_swin *e, int32_t on) {
+    VSC_REQUIRE(e, "swin set_profiling: null encoder");
+    e->profile = on != 0;
+    e->spans.clear();
+    e->ev_used = 0;
+    for (int i = 0; i < VSC_SWIN_PROF_CLASSES; ++i) {
+        e->prof_ms[i] = 0;
+        e->prof_n[i] = 0;
+    }
+    return VSC_OK;
+}
+
+extern "C" int vsc_swin_get_profile(vsc_swin *e, double *ms_out, int64_t *launches_out) {
+    VSC_REQUIRE(e && ms_out && launches_out, "swin get_profile: null argument");
+    VSC_CHECK_HIP(hipDeviceSynchronize());
+    for (const vsc_swin::Span &sp : e->spans) {
+        float ms = 0.f;
+        VSC_CHECK_HIP(hipEventElapsedTime(&ms, e->ev_pool[sp.e0], e->ev_pool[sp.e1]));
+        e->prof_ms[sp.cls] += ms;
+        e->prof_n[sp.cls] += 1;
+    }
+    e->spans.clear();
+    e->ev_used = 0;
+    for (int i = 0; i < VSC_SWIN_PROF_CLASSES; ++i) {
+        ms_out[i] = e->prof_ms[i];
+        launches_out[i] = e->prof_n[i];
+    }
     return VSC_OK;
 }
 

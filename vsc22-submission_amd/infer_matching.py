@@ -38,12 +38,25 @@ MATCH_REFINE_THRESHOLD_HIGH = 0.35    # :66
 
 
 def load_state_dict(path):
+    """State dict of a TorchScript module (what the reference ships) or of a plain checkpoint (tensors only)."""
     import torch
     try:
         return {k: v for k, v in torch.jit.load(path, map_location="cpu").state_dict().items()}
-    except RuntimeError:
-        obj = torch.load(path, map_location="cpu")
+    except (RuntimeError, ValueError, OSError):   # not a TorchScript archive: torch.jit.load raises any of these
+        obj = torch.load(path, map_location="cpu", weights_only=True)
         return obj.state_dict() if hasattr(obj, "state_dict") else obj
+
+
+def frames_per_video(vf) -> int:
+    """Frames of one query video in a (possibly multi-view) descriptor file: the query pipeline emits `views` copies of the
+    frame sequence, each with the same timestamps (extract_query_feats.py:197-210), so the frame count is the number of
+    distinct timestamp rows.  The reference carries it from extraction (infer_matching.py:155, vid_feature_len_map)."""
+    ts = np.asarray(vf.timestamps)
+    n = len(vf.feature)
+    distinct = len(np.unique(ts.reshape(n, -1), axis=0)) if n else 0
+    if distinct == 0 or n % distinct:
+        raise ValueError(f"{vf.video_id}: {n} descriptors over {distinct} distinct timestamps -- pass --query_frames")
+    return distinct
 
 
 def run(query_list, score_norm_refs, refs, sn_refs, cls_models, refine_models, query_frames=None, candidates_csv=None,
@@ -65,7 +78,7 @@ def run(query_list, score_norm_refs, refs, sn_refs, cls_models, refine_models, q
     query_list, refs = [transform_features(x, normalize) for x in (query_list, refs)]             # :272-274
     query_map = {vf.video_id: vf.feature for vf in query_list}
     ref_map = {vf.video_id: vf.feature for vf in refs}
-    len_map = {vf.video_id: len(vf.feature) for vf in query_list}
+    len_map = {vf.video_id: frames_per_video(vf) for vf in query_list}   # views share timestamps: best-view selection needs the frame count
     if query_frames:
         len_map.update(query_frames)
     cls_feature, cls_info = matching.generate_candidates_classfiy_feature(query_map, ref_map, search_res_list, len_map)   # :277-279

@@ -131,17 +131,32 @@ class FlatIPBank:
     def _exact_l2(self, x: np.ndarray, rows: np.ndarray, ids: np.ndarray) -> np.ndarray:
         """float32 sum((x[rows] - bank[ids])^2); ids < 0 (padding) -> FLT_MAX as faiss does."""
         bank = self._host_rows()
+        x = np.asarray(x, np.float32)
         out = np.full(ids.shape, np.finfo(np.float32).max, np.float32)
-        ok = ids >= 0
-        diff = np.asarray(x, np.float32)[rows[ok]] - bank[ids[ok]]
-        out[ok] = np.einsum("ij,ij->i", diff, diff, dtype=np.float32)
+        step = max(1, (64 << 20) // max(4 * self.d, 1))          # gathered rows of one piece stay within ~64 MiB per operand
+        for lo in range(0, len(ids), step):
+            sl = slice(lo, lo + step)
+            ok = ids[sl] >= 0
+            diff = x[rows[sl][ok]] - bank[ids[sl][ok]]
+            out[sl][ok] = np.einsum("ij,ij->i", diff, diff, dtype=np.float32)
         return out
 
-    def range_count(self, x: np.ndarray, radius: float) -> int:
-        """Number of pairs range_search(x, radius) would return (one sweep, nothing materialised)."""
+    def range_count(self, x: np.ndarray, radius: float, q_dev=None) -> int:
+        """Number of pairs the sweep of range_search(x, radius) holds (one sweep, nothing materialised).  q_dev: the
+        queries already on the device (_device_queries(x)) when several radii are counted for one query set.  For
+        METRIC_L2 this is the count of the expanded-form sweep, which may differ from the exact-distance count by the
+        pairs within its rounding of the radius (range_search re-filters them)."""
         from vsc_hip import ops
         radius = float(radius) if self.is_similarity else -float(radius)
-        return ops.range_count_ip(self._device_queries(x), self.device_bank(), radius)
+        return ops.range_count_ip(self._device_queries(x) if q_dev is None else q_dev, self.device_bank(), radius)
+
+    def _l2_sweep_slack(self, x: np.ndarray) -> float:
+        """Bound on |expanded form - exact squared distance| in the fp32 sweep: the chain 2 q.r - |r|^2 - |q|^2 has d + 2
+        terms, each fmaf rounds to 2^-24 of a partial sum that never exceeds (|q| + |r|)^2."""
+        host = self._host_rows()
+        qn = float(np.sqrt(np.einsum("ij,ij->i", x, x, dtype=np.float64).max())) if len(x) else 0.0
+        rn = float(np.sqrt(np.einsum("ij,ij->i", host, host, dtype=np.float64).max())) if len(host) else 0.0
+        return (self.d + 3) * 2.0 ** -23 * (qn + rn) ** 2
 
     def range_search(self, x: np.ndarray, radius: float):
         """All (query row, ref row, score) with score > radius (inner product) / distance < radius (L2) -> three flat
@@ -149,13 +164,22 @@ class FlatIPBank:
         from vsc_hip import ops
         bank = self.device_bank()
         q = self._device_queries(x)
-        lims, D, I = ops.range_search_ip(q, bank, float(radius) if self.is_similarity else -float(radius))
+        if self.is_similarity:
+            sweep_radius = float(radius)
+        else:
+            # the sweep tests the expanded form, whose cancellation on un-normalised vectors can move a pair across the
+            # radius: sweep a radius widened by the rounding bound, then keep dist < radius on the recomputed distances
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            sweep_radius = -float(np.nextafter(np.float32(float(radius) + self._l2_sweep_slack(x)), np.float32(np.inf)))
+        lims, D, I = ops.range_search_ip(q, bank, sweep_radius)
         lims = lims.cpu().numpy()
         rows = np.repeat(np.arange(len(lims) - 1), np.diff(lims))
         ids = I.cpu().numpy()
         if self.is_similarity:
             return rows, ids, D.cpu().numpy()
-        return rows, ids, self._exact_l2(x, rows, ids)
+        dist = self._exact_l2(x, rows, ids)
+        keep = dist < np.float32(radius)
+        return rows[keep], ids[keep], dist[keep]
 
     def search(self, x: np.ndarray, k: int):
         """-> (D [nq,k] float32, I [nq,k] int64), faiss.Index.search semantics: inner products descending, or squared
@@ -234,7 +258,8 @@ class VideoIndex:
         pairs over ALL pairs.  Here: per-row exact top-k' (k' <= MAX_K), the same sort/truncate on the host, and
         whenever the probe cannot be shown to contain every winner -- a query row may own more than k' of them, or the
         probe holds fewer than global_k pairs in total -- an exact range sweep at a radius found by counting replaces
-        the candidate set.  Always exact."""
+        the candidate set.  Exact for inner-product indexes; for METRIC_L2 the distances handed back are recomputed exactly and the
+        range sweep is widened by its rounding bound and re-filtered (FlatIPBank.range_search)."""
         sim = self.index.is_similarity
         nr, nq = self.index.ntotal, feats.shape[0]
         kk = int(min(global_k, nr, MAX_K))
@@ -257,22 +282,27 @@ class VideoIndex:
                     # provisional threshold (one float32 step outwards: the sweep's comparison is strict)
                     radius = np.nextafter(np.float32(threshold), np.float32(-np.inf if sim else np.inf))
             else:
-                radius = self._radius_for(feats, want, scores)
+                radius = self._radius_for(feats, want, D[:, kk - 1])
             if radius is not None:
                 rows, refs, scores = self.index.range_search(feats, radius)
                 order = np.lexsort((refs, rows, key(scores)))[:want]
         return [(int(rows[o]), int(refs[o]), float(scores[o])) for o in order]
 
-    def _radius_for(self, feats: np.ndarray, want: int, probe_scores: np.ndarray) -> float:
+    def _radius_for(self, feats: np.ndarray, want: int, kth_scores: np.ndarray) -> float:
         """A radius whose range sweep returns at least `want` pairs and, ties permitting, at most 2 * want (the
         reference's min_results / max_results window, index.py:150-156), found by count-only sweeps: step outwards
-        from the worst probe score until enough pairs are inside, then bisect."""
+        from a radius known to hold fewer than `want` pairs until enough are inside, then bisect.  kth_scores: every
+        query row's k'-th (last) probe score.  The start is the BEST of them over the rows: a pair beating it beats its
+        own row's k'-th hit, so it is inside the probe, which holds fewer than `want` pairs -- starting from the worst
+        probe score instead would admit unprobed pairs of rows whose k'-th hit beats it, and the window is lost."""
         sim = self.index.is_similarity
         out = -1.0 if sim else 1.0                      # direction of "looser"
         loose = np.float32(-3.0e38 if sim else 3.0e38)  # finite stand-in for the reference's -1e10 / 1e10 start
         if feats.shape[0] * self.index.ntotal <= 2 * want:
             return float(loose)
-        tight = float(probe_scores.min() if sim else probe_scores.max())
+        tight = float(kth_scores.max() if sim else kth_scores.min())
+        q_dev = self.index._device_queries(feats)       # uploaded once for every count below
+        count = lambda r: self.index.range_count(feats, r, q_dev)
         step = max(abs(tight), 1.0) * 2.0 ** -6
         lo = tight                                      # known: count(lo) < want (the probe found every pair inside it)
         hi = None
@@ -280,18 +310,18 @@ class VideoIndex:
             cand = lo + out * step
             if not np.isfinite(np.float32(cand)):
                 return float(loose)
-            if self.index.range_count(feats, cand) >= want:
+            if count(cand) >= want:
                 hi = cand
                 break
             lo, step = cand, step * 2.0
         if hi is None:
             return float(loose)
         for _ in range(48):                             # bisect [lo (too few), hi (enough)] until the count fits the window
-            n_hi = self.index.range_count(feats, hi)
+            n_hi = count(hi)
             mid = 0.5 * (lo + hi)
             if n_hi <= 2 * want or np.float32(mid) in (np.float32(lo), np.float32(hi)):
                 break
-            if self.index.range_count(feats, mid) >= want:
+            if count(mid) >= want:
                 hi = mid
             else:
                 lo = mid

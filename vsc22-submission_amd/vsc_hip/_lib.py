@@ -17,6 +17,11 @@ PROF_CLASSES = ("patchify", "gemm_patch", "layernorm", "gemm_qkv", "attention", 
                 "gemm_fc1", "gemm_fc2", "pool_head", "misc")
 
 
+SWIN_PROF_CLASSES = 27
+SWIN_PROF_STAGE0, SWIN_PROF_PER_STAGE = 3, 6
+SWIN_PROF_KINDS = ("qkv", "attention", "proj_ln", "fc1", "fc2_ln", "merge")
+
+
 class HipPathUnavailable(RuntimeError):
     """The HIP hot path cannot run here (library not built or no MI355X)."""
 
@@ -49,6 +54,7 @@ SIGNATURES = {
     "vsc_last_error": (c_char_p, []),
     "vsc_device_count": (c_int32, []),
     "vsc_version": (c_char_p, []),
+    "vsc_set_option": (c_int32, [c_char_p, c_char_p]),
     "vsc_encoder_create": (c_int32, [POINTER(EncoderConfigC), POINTER(c_void_p)]),
     "vsc_encoder_destroy": (None, [c_void_p]),
     "vsc_encoder_set_weight": (c_int32, [c_void_p, c_char_p, c_void_p, c_size_t]),
@@ -65,6 +71,8 @@ SIGNATURES = {
     "vsc_swin_forward": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "vsc_swin_forward_debug": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "vsc_swin_workspace_bytes": (c_int64, [c_void_p]),
+    "vsc_swin_set_profiling": (c_int32, [c_void_p, c_int32]),
+    "vsc_swin_get_profile": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "vsc_window_attention_bf16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                             c_int32, c_int32, c_void_p]),
     "vsc_ln_residual_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
@@ -94,6 +102,7 @@ SIGNATURES = {
                                        c_int32, c_int32, c_void_p]),
     "vsc_attention_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "vsc_knn_last_path": (c_int32, []),
+    "vsc_search_release_scratch": (c_int64, []),
     "vsc_video_pair_max_last_path": (c_int32, []),
     "vsc_range_search_last_path": (c_int32, []),
     "vsc_knn_set_profiling": (None, [c_int32]),
@@ -138,6 +147,27 @@ def require_device() -> ctypes.CDLL:
             "no gfx950 (MI355X) device visible to HIP "
             f"(vsc_device_count() = {n}: {lib.vsc_last_error().decode()}); there is no CPU fallback")
     return lib
+
+
+def set_option(name: str, value=None) -> None:
+    """Set (or, with None, clear) a diagnostic switch of the library -- vsc_set_option in include/vsc_hip.h.  The library
+    reads its VSC_* environment variables once per process; changing os.environ afterwards has no effect."""
+    check(load().vsc_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+class option:
+    """with option("VSC_KNN_PATH", "bf16"): ...  -- the switch is cleared on exit."""
+
+    def __init__(self, name: str, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, None)
+        return False
 
 
 def check(rc: int) -> None:

@@ -14,6 +14,8 @@ import torch
 from . import _lib
 from ._lib import check, current_stream, ptr
 
+FLOPS = None   # measurement hook (bench.py): a one-element list here accumulates 2 * MACs of every convolution call
+
 ACT = {None: 0, "none": 0, "relu": 1, "hard_swish": 2, "hard_sigmoid": 3, "gelu": 4}
 BN_EPS = 1e-5
 
@@ -87,6 +89,8 @@ class Conv:
         ldo = out.shape[3]
         if residual is not None:
             assert residual.shape == (n, ho, wo, self.cout) and residual.is_contiguous()
+        if FLOPS is not None:
+            FLOPS[0] += 2.0 * n * ho * wo * self.cout * self.cin * self.kh * self.kw
         view = out.view(-1)[coff:] if coff else out
         check(lib.vsc_conv2d_f32(ptr(x), n, h, w, c, c, ptr(self.w), ptr(self.b), self.cout, self.kh, self.kw, self.stride,
                                  self.pad, ptr(residual), self.cout, ACT[act], ptr(view), ldo, current_stream()))
@@ -108,6 +112,8 @@ class DwConv:
         ho = (h + 2 * self.pad - self.kh) // self.stride + 1
         wo = (w + 2 * self.pad - self.kw) // self.stride + 1
         out = torch.empty((n, ho, wo, c), dtype=torch.float32, device=x.device)
+        if FLOPS is not None:
+            FLOPS[0] += 2.0 * n * ho * wo * c * self.kh * self.kw
         check(lib.vsc_dwconv2d_f32(ptr(x), n, h, w, c, ptr(self.w), ptr(self.b), self.kh, self.kw, self.stride, self.pad,
                                    ACT[act], ptr(out), current_stream()))
         return out

@@ -30,12 +30,14 @@ def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_rows(local: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def all_gather_rows(local: torch.Tensor, always_collective: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Concatenate the ranks' [n_i, dim] row blocks in rank order.
     -> (bank [sum n_i, dim], offsets [world+1]).  Shards may differ in length: sizes are
-    exchanged first, shards are padded to the longest for one fixed-size all_gather."""
+    exchanged first, shards are padded to the longest for one fixed-size all_gather.
+    always_collective: run the collectives even in a one-rank group (readiness tests on one GPU: the RCCL
+    all_gather_into_tensor of a bank-sized buffer is then really issued)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (always_collective and dist.is_available() and dist.is_initialized()):
         return local, torch.tensor([0, local.shape[0]])
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     all_n = torch.zeros(ws, dtype=torch.int64, device=local.device)
@@ -58,7 +60,7 @@ def all_gather_rows(local: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def sharded_knn(queries_local: torch.Tensor, refs_local: torch.Tensor, k: int,
-                knn: Optional[Callable] = None, gather_to: Optional[int] = 0):
+                knn: Optional[Callable] = None, gather_to: Optional[int] = 0, always_collective: bool = False):
     """Exact top-k of every rank's queries against the union of every rank's references.
 
     refs_local shards are all_gathered into the full bank (ids = position in rank order);
@@ -68,12 +70,12 @@ def sharded_knn(queries_local: torch.Tensor, refs_local: torch.Tensor, k: int,
     if knn is None:
         from . import ops
         knn = ops.knn_ip
-    bank, _ = all_gather_rows(refs_local)
+    bank, _ = all_gather_rows(refs_local, always_collective)
     scores, ids = knn(queries_local, bank, k)
-    if gather_to is None or world()[1] == 1:
+    if gather_to is None or (world()[1] == 1 and not always_collective):
         return scores, ids
-    all_scores, _ = all_gather_rows(scores)
-    all_ids, _ = all_gather_rows(ids)
+    all_scores, _ = all_gather_rows(scores, always_collective)
+    all_ids, _ = all_gather_rows(ids, always_collective)
     if world()[0] == gather_to:
         return all_scores, all_ids
     return None, None

@@ -119,6 +119,20 @@ class SwinHipEncoder:
             check(self._lib.vsc_swin_forward_debug(self._h, ptr(frames), n, ptr(desc), ptr(tokens), current_stream()))
         return (desc, tokens) if return_tokens else desc
 
+    def set_profiling(self, on: bool) -> None:
+        """Per-launch HIP events (vsc_swin_set_profiling); chunks then run back to back on the caller's stream."""
+        check(self._lib.vsc_swin_set_profiling(self._h, int(on)))
+
+    def profile(self) -> dict:
+        """{class name: (ms, launches)} accumulated since profiling was switched on; stage classes are "s<stage>.<kind>"."""
+        ms = (ctypes.c_double * _lib.SWIN_PROF_CLASSES)()
+        cnt = (ctypes.c_int64 * _lib.SWIN_PROF_CLASSES)()
+        check(self._lib.vsc_swin_get_profile(self._h, ms, cnt))
+        names = ["patchify", "patch_embed", "pool_head"]
+        for s in range(4):
+            names += [f"s{s}.{k}" for k in _lib.SWIN_PROF_KINDS]
+        return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(names) if cnt[i]}
+
     def close(self):
         if getattr(self, "_h", None) is not None:
             self._lib.vsc_swin_destroy(self._h)
