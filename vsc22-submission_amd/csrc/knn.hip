@@ -622,7 +622,9 @@ struct SweepArgs {
     int *fallback;               // [1 + nqb]: [0] any, [1 + qb] this query block must be redone on the exact sweep
     int abl;                     // diagnostic (VSC_KNN_ABL): 1 = skip the filter, 2 = skip the appends (timing only; results invalid), 8 = count
     unsigned long long *dbg;     // [4] appends, compaction rounds, lists compacted, filter bodies entered (abl & 8)
-    int trig;
+    int trig;                    // longest list that does not yet ask for a compaction (<= CAP - 2 SR: flags are read a tile late)
+    int delta = 128;             // appends between two compactions of a list
+    int xcd_map = 0;             // 1: work items are dealt to the XCDs as 8 query blocks x 4 reference splits (see the kernel)
     int thr_mode = 0;            // 1: fixed-threshold sweep (video pair maxima): a pair survives when s~ >= thr0 - eps_q; lists never compact
     float thr0 = 0.f;
 };
@@ -708,6 +710,18 @@ __device__ __forceinline__ int compact_band(const unsigned long long *list, int 
     return base;
 }
 
+// v_max3_f32 without the NaN canonicalisation fmaxf() brings (a v_max x, x per operand); NaN operands are ignored
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// m = 2 m + (a >= thr): compare into vcc, add-with-carry shifts the bit in
+__device__ __forceinline__ unsigned shift_in_ge(unsigned m, float a, float thr) {
+    asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(a), "v"(thr) : "vcc");
+    return m;
+}
+
 template <int EPL, bool STREAM, bool DIAG = false>   // DIAG: the VSC_KNN_ABL switches / counters are compiled in (timing diagnostics)
 __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
     const int abl = DIAG ? p.abl : 0;
@@ -718,6 +732,8 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
     float *thr_s = (float *)(lds + ml64::RING_BYTES + 1024);
     float *eps_s = (float *)(lds + ml64::RING_BYTES + 2048);
     int *flag_s = (int *)(lds + ml64::RING_BYTES + 3072);
+    int *trig_s = (int *)(lds + ml64::RING_BYTES + 4096);   // per list: the length that asks for its next compaction
+    const int DELTA = p.delta;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -725,8 +741,27 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
     unsigned long long *mylists = p.lists + (size_t)blockIdx.x * SQ * CAP;
     const float rmax = __uint_as_float(p.rmax_bits[0]), drmax = __uint_as_float(p.rmax_bits[1]);
 
-    for (int64_t work = blockIdx.x; work < (int64_t)p.nqb * p.splits; work += gridDim.x) {
-        const int qb = (int)(work / p.splits), sp = (int)(work - (int64_t)qb * p.splits);
+    // Work order.  A work item is (query block qb, reference split sp).  Plain order: item = blockIdx, + gridDim, ...
+    // XCD-aware order (p.xcd_map, grid = 8 XCDs x 32 workgroups; block b runs on XCD b % 8): the 32 workgroups of an XCD
+    // work on ONE super-item at a time -- 8 consecutive query blocks x 4 consecutive splits, slot s of the XCD taking
+    // (qb = 8 qg + (s & 7), sp = 4 sg + (s >> 3)).  Its 8 query blocks (8 x 256 KiB of bf16) stay in the XCD's 4-MiB L2
+    // for the whole super-item and every reference tile is pulled from memory once for the 8 workgroups that walk the
+    // same split in step; in the plain order the 32 workgroups of an XCD held 32 different query blocks (8 MiB), which
+    // every one of them re-fetched from the Infinity Cache for every reference tile (PMC: 37.7 x the operand bytes).
+    const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+    const int nsg = (p.splits + 3) >> 2;
+    const int64_t n_items = p.xcd_map ? (int64_t)((p.nqb + 7) >> 3) * nsg : (int64_t)p.nqb * p.splits;
+    for (int64_t work = p.xcd_map ? xcd : blockIdx.x; work < n_items; work += p.xcd_map ? 8 : gridDim.x) {
+        int qb, sp;
+        if (p.xcd_map) {
+            const int qg = (int)(work / nsg), sg = (int)(work - (int64_t)qg * nsg);
+            qb = qg * 8 + (xslot & 7);
+            sp = sg * 4 + (xslot >> 3);
+            if (qb >= p.nqb || sp >= p.splits) continue;   // ragged super-item: this slot idles (workgroup-uniform)
+        } else {
+            qb = (int)(work / p.splits);
+            sp = (int)(work - (int64_t)qb * p.splits);
+        }
         const int64_t q0 = (int64_t)qb * SQ;
         const int64_t t_begin = sp * p.tiles_per_split;
         int64_t t_end = t_begin + p.tiles_per_split;
@@ -742,6 +777,8 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
             eps_s[tid] = e2;
             // fixed threshold: exact s <= s~ + eps, so s~ + eps <= thr0 rules a pair out; everything else is re-scored exactly
             thr_s[tid] = p.thr_mode ? p.thr0 - 0.5f * e2 : -INFINITY;
+            // first compaction as soon as a tile's worth of scores is in (everything is appended until a threshold exists)
+            trig_s[tid] = p.thr_mode ? TRIG : (p.k + 64 < SR ? SR : (p.k + 64 < TRIG ? p.k + 64 : TRIG));
         }
         if (tid < 3) flag_s[tid] = 0;
         __syncthreads();
@@ -794,7 +831,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                     if ((abl & 8) && tid == 0) atomicAdd(p.dbg + 1, 1ull);
                     for (int ql = wave * 32; ql < wave * 32 + 32; ++ql) {
                         const int n = cnt_s[ql];
-                        if (n >= TRIG / 2 && n >= p.k) {
+                        if (n + (DELTA < TRIG ? DELTA : TRIG) / 2 >= trig_s[ql] && n >= p.k) {
                             if ((abl & 8) && lane == 0) atomicAdd(p.dbg + 2, 1ull);
                             unsigned long long *l = mylists + (size_t)ql * CAP;
                             float thr;
@@ -802,6 +839,11 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                             if (lane == 0) {
                                 cnt_s[ql] = kept;
                                 thr_s[ql] = thr;
+                                // next compaction DELTA appends from here: with a stale threshold a list takes ~k (t / t0)
+                                // appends between tiles t0 and t, so rounds are geometrically spaced with ratio 1 + DELTA / k
+                                // and a sweep costs ~DELTA ln(tiles) / ln(1 + DELTA / k) appends per query (DELTA = k: 1.4 x
+                                // the ideal k (1 + ln(nr / k)); the fixed trigger of 512 gave 2.5 x)
+                                trig_s[ql] = kept + DELTA < TRIG ? kept + DELTA : TRIG;
                                 if (kept + SR > CAP || n > CAP) p.fallback[0] = p.fallback[1 + qb] = 1;   // the band does not fit: exact sweep
                             }
                         }
@@ -816,62 +858,84 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                     int lv = lane;
                     asm volatile("" : "+v"(lv));
                     const unsigned l15 = lv & 15, lq = lv >> 4;
-                    // (1) hit masks of this lane's 8 queries x 16 scores; the 16 compares of a query run only when some lane
-                    //     of the wave has a score above its threshold (wave-uniform branch)
-                    unsigned mask[8];
-                    bool any_hit = false;
+                    // (1) thresholds of this lane's 8 queries in one LDS round trip; rows past the ragged edges can never
+                    //     hit: a query past q_rows gets a NaN threshold, and in the bank's last tile (only there) the scores
+                    //     of references past r_rows become NaN (every >= with a NaN is false, v_max3 skips NaN operands; -inf
+                    //     would pass the initial threshold -inf) -- so the common path carries no per-element edge tests
+                    float thr[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) thr[i] = thr_s[wm * 128 + i * 16 + l15];
+                    if (q_rows < SQ) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (wm * 128 + i * 16 + (int)l15 >= q_rows) thr[i] = __builtin_nanf("");
+                    }
+                    if (r_rows < SR) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int x = 0; x < 4; ++x)
+                                    if (wn * 64 + j * 16 + (int)lq * 4 + x >= r_rows) acc[i][j][x] = __builtin_nanf("");
+                    }
+                    // (2) per query the best of its 16 scores (v_max3_f32 tree: 8 instructions, no NaN canonicalisation --
+                    //     fmaxf costs a v_max x, x per operand) against the threshold: one bit per query
+                    unsigned hitq = 0;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const int ql = wm * 128 + i * 16 + l15;
-                        const float thr = thr_s[ql];
-                        float bj[4];   // maxima of the four 4-score sub-groups: the wave descends only into sub-groups with a hit
+                        const float m0 = max3_raw(acc[i][0][0], acc[i][0][1], acc[i][0][2]), m1 = max3_raw(acc[i][0][3], acc[i][1][0], acc[i][1][1]);
+                        const float m2 = max3_raw(acc[i][1][2], acc[i][1][3], acc[i][2][0]), m3 = max3_raw(acc[i][2][1], acc[i][2][2], acc[i][2][3]);
+                        const float m4 = max3_raw(acc[i][3][0], acc[i][3][1], acc[i][3][2]);
+                        const float best = max3_raw(max3_raw(m0, m1, m2), m3, max3_raw(m4, acc[i][3][3], acc[i][3][3]));
+                        hitq |= best >= thr[i] ? 1u << i : 0u;
+                    }
+                    if (__any(hitq != 0)) {
+                        // (3) the 16-bit hit mask of every query some lane of the wave has a hit for (wave-uniform branch per
+                        //     query): compare + shift-in-carry, two instructions per score
+                        unsigned mask[8];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) bj[j] = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3]));
-                        const float best = fmaxf(fmaxf(bj[0], bj[1]), fmaxf(bj[2], bj[3]));
-                        mask[i] = 0;
-                        if (__any(best >= thr && ql < q_rows)) {
+                        for (int i = 0; i < 8; ++i) {
+                            mask[i] = 0;
+                            if (!__any((hitq >> i & 1u) != 0)) continue;
                             unsigned m = 0;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (!__any(bj[j] >= thr)) continue;
-#pragma unroll
-                                for (int x = 0; x < 4; ++x) {
-                                    const int rl = wn * 64 + j * 16 + (int)lq * 4 + x;
-                                    m |= (acc[i][j][x] >= thr && rl < r_rows) ? 1u << (j * 4 + x) : 0u;
-                                }
-                            }
-                            mask[i] = ql < q_rows ? m : 0u;
-                            any_hit = true;
+                            for (int e = 15; e >= 0; --e) m = shift_in_ge(m, acc[i][e >> 2][e & 3], thr[i]);
+                            mask[i] = m;
                         }
-                    }
-                    if (any_hit && !(abl & 2)) {
-                        // (2) ALL counter updates of the tile back to back (a lane without hits adds 0), one wait: an LDS
+                        if (!(abl & 2)) {
+                        // (4) ALL counter updates of the tile back to back (a lane without hits adds 0), one wait: an LDS
                         //     atomic round trip per query in sequence was most of the filter's time.  Inline asm: for the
                         //     builtin the compiler cannot tell these addresses from the ring the LDS-DMA is writing and
-                        //     puts s_waitcnt vmcnt(0) in front of every one.
-                        int base[8];
+                        //     puts s_waitcnt vmcnt(0) in front of every one.  The lists' compaction triggers ride along.
+                        int base[8], trg[8];
                         {
                             typedef __attribute__((address_space(3))) int *lds_int_t;
                             const unsigned a0 = (unsigned)(uintptr_t)(lds_int_t)(cnt_s + wm * 128 + l15);
+                            const unsigned t0 = (unsigned)(uintptr_t)(lds_int_t)(trig_s + wm * 128 + l15);
 #pragma unroll
                             for (int i = 0; i < 8; ++i) {
                                 const unsigned inc = __popc(mask[i]);
                                 asm volatile("ds_add_rtn_u32 %0, %1, %2 offset:%3" : "=v"(base[i]) : "v"(a0), "v"(inc), "n"(i * 64) : "memory");
                             }
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(trg[i]) : "v"(t0), "n"(i * 64) : "memory");
                             asm volatile("s_waitcnt lgkmcnt(0)"
                                          : "+v"(base[0]), "+v"(base[1]), "+v"(base[2]), "+v"(base[3]), "+v"(base[4]), "+v"(base[5]),
-                                           "+v"(base[6]), "+v"(base[7])
+                                           "+v"(base[6]), "+v"(base[7]), "+v"(trg[0]), "+v"(trg[1]), "+v"(trg[2]), "+v"(trg[3]),
+                                           "+v"(trg[4]), "+v"(trg[5]), "+v"(trg[6]), "+v"(trg[7])
                                          :
                                          : "memory");
                         }
-                        // (3) the keys
+                        // (5) the keys
                         const unsigned ref0 = (unsigned)r0 + wn * 64 + lq * 4;
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if (!__any(mask[i] != 0)) continue;
                             const int ql = wm * 128 + i * 16 + l15;
                             const unsigned cntm = __popc(mask[i]);
-                            if (mask[i] && base[i] + (int)cntm >= TRIG) flag_s[fcur] = 1;
+                            if (mask[i] && base[i] + (int)cntm >= trg[i]) flag_s[fcur] = 1;
                             if ((abl & 8) && mask[i]) atomicAdd(p.dbg, (unsigned long long)cntm);
                             const unsigned slot0 = (unsigned)ql * CAP + (unsigned)base[i];   // 32-bit offset from the uniform list base
 #pragma unroll
@@ -885,6 +949,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                                         mylists[slot0 + rank] = make_key(acc[i][j][x], ref0 + j * 16 + x);
                                 }
                             }
+                        }
                         }
                     }
                 }
@@ -910,6 +975,72 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
     }
 }
 
+// Union band of one query's `splits` lists, one wave per query (top-k on the XCD-aware work order, where large calls sweep
+// the bank in 4 splits so that an XCD's workgroups can share query blocks).  Each list holds its split's own band
+// [tau~_s - 2 eps, ..): together ~4 x (k + band) candidates, of which only the band under the k-th best approximate score
+// T~ of the UNION can hold members of the exact top-k -- T~ is the k-th best approximate score over the whole bank (a pair
+// with s~ >= T~ >= tau~_s survived in its split), so the proof in the sweep's header applies to s~ >= T~ - 2 eps
+// unchanged, and every such pair is present (T~ - 2 eps >= tau~_s - 2 eps).  The merged band goes where the first split's
+// list was, its length to ncand[q * splits]; the other lists' counts are zeroed.  Re-scoring then costs what it cost with
+// one split.  EPL: registers per lane; splits * KEEP <= 64 * EPL keys always fit.
+template <int EPL>
+__global__ __launch_bounds__(256) void knn_union_kernel(unsigned long long *cand, int *ncand, const float *__restrict__ qstats,
+                                                        const unsigned *__restrict__ rmax_bits, float cd, int64_t nq, int splits,
+                                                        int keep, int k, int *fallback) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int64_t l0 = q * splits;
+    int total = 0;
+    for (int s = 0; s < splits; ++s) total += ncand[l0 + s];
+    if (total > 64 * EPL) {   // cannot happen while splits * keep <= 64 * EPL; kept as a guard: the exact sweep decides
+        if (lane == 0) fallback[0] = fallback[1 + (int)(q / SQ)] = 1;
+        return;
+    }
+    unsigned long long e[EPL];
+    unsigned u[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const int idx = lane + 64 * i;   // position in the concatenation of the lists
+        int s = 0, off = idx;
+        while (s < splits - 1 && off >= ncand[l0 + s]) off -= ncand[l0 + s++];
+        e[i] = idx < total ? cand[(l0 + s) * keep + off] : 0ull;
+        u[i] = (unsigned)(e[i] >> 32);
+    }
+    unsigned thr_u = 0u;
+    if (total >= k) {
+        unsigned pfx = 0u;   // the k-th largest score image (radix search, as compact_band)
+        for (int b = 31; b >= 0; --b) {
+            const unsigned trial = pfx | (1u << b);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) c += __popcll(__ballot(lane + 64 * i < total && u[i] >= trial));
+            if (c >= k) pfx = trial;
+        }
+        const float4 st = *(const float4 *)(qstats + q * 4);
+        const float rmax = __uint_as_float(rmax_bits[0]), drmax = __uint_as_float(rmax_bits[1]);
+        const float e2 = 2.0f * (1.02f * (st.z * rmax + st.y * drmax) + cd * st.x * rmax);   // as the sweep computes it
+        const float thr = key_score((unsigned long long)pfx << 32) - e2;
+        const unsigned t = __float_as_uint(thr);
+        thr_u = t ^ ((t >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+    }
+    int base = 0;
+    unsigned long long *dst = cand + l0 * keep;   // every entry is in registers: the first list's storage is free to take the band
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+        const bool kp = lane + 64 * i < total && u[i] >= thr_u;
+        const unsigned long long m = __ballot(kp);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (kp && pos < keep) dst[pos] = e[i];
+        base += __popcll(m);
+    }
+    if (lane == 0) {
+        ncand[l0] = base < keep ? base : keep;
+        if (base > keep) fallback[0] = fallback[1 + (int)(q / SQ)] = 1;   // the union band does not fit one list: exact sweep
+    }
+    for (int s = 1 + lane; s < splits; s += 64) ncand[l0 + s] = 0;
+}
+
 // Exact scores of the survivors of one (query, split) list and their best k, one wave per list.  The chain is the
 // oracle's: acc = fmaf(q[k], r[k], acc) for k = 0 .. d-1 from acc = 0 (oracle/knn_oracle.c), one lane per candidate.
 // PAIRMAX: instead of ranking, every survivor whose exact score clears `thr` (strictly) is folded into the video-pair table
@@ -924,11 +1055,13 @@ struct PairMaxOut {
 // MODE 2 (range search on the pre-filter path): the survivors whose exact score clears `thr` go back to the FRONT of their
 // list in ascending reference id (as exact (score, id) keys), their number to counts[list] and ncand[list]; a scan and
 // range_emit_kernel turn that into the CSR output.
+// lstride > 1 (top-k after knn_union_kernel): list l is query l's merged band, stored where its first split's list was
+// (cand + l * lstride * KEEP, ncand[l * lstride]); callers then pass splits = 1.
 template <int EPL, int MODE = 0>
 __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restrict__ q, const float *__restrict__ r,
                                                           int64_t nlists, int d, int splits, int k,
                                                           const unsigned long long *cand, const int *ncand,
-                                                          unsigned long long *__restrict__ part, PairMaxOut pm) {
+                                                          unsigned long long *__restrict__ part, PairMaxOut pm, int lstride = 1) {
     constexpr int KEEP = 64 * EPL;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
@@ -936,6 +1069,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
     const int64_t list = (int64_t)blockIdx.x * 4 + wave;
     if (list >= nlists) return;
     const int64_t qi = list / splits;
+    cand += list * (int64_t)(lstride - 1) * KEEP;     // (list * KEEP is added where the entries are read)
+    ncand += list * (int64_t)(lstride - 1);
     const int n = ncand[list];
     const float *qrow = q + qi * d;
     unsigned ids[EPL];
@@ -1218,9 +1353,64 @@ static int knn_exact(const float *q_dev, int64_t nq, const float *r_dev, int64_t
     return VSC_OK;
 }
 
+// How a pre-filter sweep is cut into work items (query block, reference split) and dealt to the workgroups.
+struct SweepPlan {
+    int nqb, splits, grid, xcd_map;
+    int64_t total_tiles, tiles_per_split;
+};
+static int sweep_plan(int64_t nq, int64_t nr, int dp, SweepPlan *out) {
+    SweepPlan pl{};
+    pl.nqb = (int)((nq + SQ - 1) / SQ);
+    pl.total_tiles = (nr + SR - 1) / SR;
+    int64_t want = (256 + pl.nqb - 1) / pl.nqb;   // enough (query block, ref split) items for one workgroup per CU
+    int dev = 0, cus = 0;
+    VSC_CHECK_HIP(hipGetDevice(&dev));
+    static int cus_of[MAX_DEVICES] = {};
+    if (dev >= 0 && dev < MAX_DEVICES && cus_of[dev]) cus = cus_of[dev];
+    else {
+        VSC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (dev >= 0 && dev < MAX_DEVICES) cus_of[dev] = cus;
+    }
+    // XCD-aware order (see the kernel): super-items of 8 query blocks x 4 splits, one per XCD at a time.  The number of
+    // split groups makes the super-items a multiple of the 8 XCDs when there are few of them.
+    const char *xe = vsc_opt(OPT_KNN_XCD_MAP);
+    // Only where the plain order would cut the bank into >= 4 splits anyway (nqb <= 64): every (query, split) list pays its
+    // own warm-up (k (1 + ln(tiles / k)) appends before its threshold is worth anything), so forcing 4 splits on a call
+    // that needs one costs 3.4 x the appends (65 536 x 1M: 65.6 -> 83.4 ms) against the 5.5 % the L2 residency buys.
+    // VSC_KNN_XCD_MAP=1 forces it on for larger calls (the per-query union of the bands keeps the re-scoring cost).
+    bool xmap = cus == 256 && pl.nqb >= 8 && pl.total_tiles >= 32 && !(xe && xe[0] == '0') && (pl.nqb <= 64 || (xe && xe[0] == '1'));
+    if (xmap) {
+        const int nqg = (pl.nqb + 7) / 8;
+        int nsg = 1;
+        if (nqg < 64) {
+            double best = 1e30;
+            for (int c = (8 + nqg - 1) / nqg, e = c + 8; c < e; ++c) {
+                const int items = nqg * c;
+                const double waste = (double)((items + 7) / 8 * 8) / items;
+                if (waste < best - 1e-9) { best = waste; nsg = c; }
+            }
+        }
+        want = 4 * nsg;
+        if (want > pl.total_tiles / 4) xmap = false;   // splits of a few tiles: not worth it, plain order
+    }
+    if (!xmap) want = (256 + pl.nqb - 1) / pl.nqb;
+    if (want > 256) want = 256;
+    if (want > pl.total_tiles) want = pl.total_tiles;
+    if (want < 1) want = 1;
+    pl.tiles_per_split = (pl.total_tiles + want - 1) / want;
+    const int64_t max_tiles = ((1ll << 31) - 1) / ((int64_t)SR * dp * 2);   // a split is one buffer descriptor (32-bit extent)
+    if (pl.tiles_per_split > max_tiles) pl.tiles_per_split = max_tiles;
+    pl.splits = (int)((pl.total_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split);
+    const int64_t work = (int64_t)pl.nqb * pl.splits;
+    pl.xcd_map = xmap ? 1 : 0;
+    pl.grid = xmap ? 256 : (int)(work < 256 ? work : 256);
+    *out = pl;
+    return VSC_OK;
+}
+
 template <int EPL, bool STREAM>
 static int launch_sweep_t(const SweepArgs &a, int grid, hipStream_t stream) {
-    constexpr int smem = ml64::RING_BYTES + 4096;
+    constexpr int smem = ml64::RING_BYTES + 5120;
     if (a.abl) {   // diagnostics requested (VSC_KNN_ABL): the instrumented build of the kernel
         auto kern = knn_sweep_bf16_kernel<EPL, STREAM, true>;
         VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1248,22 +1438,16 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     const int dp = (d + 63) / 64 * 64;
     const int epl = k <= 256 ? 16 : 32;          // CAP = 1024 / 2048 keys per list, KEEP = CAP / 2 survivors
     const int cap = 64 * epl, keep = cap / 2;
-    const int nqb = (int)((nq + SQ - 1) / SQ);
-    const int64_t total_tiles = (nr + SR - 1) / SR;
-    int64_t want = (256 + nqb - 1) / nqb;        // enough (query block, ref split) items for one workgroup per CU
-    if (want > 256) want = 256;
-    if (want > total_tiles) want = total_tiles;
-    if (want < 1) want = 1;
-    int64_t tiles_per_split = (total_tiles + want - 1) / want;
-    const int64_t max_tiles = ((1ll << 31) - 1) / ((int64_t)SR * dp * 2);   // a split is one buffer descriptor (32-bit extent)
-    if (tiles_per_split > max_tiles) tiles_per_split = max_tiles;
-    const int splits = (int)((total_tiles + tiles_per_split - 1) / tiles_per_split);
-    const int64_t work = (int64_t)nqb * splits;
-    const int grid = (int)(work < 256 ? work : 256);
+    SweepPlan pl;
+    int rc;
+    if ((rc = sweep_plan(nq, nr, dp, &pl))) return rc;
+    const int nqb = pl.nqb, splits = pl.splits, grid = pl.grid;
+    const int64_t total_tiles = pl.total_tiles, tiles_per_split = pl.tiles_per_split;
+    // few splits of a large call: their bands are merged per query before the exact re-scoring (knn_union_kernel)
+    const bool merge_bands = splits > 1 && (int64_t)splits * keep <= 64 * 32 && nqb >= 64;
     const int64_t nlists = nq * splits;
 
     void *qb, *rb, *qstats, *flags, *lists, *cand, *ncand, *part;
-    int rc;
     const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 32;   // [0..1] max |r|, max |dr| bits; [4..] fallback flags; debug counters behind them
     if ((rc = scratch_get(12, (size_t)nq * dp * 2, &qb))) return rc;
     if ((rc = scratch_get(13, (size_t)nr * dp * 2, &rb))) return rc;
@@ -1288,24 +1472,44 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     SweepArgs a{(const uint16_t *)qb, (const uint16_t *)rb, (const float *)qstats, (const unsigned *)flags, nq, nr, dp, k, nqb,
                 splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
                 (int *)ncand, fb_dev, 0, nullptr, cap - 2 * SR};
+    a.xcd_map = pl.xcd_map;
     if (const char *e = vsc_opt(OPT_KNN_TRIG)) { const int t = atoi(e); if (t >= k && t <= cap - 2 * SR) a.trig = t; }
+    a.delta = cap;   // measured (tools/micro/knn_trig.py, 65536 x 1M, k = 100): 64 / 100 / 150 / 200 / 400 appends between compactions -> 79.6 / 73.4 / 71.0 / 68.7 / 66.8 ms: the
+                     // appends are already within 25 % of their floor (the 2 eps band doubles the effective k), rounds stall the workgroup
+    if (const char *e = vsc_opt(OPT_KNN_DELTA)) { const int t = atoi(e); if (t >= 16 && t <= cap) a.delta = t; }
     a.dbg = (unsigned long long *)(((uintptr_t)(fb_dev + 1 + nqb) + 7) & ~(uintptr_t)7);
     if (const char *e = vsc_opt(OPT_KNN_ABL)) a.abl = atoi(e);
     if ((rc = epl == 16 ? launch_sweep<16>(a, grid, stream) : launch_sweep<32>(a, grid, stream))) return rc;
     knn_mark(2, stream);
-    const unsigned rgrid = (unsigned)((nlists + 3) / 4);
+    // re-scoring and the merge across splits: per (query, split) list, or -- after the union -- per query
+    int64_t rlists = nlists;
+    int rsplits = splits, lstride = 1;
+    if (merge_bands) {
+        const unsigned ugrid = (unsigned)((nq + 3) / 4);
+        if ((int64_t)splits * keep <= 64 * 16)
+            hipLaunchKernelGGL(knn_union_kernel<16>, dim3(ugrid), dim3(256), 0, stream, (unsigned long long *)cand, (int *)ncand,
+                               (const float *)qstats, (const unsigned *)flags, cd, nq, splits, keep, k, fb_dev);
+        else
+            hipLaunchKernelGGL(knn_union_kernel<32>, dim3(ugrid), dim3(256), 0, stream, (unsigned long long *)cand, (int *)ncand,
+                               (const float *)qstats, (const unsigned *)flags, cd, nq, splits, keep, k, fb_dev);
+        VSC_CHECK_LAUNCH();
+        rlists = nq;
+        rsplits = 1;
+        lstride = splits;
+    }
+    const unsigned rgrid = (unsigned)((rlists + 3) / 4);
     VSC_CHECK_HIP(hipFuncSetAttribute((const void *)knn_rescore_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 36 * 4));
     VSC_CHECK_HIP(hipFuncSetAttribute((const void *)knn_rescore_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 36 * 4));
     if (epl == 16)
-        hipLaunchKernelGGL(knn_rescore_kernel<8>, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d, splits,
-                           k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part, PairMaxOut{});
+        hipLaunchKernelGGL(knn_rescore_kernel<8>, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, rlists, d, rsplits,
+                           k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part, PairMaxOut{}, lstride);
     else
-        hipLaunchKernelGGL(knn_rescore_kernel<16>, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d,
-                           splits, k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part, PairMaxOut{});
+        hipLaunchKernelGGL(knn_rescore_kernel<16>, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, rlists, d,
+                           rsplits, k, (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)part, PairMaxOut{}, lstride);
     VSC_CHECK_LAUNCH();
     knn_mark(3, stream);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream,
-                       (const unsigned long long *)part, nq, splits, k, ref_id_offset, out_scores_dev, out_ids_dev);
+                       (const unsigned long long *)part, nq, rsplits, k, ref_id_offset, out_scores_dev, out_ids_dev);
     VSC_CHECK_LAUNCH();
     knn_mark(4, stream);
     const bool was_profiling = g_knn_profiling;
@@ -1391,21 +1595,13 @@ static int range_prefilter(const float *q_dev, int64_t nq, const float *r_dev, i
     constexpr int EPL = 32;
     const int dp = (d + 63) / 64 * 64;
     const int cap = 64 * EPL, keep = cap / 2;
-    const int nqb = (int)((nq + SQ - 1) / SQ);
-    const int64_t total_tiles = (nr + SR - 1) / SR;
-    int64_t want = (256 + nqb - 1) / nqb;
-    if (want > 256) want = 256;
-    if (want > total_tiles) want = total_tiles;
-    if (want < 1) want = 1;
-    int64_t tiles_per_split = (total_tiles + want - 1) / want;
-    const int64_t max_tiles = ((1ll << 31) - 1) / ((int64_t)SR * dp * 2);
-    if (tiles_per_split > max_tiles) tiles_per_split = max_tiles;
-    const int splits = (int)((total_tiles + tiles_per_split - 1) / tiles_per_split);
-    const int64_t work = (int64_t)nqb * splits;
-    const int grid = (int)(work < 256 ? work : 256);
+    SweepPlan pl;
+    int rc;
+    if ((rc = sweep_plan(nq, nr, dp, &pl))) return rc;
+    const int nqb = pl.nqb, splits = pl.splits, grid = pl.grid;
+    const int64_t total_tiles = pl.total_tiles, tiles_per_split = pl.tiles_per_split;
     const int64_t nlists = nq * splits;
     void *qb, *rb, *qstats, *flags, *lists, *cand, *ncand, *counts;
-    int rc;
     const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 32;
     if ((rc = scratch_get(12, (size_t)nq * dp * 2, &qb))) return rc;
     if ((rc = scratch_get(13, (size_t)nr * dp * 2, &rb))) return rc;
@@ -1428,6 +1624,7 @@ static int range_prefilter(const float *q_dev, int64_t nq, const float *r_dev, i
                 splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
                 (int *)ncand, fb_dev, 0, nullptr, cap - 2 * SR};
     a.thr_mode = 1;
+    a.xcd_map = pl.xcd_map;
     a.thr0 = radius;
     a.dbg = (unsigned long long *)(((uintptr_t)(fb_dev + 1 + nqb) + 7) & ~(uintptr_t)7);
     if ((rc = launch_sweep<EPL>(a, grid, stream))) return rc;
@@ -1438,7 +1635,7 @@ static int range_prefilter(const float *q_dev, int64_t nq, const float *r_dev, i
     pm.thr = radius;
     pm.counts = (long long *)counts;
     hipLaunchKernelGGL(rk, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d, splits, cap,
-                       (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)nullptr, pm);
+                       (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)nullptr, pm, 1);
     VSC_CHECK_LAUNCH();
     hipLaunchKernelGGL(range_scan_kernel, dim3(1), dim3(1024), 0, stream, (long long *)counts, nlists, splits, nq, lims_dev);
     VSC_CHECK_LAUNCH();
@@ -1615,21 +1812,13 @@ static int pair_max_prefilter(const float *q_dev, int64_t nq, const int32_t *qvi
     constexpr int EPL = 32;
     const int dp = (d + 63) / 64 * 64;
     const int cap = 64 * EPL, keep = cap / 2;
-    const int nqb = (int)((nq + SQ - 1) / SQ);
-    const int64_t total_tiles = (nr + SR - 1) / SR;
-    int64_t want = (256 + nqb - 1) / nqb;
-    if (want > 256) want = 256;
-    if (want > total_tiles) want = total_tiles;
-    if (want < 1) want = 1;
-    int64_t tiles_per_split = (total_tiles + want - 1) / want;
-    const int64_t max_tiles = ((1ll << 31) - 1) / ((int64_t)SR * dp * 2);
-    if (tiles_per_split > max_tiles) tiles_per_split = max_tiles;
-    const int splits = (int)((total_tiles + tiles_per_split - 1) / tiles_per_split);
-    const int64_t work = (int64_t)nqb * splits;
-    const int grid = (int)(work < 256 ? work : 256);
+    SweepPlan pl;
+    int rc;
+    if ((rc = sweep_plan(nq, nr, dp, &pl))) return rc;
+    const int nqb = pl.nqb, splits = pl.splits, grid = pl.grid;
+    const int64_t total_tiles = pl.total_tiles, tiles_per_split = pl.tiles_per_split;
     const int64_t nlists = nq * splits;
     void *qb, *rb, *qstats, *flags, *lists, *cand, *ncand;
-    int rc;
     const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 32;
     if ((rc = scratch_get(12, (size_t)nq * dp * 2, &qb))) return rc;
     if ((rc = scratch_get(13, (size_t)nr * dp * 2, &rb))) return rc;
@@ -1651,6 +1840,7 @@ static int pair_max_prefilter(const float *q_dev, int64_t nq, const int32_t *qvi
                 splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
                 (int *)ncand, fb_dev, 0, nullptr, cap - 2 * SR};
     a.thr_mode = 1;
+    a.xcd_map = pl.xcd_map;
     a.thr0 = threshold;
     a.dbg = (unsigned long long *)(((uintptr_t)(fb_dev + 1 + nqb) + 7) & ~(uintptr_t)7);
     if ((rc = launch_sweep<EPL>(a, grid, stream))) return rc;
@@ -1659,7 +1849,7 @@ static int pair_max_prefilter(const float *q_dev, int64_t nq, const int32_t *qvi
     VSC_CHECK_HIP(hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 64 * 36 * 4));
     hipLaunchKernelGGL(rk, dim3(rgrid), dim3(256), 4 * 2 * 64 * 36 * 4, stream, q_dev, r_dev, nlists, d, splits, cap,
                        (const unsigned long long *)cand, (const int *)ncand, (unsigned long long *)nullptr,
-                       PairMaxOut{qvid, rvid, table, (int64_t)n_r_videos, threshold});
+                       PairMaxOut{qvid, rvid, table, (int64_t)n_r_videos, threshold}, 1);
     VSC_CHECK_LAUNCH();
     std::vector<int> fb(1 + nqb);
     VSC_CHECK_HIP(hipMemcpyAsync(fb.data(), fb_dev, fb.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
