@@ -671,7 +671,11 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 
 // Keep the band [k-th best - eps2, ...] of one candidate list (n <= 64 * EPL keys), one wave.  Survivors go to dst
 // (may be the list itself: everything is in registers before the first store).  Returns the number kept.
-template <int EPL>
+// STEPS: bits of the radix search.  32 = the exact k-th best.  Fewer steps leave the low bits of the search prefix zero: a
+// LOWER bound of the k-th best (still >= k scores at or above it), i.e. a valid, marginally looser threshold -- the
+// in-sweep compactions use 20 (sign, exponent, 11 mantissa bits: 2^-11 of the score against a band of ~3 % of it) and
+// cost a third less; the final emit of a list uses 32.
+template <int EPL, int STEPS = 32>
 __device__ __forceinline__ int compact_band(const unsigned long long *list, int n, int k, float eps2,
                                             unsigned long long *dst, int dst_cap, float *thr_out, int lane) {
     unsigned long long e[EPL];
@@ -680,17 +684,19 @@ __device__ __forceinline__ int compact_band(const unsigned long long *list, int 
     for (int i = 0; i < EPL; ++i) {
         const int idx = lane + 64 * i;
         e[i] = idx < n ? list[idx] : 0ull;
-        u[i] = (unsigned)(e[i] >> 32);
+        u[i] = (unsigned)(e[i] >> 32);   // 0 for the empty slots: below every trial value (the image of a finite score is > 0)
     }
+    const int live = (n + 63) >> 6;      // register rows that hold keys (wave-uniform)
     float thr = -INFINITY;
     unsigned thr_u = 0u;
     if (n >= k) {
-        unsigned pfx = 0u;   // largest v with #(u >= v) >= k == the k-th largest u
-        for (int b = 31; b >= 0; --b) {   // counting on the scalar unit: one ballot + popcount per register row
+        unsigned pfx = 0u;   // largest v (low 32 - STEPS bits zero) with #(u >= v) >= k
+        for (int b = 31; b >= 32 - STEPS; --b) {   // counting on the scalar unit: one ballot + popcount per live register row
             const unsigned trial = pfx | (1u << b);
             int c = 0;
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) c += __popcll(__ballot(lane + 64 * i < n && u[i] >= trial));
+            for (int i = 0; i < EPL; ++i)
+                if (i < live) c += __popcll(__ballot(u[i] >= trial));
             if (c >= k) pfx = trial;
         }
         thr = key_score((unsigned long long)pfx << 32) - eps2;
@@ -700,6 +706,7 @@ __device__ __forceinline__ int compact_band(const unsigned long long *list, int 
     int base = 0;
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
+        if (i >= live) continue;
         const bool keep = lane + 64 * i < n && u[i] >= thr_u;
         const unsigned long long m = __ballot(keep);
         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
@@ -733,6 +740,8 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
     float *eps_s = (float *)(lds + ml64::RING_BYTES + 2048);
     int *flag_s = (int *)(lds + ml64::RING_BYTES + 3072);
     int *trig_s = (int *)(lds + ml64::RING_BYTES + 4096);   // per list: the length that asks for its next compaction
+    constexpr int QD = 4;                                   // key queue slots per lane (see the filter, step 5)
+    char *kq_s = lds + ml64::RING_BYTES + 5120;             // [wave][QD x 64 keys (8 B) | QD x 64 list slots (4 B)]
     const int DELTA = p.delta;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -751,6 +760,16 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
     const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
     const int nsg = (p.splits + 3) >> 2;
     const int64_t n_items = p.xcd_map ? (int64_t)((p.nqb + 7) >> 3) * nsg : (int64_t)p.nqb * p.splits;
+    // phase timer of the instrumented build (abl & 16): shader cycles of wave 0 of workgroup 1, by filter phase
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool timing = DIAG && (abl & 16) && blockIdx.x == 1 && wave == 0;
+#define VSC_TMARK(idx)                                                       \
+    if (timing) {                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+        tacc[idx] += now_ - tprev;                                           \
+        tprev = now_;                                                        \
+    }
+    if (timing) tprev = __builtin_amdgcn_s_memtime();
     for (int64_t work = p.xcd_map ? xcd : blockIdx.x; work < n_items; work += p.xcd_map ? 8 : gridDim.x) {
         int qb, sp;
         if (p.xcd_map) {
@@ -815,6 +834,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                 ml64::run(c, acc, nkt);
             }
 
+            VSC_TMARK(0)
             // ---- filter.  acc[i][j][x] = s~(query q0 + wm*128 + i*16 + (lane & 15), ref r0 + wn*64 + j*16 + (lane >> 4)*4 + x)
             // Lists that are getting full are compacted here, one tile late: an append at position >= TRIG raises
             // flag[tile % 3], which every wave reads at the start of the NEXT tile's filter (stable by then: all appends
@@ -835,7 +855,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                             if ((abl & 8) && lane == 0) atomicAdd(p.dbg + 2, 1ull);
                             unsigned long long *l = mylists + (size_t)ql * CAP;
                             float thr;
-                            const int kept = compact_band<EPL>(l, n < CAP ? n : CAP, p.k, eps_s[ql], l, CAP, &thr, lane);
+                            const int kept = compact_band<EPL, 20>(l, n < CAP ? n : CAP, p.k, eps_s[ql], l, CAP, &thr, lane);
                             if (lane == 0) {
                                 cnt_s[ql] = kept;
                                 thr_s[ql] = thr;
@@ -850,6 +870,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                     }
                     __syncthreads();
                 }
+                VSC_TMARK(1)
                 if (!(abl & 1)) {
                     // Everything per-lane below derives from an opaque copy of the lane id: otherwise the compiler hoists
                     // the eight list pointers / counter addresses out of the tile loop, spills them around the K loop
@@ -882,14 +903,17 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                     // (2) per query the best of its 16 scores (v_max3_f32 tree: 8 instructions, no NaN canonicalisation --
                     //     fmaxf costs a v_max x, x per operand) against the threshold: one bit per query
                     unsigned hitq = 0;
+                    float best8[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float m0 = max3_raw(acc[i][0][0], acc[i][0][1], acc[i][0][2]), m1 = max3_raw(acc[i][0][3], acc[i][1][0], acc[i][1][1]);
                         const float m2 = max3_raw(acc[i][1][2], acc[i][1][3], acc[i][2][0]), m3 = max3_raw(acc[i][2][1], acc[i][2][2], acc[i][2][3]);
                         const float m4 = max3_raw(acc[i][3][0], acc[i][3][1], acc[i][3][2]);
                         const float best = max3_raw(max3_raw(m0, m1, m2), m3, max3_raw(m4, acc[i][3][3], acc[i][3][3]));
+                        best8[i] = best;
                         hitq |= best >= thr[i] ? 1u << i : 0u;
                     }
+                    VSC_TMARK(2)
                     if (__any(hitq != 0)) {
                         // (3) the 16-bit hit mask of every query some lane of the wave has a hit for (wave-uniform branch per
                         //     query): compare + shift-in-carry, two instructions per score
@@ -903,6 +927,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                             for (int e = 15; e >= 0; --e) m = shift_in_ge(m, acc[i][e >> 2][e & 3], thr[i]);
                             mask[i] = m;
                         }
+                        VSC_TMARK(3)
                         if (!(abl & 2)) {
                         // (4) ALL counter updates of the tile back to back (a lane without hits adds 0), one wait: an LDS
                         //     atomic round trip per query in sequence was most of the filter's time.  Inline asm: for the
@@ -928,8 +953,17 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                                          :
                                          : "memory");
                         }
-                        // (5) the keys
+                        VSC_TMARK(4)
+                        // (5) the keys.  A lane that has ONE hit for a query (nearly always, once thresholds exist: a tile brings
+                        //     ~0.3 hits per lane) knows the score already -- it is the maximum of step (2) -- and the reference from
+                        //     the position of the mask's only bit: one store per query with hits, no walk over the 16 scores.  Only
+                        //     when some lane of the wave holds two or more hits of a query (the first tiles) does the wave walk
+                        //     that query's scores with a predicated store each.
                         const unsigned ref0 = (unsigned)r0 + wn * 64 + lq * 4;
+                        typedef __attribute__((address_space(3))) char *lds_char_t;
+                        const unsigned kq0 = (unsigned)(uintptr_t)(lds_char_t)(kq_s + (size_t)wave * (QD * 64 * 12)) + (unsigned)lv * 8u;
+                        const unsigned oq0 = kq0 + QD * 64 * 8 - (unsigned)lv * 4u;
+                        int nl = 0;   // keys this lane has queued
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if (!__any(mask[i] != 0)) continue;
@@ -938,6 +972,25 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                             if (mask[i] && base[i] + (int)cntm >= trg[i]) flag_s[fcur] = 1;
                             if ((abl & 8) && mask[i]) atomicAdd(p.dbg, (unsigned long long)cntm);
                             const unsigned slot0 = (unsigned)ql * CAP + (unsigned)base[i];   // 32-bit offset from the uniform list base
+                            if (!__any(cntm > 1u)) {
+                                const unsigned bit = __builtin_ctz(mask[i] | 0x10000u);
+                                if (mask[i] && base[i] < CAP && !(abl & 4)) {
+                                    // A global store instruction costs the CU ~70 cycles of issue whatever its active lanes, and
+                                    // the ~6 queries with hits per wave and tile were ~50 such stores per CU and tile (15 % of the
+                                    // sweep): the key and its list slot go to the lane's LDS queue instead (QD entries), flushed
+                                    // below with one store instruction per queue level for the whole wave.
+                                    const unsigned long long key = make_key(best8[i], ref0 + (bit >> 2) * 16 + (bit & 3u));
+                                    if (nl < QD)
+                                        asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %2, %3"
+                                                     :
+                                                     : "v"(kq0 + (unsigned)nl * 512u), "v"(key), "v"(oq0 + (unsigned)nl * 256u), "v"(slot0)
+                                                     : "memory");
+                                    else
+                                        mylists[slot0] = key;
+                                    ++nl;
+                                }
+                                continue;
+                            }
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 if (!__any((mask[i] >> (4 * j) & 15u) != 0)) continue;
@@ -950,10 +1003,23 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                                 }
                             }
                         }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                        for (int t = 0; t < QD; ++t) {
+                            if (!__any(nl > t)) break;
+                            unsigned long long key;
+                            unsigned off;
+                            asm volatile("ds_read_b64 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                         : "=&v"(key), "=&v"(off)
+                                         : "v"(kq0 + (unsigned)t * 512u), "v"(oq0 + (unsigned)t * 256u)
+                                         : "memory");
+                            if (nl > t) mylists[off] = key;
+                        }
                         }
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // counter / flag updates are in LDS before this wave's next barrier
+                VSC_TMARK(5)
             }
         }
         __syncthreads();   // the last tile's appends
@@ -973,6 +1039,9 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
         }
         __syncthreads();
     }
+    if (timing && lane == 0)
+        for (int i = 0; i < 6; ++i) p.dbg[4 + i] = tacc[i];
+#undef VSC_TMARK
 }
 
 // Union band of one query's `splits` lists, one wave per query (top-k on the XCD-aware work order, where large calls sweep
@@ -1410,7 +1479,7 @@ static int sweep_plan(int64_t nq, int64_t nr, int dp, SweepPlan *out) {
 
 template <int EPL, bool STREAM>
 static int launch_sweep_t(const SweepArgs &a, int grid, hipStream_t stream) {
-    constexpr int smem = ml64::RING_BYTES + 5120;
+    constexpr int smem = ml64::RING_BYTES + 5120 + 8 * 4 * 64 * 12;
     if (a.abl) {   // diagnostics requested (VSC_KNN_ABL): the instrumented build of the kernel
         auto kern = knn_sweep_bf16_kernel<EPL, STREAM, true>;
         VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1448,7 +1517,7 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     const int64_t nlists = nq * splits;
 
     void *qb, *rb, *qstats, *flags, *lists, *cand, *ncand, *part;
-    const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 32;   // [0..1] max |r|, max |dr| bits; [4..] fallback flags; debug counters behind them
+    const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 96;   // [0..1] max |r|, max |dr| bits; [4..] fallback flags; debug counters behind them
     if ((rc = scratch_get(12, (size_t)nq * dp * 2, &qb))) return rc;
     if ((rc = scratch_get(13, (size_t)nr * dp * 2, &rb))) return rc;
     if ((rc = scratch_get(14, (size_t)nq * 16, &qstats))) return rc;
@@ -1519,6 +1588,12 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     VSC_CHECK_HIP(hipMemcpyAsync(fb.data(), fb_dev, fb.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
     VSC_CHECK_HIP(hipStreamSynchronize(stream));
     *fell_back = 0;
+    if (a.abl & 16) {
+        unsigned long long h[10];
+        VSC_CHECK_HIP(hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "knn sweep phase cycles (wave 0 of workgroup 1): K loop + barrier %llu, compaction rounds %llu, thresholds + best-of-16 %llu, "
+                        "masks %llu, counters %llu, keys + flush %llu\n", h[4], h[5], h[6], h[7], h[8], h[9]);
+    }
     if (a.abl & 8) {
         unsigned long long h[4];
         VSC_CHECK_HIP(hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost));
@@ -1602,7 +1677,7 @@ static int range_prefilter(const float *q_dev, int64_t nq, const float *r_dev, i
     const int64_t total_tiles = pl.total_tiles, tiles_per_split = pl.tiles_per_split;
     const int64_t nlists = nq * splits;
     void *qb, *rb, *qstats, *flags, *lists, *cand, *ncand, *counts;
-    const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 32;
+    const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 96;
     if ((rc = scratch_get(12, (size_t)nq * dp * 2, &qb))) return rc;
     if ((rc = scratch_get(13, (size_t)nr * dp * 2, &rb))) return rc;
     if ((rc = scratch_get(14, (size_t)nq * 16, &qstats))) return rc;
@@ -1819,7 +1894,7 @@ static int pair_max_prefilter(const float *q_dev, int64_t nq, const int32_t *qvi
     const int64_t total_tiles = pl.total_tiles, tiles_per_split = pl.tiles_per_split;
     const int64_t nlists = nq * splits;
     void *qb, *rb, *qstats, *flags, *lists, *cand, *ncand;
-    const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 32;
+    const size_t flag_bytes = 16 + (size_t)(1 + nqb) * 4 + 8 + 96;
     if ((rc = scratch_get(12, (size_t)nq * dp * 2, &qb))) return rc;
     if ((rc = scratch_get(13, (size_t)nr * dp * 2, &rb))) return rc;
     if ((rc = scratch_get(14, (size_t)nq * 16, &qstats))) return rc;
