@@ -10,11 +10,12 @@ export TMPDIR=/tmp
 # --lanes 1: under the profiler the two chunks of a step run back to back, so a kernel's average duration is its own (with the
 # default two lanes the launches of the two chunks overlap and stretch each other: rocprofv3 then reports 300 us where the
 # kernel alone takes 207) -- the same serialisation bench.py applies to its per-launch event loop
-SHORT="--steps 3 --warmup 1 --profile-steps 3 --no-cpu-baseline --no-search --no-swin --lanes 1"
+SHORT="--steps 3 --warmup 1 --profile-steps 3 --no-cpu-baseline --no-search --no-swin --no-matching --lanes 1"
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 tail -c 600 "$OUT/bench_default.json"
 (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o enc -- python $OLDPWD/bench.py $SHORT > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err")
 (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats_knn" -o knn -- python $OLDPWD/tools/knn_bench.py 65536 1000000 100 2 > "$OUT/knn_under_rocprof.txt" 2> "$OUT/stats_knn.err")
+(cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats_swin" -o swin -- python $OLDPWD/tools/swin_bench.py 256 3 256 > "$OUT/swin_under_rocprof.txt" 2> "$OUT/stats_swin.err")
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && rocprofv3 --pmc $c -d "$OUT/pmc_$c" -o enc --output-format csv -- python $OLDPWD/bench.py $SHORT > /dev/null 2> "$OUT/pmc_$c.err")
   (cd /tmp && timeout 600 rocprofv3 --pmc $c -d "$OUT/pmcknn_$c" -o knn --output-format csv -- python $OLDPWD/tools/knn_bench.py 8192 1000000 100 1 > /dev/null 2> "$OUT/pmcknn_$c.err")
