@@ -89,7 +89,8 @@ def test_gemm_residual_epilogue_in_place(dev, m, n, k):
 @pytest.mark.parametrize("m,n,k", [(23040 + 77, 768, 256),      # 273 tiles on 256 CUs: some workgroups take two, ragged M
                                    (30001, 1000, 384),           # ragged N tile (n % 256 = 232), 6 K-tiles
                                    (18000, 2304, 1152),          # 639 tiles, several N-groups, 18 K-tiles
-                                   (65404, 768, 768)])           # the encoder's proj shape at B = 332: 3 whole rounds
+                                   (65404, 768, 768),            # the encoder's proj shape at B = 332: 3 whole rounds
+                                   (70000, 512, 128)])           # K = 128: two K-tiles per output tile, every one of them stages the next tile (Swin stage-1 shapes)
 def test_gemm_persistent_kernel_equals_one_tile_per_workgroup(dev, epi, m, n, k):
     """v4 (persistent: the operand ring streams across output tiles, write-out through 4 KiB per wave) runs the same
     MFMA chain and the same epilogue arithmetic as v3 -> identical bits; v3 itself is checked against fp32 above."""

@@ -1036,7 +1036,7 @@ int launch_v34(GemmArgs p, hipStream_t stream) {
         }
         const int64_t a_span = (int64_t)p.tiles_m * 256 * p.k * 2, w_span = (int64_t)p.tiles_n * 256 * p.k * 2;
         // (K > 3072: the per-tile costs v4 removes are < 1 % of a tile and its lockstep costs ~3 % -- 8192^3 680 vs 701 us)
-        if (!off && p.k % 128 == 0 && p.k >= 256 && p.k <= 3072 && cus % 8 == 0 && (int64_t)p.tiles_m * p.tiles_n > cus &&
+        if (!off && p.k % 128 == 0 && p.k >= 128 && p.k <= 3072 && cus % 8 == 0 && (int64_t)p.tiles_m * p.tiles_n > cus &&
             a_span < (1ll << 32) && w_span < (1ll << 32) && (EPI != VSC_EPI_RESADD_F32 || p.aux))
         {
             int grid = cus;
@@ -1134,7 +1134,7 @@ int launch_v2_pick(const GemmArgs &p, hipStream_t stream) {
         cfg = (p.n % 256 != 0 && p.n % 128 == 0) ? 'D' : 'C';
         // ... unless the persistent kernel takes it (v4: K = 256 / 384 / 512, more 256 x 256 tiles than CUs): without the per-tile
         // launch / prologue / drain the big tile wins here too (Swin-V2-B batch 256: 12.15 k -> 12.95 k frames/s)
-        if (epi_v4(EPI) && p.k % 128 == 0 && p.k >= 256 && p.n % 256 == 0 && ((p.m + 255) / 256) * (p.n / 256) > 256) cfg = 'A';
+        if (epi_v4(EPI) && p.k % 128 == 0 && p.k >= 128 && p.n % 256 == 0 && ((p.m + 255) / 256) * (p.n / 256) > 256) cfg = 'A';
     }
     if (force) cfg = force[0];
     const char *v3e = vsc_opt(OPT_GEMM_V3);   // diagnostic A/B switch, read per launch

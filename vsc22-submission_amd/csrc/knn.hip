@@ -761,7 +761,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
     const int nsg = (p.splits + 3) >> 2;
     const int64_t n_items = p.xcd_map ? (int64_t)((p.nqb + 7) >> 3) * nsg : (int64_t)p.nqb * p.splits;
     // phase timer of the instrumented build (abl & 16): shader cycles of wave 0 of workgroup 1, by filter phase
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     const bool timing = DIAG && (abl & 16) && blockIdx.x == 1 && wave == 0;
 #define VSC_TMARK(idx)                                                       \
     if (timing) {                                                            \
@@ -991,6 +991,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                                 }
                                 continue;
                             }
+                            if ((abl & 8) && lane == 0) atomicAdd(p.dbg + 3, 1ull);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 if (!__any((mask[i] >> (4 * j) & 15u) != 0)) continue;
@@ -1004,6 +1005,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                             }
                         }
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        VSC_TMARK(6)
 #pragma unroll
                         for (int t = 0; t < QD; ++t) {
                             if (!__any(nl > t)) break;
@@ -1040,7 +1042,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
         __syncthreads();
     }
     if (timing && lane == 0)
-        for (int i = 0; i < 6; ++i) p.dbg[4 + i] = tacc[i];
+        for (int i = 0; i < 7; ++i) p.dbg[4 + i] = tacc[i];
 #undef VSC_TMARK
 }
 
@@ -1589,15 +1591,15 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     VSC_CHECK_HIP(hipStreamSynchronize(stream));
     *fell_back = 0;
     if (a.abl & 16) {
-        unsigned long long h[10];
+        unsigned long long h[11];
         VSC_CHECK_HIP(hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost));
         fprintf(stderr, "knn sweep phase cycles (wave 0 of workgroup 1): K loop + barrier %llu, compaction rounds %llu, thresholds + best-of-16 %llu, "
-                        "masks %llu, counters %llu, keys + flush %llu\n", h[4], h[5], h[6], h[7], h[8], h[9]);
+                        "masks %llu, counters %llu, keys (queued) %llu, flush + tail %llu\n", h[4], h[5], h[6], h[7], h[8], h[10], h[9]);
     }
     if (a.abl & 8) {
         unsigned long long h[4];
         VSC_CHECK_HIP(hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "knn sweep counters: appends %llu (%.1f per query and split), compaction rounds %llu, lists compacted %llu, filter bodies entered %llu\n",
+        fprintf(stderr, "knn sweep counters: appends %llu (%.1f per query and split), compaction rounds %llu, lists compacted %llu, (wave, query) key walks with two or more hits in a lane %llu\n",
                 h[0], (double)h[0] / (double)nlists, h[1], h[2], h[3]);
     }
     if (!fb[0]) return VSC_OK;
