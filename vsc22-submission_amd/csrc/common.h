@@ -44,7 +44,7 @@ void vsc_set_error(const char *fmt, ...);
     X(ATTN_SKEW) X(ATTN_ABL) X(ATTN_NI) X(CONV_IMPLICIT) X(CONV_REMAP) X(CONV_PERSIST) X(CONV_STAGES) X(CONV_WAVES)      \
     X(GEMM_GROUP_N) X(GEMM_V4_SKEW) X(GEMM_TIMING_PRINT) X(GEMM_V4) X(GEMM_V4_GRID) X(GEMM_SKEW_NS_PER_K) X(GEMM_CFG)    \
     X(GEMM_V3) X(GEMM_ABL) X(GEMM_V1) X(KNN_TRIG) X(KNN_ABL) X(KNN_PATH) X(KNN_XCD_MAP) X(KNN_DELTA) X(RANGE_PATH) X(PAIRMAX_PATH) X(WATTN_ABL)      \
-    X(SWIN_SPLIT_LN) X(SWIN_SPLIT_K)
+    X(SWIN_SPLIT_LN) X(SWIN_SPLIT_K) X(GEMM_LN_V4)
 enum VscOpt {
 #define X(n) OPT_##n,
     VSC_OPT_LIST(X)
@@ -105,22 +105,32 @@ __device__ inline int xcd_remap(int bid, int nblk) {
 int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux,
                      void *out, int64_t m, int n, int k, int epilogue, int tokens,
                      hipStream_t stream);
+// pair_ws: VSC_GEMM_LN_WS_BYTES of device memory private to `stream` (nullptr: a per-device buffer -- one call at a time then)
 int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *gamma,
                         const float *beta, const float *x_in, float *x_out, uint16_t *xb_out, int64_t m, int n,
-                        int k, float eps, hipStream_t stream);
+                        int k, float eps, hipStream_t stream, void *pair_ws = nullptr);
 bool gemm_ln_supported(int n, int k);
 // Internal epilogue kinds of the encoder's LayerNorm folding (not part of the public enum in vsc_hip.h):
 //   LNF_*            the A operand is bf16(x) itself and gamma is folded into W: out = act(rstd_m * (acc - mu_m * colsum_n)
 //                    + bias_n) with (mu_m, rstd_m) = rowstats[m], colsum_n = sum_k W'[n,k], bias_n = b_n + sum_k beta_k W[n,k]
 //   RESADD_STATS_F32 RESADD_F32 that also stores bf16(out) to xb and, per row and 64-column slice, (mean, centred sum of
 //                    squares) to stats[slice][m]; ln_stats_merge turns the slices into rowstats
-enum { VSC_EPI_LNF_BF16 = 6, VSC_EPI_LNF_GELU_BF16 = 7, VSC_EPI_LNF_QGELU_BF16 = 8, VSC_EPI_RESADD_STATS_F32 = 9 };
+//   LN_RES_F32       Swin-V2's res-post-norm update on the persistent kernel: out = (aux ? aux : 0) + LayerNorm(acc + bias) * gamma + beta
+//                    over the whole row (N = 256: one tile; N = 512: the two workgroups holding a row's two tiles exchange their
+//                    (mean, M2) through L2), plus xb = bf16(out)
+enum { VSC_EPI_LNF_BF16 = 6, VSC_EPI_LNF_GELU_BF16 = 7, VSC_EPI_LNF_QGELU_BF16 = 8, VSC_EPI_RESADD_STATS_F32 = 9, VSC_EPI_LN_RES_F32 = 10 };
 struct GemmExtra {
     uint16_t *xb = nullptr;          // RESADD_STATS: bf16 copy of out [m, n]
     float *stats = nullptr;          // RESADD_STATS: [n / 64][m][2]
     const float *rowstats = nullptr; // LNF: [m][2] = (mean, rstd)
     const float *colsum = nullptr;   // LNF: [n]
+    const float *gamma = nullptr, *beta = nullptr;   // LN_RES: [n]
+    float eps = 0.f;                 // LN_RES
+    float *xch = nullptr;            // LN_RES, N = 512: [2][256 workgroups][256 rows][2] partial row statistics
+    int *xflags = nullptr;           // LN_RES, N = 512: [256 workgroups][2] tiles published (zeroed before the launch)
 };
+// bytes of the pair-exchange workspace of launch_gemm_ln_bf16 (one per stream that may run it)
+constexpr size_t VSC_GEMM_LN_WS_BYTES = 2 * 256 * 256 * 2 * 4 + 256 * 2 * 4;
 int launch_gemm_bf16_ex(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux, void *out, int64_t m,
                         int n, int k, int epilogue, int tokens, const GemmExtra &ex, hipStream_t stream);
 int launch_ln_stats_merge(const float *stats, float *rowstats, int64_t rows, int slices, int width, float eps,

@@ -763,7 +763,8 @@ int launch_v3(GemmArgs p, hipStream_t stream) {
 // the per-tile bias sits in a double-buffered 1-KiB row behind the ring, fetched during the previous write-out.
 // Serves the plain, GELU and residual epilogues; K % 128 == 0 (an even number of K-tiles), K >= 256.
 constexpr bool epi_v4(int e) {
-    return e == VSC_EPI_BF16 || e == VSC_EPI_GELU_BF16 || e == VSC_EPI_QGELU_BF16 || e == VSC_EPI_RESADD_F32 || e == VSC_EPI_F32;
+    return e == VSC_EPI_BF16 || e == VSC_EPI_GELU_BF16 || e == VSC_EPI_QGELU_BF16 || e == VSC_EPI_RESADD_F32 || e == VSC_EPI_F32 ||
+           e == VSC_EPI_LN_RES_F32;
 }
 
 #ifdef VSC_GEMM_TIMING
@@ -871,6 +872,144 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
     }
 }
 
+// LN_RES write-out of one 256 x 256 tile of the persistent kernel (Swin-V2 res-post-norm, torch2scripts.py:297-300, 361-362):
+//   x_out = (x_in ? x_in : 0) + LayerNorm_row(acc + bias) * gamma + beta,   xb = bf16(x_out)
+// Row statistics are two-pass on the registers (mean, then centred squares), combined over the four column waves through
+// the two free ring slots.  With N = 512 a row's other half lives in the workgroup that runs the neighbouring tile in the
+// same round (t ^ 1 -> blockIdx ^ 8: same XCD, same L2): both publish their 256 rows' (mean, M2) with L2-scope stores
+// and a flag word, read the partner's and merge (Chan, equal counts).  No fence: writer and reader share the XCD's L2, the
+// stores are waited for (vmcnt) before the flag, the loads bypass L1 (agent-scope atomics).  Slots are double-buffered by
+// round parity: a workgroup cannot publish round i + 2 before its partner has published i + 1, i.e. finished reading i.
+__device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8][4], char *slots, char *reg, const char *bias_lds,
+                                            int lane, int wm, int wn, int64_t m0, int n0, int iter) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int ncol0 = n0 + wn * 64;
+    const int64_t mrow0 = m0 + wm * 128;
+    ml64::wait_vmcnt<0>();   // this wave's pieces of the next tile's units 0..5 (tile_p's `first` contract)
+    float *part = (float *)slots;           // [4][256] row sums of the column waves
+    float *part2 = part + 4 * 256;          // [4][256] centred squares
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4_t bz = *(const f32x4_t *)(bias_lds + (wn * 64 + j * 16 + fq * 4) * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i][j] += bz;
+    }
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        if (fq == 0) part[wn * 256 + wm * 128 + i * 16 + fr] = sm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + i * 16 + fr;
+        mean[i] = ((part[row] + part[256 + row]) + (part[512 + row] + part[768 + row])) * (1.0f / 256.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[i][j][r] - mean[i];
+                sq = fmaf(d, d, sq);
+            }
+        sq += __shfl_xor(sq, 16, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (fq == 0) part2[wn * 256 + row] = sq;
+    }
+    __syncthreads();
+    const bool paired = p.tiles_n == 2;
+    float m2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + i * 16 + fr;
+        m2[i] = (part2[row] + part2[256 + row]) + (part2[512 + row] + part2[768 + row]);
+    }
+    if (paired) {
+        float2 *mine = (float2 *)p.ex.xch + ((size_t)(iter & 1) * 256 + blockIdx.x) * 256;
+        const float2 *theirs = (const float2 *)p.ex.xch + ((size_t)(iter & 1) * 256 + (blockIdx.x ^ 8)) * 256;
+        if (wn == 0) {   // wave-uniform: the two waves of column 0 publish their 128 rows each
+            if (fq == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    union { float2 f; unsigned long long u; } v;
+                    v.f = make_float2(mean[i], m2[i]);
+                    __hip_atomic_store((unsigned long long *)(mine + wm * 128 + i * 16 + fr), v.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            ml64::wait_vmcnt<0>();   // the statistics are in L2 ...
+            if (lane == 0) __hip_atomic_store(p.ex.xflags + blockIdx.x * 2 + wm, iter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag
+        }
+        const int *flag = p.ex.xflags + (blockIdx.x ^ 8) * 2 + wm;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < iter + 1) __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            union { float2 f; unsigned long long u; } v;
+            v.u = __hip_atomic_load((const unsigned long long *)(theirs + wm * 128 + i * 16 + fr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float d = mean[i] - v.f.x;
+            m2[i] = (m2[i] + v.f.y) + d * d * 128.0f;      // Chan: n_a n_b / (n_a + n_b) = 128
+            mean[i] = 0.5f * (mean[i] + v.f.x);
+        }
+    }
+    // normalisation as one FMA per value at staging time (row scalars a = rstd, b = -mean rstd); gamma / beta are applied
+    // after the transposition through the staging rows, where a lane owns 4 fixed columns for all passes (8 registers
+    // instead of 32) -- normalising all 128 accumulators up front spilled 40 of them
+    const float inv_n = paired ? 1.0f / 512.0f : 1.0f / 256.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        rstd[i] = rsqrtf(m2[i] * inv_n + p.ex.eps);
+        mean[i] = -mean[i] * rstd[i];
+    }
+    __syncthreads();   // every wave is done with the partials: the slots become the waves' private staging
+    // write-out as the residual epilogue of epilogue_small (16-row passes through 4 KiB per wave), plus the bf16 shadow
+    const int c = lane & 15, rq = lane >> 4;
+    const int n = ncol0 + c * 4;
+    const f32x4_t gm = *(const f32x4_t *)(p.ex.gamma + n), bt = *(const f32x4_t *)(p.ex.beta + n);
+    f32x4_t ax[3][4];
+    auto load_aux = [&](int i, f32x4_t (&dst)[4]) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int64_t m = mrow0 + i * 16 + it * 4 + rq;
+            m = m < p.m ? m : p.m - 1;
+            dst[it] = *(const f32x4_t *)(p.aux + m * p.n + n);
+        }
+    };
+    const bool res = p.aux != nullptr;
+    if (res) {
+        load_aux(0, ax[0]);
+        load_aux(1, ax[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (res && i + 2 < 8) load_aux(i + 2, ax[(i + 2) % 3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(f32x4_t *)(reg + fr * 256 + (((4 * j + fq) ^ fr) << 4)) = acc[i][j] * rstd[i] + mean[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 4 + rq;
+            f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ row) << 4));
+            v = v * gm + bt;
+            if (res) v += ax[i % 3][it];
+            const int64_t m = mrow0 + i * 16 + row;
+            if (m < p.m) {
+                *(f32x4_t *)((float *)p.out + m * p.n + n) = v;
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0], v[1]);
+                pk.y = pack_bf16x2(v[2], v[3]);
+                *(uint2 *)(p.ex.xb + m * p.n + n) = pk;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs p) {
     typedef __attribute__((address_space(3))) void *lptr_t;
@@ -948,7 +1087,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs p) {
         // instead of hoisted out of the tile loop and carried (spilled) across the K loop
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        epilogue_small<EPI>(p, acc, reg, ext + (i & 1) * 1024, lane_e, wm, wn, (int64_t)tm * 256, tn * 256);
+        if constexpr (EPI == VSC_EPI_LN_RES_F32)
+            epilogue_ln(p, acc, lds2 + 6 * ml64::UNIT_BYTES, reg, ext + (i & 1) * 1024, lane_e, wm, wn, (int64_t)tm * 256, tn * 256, i);
+        else
+            epilogue_small<EPI>(p, acc, reg, ext + (i & 1) * 1024, lane_e, wm, wn, (int64_t)tm * 256, tn * 256);
 #ifdef VSC_GEMM_TIMING
         if (rec && i < 6) {
             tb[3 + i * 5] = g_v4_t_mid[wave];
@@ -1520,9 +1662,50 @@ int launch_ln_stats_merge(const float *stats, float *rowstats, int64_t rows, int
 
 int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *gamma,
                         const float *beta, const float *x_in, float *x_out, uint16_t *xb_out, int64_t m, int n,
-                        int k, float eps, hipStream_t stream) {
+                        int k, float eps, hipStream_t stream, void *pair_ws) {
     VSC_REQUIRE(a && w && gamma && beta && x_out && xb_out, "gemm_ln: null operand");
     VSC_REQUIRE(m > 0 && k > 0 && k % 32 == 0, "gemm_ln: m=%lld k=%d (k must be a multiple of 32)", (long long)m, k);
+    // Widths 256 / 512 with more 256 x 256 tiles than CUs: the persistent kernel (v4 K loop, ring streaming across tiles)
+    // with the LN_RES write-out -- the row-owning 128 x 512 tile below stages 25 % more operand bytes per MFMA on the
+    // BK = 32 loop and pays a prologue per tile.  N = 512 needs whole tile pairs per XCD range (tiles_m % 8 == 0).
+    {
+        const int64_t tiles_m = (m + 255) / 256;
+        const int tiles_n = n / 256;
+        const char *opt = vsc_opt(OPT_GEMM_LN_V4);
+        int dev = 0, cus = 0;
+        VSC_CHECK_HIP(hipGetDevice(&dev));
+        static int cus_of[16] = {};
+        if (dev >= 0 && dev < 16 && cus_of[dev]) cus = cus_of[dev];
+        else {
+            VSC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            if (dev >= 0 && dev < 16) cus_of[dev] = cus;
+        }
+        const bool shape_ok = (n == 256 || (n == 512 && tiles_m % 8 == 0)) && k % 128 == 0 && k >= 128 && k <= 3072 && cus == 256 &&
+                              tiles_m * tiles_n > cus && tiles_m * 256 * k * 2 < (1ll << 32) && dev >= 0 && dev < 16;
+        // Where it pays (tools/micro/gemm_ln_ab.py, 256 Swin-V2-B frames): only the long-K launches.  With K <= 1024 the call is
+        // bound by its bytes whichever kernel runs it -- x read + x written + bf16 shadow + A: 805 MB in 165 us (N = 256, K = 256),
+        // 402 MB in 100 us (N = 512, K = 512) = 4-4.9 TB/s -- and the row-owning tiles' two rounds of workgroups de-phase their
+        // write-outs for free (s2 proj 99 vs 110 us here); at N = 512, K = 2048 the K loop matters: 196 -> 177 us.
+        // VSC_GEMM_LN_V4=1 forces the persistent kernel on every shape it supports (tests), 0 switches it off.
+        const bool pays = n == 512 && k >= 1536;
+        if (shape_ok && !(opt && opt[0] == '0') && (pays || (opt && opt[0] == '1'))) {
+            static void *dev_ws[16] = {};   // callers without a workspace of their own: one call at a time per device
+            if (!pair_ws) {
+                if (!dev_ws[dev]) VSC_CHECK_HIP(hipMalloc(&dev_ws[dev], VSC_GEMM_LN_WS_BYTES));
+                pair_ws = dev_ws[dev];
+            }
+            GemmArgs p{a, w, bias, x_in, x_out, m, n, k, 0, tiles_n, (int)tiles_m, 1, 0};
+            p.abl = 0;
+            p.ex.xb = xb_out;
+            p.ex.gamma = gamma;
+            p.ex.beta = beta;
+            p.ex.eps = eps;
+            p.ex.xch = (float *)pair_ws;
+            p.ex.xflags = (int *)((char *)pair_ws + 2 * 256 * 256 * 2 * 4);
+            if (tiles_n == 2) VSC_CHECK_HIP(hipMemsetAsync(p.ex.xflags, 0, 256 * 2 * 4, stream));
+            return launch_v4<VSC_EPI_LN_RES_F32>(p, cus, stream);
+        }
+    }
     GemmLnArgs p{a, w, bias, gamma, beta, x_in, x_out, xb_out, m, n, k, eps};
     switch (n) {
         case 128: return launch_ln_t<8, 1, 4>(p, stream);  // 4 x 40 KiB = the whole 160 KiB: two tiles stay in flight across a barrier

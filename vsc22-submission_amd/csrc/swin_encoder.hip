@@ -46,6 +46,7 @@ struct vsc_swin {
     struct Workspace {
         uint16_t *patches = nullptr, *xb = nullptr, *qkv = nullptr, *att = nullptr, *h = nullptr, *merged = nullptr;
         float *x = nullptr, *t = nullptr, *pooled = nullptr;
+        void *lnws = nullptr;   // pair-exchange workspace of the persistent gemm_ln (private to the lane's stream)
     } ws[2];
     hipStream_t lane_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
@@ -242,6 +243,9 @@ static int swin_alloc_workspace(vsc_swin *e, int l) {
         if (rc) return rc;
         e->ws_bytes += (int64_t)e->ws_sizes[i];
     }
+    int rc = sw_alloc(e, VSC_GEMM_LN_WS_BYTES, &w.lnws);
+    if (rc) return rc;
+    e->ws_bytes += (int64_t)VSC_GEMM_LN_WS_BYTES;
     return VSC_OK;
 }
 // The two lanes (second workspace, two internal streams, fork / join events) exist from the first call with more than one
@@ -362,7 +366,7 @@ static int gemm_ln(vsc_swin *e, vsc_swin::Workspace &ws, const uint16_t *a, cons
     const char *split_k_opt = vsc_opt(OPT_SWIN_SPLIT_K);
     const int split_k = split_k_opt ? atoi(split_k_opt) : 1 << 30;
     if (!split && k < split_k && gemm_ln_supported(n, k))
-        return launch_gemm_ln_bf16(a, w, bias, g, b, x_in, ws.x, ws.xb, m, n, k, e->cfg.ln_eps, st);
+        return launch_gemm_ln_bf16(a, w, bias, g, b, x_in, ws.x, ws.xb, m, n, k, e->cfg.ln_eps, st, ws.lnws);
     int rc = launch_gemm_bf16(a, w, bias, nullptr, ws.t, m, n, k, VSC_EPI_F32, 0, st);
     if (rc) return rc;
     return launch_ln_residual(ws.t, g, b, x_in, ws.x, ws.xb, m, n, e->cfg.ln_eps, st);
