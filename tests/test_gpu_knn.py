@@ -563,3 +563,18 @@ def test_concat_pca_sn_entry_point(dev, tmp_path):
             np.testing.assert_allclose(merged[v].feature, fitted.transform(cat), rtol=1e-4, atol=2e-5)
         sn = load_features(str(tmp_path / f"{name}_sn.npz"))
         assert all(vf.feature.shape[1] == 16 for vf in sn)   # one low-variance dim replaced by the bias column
+
+
+def test_search_scratch_release(dev):
+    """vsc_search_release_scratch frees the grow-only search scratch of the device; the next call allocates again and returns
+    the same bits."""
+    from vsc_hip import _lib, ops
+    lib = _lib.require_device()
+    q = torch.from_numpy(synth.descriptor_bank(1, 300, 128)).to(dev)
+    r = torch.from_numpy(synth.descriptor_bank(2, 70000, 128)).to(dev)
+    D0, I0 = ops.knn_ip(q, r, 20)
+    freed = lib.vsc_search_release_scratch()
+    assert freed >= 70000 * 128 * 2
+    assert lib.vsc_search_release_scratch() == 0
+    D1, I1 = ops.knn_ip(q, r, 20)
+    assert torch.equal(I0, I1) and torch.equal(D0.view(torch.int32), D1.view(torch.int32))

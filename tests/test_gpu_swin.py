@@ -183,3 +183,27 @@ def test_swin_encoder_in_the_benchmarked_configuration_vs_oracle(dev):
         ref = swin_oracle.descriptors({k: torch.from_numpy(v) for k, v in w.items()}, cfg, x[sample]).numpy()
     np.testing.assert_allclose(out_big[sample], ref, rtol=0, atol=1e-3)
     assert np.array_equal(big(xd).cpu().numpy(), out_big)
+
+
+def test_swin_profiling_classes(dev):
+    """vsc_swin_set_profiling / get_profile: every kernel class of every stage reports its launches, results are unchanged,
+    and a multi-chunk call while profiling runs its chunks back to back (no lanes)."""
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    cfg = get_swin_config("tiny_swin")
+    enc = SwinHipEncoder(cfg, synth.swin_weights(4, cfg), max_batch=3, l2_normalize=True)
+    x = torch.from_numpy(synth.swin_frames(6, 7, cfg)).to(dev)
+    ref = enc(x)
+    enc.set_profiling(True)
+    out = enc(x)
+    prof = enc.profile()
+    enc.set_profiling(False)
+    assert torch.equal(out, ref)
+    chunks = 3
+    assert prof["patchify"][1] == chunks and prof["pool_head"][1] == chunks
+    for s in range(cfg.stages):
+        for kind in ("qkv", "attention", "proj_ln", "fc1", "fc2_ln"):
+            ms, n = prof[f"s{s}.{kind}"]
+            assert n == chunks * cfg.depths[s] and ms > 0
+        if s + 1 < cfg.stages:
+            assert prof[f"s{s}.merge"][1] == chunks
+    assert torch.equal(enc(x), ref)

@@ -38,7 +38,7 @@ void vsc_set_error(const char *fmt, ...);
 #define VSC_CHECK_LAUNCH() VSC_CHECK_HIP(hipGetLastError())
 
 // ---- diagnostic / test switches ------------------------------------------------------------------
-// Every switch that used to be a getenv() on the launch path.  The environment is read ONCE per process (first use of any
+// Every switch that used to be an environment lookup on the launch path.  The environment is read ONCE per process (first use of any
 // switch); afterwards a switch changes only through vsc_set_option() (include/vsc_hip.h).  vsc_opt() is an array read.
 #define VSC_OPT_LIST(X)                                                                                                  \
     X(ATTN_SKEW) X(ATTN_ABL) X(ATTN_NI) X(CONV_IMPLICIT) X(CONV_REMAP) X(CONV_PERSIST) X(CONV_STAGES) X(CONV_WAVES)      \
