@@ -37,15 +37,28 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
     const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, const float *__restrict__ bias,
     const float *__restrict__ scale, int res, int ws, int shift, int heads) {
     constexpr int N = NT * 16, NWAVES = NT / 2, NTHREADS = NWAVES * 64;
-    constexpr int VSTRIDE = N * 2 + 8;
+    // V^T rows: 16-byte aligned, +32 B of padding (conflict-free ds_read_b128 over a 16-lane group's rows); inside a 32-key block
+    // the 4-key groups are stored in the order a lane consumes them (group g of the even 16-key tile, then group g of the odd
+    // one), so a lane's 8 keys of a PV step are ONE ds_read_b128 -- as two 8-byte pieces 32 B apart the compiler fused them
+    // into ds_read2_b64, which moves 128 B/clk against 256
+    constexpr int VSTRIDE = N * 2 + 32;
     constexpr int WS = NT == 16 ? 16 : 8, SIDE = 2 * WS - 1;
-    __shared__ __attribute__((aligned(16))) char smem[N * 64 + HD * VSTRIDE + N * 4 + N + SIDE * SIDE * 4];
+    // bias table in LDS: columns mirrored (a lane's 4 consecutive keys then read 4 ASCENDING floats), rows padded to TSTRIDE
+    // floats, four copies shifted by 0..3 floats -- the copy whose start is 16-byte aligned for this lane's query column gives
+    // the 4 bias values of 4 scores in one ds_read_b128 (four ds_read_b32 gathers per 4 scores were 30 % of the kernel's LDS
+    // cycles; 8-byte pairs get fused into the half-rate ds_read2_b64)
+    constexpr int TSTRIDE = WS == 16 ? 36 : 20, TCOPY = SIDE * TSTRIDE;
+    // + 9 rows [N] of mask addends (0 or -100 log2 e), one per region a query can lie in: a masked tile costs one ds_read_b128
+    // and two v_pk_add_f32 per 4 scores (compare + select + add per SCORE before: the masked body issued 75 % more VALU)
+    __shared__ __attribute__((aligned(16))) char smem[N * 64 + HD * VSTRIDE + N * 4 + N + 4 * TCOPY * 4 + 9 * N * 4];
     char *klds = smem;                                   // [N][32] bf16, 64-B rows, chunk ^= (-(row>>2)) & 3
     char *vt = smem + N * 64;                            // [32][VSTRIDE]
     int *rowmap = (int *)(smem + N * 64 + HD * VSTRIDE);  // image token index of window token i
     unsigned char *region = (unsigned char *)(rowmap + N);
     float *tbl = (float *)(smem + N * 64 + HD * VSTRIDE + N * 4 + N);  // this head's bias table, * log2(e)
+    float *maskrow = tbl + 4 * TCOPY;                                    // [9][N]
 
+    const float LOG2E = 1.44269504088896340736f;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwx = res / ws, nw = nwx * nwx;
@@ -61,8 +74,9 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
     const int64_t ld = 3 * (int64_t)C;
     const uint16_t *base = qkv + (int64_t)frame * res * res * ld + head * HD;
 
+    // (ws == WS: the launcher picks the instantiation by the window size, so the window decomposition is shifts)
     for (int i = tid; i < N; i += NTHREADS) {
-        const int wy = i / ws, wx = i - wy * ws;
+        const int wy = i / WS, wx = i - wy * WS;
         const int sy = wh * ws + wy, sx = wwx * ws + wx;
         int y = sy + shift, x = sx + shift;
         y = y >= res ? y - res : y;
@@ -72,8 +86,12 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
         const int wr = sx < res - ws ? 0 : (sx < res - shift ? 1 : 2);
         region[i] = (unsigned char)(3 * hr + wr);
     }
-    for (int i = tid; i < SIDE * SIDE; i += NTHREADS)
-        tbl[i] = bias[(int64_t)head * SIDE * SIDE + i] * 1.44269504088896340736f;
+    for (int i = tid; i < SIDE * SIDE; i += NTHREADS) {
+        const float v = bias[(int64_t)head * SIDE * SIDE + i] * 1.44269504088896340736f;
+        const int at = (i / SIDE) * TSTRIDE + (SIDE - 1 - i % SIDE);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tbl[c * TCOPY + at + c] = v;
+    }
     __syncthreads();
 
     const int fr = lane & 15, g = lane >> 4;
@@ -93,7 +111,7 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
         }
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
-        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // 1 / max(|x|, 1e-12): F.normalize's eps
         union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
         for (int j = 0; j < 4; ++j) pk.w[j] = pack_bf16x2(v[2 * j] * inv, v[2 * j + 1] * inv);
@@ -121,7 +139,7 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
         }
         ss += __shfl_xor(ss, 1, 64);
         ss += __shfl_xor(ss, 2, 64);
-        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // 1 / max(|x|, 1e-12): F.normalize's eps
         uint4 pk;
         pk.x = pack_bf16x2(v[0] * inv, v[1] * inv);
         pk.y = pack_bf16x2(v[2] * inv, v[3] * inv);
@@ -132,6 +150,7 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
     // ---- stage V transposed: task = (4 keys) x (8 dims); 16 consecutive lanes = 16 key groups
     for (int e = tid; e < (N / 4) * 4; e += NTHREADS) {
         const int blk = e >> 6, c8 = (e >> 4) & 3, kg = blk * 16 + (e & 15);
+        const int slot = (kg & ~7) | ((kg & 3) << 1) | ((kg >> 2) & 1);   // consumption order inside the 32-key block
         bf16x8_t r[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = (ABL & 8) ? (bf16x8_t){1, 2, 3, 4, 5, 6, 7, 8} : *(const bf16x8_t *)(base + 2 * C + rowmap[kg * 4 + i] * ld + c8 * 8);
@@ -140,26 +159,34 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
             uint2 pk;
             pk.x = (uint32_t)(uint16_t)r[0][j] | ((uint32_t)(uint16_t)r[1][j] << 16);
             pk.y = (uint32_t)(uint16_t)r[2][j] | ((uint32_t)(uint16_t)r[3][j] << 16);
-            *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + kg * 8) = pk;
+            // head dim d sits in row 16 ((d >> 2) & 1) + 4 (d >> 3) + (d & 3): the PV accumulators of a lane are then 8
+            // CONSECUTIVE head dims of its query (8 g + 4 ct + r) -- one 16-byte store per lane, 64 contiguous bytes per query
+            const int d = c8 * 8 + j;
+            *(uint2 *)(vt + (16 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3)) * VSTRIDE + slot * 8) = pk;
         }
     }
     __syncthreads();
 
-    const float LOG2E = 1.44269504088896340736f;
     const float sc = scale[head] * LOG2E;
 
     // Only windows in the last window row / column of a shifted layer hold more than one mask region
     // (torch2scripts.py:236-254): every other workgroup runs the body without the mask compares/selects
     // (3 of the ~15 VALU instructions per score; the kernel is VALU-bound).
     const bool need_mask = shift > 0 && (wh == nwx - 1 || wwx == nwx - 1);
+    if (need_mask) {   // workgroup-uniform
+        for (int i = tid; i < 9 * N; i += NTHREADS) maskrow[i] = region[i % N] != i / N ? -100.0f * LOG2E : 0.f;
+        __syncthreads();
+    }
     auto rows = [&](auto masked_c) {
         constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             const int q = (wave * 2 + qi) * 16 + fr;
             const int rq = region[q];
-            // table index of (query q, key j) = tq - (yj * SIDE + xj),  tq = (yq + WS-1) * SIDE + xq + WS-1
-            const int tq = (q / WS + WS - 1) * SIDE + (q % WS) + WS - 1;
+            // bias of (query q, key j) = table[yq - yj + WS-1][xq - xj + WS-1]; this lane's keys of a tile are xj0 .. xj0 + 3 of one
+            // window row: mirrored columns WS-1 - xq + xj0 .. + 3, which start at a multiple of 4 in copy (xq + 1) % 4
+            const int tcopy = (q + 1) & 3;
+            const float *lt = tbl + tcopy * (TCOPY + 1) + (q / WS + WS - 1) * TSTRIDE + WS - 1 - (q % WS);
             f32x2_t s[NT][2];
             float mx = -INFINITY;
             const f32x2_t sc2 = (f32x2_t){sc, sc};
@@ -171,16 +198,15 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                 if (ABL & 2) z[0] = (float)kf[0] + (float)qf[qi][1];
                 else z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi], z, 0, 0, 0);
                 float tb[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = t * 16 + g * 4 + r;
-                    tb[r] = tbl[tq - ((j / WS) * SIDE + (j % WS))];
+                {
+                    const int j0 = t * 16 + g * 4;
+                    const f32x4_t b4 = *(const f32x4_t *)(lt - (j0 / WS) * TSTRIDE + (j0 % WS));
+                    tb[0] = b4[0], tb[1] = b4[1], tb[2] = b4[2], tb[3] = b4[3];
                 }
                 if (MASKED) {
-                    const uint32_t rk = *(const uint32_t *)(region + t * 16 + g * 4);
+                    const f32x4_t m4 = *(const f32x4_t *)(maskrow + rq * N + t * 16 + g * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if ((int)((rk >> (8 * r)) & 0xff) != rq) tb[r] -= 100.0f * LOG2E;
+                    for (int r = 0; r < 4; ++r) tb[r] += m4[r];
                 }
                 s[t][0] = (f32x2_t){z[0], z[1]} * sc2 + (f32x2_t){tb[0], tb[1]};  // v_pk_fma_f32
                 s[t][1] = (f32x2_t){z[2], z[3]} * sc2 + (f32x2_t){tb[2], tb[3]};
@@ -191,7 +217,6 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const f32x2_t nmx = (f32x2_t){-mx, -mx};
-            f32x2_t sum2 = (f32x2_t){0.f, 0.f};
             bf16x8_t pb[NT / 2];
 #pragma unroll
             for (int u = 0; u < NT / 2; ++u) {
@@ -201,40 +226,37 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                     const f32x2_t d = s[2 * u + (h >> 1)][h & 1] + nmx;  // v_pk_add_f32
                     e[h] = (ABL & 1) ? d : (f32x2_t){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
                 }
-                sum2 += (e[0] + e[1]) + (e[2] + e[3]);
                 union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
                 for (int h = 0; h < 4; ++h) pk.w[h] = pack_bf16x2(e[h][0], e[h][1]);
                 pb[u] = pk.v;
             }
-            float sum = sum2[0] + sum2[1];
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = __builtin_amdgcn_rcpf(sum);
-
-            f32x4_t o[2];
+            // O^T[dh][query] += V^T[dh][key] . P^T[key][query]; a third A operand of ones gives the row sums of the bf16 P the
+            // products use (every row of that tile = sum over the keys: no VALU adds, no cross-lane reduction; the matrix pipe
+            // is 15 % busy in this kernel, the vector pipe 80 %)
+            const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+            f32x4_t o[2], osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < NT / 2; ++u) {
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    const char *vrow = vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 4 * g) * 2;
-                    union { uint2 h[2]; bf16x8_t v; } vf;
-                    vf.h[0] = *(const uint2 *)(vrow);
-                    vf.h[1] = *(const uint2 *)(vrow + 32);
-                    if (ABL & 2) o[ct][u & 3] += (float)vf.v[0] + (float)pb[u][ct];
-                    else o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
+                    const bf16x8_t vf = *(const bf16x8_t *)(vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 8 * g) * 2);
+                    if (ABL & 2) o[ct][u & 3] += (float)vf[0] + (float)pb[u][ct];
+                    else o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[u], o[ct], 0, 0, 0);
                 }
+                if (ABL & 2) osum[0] += (float)pb[u][0];
+                else osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[u], osum, 0, 0, 0);
                 if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            uint16_t *orow = out + ((int64_t)frame * res * res + qrow[qi]) * C + head * HD + g * 4;
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                uint2 pk;
-                pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
-                pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
-                if (!((ABL & 16) && inv != 12345.f)) *(uint2 *)(orow + ct * 16) = pk;
-            }
+            const float inv = __builtin_amdgcn_rcpf(osum[0]);
+            uint16_t *orow = out + ((int64_t)frame * res * res + qrow[qi]) * C + head * HD + g * 8;
+            uint4 pk;
+            pk.x = pack_bf16x2(o[0][0] * inv, o[0][1] * inv);
+            pk.y = pack_bf16x2(o[0][2] * inv, o[0][3] * inv);
+            pk.z = pack_bf16x2(o[1][0] * inv, o[1][1] * inv);
+            pk.w = pack_bf16x2(o[1][2] * inv, o[1][3] * inv);
+            if (!((ABL & 16) && inv != 12345.f)) *(uint4 *)orow = pk;
         }
     };
     if (need_mask)
