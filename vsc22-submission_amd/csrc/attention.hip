@@ -31,12 +31,22 @@
 //     (all workgroups last equally long, so the two residents of a CU otherwise load together and compute together for
 //     the whole launch: 126 -> 104 us warm, 149 -> 122 cold).  In the encoder step: 124 -> 107 us per launch.
 //   * softmax runs in fp32 with exp2 and a folded scale (1/8 * log2 e); probabilities are
-//     rounded to bf16 for the PV MFMA, the row sum is kept in fp32 from the unrounded values.
+//     rounded to bf16 for the PV MFMA, and the row sum is the sum of those bf16 values, taken by the matrix pipe (an A
+//     operand of ones): the context is an exact weighted mean of the V rows.
 #include "common.h"
 
 namespace {
 
 constexpr int DH = 64;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// fmaxf(fmaxf(a, b), c) on MFMA outputs compiles to three v_max_f32 plus a canonicalising v_max x, x per operand; the scores
+// are never signalling NaNs, so one v_max3_f32
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 template <int KT, int NI, int ABL = 0>  // key tiles of 32 -> padded token count 32*KT; NI: (frame, head) items per workgroup;
                                          // ABL: diagnostic ablation bits (VSC_ATTN_ABL, KT = 7 only)
@@ -50,7 +60,11 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)skew) __builtin_amdgcn_s_sleep(8);
     }
-    constexpr int VSTRIDE = TP * 2 + 8;  // bytes per head-dim row of V^T (8-B aligned, odd multiple of 8)
+    // bytes per head-dim row of V^T: 16-byte aligned, +32 B (conflict-free ds_read_b128 over a 16-lane group's rows).  Inside a
+    // 32-key block the 4-key groups sit in the order a lane consumes them (group g of the even 16-key tile, then group g of the
+    // odd one): a lane's 8 keys of a PV step are ONE ds_read_b128.  (As two 8-byte reads 32 B apart the compiler fused them
+    // into ds_read2_b64, which moves 128 B/clk against the 256 of b64 / b128.)
+    constexpr int VSTRIDE = TP * 2 + 32;
     constexpr int QT_MAX = (2 * KT + 7) / 8;  // 16-query tiles per wave (8 waves)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *klds = smem;             // [TP][64] bf16, 128-B rows, chunk ^= (row >> 1) & 7
@@ -64,7 +78,6 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
     const int fr = lane & 15, g = lane >> 4;
     const int qtiles = (tokens + 15) >> 4;
     const float scale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) * log2(e)
-    const int full_tiles = tokens >> 4;                    // 16-key tiles without padding
 
     constexpr int KIT = (TP * 8 + 511) / 512;
     constexpr int VTASKS = ((TP / 4 + 15) / 16) * 128;   // 16 key groups x 8 column blocks per 128 tasks
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
                 uint2 pk;
                 pk.x = (uint32_t)(uint16_t)r.vr[it][0][j] | ((uint32_t)(uint16_t)r.vr[it][1][j] << 16);
                 pk.y = (uint32_t)(uint16_t)r.vr[it][2][j] | ((uint32_t)(uint16_t)r.vr[it][3][j] << 16);
-                *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + kg * 8) = pk;
+                *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + ((kg & ~7) | ((kg & 3) << 1) | ((kg >> 2) & 1)) * 8) = pk;
             }
         }
     };
@@ -158,37 +171,37 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 2 * KT; ++t) {
-                if (t >= full_tiles) {  // wave-uniform
+                if (t >= 2 * KT - 2) {  // KT = ceil(tokens / 32): only the last two 16-key tiles can hold padding
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (t * 16 + g * 4 + r >= tokens) s[t][r] = -INFINITY;
                 }
-                mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+                mx = max3(max3(mx, s[t][0], s[t][1]), s[t][2], s[t][3]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mxs = mx * scale;
-            float sum = 0.f;
+            const f32x2_t sc2 = (f32x2_t){scale, scale}, nm2 = (f32x2_t){-mxs, -mxs};
             bf16x8_t pb[KT];
 #pragma unroll
             for (int u = 0; u < KT; ++u) {
                 float e[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    e[r] = (ABL & 1) ? fmaf(s[2 * u][r], scale, -mxs) : __builtin_amdgcn_exp2f(fmaf(s[2 * u][r], scale, -mxs));
-                    e[4 + r] = (ABL & 1) ? fmaf(s[2 * u + 1][r], scale, -mxs) : __builtin_amdgcn_exp2f(fmaf(s[2 * u + 1][r], scale, -mxs));
+                for (int h = 0; h < 4; ++h) {   // v_pk_fma_f32: two scores per instruction
+                    const f32x4_t &sv = s[2 * u + (h >> 1)];
+                    const f32x2_t d = (f32x2_t){sv[2 * (h & 1)], sv[2 * (h & 1) + 1]} * sc2 + nm2;
+                    e[2 * h] = (ABL & 1) ? d[0] : __builtin_amdgcn_exp2f(d[0]);
+                    e[2 * h + 1] = (ABL & 1) ? d[1] : __builtin_amdgcn_exp2f(d[1]);
                 }
-                sum += ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
                 union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk.w[r] = pack_bf16x2(e[2 * r], e[2 * r + 1]);
                 pb[u] = pk.v;
             }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = __builtin_amdgcn_rcpf(sum);
-
-            // O^T[dh][query] += V^T[dh][key] . P^T[key][query]
+            // O^T[dh][query] += V^T[dh][key] . P^T[key][query]; a fifth A operand of ones gives the row sums of the bf16 P the
+            // products use (every row of that tile = the sum over the keys: no VALU adds, no cross-lane reduction)
+            const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+            f32x4_t osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             f32x4_t o[4];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) o[ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -196,15 +209,15 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
             for (int u = 0; u < KT; ++u) {
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
-                    const char *vrow = vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 4 * g) * 2;
-                    union { uint2 h[2]; bf16x8_t v; } vf;
-                    vf.h[0] = *(const uint2 *)(vrow);
-                    vf.h[1] = *(const uint2 *)(vrow + 32);
-                    if (ABL & 2) o[ct][u & 3] += (float)vf.v[0] + (float)pb[u][ct];
-                    else o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
+                    const bf16x8_t vf = *(const bf16x8_t *)(vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 8 * g) * 2);
+                    if (ABL & 2) o[ct][u & 3] += (float)vf[0] + (float)pb[u][ct];
+                    else o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[u], o[ct], 0, 0, 0);
                 }
+                if (ABL & 2) osum[0] += (float)pb[u][0];
+                else osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[u], osum, 0, 0, 0);
                 if (u & 1) __builtin_amdgcn_sched_barrier(0);
             }
+            const float inv = __builtin_amdgcn_rcpf(osum[0]);
             // write-out through 2 KiB of wave-private LDS: a lane's accumulators are 4 head-dim columns of 16 different queries,
             // stored directly that is 32-byte pieces of 16 rows per instruction (four instructions per 128-byte row: 4 x the
             // store requests -- the stores cost 43 of the launch's 135 us).  Transposed, eight lanes write one whole 128-byte
@@ -266,7 +279,7 @@ template <int KT>
 int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int heads,
               hipStream_t stream) {
     constexpr int TP = KT * 32;
-    constexpr int smem = TP * 128 + 64 * (TP * 2 + 8) + 8 * 2048;
+    constexpr int smem = TP * 128 + 64 * (TP * 2 + 32) + 8 * 2048;
     static bool attr_set[16] = {};   // per device (one process may drive several)
     int dev = 0;
     VSC_CHECK_HIP(hipGetDevice(&dev));
