@@ -316,6 +316,15 @@ int vsc_gemm_ln_bf16(const uint16_t *a_dev, const uint16_t *w_dev, const float *
                      const float *gamma_dev, const float *beta_dev, const float *x_in_dev,
                      float *x_out_dev, uint16_t *xb_dev, int64_t m, int32_t n, int32_t k, float eps,
                      void *stream);
+/* The whole MLP of a Swin-V2 block in one kernel, for the narrow stages (c = 128 or 256), in place on the residual stream:
+ *   x += LayerNorm(GELU(xb W1[4c,c]^T + b1) W2[c,4c]^T + b2) * gamma + beta ;  xb = bf16(x)
+ * (Mlp + norm2 + residual of SwinTransformerBlock.forward, torch2scripts.py:190-215, 297-300) -- the hidden activations
+ * [m, 4c] never reach memory.  w2p_dev is fc2.weight with its hidden axis in the kernel's contraction order, as made by
+ * vsc_swin_mlp_permute_hidden_f32 (host arrays [c, 4c], once per model load) and then converted to bf16. */
+int vsc_swin_mlp_bf16(const uint16_t *w1_dev, const float *b1_dev, const uint16_t *w2p_dev, const float *b2_dev,
+                      const float *gamma_dev, const float *beta_dev, float *x_dev, uint16_t *xb_dev, int64_t m, int32_t c,
+                      float eps, void *stream);
+int vsc_swin_mlp_permute_hidden_f32(const float *w2_host, float *w2p_host, int32_t c);
 /* PatchMerging gather on bf16 tokens [frames, res, res, c] -> [frames*(res/2)^2, 4c] */
 int vsc_merge_gather_bf16(const uint16_t *xb_dev, uint16_t *out_dev, int64_t frames, int32_t res,
                           int32_t c, void *stream);

@@ -109,6 +109,18 @@ extern "C" int vsc_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const floa
     return launch_gemm_ln_bf16(a, w, bias, g, b, x_in, x_out, xb, m, n, k, eps, (hipStream_t)stream);
 }
 
+extern "C" int vsc_swin_mlp_bf16(const uint16_t *w1, const float *b1, const uint16_t *w2p, const float *b2, const float *g, const float *b,
+                                 float *x, uint16_t *xb, int64_t m, int32_t c, float eps, void *stream) {
+    return launch_swin_mlp(w1, b1, w2p, b2, g, b, x, xb, m, c, eps, (hipStream_t)stream);
+}
+
+extern "C" int vsc_swin_mlp_permute_hidden_f32(const float *w2, float *w2p, int32_t c) {
+    VSC_REQUIRE(w2 && w2p && w2 != w2p, "swin_mlp_permute_hidden: null / aliased arrays");
+    VSC_REQUIRE(swin_mlp_supported(c), "swin_mlp_permute_hidden: width %d unsupported (128 or 256)", c);
+    swin_mlp_permute_hidden(w2, w2p, c);
+    return VSC_OK;
+}
+
 extern "C" int vsc_merge_gather_bf16(const uint16_t *xb, uint16_t *out, int64_t frames, int32_t res, int32_t c,
                                      void *stream) {
     return launch_merge_gather(xb, out, frames, res, c, (hipStream_t)stream);

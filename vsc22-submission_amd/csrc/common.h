@@ -44,7 +44,7 @@ void vsc_set_error(const char *fmt, ...);
     X(ATTN_SKEW) X(ATTN_ABL) X(ATTN_NI) X(CONV_IMPLICIT) X(CONV_REMAP) X(CONV_PERSIST) X(CONV_STAGES) X(CONV_WAVES)      \
     X(GEMM_GROUP_N) X(GEMM_V4_SKEW) X(GEMM_TIMING_PRINT) X(GEMM_V4) X(GEMM_V4_GRID) X(GEMM_SKEW_NS_PER_K) X(GEMM_CFG)    \
     X(GEMM_V3) X(GEMM_ABL) X(GEMM_V1) X(KNN_TRIG) X(KNN_ABL) X(KNN_PATH) X(KNN_XCD_MAP) X(KNN_DELTA) X(RANGE_PATH) X(PAIRMAX_PATH) X(WATTN_ABL)      \
-    X(SWIN_SPLIT_LN) X(SWIN_SPLIT_K) X(GEMM_LN_V4)
+    X(SWIN_SPLIT_LN) X(SWIN_SPLIT_K) X(GEMM_LN_V4) X(SWIN_FUSED_MLP) X(SWIN_MLP_ABL)
 enum VscOpt {
 #define X(n) OPT_##n,
     VSC_OPT_LIST(X)
@@ -154,6 +154,12 @@ int launch_window_attention(const uint16_t *qkv, uint16_t *out, const float *bia
                             int frames, int res, int ws, int shift, int heads, hipStream_t stream);
 int launch_ln_residual(const float *t, const float *gamma, const float *beta, const float *x_in, float *x_out,
                        uint16_t *xb, int64_t rows, int width, float eps, hipStream_t stream);
+// fused Swin MLP (swin_mlp.hip): x += LN(GELU(xb W1^T + b1) W2^T + b2) gamma + beta, xb = bf16(x), widths 128 / 256;
+// w2p = fc2.weight with its hidden axis reordered by swin_mlp_permute_hidden (host, at model load)
+bool swin_mlp_supported(int c);
+void swin_mlp_permute_hidden(const float *src, float *dst, int c);
+int launch_swin_mlp(const uint16_t *w1, const float *b1, const uint16_t *w2p, const float *b2, const float *gamma, const float *beta,
+                    float *x, uint16_t *xb, int64_t m, int c, float eps, hipStream_t stream);
 int launch_merge_gather(const uint16_t *xb, uint16_t *out, int64_t frames, int res, int c, hipStream_t stream);
 int launch_l2_normalize(float *x, int64_t n, int d, hipStream_t stream);
 int launch_patchify_u8(const uint8_t *frames, uint16_t *patches, int64_t n, int channels, int image, int patch, int kpad,

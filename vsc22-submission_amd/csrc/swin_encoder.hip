@@ -21,6 +21,7 @@
 
 struct SwinBlockW {
     uint16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    uint16_t *fc2_wp = nullptr;   // widths 128 / 256: fc2.weight with the hidden axis in the fused MLP's contraction order
     float *qkv_b, *proj_b, *fc1_b, *fc2_b, *n1_g, *n1_b, *n2_g, *n2_b, *bias, *scale;
 };
 struct SwinStageW {
@@ -88,8 +89,7 @@ int sw_upload_f32v(vsc_swin *e, const std::vector<float> &v, float **out) {
 }
 int sw_upload_f32(vsc_swin *e, const std::string &name, float **out) { return sw_upload_f32v(e, e->host_w.at(name), out); }
 
-int sw_upload_bf16(vsc_swin *e, const std::string &name, int64_t rows, int cols, int cols_pad, uint16_t **out) {
-    const std::vector<float> &v = e->host_w.at(name);
+int sw_upload_bf16v(vsc_swin *e, const std::vector<float> &v, const std::string &name, int64_t rows, int cols, int cols_pad, uint16_t **out) {
     float *tmp = nullptr;
     VSC_CHECK_HIP(hipMalloc((void **)&tmp, v.size() * 4));
     hipError_t err = hipMemcpy(tmp, v.data(), v.size() * 4, hipMemcpyHostToDevice);
@@ -102,6 +102,9 @@ int sw_upload_bf16(vsc_swin *e, const std::string &name, int64_t rows, int cols,
         return VSC_ERR_HIP;
     }
     return rc;
+}
+int sw_upload_bf16(vsc_swin *e, const std::string &name, int64_t rows, int cols, int cols_pad, uint16_t **out) {
+    return sw_upload_bf16v(e, e->host_w.at(name), name, rows, cols, cols_pad, out);
 }
 
 // 16 * sigmoid(cpb_mlp(log-spaced relative coords)) -> compact table [heads, (2w-1)^2]
@@ -330,6 +333,12 @@ extern "C" int vsc_swin_finalize(vsc_swin *e) {
             TRY(sw_upload_bf16(e, p + "mlp.fc1.weight", 4 * C, C, C, &B.fc1_w));
             TRY(sw_upload_f32(e, p + "mlp.fc1.bias", &B.fc1_b));
             TRY(sw_upload_bf16(e, p + "mlp.fc2.weight", C, 4 * C, 4 * C, &B.fc2_w));
+            if (swin_mlp_supported(C)) {
+                const std::vector<float> &w2 = e->host_w.at(p + "mlp.fc2.weight");
+                std::vector<float> w2p(w2.size());
+                swin_mlp_permute_hidden(w2.data(), w2p.data(), C);
+                TRY(sw_upload_bf16v(e, w2p, p + "mlp.fc2.weight (hidden axis reordered)", C, 4 * C, 4 * C, &B.fc2_wp));
+            }
             TRY(sw_upload_f32(e, p + "mlp.fc2.bias", &B.fc2_b));
             TRY(sw_upload_f32(e, p + "norm2.weight", &B.n2_g));
             TRY(sw_upload_f32(e, p + "norm2.bias", &B.n2_b));
@@ -382,6 +391,8 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
     int rc;
 #define TRY(x) do { if ((rc = (x))) return rc; } while (0)
 #define PROF(cls) SwinProfScope _ps(e, (cls), st)
+    const char *fm = vsc_opt(OPT_SWIN_FUSED_MLP);   // diagnostic / test switch: 0 = fc1 and fc2 as two GEMM launches
+    const bool unfused_mlp = fm && fm[0] == '0';
     int chunk = 0;
     for (int64_t off = 0; off < n; off += c.max_batch, ++chunk) {
         const int lane = fork ? (chunk & 1) : 0;
@@ -407,8 +418,15 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
                 { PROF(pc + VSC_SWIN_PROF_QKV); TRY(launch_gemm_bf16(w.xb, K.qkv_w, K.qkv_b, nullptr, w.qkv, M, 3 * C, C, VSC_EPI_BF16, 0, st)); }
                 { PROF(pc + VSC_SWIN_PROF_ATTENTION); TRY(launch_window_attention(w.qkv, w.att, K.bias, K.scale, (int)B, R, W, e->shift(s, b), H, st)); }
                 { PROF(pc + VSC_SWIN_PROF_PROJ_LN); TRY(gemm_ln(e, w, w.att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, w.x, M, C, C, st)); }
-                { PROF(pc + VSC_SWIN_PROF_FC1); TRY(launch_gemm_bf16(w.xb, K.fc1_w, K.fc1_b, nullptr, w.h, M, 4 * C, C, VSC_EPI_GELU_BF16, 0, st)); }
-                { PROF(pc + VSC_SWIN_PROF_FC2_LN); TRY(gemm_ln(e, w, w.h, K.fc2_w, K.fc2_b, K.n2_g, K.n2_b, w.x, M, C, 4 * C, st)); }
+                if (K.fc2_wp && !unfused_mlp) {
+                    // both Linears, the GELU between them and the LayerNorm behind them in one kernel (swin_mlp.hip); its time is
+                    // booked under fc2_ln, fc1 stays empty
+                    PROF(pc + VSC_SWIN_PROF_FC2_LN);
+                    TRY(launch_swin_mlp(K.fc1_w, K.fc1_b, K.fc2_wp, K.fc2_b, K.n2_g, K.n2_b, w.x, w.xb, M, C, e->cfg.ln_eps, st));
+                } else {
+                    { PROF(pc + VSC_SWIN_PROF_FC1); TRY(launch_gemm_bf16(w.xb, K.fc1_w, K.fc1_b, nullptr, w.h, M, 4 * C, C, VSC_EPI_GELU_BF16, 0, st)); }
+                    { PROF(pc + VSC_SWIN_PROF_FC2_LN); TRY(gemm_ln(e, w, w.h, K.fc2_w, K.fc2_b, K.n2_g, K.n2_b, w.x, M, C, 4 * C, st)); }
+                }
             }
             if (s + 1 < c.stages) {
                 PROF(pc + VSC_SWIN_PROF_MERGE);

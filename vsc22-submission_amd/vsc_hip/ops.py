@@ -236,6 +236,27 @@ def gemm_ln_bf16(a, w, bias, gamma, beta, eps: float, x_in=None):
     return x, xb
 
 
+def swin_mlp_bf16(x, w1, b1, w2, b2, gamma, beta, eps: float):
+    """Fused Swin-V2 MLP, widths 128 / 256: -> (x + LayerNorm(gelu(bf16(x) @ w1.T + b1) @ w2.T + b2), its bf16 shadow).
+    w1 [4c, c], w2 [c, 4c] as the module holds them (the hidden-axis reordering the kernel wants is done here)."""
+    import numpy as np
+    lib = _lib.require_device()
+    x = _dev(x, torch.float32).clone()
+    m, c = x.shape
+    xb = x.to(torch.bfloat16)
+    w2h = np.ascontiguousarray(w2.detach().float().cpu().numpy())
+    assert w2h.shape == (c, 4 * c) and tuple(w1.shape) == (4 * c, c)
+    w2p = np.empty_like(w2h)
+    check(lib.vsc_swin_mlp_permute_hidden_f32(w2h.ctypes.data, w2p.ctypes.data, c))
+    w1d = _dev(w1.to(x.device), torch.bfloat16)
+    w2d = torch.from_numpy(w2p).to(x.device).to(torch.bfloat16)
+    b1, b2 = _dev(b1.to(x.device), torch.float32), _dev(b2.to(x.device), torch.float32)
+    gamma, beta = _dev(gamma.to(x.device), torch.float32), _dev(beta.to(x.device), torch.float32)
+    check(lib.vsc_swin_mlp_bf16(ptr(w1d), ptr(b1), ptr(w2d), ptr(b2), ptr(gamma), ptr(beta), ptr(x), ptr(xb), m, c, eps,
+                                current_stream()))
+    return x, xb
+
+
 def merge_gather_bf16(xb, frames: int, res: int):
     lib = _lib.require_device()
     xb = _dev(xb, torch.bfloat16)
