@@ -60,10 +60,10 @@ __device__ __forceinline__ int w2_swz(int row) { return ((row >> 1) & 1) | (((ro
 // NW waves per workgroup: eight.  One workgroup fits a CU (registers), so its phases add up -- ablations at 256 frames of
 // stage 0 (705 us): GELU 235, MFMAs 162, residual loads + stores 273 (at the HBM roof while they run), weight DMA + barriers
 // 35, everything else 100.  Measured and dropped: four waves per workgroup so that two workgroups share a CU and one
-// computes while the other moves its rows -- 882 us (a lone wave per SIMD pays for every MFMA between its vector
-// instructions: the MFMAs' share went from 162 to 422 us).
+// computes while the other moves its rows -- 710 us, no gain (and 882 us when the launch bounds let the compiler spread to one
+// workgroup per CU): the two pipes do not overlap in this instruction mix whichever waves issue them.
 template <int C, int NW, int ABL = 0>
-__global__ __launch_bounds__(NW * 64, 1) void swin_mlp_kernel(MlpArgs p) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpArgs p) {
 #define MFMA(a, b, c) ((ABL & 2) ? (c) + (f32x4_t){(float)(a)[0], (float)(b)[0], 0.f, 0.f} : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0))
     constexpr int RW = C == 128 ? 32 : 16, MT = RW / 16, R = NW * RW;
     constexpr int KS1 = C / 32, JO = C / 16, H = 4 * C, HC = 64, NCH = H / HC;
