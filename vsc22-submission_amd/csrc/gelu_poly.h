@@ -4,52 +4,27 @@
 
 namespace vscgelu {
 // GELU(x) = x Phi(x) without transcendentals, on packed fp32 (v_pk_fma_f32: two elements per instruction):
-//     Phi(x) = 1/2 + t Q(z),   t = clamp(x, -5, 5),   z = 0.08 t^2 - 1 in [-1, 1],
-// Q = the degree-11 polynomial fitted (Chebyshev nodes, weights t^2, then converted to powers of z -- the powers of t^2
-// itself cancel badly in fp32) to (Phi(t) - 1/2) / t by tools/micro/gelu_poly_fit.py.  Error of the fp32 evaluation against
-// erf in float64: |GELU error| <= 2.2e-6 + 6.6e-7 |x| (tests/test_gelu_poly.py) -- under half a bf16 ulp of the stored
-// value wherever |GELU| > 2e-3.  17 packed/scalar instructions per TWO elements against ~19 per ONE (two of them
-// quarter-rate: v_rcp_f32, v_exp_f32) for the Abramowitz-Stegun 7.1.26 form used before: the fc1 write-out was
-// VALU-bound on it (18 k of the 48 k cycles a tile took).
+//     Phi(x) = 1/2 + t Q(z),   t = clamp(x, -U, U),   z = 2 t^2 / U^2 - 1 in [-1, 1],   U = 4.5,
+// Q = the degree-8 polynomial fitted (Chebyshev nodes, weights t^2, then converted to powers of z -- the powers of t^2
+// itself cancel badly in fp32) to (Phi(t) - 1/2) / t by tools/micro/gelu_poly_fit.py 4.5 8.  Error of the fp32 evaluation
+// against erf in float64: |GELU error| <= 4.3e-5 + 3.5e-6 |x| (tests/test_gelu_poly.py) -- 1/25 of half a bf16 ulp of the
+// stored value where the polynomial error peaks (|x| ~ 0.6).  Round 3: degree 11 -> 8 (it was 2.2e-6, forty times finer than
+// anything downstream resolves): the vector pipe's time ADDS to the matrix pipe's on this part (tools/micro/pipe_overlap.hip:
+// MFMAs and v_pk_fma_f32 of two waves of one SIMD take the sum of their times, not the maximum), so a write-out's
+// instruction count is paid in full: 16 packed/scalar instructions per TWO elements (19 before).
+constexpr int GELU_DEG = 8;
+constexpr float GELU_U = 4.5f, GELU_ZS = 2.0f / (4.5f * 4.5f);
+constexpr float GELU_C[GELU_DEG + 1] = {1.569020897e-01f, -7.717858255e-02f, 5.482625961e-02f, -4.047540203e-02f, 2.754251473e-02f,
+                                        -1.697185636e-02f, 1.244884357e-02f, -9.152771905e-03f, 3.170517040e-03f};
 __device__ __forceinline__ f32x2_t gelu2(f32x2_t x) {
     f32x2_t t;
-    t[0] = __builtin_amdgcn_fmed3f(x[0], -5.0f, 5.0f);
-    t[1] = __builtin_amdgcn_fmed3f(x[1], -5.0f, 5.0f);
-    const f32x2_t z = __builtin_elementwise_fma(t * t, (f32x2_t){0.08f, 0.08f}, (f32x2_t){-1.0f, -1.0f});
-    constexpr float C[12] = {1.413637698e-01f, -7.029826939e-02f, 5.152343214e-02f, -4.038983583e-02f, 3.137785569e-02f,
-                             -2.364724688e-02f, 1.683344319e-02f, -1.008572429e-02f, 5.223751534e-03f, -4.000799730e-03f,
-                             3.139984794e-03f, -1.040469273e-03f};
-    f32x2_t q = (f32x2_t){C[11], C[11]};
+    t[0] = __builtin_amdgcn_fmed3f(x[0], -GELU_U, GELU_U);
+    t[1] = __builtin_amdgcn_fmed3f(x[1], -GELU_U, GELU_U);
+    const f32x2_t z = __builtin_elementwise_fma(t * t, (f32x2_t){GELU_ZS, GELU_ZS}, (f32x2_t){-1.0f, -1.0f});
+    f32x2_t q = (f32x2_t){GELU_C[GELU_DEG], GELU_C[GELU_DEG]};
 #pragma unroll
-    for (int i = 10; i >= 0; --i) q = __builtin_elementwise_fma(q, z, (f32x2_t){C[i], C[i]});
+    for (int i = GELU_DEG - 1; i >= 0; --i) q = __builtin_elementwise_fma(q, z, (f32x2_t){GELU_C[i], GELU_C[i]});
     return x * __builtin_elementwise_fma(t, q, (f32x2_t){0.5f, 0.5f});
-}
-// NP independent pairs in lock-step: every Horner step is issued for all pairs before the next one, so the dependent
-// v_pk_fma_f32 of one pair are NP instructions apart (one pair at a time the chain runs at its latency, ~2.5 x slower: the
-// GEMM write-outs interleave their pairs with LDS and store traffic, a register-resident caller has only this)
-template <int NP>
-__device__ __forceinline__ void gelu_pairs(f32x2_t (&x)[NP]) {
-    constexpr float C[12] = {1.413637698e-01f, -7.029826939e-02f, 5.152343214e-02f, -4.038983583e-02f, 3.137785569e-02f,
-                             -2.364724688e-02f, 1.683344319e-02f, -1.008572429e-02f, 5.223751534e-03f, -4.000799730e-03f,
-                             3.139984794e-03f, -1.040469273e-03f};
-    f32x2_t t[NP], z[NP], q[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        t[p][0] = __builtin_amdgcn_fmed3f(x[p][0], -5.0f, 5.0f);
-        t[p][1] = __builtin_amdgcn_fmed3f(x[p][1], -5.0f, 5.0f);
-    }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) z[p] = __builtin_elementwise_fma(t[p] * t[p], (f32x2_t){0.08f, 0.08f}, (f32x2_t){-1.0f, -1.0f});
-#pragma unroll
-    for (int p = 0; p < NP; ++p) q[p] = __builtin_elementwise_fma((f32x2_t){C[11], C[11]}, z[p], (f32x2_t){C[10], C[10]});
-#pragma unroll
-    for (int i = 9; i >= 0; --i) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) q[p] = __builtin_elementwise_fma(q[p], z[p], (f32x2_t){C[i], C[i]});
-        __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise re-serialises the chains, depth first)
-    }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) x[p] = x[p] * __builtin_elementwise_fma(t[p], q[p], (f32x2_t){0.5f, 0.5f});
 }
 __device__ __forceinline__ void gelu4(f32x4_t &v) {
     const f32x2_t lo = gelu2((f32x2_t){v[0], v[1]}), hi = gelu2((f32x2_t){v[2], v[3]});

@@ -11,6 +11,18 @@ namespace {
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int HD = 32;  // head dim of every Swin-V2 stage (C / heads)
 
+// sum of the squares of 8 bf16 values: four v_dot2c_f32_bf16 (exact products, fp32 accumulation) instead of 8 conversions'
+// worth of multiplies and adds -- the kernel is bound by its vector instructions, and the matrix pipe does not hide them
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16pair_t;
+__device__ __forceinline__ float sumsq8(bf16x8_t raw) {
+    union { bf16x8_t v; hw_bf16pair_t p[4]; } u;
+    u.v = raw;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ss = __builtin_amdgcn_fdot2_f32_bf16(u.p[j], u.p[j], ss, false);
+    return ss;
+}
+
 // ------------------------------------------------------------------------------------------
 // One workgroup per (frame, window, head).  The cyclic shift, the window partition and their
 // inverses (torch.roll + window_partition / window_reverse, torch2scripts.py:37-67,275-296) are
@@ -103,12 +115,10 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
         const int q = (wave * 2 + qi) * 16 + fr;
         qrow[qi] = rowmap[q];
         const bf16x8_t raw = *(const bf16x8_t *)(base + qrow[qi] * ld + g * 8);
-        float v[8], ss = 0.f;
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[j] = bf16_to_f32((uint16_t)raw[j]);
-            ss += v[j] * v[j];
-        }
+        for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+        float ss = sumsq8(raw);
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
         const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // 1 / max(|x|, 1e-12): F.normalize's eps
@@ -131,12 +141,10 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
         const int e = tid + it * NTHREADS;
         const int i = e >> 2, c = e & 3;
         const bf16x8_t raw = kraw[it];
-        float v[8], ss = 0.f;
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            v[j] = bf16_to_f32((uint16_t)raw[j]);
-            ss += v[j] * v[j];
-        }
+        for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+        float ss = sumsq8(raw);
         ss += __shfl_xor(ss, 1, 64);
         ss += __shfl_xor(ss, 2, 64);
         const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // 1 / max(|x|, 1e-12): F.normalize's eps

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
         // The chunk as a four-phase software pipeline inside the wave (two waves share a SIMD and leave every barrier in
         // phase, so matrix work and vector work overlap only if each wave interleaves them itself):
         //   A  GEMM 1 for hidden tiles j = 0, 1                         (matrix pipe)
-        //   B  bias + GELU of tiles 0, 1   ||  GEMM 1 for tiles 2, 3    (one MFMA group per polynomial step)
+        //   B  bias + GELU of tiles 0, 1   ||  GEMM 1 for tiles 2, 3    (MFMA groups spread over the polynomial steps)
         //   C  bias + GELU of tiles 2, 3   ||  GEMM 2, k-step 0         (h of tiles 0, 1)
         //   D  GEMM 2, k-step 1                                         (matrix pipe)
         // Operand fragments are read one MFMA group ahead of their use.
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
                 hacc[mt][j] = MFMA(wq[e & 1], xf[mt][ks], (ks == 0 ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : hacc[mt][j]));
         }
         // the lock-step GELU of NP pairs with `fill(step)` issued behind each of its NSTEP steps
-        constexpr int NP = MT * 4, NSTEP = 14;
+        constexpr int NP = MT * 4, NSTEP = vscgelu::GELU_DEG + 3;
         auto gelu_with = [&](f32x2_t (&x)[NP], auto &&fill) {
             if (ABL & 1) {
 #pragma unroll
@@ -168,40 +168,41 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
             }
             // (measured and dropped: the same polynomial on scalar v_fma_f32 -- twice the instructions, and the vector pipe is the
             //  limiter: GELU 235 -> 474 us of the stage-0 launch)
-            constexpr float Q[12] = {1.413637698e-01f, -7.029826939e-02f, 5.152343214e-02f, -4.038983583e-02f, 3.137785569e-02f,
-                                     -2.364724688e-02f, 1.683344319e-02f, -1.008572429e-02f, 5.223751534e-03f, -4.000799730e-03f,
-                                     3.139984794e-03f, -1.040469273e-03f};   // gelu_poly.h
+            using vscgelu::GELU_C;
+            using vscgelu::GELU_DEG;
+            using vscgelu::GELU_U;
+            using vscgelu::GELU_ZS;
             f32x2_t t[NP], z[NP], q[NP];
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                t[i][0] = __builtin_amdgcn_fmed3f(x[i][0], -5.0f, 5.0f);
-                t[i][1] = __builtin_amdgcn_fmed3f(x[i][1], -5.0f, 5.0f);
+                t[i][0] = __builtin_amdgcn_fmed3f(x[i][0], -GELU_U, GELU_U);
+                t[i][1] = __builtin_amdgcn_fmed3f(x[i][1], -GELU_U, GELU_U);
             }
             pin(t);
             fill(0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < NP; ++i) z[i] = __builtin_elementwise_fma(t[i] * t[i], (f32x2_t){0.08f, 0.08f}, (f32x2_t){-1.0f, -1.0f});
+            for (int i = 0; i < NP; ++i) z[i] = __builtin_elementwise_fma(t[i] * t[i], (f32x2_t){GELU_ZS, GELU_ZS}, (f32x2_t){-1.0f, -1.0f});
             pin(z);
             fill(1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma((f32x2_t){Q[11], Q[11]}, z[i], (f32x2_t){Q[10], Q[10]});
+            for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma((f32x2_t){GELU_C[GELU_DEG], GELU_C[GELU_DEG]}, z[i], (f32x2_t){GELU_C[GELU_DEG - 1], GELU_C[GELU_DEG - 1]});
             pin(q);
             fill(2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int c = 9; c >= 0; --c) {
+            for (int c = GELU_DEG - 2; c >= 0; --c) {
 #pragma unroll
-                for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(q[i], z[i], (f32x2_t){Q[c], Q[c]});
+                for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(q[i], z[i], (f32x2_t){GELU_C[c], GELU_C[c]});
                 pin(q);
-                fill(12 - c);
+                fill(GELU_DEG + 1 - c);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int i = 0; i < NP; ++i) x[i] = x[i] * __builtin_elementwise_fma(t[i], q[i], (f32x2_t){0.5f, 0.5f});
             pin(x);
-            fill(13);
+            fill(NSTEP - 1);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto bias_of = [&](int jp, f32x2_t (&v)[NP]) {   // tiles 2 jp, 2 jp + 1 of every 16-row tile, + bias
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
                     hf[mt][jp].w[jj * 2 + 1] = pack_bf16x2(v[mt * 4 + jj * 2 + 1][0], v[mt * 4 + jj * 2 + 1][1]);
                 }
         };
-        // ---- B: GELU(tiles 0, 1) || GEMM 1 (tiles 2, 3): 2 KS1 MFMA groups over the 14 steps
+        // ---- B: GELU(tiles 0, 1) || GEMM 1 (tiles 2, 3): 2 KS1 MFMA groups over the NSTEP steps
         {
             f32x2_t v[NP];
             bias_of(0, v);
