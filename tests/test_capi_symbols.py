@@ -62,3 +62,38 @@ def test_option_table_is_read_once_and_set_through_the_api(lib, monkeypatch):
     assert len(re.findall(r"\bgetenv\(", src)) == 1, "getenv outside the once-per-process loader in capi.hip"
     for name in set(re.findall(r"vsc_opt\(OPT_([A-Z0-9_]+)\)", src)):
         assert lib.vsc_set_option(("VSC_" + name).encode(), None) == 0, name
+
+
+def test_swin_mlp_hidden_permutation_is_the_documented_bijection(lib):
+    """vsc_swin_mlp_permute_hidden_f32 is host code (no GPU): dst[n][32 S + 8 g + 4 t + i] = src[n][32 S + 16 t + 4 g + i], a
+    bijection of every row's hidden axis; other widths are refused."""
+    import numpy as np
+    from vsc_hip._lib import VscHipError, check
+    for c in (128, 256):
+        src = np.arange(c * 4 * c, dtype=np.float32).reshape(c, 4 * c)
+        dst = np.full_like(src, -1.0)
+        check(lib.vsc_swin_mlp_permute_hidden_f32(src.ctypes.data, dst.ctypes.data, c))
+        k = np.arange(4 * c)
+        S, t, g, i = k >> 5, (k >> 4) & 1, (k >> 2) & 3, k & 3
+        assert np.array_equal(dst[:, 32 * S + 8 * g + 4 * t + i], src[:, k])
+        assert np.array_equal(np.sort(dst, axis=1), src)
+    with pytest.raises(VscHipError, match="unsupported"):
+        buf = np.zeros((64, 256), dtype=np.float32)
+        check(lib.vsc_swin_mlp_permute_hidden_f32(buf.ctypes.data, buf.copy().ctypes.data, 64))
+
+
+def test_lds_layouts_are_conflict_free():
+    """The LDS layouts the attention kernels and the fused Swin MLP read with ds_read_b128, checked exhaustively against the
+    bank rule (tools/micro/lds_swizzle_check.py): one LDS cycle per 16-lane group."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools", "micro"))
+    import lds_swizzle_check as L
+    for C in (128, 256):
+        assert max(L.cycles(lambda l, j=j, ks=ks: (16 * j + (l & 15)) * 2 * C + (((4 * ks + (l >> 4)) ^ (l & 15)) << 4))
+                   for j in range(4) for ks in range(C // 32)) == 4
+    for tp in range(32, 321, 32):
+        s = tp * 2 + 32
+        assert max(L.cycles(lambda l, ct=ct, u=u: (ct * 16 + (l & 15)) * s + (32 * u + 8 * (l >> 4)) * 2)
+                   for ct in range(2) for u in range(tp // 32)) == 4
+    # and the old V^T row stride (2 TP + 8 bytes) is what a b128 read could NOT have used: misaligned rows
+    assert (224 * 2 + 8) % 16 != 0
