@@ -57,6 +57,13 @@ struct Ctx {
     char *lds;             // ring base
     uint32_t rd_a;         // LDS byte offset of this lane's A fragment chunk (kh = 0) inside its unit: wm * 8192 + lane part
     uint32_t rd_w;         // same for W: wn * 4096 + lane part
+    // fragment read bases [A / W][slot >> 2][kh]: ring base + 64 KiB * (slot >> 2) + (rd ^ 64 kh).  Every fragment address is one
+    // of these eight registers plus a compile-time offset below 64 KiB ((slot & 3) * 16 KiB + f * 2 KiB), i.e. the ds_read's
+    // immediate: formed as ring + slot * 16 KiB + ((rd + 2048 f) ^ 64 kh) the slot part did not fit the 16-bit immediate and
+    // cost a v_add_u32 per fragment pair -- 17 vector instructions per K-tile and wave, and the vector pipe's time adds to the
+    // matrix pipe's (tools/micro/pipe_overlap.hip).  (rd < 16 KiB - 6 KiB and bit 6 of rd belongs to the chunk index alone, so
+    // (rd + 2048 f) ^ 64 = (rd ^ 64) + 2048 f.)
+    const char *fr[2][2][2];
     int wave;
     // K-tile index t -> source offsets.  One tile pair (GEMM): A and W both advance 128 bytes per K-tile.  Stream
     // (similarity sweep): t = (W tile index << kt_shift) | k-tile inside it; A restarts with every W tile, W moves on by
@@ -90,6 +97,13 @@ __device__ __forceinline__ void init(Ctx &c, const uint16_t *a_tile, int64_t lda
     const uint32_t lane_part = (uint32_t)((lane & 15) * 128 + (((lane >> 4) ^ ((lane >> 1) & 7)) << 4));
     c.rd_a = wm * 8192 + lane_part;
     c.rd_w = wn * 4096 + lane_part;
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            c.fr[0][par][kh] = lds + par * 4 * UNIT_BYTES + (c.rd_a ^ (uint32_t)(kh * 64));
+            c.fr[1][par][kh] = lds + par * 4 * UNIT_BYTES + (c.rd_w ^ (uint32_t)(kh * 64));
+        }
 }
 
 template <int KIND, int HALF>   // KIND 0 = A, 1 = W
@@ -104,8 +118,9 @@ __device__ __forceinline__ void stage_unit(const Ctx &c, int slot, int ktile) {
     }
 }
 
-__device__ __forceinline__ bf16x8_t frag(const Ctx &c, int slot, uint32_t rd, int f, int kh) {
-    return *(const bf16x8_t *)(c.lds + slot * UNIT_BYTES + ((rd + f * 2048) ^ (kh * 64)));
+template <int KIND>   // 0 = A, 1 = W
+__device__ __forceinline__ bf16x8_t frag(const Ctx &c, int slot, int f, int kh) {
+    return *(const bf16x8_t *)(c.fr[KIND][slot >> 2][kh] + (slot & 3) * UNIT_BYTES + f * 2048);
 }
 
 // fragments: af[i][kh] (i = 0..3: the A sub-tile in use), w1[j][kh] (W sub-tile 1 of the K-tile at hand) and, by tile parity,
@@ -162,7 +177,7 @@ __device__ __forceinline__ void ktile_g(const Ctx &c, f32x4_t (&acc)[8][4], Frag
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) f.af[i][kh] = frag(c, S_A0, c.rd_a, i, kh);
+        for (int kh = 0; kh < 2; ++kh) f.af[i][kh] = frag<0>(c, S_A0, i, kh);
     if (STEADY || rem > 1) stage_unit<1, 1>(c, N_W1, kt1);
     end_l<STEADY, 8, 2>(rem, nowait);
     mfma_quadrant<B, 0, 0>(acc, f);
@@ -171,7 +186,7 @@ __device__ __forceinline__ void ktile_g(const Ctx &c, f32x4_t (&acc)[8][4], Frag
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) f.w1[j][kh] = frag(c, S_W1, c.rd_w, j, kh);
+        for (int kh = 0; kh < 2; ++kh) f.w1[j][kh] = frag<1>(c, S_W1, j, kh);
     if (STEADY || rem > 1) stage_unit<0, 1>(c, N_A1, kt1);
     end_l<STEADY, 8, 0>(rem, nowait);
     mfma_quadrant<B, 0, 1>(acc, f);
@@ -180,7 +195,7 @@ __device__ __forceinline__ void ktile_g(const Ctx &c, f32x4_t (&acc)[8][4], Frag
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) f.af[i][kh] = frag(c, S_A1, c.rd_a, i, kh);
+        for (int kh = 0; kh < 2; ++kh) f.af[i][kh] = frag<0>(c, S_A1, i, kh);
     if (STEADY || rem > 2) stage_unit<1, 0>(c, S_W0, kt2);
     end_l<STEADY, 6, 0>(rem, nowait);
     mfma_quadrant<B, 1, 1>(acc, f);
@@ -190,7 +205,7 @@ __device__ __forceinline__ void ktile_g(const Ctx &c, f32x4_t (&acc)[8][4], Frag
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) f.w0[B ^ 1][j][kh] = frag(c, N_W0, c.rd_w, j, kh);
+            for (int kh = 0; kh < 2; ++kh) f.w0[B ^ 1][j][kh] = frag<1>(c, N_W0, j, kh);
     }
     if (STEADY || rem > 2) stage_unit<0, 0>(c, S_A0, kt2);
     end_l<STEADY, 4, 0>(rem, nowait);
@@ -229,7 +244,7 @@ __device__ __forceinline__ void tiles(const Ctx &c, f32x4_t (&acc)[8][4], Frags 
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) f.w0[0][j][kh] = frag(c, 0, c.rd_w, j, kh);
+            for (int kh = 0; kh < 2; ++kh) f.w0[0][j][kh] = frag<1>(c, 0, j, kh);
     }
     int t = t0;
     const int end = t0 + n;
@@ -304,7 +319,7 @@ __device__ __forceinline__ void tile_p(Ctx &c, f32x4_t (&acc)[8][4], Frags &f, i
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) f.w0[0][j][kh] = frag(c, 0, c.rd_w, j, kh);
+            for (int kh = 0; kh < 2; ++kh) f.w0[0][j][kh] = frag<1>(c, 0, j, kh);
     }
 #pragma nounroll   // (also keeps the t == 0 iteration from being peeled into a third copy of the two bodies: that spills)
     for (int t = 0; t < nk; t += 2) {
