@@ -40,6 +40,8 @@ namespace ml64 {
 
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
+typedef __attribute__((address_space(3))) const char *ldsc_t;                 // 32-bit LDS address
+typedef __attribute__((address_space(3))) const bf16x8_t *ldsfrag_t;
 
 constexpr int UNIT_BYTES = 16384;
 constexpr int RING_BYTES = 8 * UNIT_BYTES;   // 128 KiB
@@ -63,7 +65,7 @@ struct Ctx {
     // cost a v_add_u32 per fragment pair -- 17 vector instructions per K-tile and wave, and the vector pipe's time adds to the
     // matrix pipe's (tools/micro/pipe_overlap.hip).  (rd < 16 KiB - 6 KiB and bit 6 of rd belongs to the chunk index alone, so
     // (rd + 2048 f) ^ 64 = (rd ^ 64) + 2048 f.)
-    const char *fr[2][2][2];
+    ldsc_t fr[2][2][2];
     int wave;
     // K-tile index t -> source offsets.  One tile pair (GEMM): A and W both advance 128 bytes per K-tile.  Stream
     // (similarity sweep): t = (W tile index << kt_shift) | k-tile inside it; A restarts with every W tile, W moves on by
@@ -101,8 +103,12 @@ __device__ __forceinline__ void init(Ctx &c, const uint16_t *a_tile, int64_t lda
     for (int par = 0; par < 2; ++par)
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            c.fr[0][par][kh] = lds + par * 4 * UNIT_BYTES + (c.rd_a ^ (uint32_t)(kh * 64));
-            c.fr[1][par][kh] = lds + par * 4 * UNIT_BYTES + (c.rd_w ^ (uint32_t)(kh * 64));
+            // opaque values: the compiler otherwise keeps four of the eight and re-derives the other parity's by a v_add_u32 per use
+            ldsc_t pa = (ldsc_t)(lds + par * 4 * UNIT_BYTES + (c.rd_a ^ (uint32_t)(kh * 64)));
+            ldsc_t pw = (ldsc_t)(lds + par * 4 * UNIT_BYTES + (c.rd_w ^ (uint32_t)(kh * 64)));
+            asm volatile("" : "+v"(pa), "+v"(pw));
+            c.fr[0][par][kh] = pa;
+            c.fr[1][par][kh] = pw;
         }
 }
 
@@ -120,7 +126,7 @@ __device__ __forceinline__ void stage_unit(const Ctx &c, int slot, int ktile) {
 
 template <int KIND>   // 0 = A, 1 = W
 __device__ __forceinline__ bf16x8_t frag(const Ctx &c, int slot, int f, int kh) {
-    return *(const bf16x8_t *)(c.fr[KIND][slot >> 2][kh] + (slot & 3) * UNIT_BYTES + f * 2048);
+    return *(ldsfrag_t)(c.fr[KIND][slot >> 2][kh] + (slot & 3) * UNIT_BYTES + f * 2048);
 }
 
 // fragments: af[i][kh] (i = 0..3: the A sub-tile in use), w1[j][kh] (W sub-tile 1 of the K-tile at hand) and, by tile parity,
@@ -324,10 +330,11 @@ __device__ __forceinline__ void tile_p(Ctx &c, f32x4_t (&acc)[8][4], Frags &f, i
 #pragma nounroll   // (also keeps the t == 0 iteration from being peeled into a third copy of the two bodies: that spills)
     for (int t = 0; t < nk; t += 2) {
         const bool wrap = t + 2 == nk;               // the two K-tiles that stage the next output tile
-        const uint32_t ba = wrap ? da : 0u, bw = wrap ? dw : 0u;
-        bump<0>(c, ba, bw);                          // half-0 units (j = 0, 1) are staged for kt2: next tile from here on
+        // (workgroup-uniform branches: the eight v_add_u32 of the two bumps are vector instructions, paid in every iteration
+        //  when they were unconditional adds of zero)
+        if (wrap) bump<0>(c, da, dw);                // half-0 units (j = 0, 1) are staged for kt2: next tile from here on
         ktile_g<0, true>(c, acc, f, t + 1, wrap ? 0 : t + 2, 0, NOWAIT_TEST && !first && t == 0);
-        bump<1>(c, ba, bw);                          // half-1 units (j = 2, 3) are staged for kt1
+        if (wrap) bump<1>(c, da, dw);                // half-1 units (j = 2, 3) are staged for kt1
         ktile_g<1, true>(c, acc, f, wrap ? 0 : t + 2, wrap ? 1 : t + 3, 0, false);
     }
     if (group == 0) __builtin_amdgcn_s_barrier();
