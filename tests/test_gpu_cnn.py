@@ -61,6 +61,9 @@ def test_conv2d_matches_torch(dev, n, h, w, cin, cout, k, stride, act, res):
     (1, 7, 9, 24, 8, 5, 1),         # 5 x 5, K = 600 (19 K-steps, the last one past K)
     (2, 33, 17, 64, 64, 3, 1),      # several pixel tiles, the last one ragged
     (5, 6, 6, 40, 80, 1, 2),        # 1 x 1 with a stride: not the in-place case
+    (3, 40, 56, 20, 18, 3, 1),      # 6720 pixels: 27 pixel tiles walked persistently, images change inside tiles
+    (1, 3, 2, 8, 16, 3, 1),         # an image smaller than the window on one axis: most taps outside on every pixel
+    (2, 9, 9, 12, 24, 5, 2),        # 5 x 5 (25 taps), stride 2
 ])
 def test_conv2d_implicit_gather_equals_materialised_patches(dev, n, h, w, cin, cout, k, stride):
     """The narrow convolution kernel gathers its patch operand from the feature map while staging it (no im2col matrix);
