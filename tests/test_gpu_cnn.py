@@ -88,6 +88,39 @@ def test_conv2d_implicit_gather_equals_materialised_patches(dev, n, h, w, cin, c
     assert torch.allclose(outs[1].cpu().permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,res", [
+    (2, 16, 32, 20, 18, True),      # whole tiles: two tile rows of one 32-pixel tile column
+    (3, 21, 45, 20, 20, True),      # ragged in both directions, images change between tiles
+    (1, 5, 3, 20, 18, False),       # an image smaller than one tile (and than the halo)
+    (16, 56, 56, 20, 18, True),     # 1568 tiles: every workgroup walks several (the halo double buffer)
+    (2, 19, 40, 36, 18, False),     # 36 input channels (9 chunks per pixel, an odd chunk count: the zero weight chunk)
+    (1, 8, 33, 20, 32, False),      # all 32 channel rows of the accumulator
+])
+def test_conv2d_direct_3x3_matches_torch_and_the_gemm_path(dev, n, h, w, cin, cout, res):
+    """conv3x3_direct_kernel (halo tile in LDS, nine taps read from it) against torch and against the implicit-GEMM kernel it
+    replaces for the thin 3 x 3 layers (VSC_CONV_DIRECT=0): the same products in a different summation order."""
+    from vsc_hip import cnn
+    rng = np.random.RandomState(cin + h)
+    sd = {"c.weight": torch.from_numpy((rng.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)).astype(np.float32)),
+          "c.bias": torch.from_numpy(rng.randn(cout).astype(np.float32) * 0.1)}
+    x = torch.from_numpy(rng.randn(n, h, w, cin).astype(np.float32)).to(dev)
+    r = torch.from_numpy(rng.randn(n, h, w, cout).astype(np.float32)).to(dev) if res else None
+    conv = cnn.Conv(sd, "c", None, 1, dev)
+    got = conv(x, act="relu", residual=r).clone()
+    _vsc_lib.set_option("VSC_CONV_DIRECT", "0")
+    try:
+        gemm = conv(x, act="relu", residual=r).clone()
+    finally:
+        _vsc_lib.set_option("VSC_CONV_DIRECT", None)
+    want = F.conv2d(x.cpu().permute(0, 3, 1, 2), sd["c.weight"], sd["c.bias"], padding=1)
+    if res:
+        want = want + r.cpu().permute(0, 3, 1, 2)
+    want = F.relu(want)
+    assert torch.allclose(got.cpu().permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(got, gemm, atol=5e-6, rtol=1e-5)
+    assert not torch.equal(got, torch.zeros_like(got))
+
+
 def test_depthwise_pool_scale_upsample(dev):
     from vsc_hip import cnn
     rng = np.random.RandomState(0)

@@ -399,6 +399,128 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_gemm_narrow_kernel(ConvGemmAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Direct 3 x 3 / stride 1 / pad 1 convolution for the thin high-resolution layers (<= 32 output channels, cin = 4 CQ): the
+// implicit-GEMM kernel above fetches every input pixel once per tap -- nine 16-byte L2 requests per 4 channels and pixel, 18
+// B/clk/CU asked of a path that sustains ~12 -- and waits for them (PMC: matrix pipe 43 % busy, vector pipe 10 %).  Here a
+// workgroup stages the (8 + 2) x (32 + 2)-pixel HALO of its 8 x 32 output tile ONCE (dense [pixel][cin] image in LDS, by
+// LDS-DMA; pixels outside the image point past the buffer descriptor and arrive as zeros: the padding) and reads the nine
+// taps' operands from it at shifted pixel positions: 1/9 of the requests.  The weights (<= 32 rows x 9 cin) sit in LDS for
+// the workgroup's whole walk over tiles; the next tile's halo streams in under the current tile's MFMAs (two halo buffers).
+//   * wave w = output row w of the tile, lane & 31 = output column, one 32 x 32 accumulator (channels x pixels);
+//   * k runs over (tap, channel) in the packed weights' order; a K-step is a PAIR of 16-byte chunks (2 p, 2 p + 1), the
+//     lane half (lane >> 5) takes chunk 2 p + half of both operands -- four MFMAs per pair, as in the implicit kernel.  With
+//     5 chunks per tap a pair may straddle two taps: the halo offset of a chunk is a compile-time constant, the half picks one
+//     of two (one v_cndmask per four MFMAs); an odd chunk count gets a zero weight chunk at the end;
+//   * LDS strides: pixels 16 CQ bytes apart (an odd multiple of 16 for CQ = 5, 9: conflict-free ds_read_b128 over 32
+//     consecutive pixels), weight rows (2 NPAIR + 1) 16-byte chunks.
+// Same products as the implicit kernel, summed in a different order (its K-steps pair the chunks of 32-float slabs).
+struct DirectArgs {
+    const float *x, *wp, *bias, *res;
+    float *out;
+    int n, h, w, ldx, cout, kpad, ldo, ldr, act;
+    int tiles_x, tiles_y;
+    int64_t ntiles;
+    unsigned xbytes;
+};
+
+template <int CQ>
+__global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(DirectArgs p) {
+    constexpr int TH = 8, TW = 32, HW = TW + 2, HH = TH + 2, HPIX = HW * HH;
+    constexpr int NCH = 9 * CQ, NPAIR = (NCH + 1) / 2, WROW = (2 * NPAIR + 1) * 16;   // bytes per weight row in LDS
+    constexpr int PIECES = (HPIX * CQ + 63) / 64, HALO_BYTES = PIECES * 1024, W_BYTES = (32 * WROW + 1023) / 1024 * 1024;
+    __shared__ __attribute__((aligned(16))) char lds[W_BYTES + 2 * HALO_BYTES];
+    char *wl = lds, *halo = lds + W_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    // ---- weights: row r (output channel), chunk c (k = 4 c .. 4 c + 3 of the packed row), zeros past cout / past K
+    for (int e = tid; e < 32 * 2 * NPAIR; e += 512) {
+        const int r = e / (2 * NPAIR), c = e - r * (2 * NPAIR);
+        f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (r < p.cout && c < NCH) v = *(const f32x4_t *)(p.wp + (int64_t)r * p.kpad + c * 4);
+        *(f32x4_t *)(wl + r * WROW + c * 16) = v;
+    }
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.xbytes, 0x00020000);
+    // halo of tile t into buffer b: chunk e of the dense image = pixel e / CQ (row-major over the HH x HW halo), channels 4 (e % CQ)..
+    auto stage = [&](int64_t t, int b) {
+        const int tx = (int)(t % p.tiles_x);
+        const int64_t t2 = t / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y), img = (int)(t2 / p.tiles_y);
+#pragma unroll
+        for (int qq = 0; qq < (PIECES + 7) / 8; ++qq) {
+            const int q = qq * 8 + wave;
+            if (q >= PIECES) break;   // wave-uniform
+            const int e = q * 64 + lane;
+            const int pix = e / CQ, ch = e - pix * CQ;
+            const int hy = pix / HW, hx = pix - hy * HW;
+            const int iy = ty * TH - 1 + hy, ix = tx * TW - 1 + hx;
+            const bool ok = pix < HPIX && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+            const unsigned voff = ok ? (unsigned)((((img * p.h + iy) * p.w + ix) * p.ldx + ch * 4) * 4) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(halo + b * HALO_BYTES + q * 1024), 16, voff, 0, 0, 0);
+        }
+    };
+    int64_t t = blockIdx.x;
+    if (t >= p.ntiles) return;
+    stage(t, 0);
+    int buf = 0;
+    const char *wrow = wl + l31 * WROW + hi * 16;
+    for (; t < p.ntiles; t += gridDim.x, buf ^= 1) {
+        // this wave's pieces of the tile's halo have landed; behind the barrier everyone's have (and, the first time, the
+        // weights are written), and every wave is done reading the other buffer
+        __syncthreads();
+        if (t + gridDim.x < p.ntiles) stage(t + gridDim.x, buf ^ 1);
+        const char *hb = halo + buf * HALO_BYTES + (wave * HW + l31) * (CQ * 16);
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int pr = 0; pr < NPAIR; ++pr) {
+            // halo byte offset of chunk c relative to the lane's pixel: tap (c / CQ) -> rows (tap / 3), columns (tap % 3)
+            constexpr auto off_of = [](int c) { return (((c / CQ) / 3) * HW + (c / CQ) % 3) * (CQ * 16) + (c % CQ) * 16; };
+            const int c0 = 2 * pr, c1 = 2 * pr + 1 < NCH ? 2 * pr + 1 : 2 * pr;   // the pad chunk re-reads finite data (its weights are 0)
+            const int bo = hi ? off_of(c1) : off_of(c0);
+            const f32x4_t bf = *(const f32x4_t *)(hb + bo);
+            const f32x4_t af = *(const f32x4_t *)(wrow + pr * 32);
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k4], bf[k4], acc, 0, 0, 0);
+        }
+        // acc[reg] = <w[8 (reg >> 2) + 4 hi + (reg & 3)], patch of output pixel (row wave, column l31) of the tile>
+        const int tx = (int)(t % p.tiles_x);
+        const int64_t t2 = t / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y);
+        const int64_t img = t2 / p.tiles_y;
+        const int oy = ty * TH + wave, ox = tx * TW + l31;
+        if (oy < p.h && ox < p.w) {
+            const int64_t pix = (img * p.h + oy) * p.w + ox;
+            float *orow = p.out + pix * p.ldo;
+            const float *rrow = p.res ? p.res + pix * p.ldr : nullptr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = 8 * g + 4 * hi;
+                if (co >= p.cout) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[4 * g + r];
+                    if (co + r < p.cout) {
+                        if (p.bias) v[r] += p.bias[co + r];
+                        if (rrow) v[r] += rrow[co + r];
+                        v[r] = activate(v[r], p.act);
+                    }
+                }
+                if (co + 3 < p.cout && ((p.ldo | co) & 3) == 0) {
+                    *(float4 *)(orow + co) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.cout) orow[co + r] = v[r];
+                }
+            }
+        }
+    }
+}
+
 // depthwise: one thread per (pixel, channel); w [c, kh * kw]
 __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
                                                      const float *__restrict__ bias, float *__restrict__ out, int64_t total,
@@ -599,6 +721,27 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     int dev = 0;
     VSC_CHECK_HIP(hipGetDevice(&dev));
     VSC_REQUIRE(dev >= 0 && dev < 16, "conv2d: device %d out of range", dev);
+    // thin 3 x 3 / stride 1 / pad 1 layers: direct convolution from a halo tile in LDS (conv3x3_direct_kernel)
+    {
+        const char *de = vsc_opt(OPT_CONV_DIRECT);   // diagnostic / test switch: 0 = the implicit-GEMM path
+        const int64_t xbytes = n * (int64_t)h * w * ldx * 4;
+        const bool direct = !(de && de[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cout <= 32 && (cin == 20 || cin == 36) &&
+                            (ldx & 3) == 0 && (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 && xbytes < (1ll << 31) &&
+                            (!res_dev || ldr >= cout);
+        if (direct) {
+            DirectArgs a{x_dev, w_packed_dev, bias_dev, res_dev, out_dev, (int)n, h, w, ldx, cout, kpad, ldo, ldr, act,
+                         (w + 31) / 32, (h + 7) / 8, 0, (unsigned)xbytes};
+            a.ntiles = (int64_t)a.tiles_x * a.tiles_y * n;
+            static int cus_direct[16] = {};
+            if (!cus_direct[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_direct[dev], hipDeviceAttributeMultiprocessorCount, dev));
+            const int64_t resident = 2ll * cus_direct[dev];
+            const unsigned grid = (unsigned)(a.ntiles < resident ? a.ntiles : resident);
+            if (cin == 20) hipLaunchKernelGGL(conv3x3_direct_kernel<5>, dim3(grid), dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL(conv3x3_direct_kernel<9>, dim3(grid), dim3(512), 0, stream, a);
+            VSC_CHECK_LAUNCH();
+            return VSC_OK;
+        }
+    }
     // 1 x 1, stride 1, dense rows of a multiple of 32 channels: the input IS the patch matrix
     const bool in_place = kh == 1 && kw == 1 && stride == 1 && pad == 0 && ldx == cin && (cin % KS) == 0 && (((uintptr_t)x_dev) & 15) == 0;
     const bool narrow = cout <= 80;   // <= 3 channel tiles of 32: the thin layers (see conv_gemm_narrow_kernel)
