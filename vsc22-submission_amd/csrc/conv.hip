@@ -471,6 +471,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(DirectArgs p) {
         __syncthreads();
         if (t + gridDim.x < p.ntiles) stage(t + gridDim.x, buf ^ 1);
         const char *hb = halo + buf * HALO_BYTES + (wave * HW + l31) * (CQ * 16);
+        // this lane's output pixel; its residual values are requested now and arrive under the MFMAs
+        const int tx = (int)(t % p.tiles_x);
+        const int64_t t2 = t / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y);
+        const int64_t img = t2 / p.tiles_y;
+        const int oy = ty * TH + wave, ox = tx * TW + l31;
+        const bool inside = oy < p.h && ox < p.w;
+        const int64_t pix = (img * p.h + (inside ? oy : 0)) * p.w + (inside ? ox : 0);
+        f32x4_t rs[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            rs[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            const int co = 8 * g + 4 * hi;
+            if (p.res && inside && co + 3 < p.cout && ((p.ldr | co) & 3) == 0) rs[g] = *(const f32x4_t *)(p.res + pix * p.ldr + co);
+            else if (p.res && inside) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < p.cout) rs[g][r] = p.res[pix * p.ldr + co + r];
+            }
+        }
         f32x16_t acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -486,15 +506,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(DirectArgs p) {
             for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k4], bf[k4], acc, 0, 0, 0);
         }
         // acc[reg] = <w[8 (reg >> 2) + 4 hi + (reg & 3)], patch of output pixel (row wave, column l31) of the tile>
-        const int tx = (int)(t % p.tiles_x);
-        const int64_t t2 = t / p.tiles_x;
-        const int ty = (int)(t2 % p.tiles_y);
-        const int64_t img = t2 / p.tiles_y;
-        const int oy = ty * TH + wave, ox = tx * TW + l31;
-        if (oy < p.h && ox < p.w) {
-            const int64_t pix = (img * p.h + oy) * p.w + ox;
+        if (inside) {
             float *orow = p.out + pix * p.ldo;
-            const float *rrow = p.res ? p.res + pix * p.ldr : nullptr;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = 8 * g + 4 * hi;
@@ -505,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(DirectArgs p) {
                     v[r] = acc[4 * g + r];
                     if (co + r < p.cout) {
                         if (p.bias) v[r] += p.bias[co + r];
-                        if (rrow) v[r] += rrow[co + r];
+                        v[r] += rs[g][r];
                         v[r] = activate(v[r], p.act);
                     }
                 }
