@@ -149,6 +149,27 @@ def test_swin_fused_mlp_equals_two_gemm_path(dev):
     assert np.abs(fused - plain).max() < 4e-4
 
 
+@pytest.mark.parametrize("preset,frames", [("tiny_swin", 5), ("swinv2_base_256", 3)])
+def test_swin_patch_merging_inside_the_gemm_is_bit_identical(dev, preset, frames):
+    """PatchMerging's 2 x 2 gather done by the reduction GEMM's operand staging (default) against the gather kernel + GEMM
+    (VSC_SWIN_FUSED_MERGE=0): the same values reach the same MFMAs in the same order -> identical descriptors; and the
+    buffer swap behind the fused form survives repeated calls."""
+    from vsc_hip import _lib
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    cfg = get_swin_config(preset)
+    enc = SwinHipEncoder(cfg, synth.swin_weights(5, cfg), max_batch=2, l2_normalize=True)
+    x = torch.from_numpy(synth.swin_frames(6, frames, cfg)).to(dev)
+    fused = enc(x).clone()
+    assert torch.equal(enc(x), fused)
+    _lib.set_option("VSC_SWIN_FUSED_MERGE", "0")
+    try:
+        plain = enc(x).clone()
+    finally:
+        _lib.set_option("VSC_SWIN_FUSED_MERGE", None)
+    assert torch.equal(fused.view(torch.int32), plain.view(torch.int32))
+    assert torch.equal(enc(x), fused)
+
+
 def test_gemm_ln_rejects_other_widths(dev):
     from vsc_hip import ops
     from vsc_hip._lib import VscHipError

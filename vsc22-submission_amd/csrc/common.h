@@ -44,7 +44,7 @@ void vsc_set_error(const char *fmt, ...);
     X(ATTN_SKEW) X(ATTN_ABL) X(ATTN_NI) X(CONV_IMPLICIT) X(CONV_DIRECT) X(CONV_REMAP) X(CONV_PERSIST) X(CONV_STAGES) X(CONV_WAVES)      \
     X(GEMM_GROUP_N) X(GEMM_V4_SKEW) X(GEMM_TIMING_PRINT) X(GEMM_V4) X(GEMM_V4_GRID) X(GEMM_SKEW_NS_PER_K) X(GEMM_CFG)    \
     X(GEMM_V3) X(GEMM_ABL) X(GEMM_V1) X(KNN_TRIG) X(KNN_ABL) X(KNN_PATH) X(KNN_XCD_MAP) X(KNN_DELTA) X(RANGE_PATH) X(PAIRMAX_PATH) X(WATTN_ABL)      \
-    X(SWIN_SPLIT_LN) X(SWIN_SPLIT_K) X(GEMM_LN_V4) X(SWIN_FUSED_MLP) X(SWIN_MLP_ABL)
+    X(SWIN_SPLIT_LN) X(SWIN_SPLIT_K) X(GEMM_LN_V4) X(SWIN_FUSED_MLP) X(SWIN_MLP_ABL) X(SWIN_FUSED_MERGE)
 enum VscOpt {
 #define X(n) OPT_##n,
     VSC_OPT_LIST(X)
@@ -108,7 +108,7 @@ int launch_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, co
 // pair_ws: VSC_GEMM_LN_WS_BYTES of device memory private to `stream` (nullptr: a per-device buffer -- one call at a time then)
 int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *gamma,
                         const float *beta, const float *x_in, float *x_out, uint16_t *xb_out, int64_t m, int n,
-                        int k, float eps, hipStream_t stream, void *pair_ws = nullptr);
+                        int k, float eps, hipStream_t stream, void *pair_ws = nullptr, int merge_res = 0, int merge_c = 0);
 bool gemm_ln_supported(int n, int k);
 // Internal epilogue kinds of the encoder's LayerNorm folding (not part of the public enum in vsc_hip.h):
 //   LNF_*            the A operand is bf16(x) itself and gamma is folded into W: out = act(rstd_m * (acc - mu_m * colsum_n)

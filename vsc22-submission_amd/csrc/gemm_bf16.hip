@@ -245,6 +245,31 @@ __device__ __forceinline__ void stage_rows32(const uint16_t *src, int64_t ld, in
     }
 }
 
+// The same for Swin's PatchMerging GEMM with the 2 x 2 gather done here instead of by a copy kernel: row r of the operand is
+// the merged token (b, Y, X) of a [frames, res, res, c] bf16 tensor, its columns part * c + cc the channels cc of token
+// (b, 2 Y + (part & 1), 2 X + (part >> 1)) (torch2scripts.py:353-358).  res is a power of two (lh = log2(res / 2)), c a
+// multiple of 32, so a 32-column slab lies inside one part: a uniform offset per K-step on top of a per-row base.
+template <int ROWS, int NW>
+__device__ __forceinline__ void stage_rows32_merge(const uint16_t *src, int res, int lh, int c, int64_t row0, int64_t row_last,
+                                                   int k0, char *region, int wave, int lane) {
+    constexpr int PIECES = ROWS / 16;
+    const int part = k0 / c, cc = k0 - part * c;                       // wave-uniform
+    const int64_t poff = ((int64_t)(part & 1) * res + (part >> 1)) * c + cc;
+    const int hmask = (1 << lh) - 1;
+#pragma unroll
+    for (int j = 0; j < PIECES / NW; ++j) {
+        const int piece = j * NW + wave;
+        const int r = piece * 16 + (lane >> 2);
+        const int ch = (lane & 3) ^ ((-(r >> 2)) & 3);
+        int64_t gr = row0 + r;
+        gr = gr > row_last ? row_last : gr;
+        const int X = (int)gr & hmask, Y = (int)(gr >> lh) & hmask;
+        const int64_t b = gr >> (2 * lh);
+        const int64_t tok = (b * res + 2 * Y) * res + 2 * X;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + tok * c + poff + ch * 8), (lptr_t)(region + piece * 1024), 16, 0, 0);
+    }
+}
+
 __device__ __forceinline__ bf16x8_t lds_frag32(const char *region, int row, int g) {
     return *(const bf16x8_t *)(region + row * 64 + ((g ^ ((-(row >> 2)) & 3)) << 4));
 }
@@ -1292,6 +1317,7 @@ struct GemmLnArgs {
     int64_t m;
     int n, k;
     float eps;
+    int g_res = 0, g_lh = 0, g_c = 0;   // PatchMerging gather on the A operand (stage_rows32_merge); g_res = 0: plain rows
 };
 
 #ifdef VSC_GEMM_TIMING
@@ -1333,7 +1359,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
     for (int s = 0; s < STAGES - 1; ++s) {
         if (s < nk) {
             char *st = lds2 + s * STAGE_BYTES;
-            stage_rows32<BM2, NW>(p.a, p.k, m0, a_last, s * BK2, st, wave, lane);
+            if (p.g_res) stage_rows32_merge<BM2, NW>(p.a, p.g_res, p.g_lh, p.g_c, m0, a_last, s * BK2, st, wave, lane);
+            else stage_rows32<BM2, NW>(p.a, p.k, m0, a_last, s * BK2, st, wave, lane);
             stage_rows32<BN2, NW>(p.w, p.k, 0, w_last, s * BK2, st + A_BYTES, wave, lane);
         }
     }
@@ -1353,7 +1380,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
             int ns = cur + STAGES - 1;
             ns = ns >= STAGES ? ns - STAGES : ns;
             char *st = lds2 + ns * STAGE_BYTES;
-            stage_rows32<BM2, NW>(p.a, p.k, m0, a_last, (kt + STAGES - 1) * BK2, st, wave, lane);
+            if (p.g_res) stage_rows32_merge<BM2, NW>(p.a, p.g_res, p.g_lh, p.g_c, m0, a_last, (kt + STAGES - 1) * BK2, st, wave, lane);
+            else stage_rows32<BM2, NW>(p.a, p.k, m0, a_last, (kt + STAGES - 1) * BK2, st, wave, lane);
             stage_rows32<BN2, NW>(p.w, p.k, 0, w_last, (kt + STAGES - 1) * BK2, st + A_BYTES, wave, lane);
         }
         const char *at = lds2 + cur * STAGE_BYTES;
@@ -1639,8 +1667,12 @@ int launch_ln_stats_merge(const float *stats, float *rowstats, int64_t rows, int
 
 int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *gamma,
                         const float *beta, const float *x_in, float *x_out, uint16_t *xb_out, int64_t m, int n,
-                        int k, float eps, hipStream_t stream, void *pair_ws) {
+                        int k, float eps, hipStream_t stream, void *pair_ws, int merge_res, int merge_c) {
     VSC_REQUIRE(a && w && gamma && beta && x_out && xb_out, "gemm_ln: null operand");
+    // merge_res > 0: a is the [frames, merge_res, merge_res, merge_c] token tensor, the operand its 2 x 2 PatchMerging gather
+    VSC_REQUIRE(merge_res == 0 || (merge_res >= 2 && (merge_res & (merge_res - 1)) == 0 && merge_c % 32 == 0 && k == 4 * merge_c &&
+                                   a != xb_out && m % ((int64_t)(merge_res / 2) * (merge_res / 2)) == 0),
+                "gemm_ln: merge gather needs a power-of-two map (%d), channels %% 32 (%d), k = 4 c and an output outside the input", merge_res, merge_c);
     VSC_REQUIRE(m > 0 && k > 0 && k % 32 == 0, "gemm_ln: m=%lld k=%d (k must be a multiple of 32)", (long long)m, k);
     // Widths 256 / 512 with more 256 x 256 tiles than CUs: the persistent kernel (v4 K loop, ring streaming across tiles)
     // with the LN_RES write-out -- the row-owning 128 x 512 tile below stages 25 % more operand bytes per MFMA on the
@@ -1665,7 +1697,7 @@ int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias,
         // write-outs for free (s2 proj 99 vs 110 us here); at N = 512, K = 2048 the K loop matters: 196 -> 177 us.
         // VSC_GEMM_LN_V4=1 forces the persistent kernel on every shape it supports (tests), 0 switches it off.
         const bool pays = n == 512 && k >= 1536;
-        if (shape_ok && !(opt && opt[0] == '0') && (pays || (opt && opt[0] == '1'))) {
+        if (shape_ok && merge_res == 0 && !(opt && opt[0] == '0') && (pays || (opt && opt[0] == '1'))) {
             static void *dev_ws[16] = {};   // callers without a workspace of their own: one call at a time per device
             if (!pair_ws) {
                 if (!dev_ws[dev]) VSC_CHECK_HIP(hipMalloc(&dev_ws[dev], VSC_GEMM_LN_WS_BYTES));
@@ -1684,6 +1716,11 @@ int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias,
         }
     }
     GemmLnArgs p{a, w, bias, gamma, beta, x_in, x_out, xb_out, m, n, k, eps};
+    if (merge_res) {
+        p.g_res = merge_res;
+        p.g_c = merge_c;
+        for (int half = merge_res / 2; half > 1; half >>= 1) ++p.g_lh;
+    }
     switch (n) {
         case 128: return launch_ln_t<8, 1, 4>(p, stream);  // 4 x 40 KiB = the whole 160 KiB: two tiles stay in flight across a barrier
         case 256: return launch_ln_t<4, 2, 4>(p, stream);

@@ -393,6 +393,8 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
 #define PROF(cls) SwinProfScope _ps(e, (cls), st)
     const char *fm = vsc_opt(OPT_SWIN_FUSED_MLP);   // diagnostic / test switch: 0 = fc1 and fc2 as two GEMM launches
     const bool unfused_mlp = fm && fm[0] == '0';
+    const char *fg = vsc_opt(OPT_SWIN_FUSED_MERGE);   // diagnostic / test switch: 0 = PatchMerging as a gather kernel + GEMM
+    const bool unfused_merge = fg && fg[0] == '0';
     int chunk = 0;
     for (int64_t off = 0; off < n; off += c.max_batch, ++chunk) {
         const int lane = fork ? (chunk & 1) : 0;
@@ -430,9 +432,20 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
             }
             if (s + 1 < c.stages) {
                 PROF(pc + VSC_SWIN_PROF_MERGE);
-                TRY(launch_merge_gather(w.xb, w.merged, B, R, C, st));
-                TRY(gemm_ln(e, w, w.merged, e->stages[s].red_w, nullptr, e->stages[s].dn_g, e->stages[s].dn_b, nullptr,
-                            M / 4, 2 * C, 4 * C, st));
+                if (!unfused_merge && gemm_ln_supported(2 * C, 4 * C) && (R & (R - 1)) == 0 && C % 32 == 0) {
+                    // the 2 x 2 gather inside the GEMM's operand staging (no [M/4, 4C] copy out and back in).  The shadow of the
+                    // merged tokens cannot overwrite the tensor other workgroups are still gathering from: it goes to the
+                    // buffer the copy used to fill, and the two (equally sized) buffers change roles.
+                    TRY(launch_gemm_ln_bf16(w.xb, e->stages[s].red_w, nullptr, e->stages[s].dn_g, e->stages[s].dn_b, nullptr, w.x, w.merged,
+                                            M / 4, 2 * C, 4 * C, e->cfg.ln_eps, st, w.lnws, R, C));
+                    uint16_t *t = w.xb;
+                    w.xb = w.merged;
+                    w.merged = t;
+                } else {
+                    TRY(launch_merge_gather(w.xb, w.merged, B, R, C, st));
+                    TRY(gemm_ln(e, w, w.merged, e->stages[s].red_w, nullptr, e->stages[s].dn_g, e->stages[s].dn_b, nullptr,
+                                M / 4, 2 * C, 4 * C, st));
+                }
             }
         }
         {
