@@ -95,6 +95,9 @@ def test_conv2d_implicit_gather_equals_materialised_patches(dev, n, h, w, cin, c
     (16, 56, 56, 20, 18, True),     # 1568 tiles: every workgroup walks several (the halo double buffer)
     (2, 19, 40, 36, 18, False),     # 36 input channels (9 chunks per pixel, an odd chunk count: the zero weight chunk)
     (1, 8, 33, 20, 32, False),      # all 32 channel rows of the accumulator
+    (2, 19, 40, 36, 36, True),      # HRNet's second branch: two accumulators per wave, 36 of their 64 rows exist
+    (1, 9, 33, 20, 36, False),      # a transition: 20 -> 36 channels
+    (16, 28, 28, 36, 36, True),     # several tiles per workgroup with the large halos (one workgroup per CU)
 ])
 def test_conv2d_direct_3x3_matches_torch_and_the_gemm_path(dev, n, h, w, cin, cout, res):
     """conv3x3_direct_kernel (halo tile in LDS, nine taps read from it) against torch and against the implicit-GEMM kernel it

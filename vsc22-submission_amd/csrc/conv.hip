@@ -424,18 +424,21 @@ struct DirectArgs {
     unsigned xbytes;
 };
 
-template <int CQ>
-__global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(DirectArgs p) {
+// NACC accumulators per wave (32 output channels each), WR weight rows kept in LDS (>= cout; a lane whose channel row does not
+// exist reads the last one -- its accumulator rows are never stored).  <5, 1, 32> leaves room for two workgroups per CU; the
+// 36-channel layers (<9, 2, 40>: 52 KiB of weights + two 48-KiB halos) run one.
+template <int CQ, int NACC, int WR>
+__global__ __launch_bounds__(512, NACC == 1 && CQ <= 5 ? 2 : 1) void conv3x3_direct_kernel(DirectArgs p) {
     constexpr int TH = 8, TW = 32, HW = TW + 2, HH = TH + 2, HPIX = HW * HH;
     constexpr int NCH = 9 * CQ, NPAIR = (NCH + 1) / 2, WROW = (2 * NPAIR + 1) * 16;   // bytes per weight row in LDS
-    constexpr int PIECES = (HPIX * CQ + 63) / 64, HALO_BYTES = PIECES * 1024, W_BYTES = (32 * WROW + 1023) / 1024 * 1024;
+    constexpr int PIECES = (HPIX * CQ + 63) / 64, HALO_BYTES = PIECES * 1024, W_BYTES = (WR * WROW + 1023) / 1024 * 1024;
     __shared__ __attribute__((aligned(16))) char lds[W_BYTES + 2 * HALO_BYTES];
     char *wl = lds, *halo = lds + W_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     // ---- weights: row r (output channel), chunk c (k = 4 c .. 4 c + 3 of the packed row), zeros past cout / past K
-    for (int e = tid; e < 32 * 2 * NPAIR; e += 512) {
+    for (int e = tid; e < WR * 2 * NPAIR; e += 512) {
         const int r = e / (2 * NPAIR), c = e - r * (2 * NPAIR);
         f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         if (r < p.cout && c < NCH) v = *(const f32x4_t *)(p.wp + (int64_t)r * p.kpad + c * 4);
@@ -464,7 +467,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(DirectArgs p) {
     if (t >= p.ntiles) return;
     stage(t, 0);
     int buf = 0;
-    const char *wrow = wl + l31 * WROW + hi * 16;
+    const char *wrow[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        const int r = a * 32 + l31;
+        wrow[a] = wl + (r < WR ? r : WR - 1) * WROW + hi * 16;
+    }
     for (; t < p.ntiles; t += gridDim.x, buf ^= 1) {
         // this wave's pieces of the tile's halo have landed; behind the barrier everyone's have (and, the first time, the
         // weights are written), and every wave is done reading the other buffer
@@ -479,21 +487,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(DirectArgs p) {
         const int oy = ty * TH + wave, ox = tx * TW + l31;
         const bool inside = oy < p.h && ox < p.w;
         const int64_t pix = (img * p.h + (inside ? oy : 0)) * p.w + (inside ? ox : 0);
-        f32x4_t rs[4];
+        f32x4_t rs[NACC][4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            rs[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            const int co = 8 * g + 4 * hi;
-            if (p.res && inside && co + 3 < p.cout && ((p.ldr | co) & 3) == 0) rs[g] = *(const f32x4_t *)(p.res + pix * p.ldr + co);
-            else if (p.res && inside) {
+        for (int a = 0; a < NACC; ++a)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co + r < p.cout) rs[g][r] = p.res[pix * p.ldr + co + r];
+            for (int g = 0; g < 4; ++g) {
+                rs[a][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                const int co = a * 32 + 8 * g + 4 * hi;
+                if (p.res && inside && co + 3 < p.cout && ((p.ldr | co) & 3) == 0) rs[a][g] = *(const f32x4_t *)(p.res + pix * p.ldr + co);
+                else if (p.res && inside) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.cout) rs[a][g][r] = p.res[pix * p.ldr + co + r];
+                }
             }
-        }
-        f32x16_t acc;
+        f32x16_t acc[NACC];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 #pragma unroll
         for (int pr = 0; pr < NPAIR; ++pr) {
             // halo byte offset of chunk c relative to the lane's pixel: tap (c / CQ) -> rows (tap / 3), columns (tap % 3)
@@ -501,24 +513,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_kernel(DirectArgs p) {
             const int c0 = 2 * pr, c1 = 2 * pr + 1 < NCH ? 2 * pr + 1 : 2 * pr;   // the pad chunk re-reads finite data (its weights are 0)
             const int bo = hi ? off_of(c1) : off_of(c0);
             const f32x4_t bf = *(const f32x4_t *)(hb + bo);
-            const f32x4_t af = *(const f32x4_t *)(wrow + pr * 32);
+            f32x4_t af[NACC];
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k4], bf[k4], acc, 0, 0, 0);
+            for (int a = 0; a < NACC; ++a) af[a] = *(const f32x4_t *)(wrow[a] + pr * 32);
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4)
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][k4], bf[k4], acc[a], 0, 0, 0);
         }
-        // acc[reg] = <w[8 (reg >> 2) + 4 hi + (reg & 3)], patch of output pixel (row wave, column l31) of the tile>
+        // acc[a][reg] = <w[32 a + 8 (reg >> 2) + 4 hi + (reg & 3)], patch of output pixel (row wave, column l31) of the tile>
         if (inside) {
             float *orow = p.out + pix * p.ldo;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = 8 * g + 4 * hi;
+            for (int ag = 0; ag < NACC * 4; ++ag) {
+                const int a = ag >> 2, g = ag & 3;
+                const int co = a * 32 + 8 * g + 4 * hi;
                 if (co >= p.cout) continue;
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[4 * g + r];
+                    v[r] = acc[a][4 * g + r];
                     if (co + r < p.cout) {
                         if (p.bias) v[r] += p.bias[co + r];
-                        v[r] += rs[g][r];
+                        v[r] += rs[a][g][r];
                         v[r] = activate(v[r], p.act);
                     }
                 }
@@ -738,7 +755,7 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     {
         const char *de = vsc_opt(OPT_CONV_DIRECT);   // diagnostic / test switch: 0 = the implicit-GEMM path
         const int64_t xbytes = n * (int64_t)h * w * ldx * 4;
-        const bool direct = !(de && de[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cout <= 32 && (cin == 20 || cin == 36) &&
+        const bool direct = !(de && de[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cout <= 40 && (cin == 20 || cin == 36) &&
                             (ldx & 3) == 0 && (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 && xbytes < (1ll << 31) &&
                             (!res_dev || ldr >= cout);
         if (direct) {
@@ -747,10 +764,13 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
             a.ntiles = (int64_t)a.tiles_x * a.tiles_y * n;
             static int cus_direct[16] = {};
             if (!cus_direct[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_direct[dev], hipDeviceAttributeMultiprocessorCount, dev));
-            const int64_t resident = 2ll * cus_direct[dev];
+            const bool two = cin == 20 && cout <= 32;   // workgroups per CU (LDS)
+            const int64_t resident = (two ? 2ll : 1ll) * cus_direct[dev];
             const unsigned grid = (unsigned)(a.ntiles < resident ? a.ntiles : resident);
-            if (cin == 20) hipLaunchKernelGGL(conv3x3_direct_kernel<5>, dim3(grid), dim3(512), 0, stream, a);
-            else hipLaunchKernelGGL(conv3x3_direct_kernel<9>, dim3(grid), dim3(512), 0, stream, a);
+            if (cin == 20 && cout <= 32) hipLaunchKernelGGL((conv3x3_direct_kernel<5, 1, 32>), dim3(grid), dim3(512), 0, stream, a);
+            else if (cin == 20) hipLaunchKernelGGL((conv3x3_direct_kernel<5, 2, 40>), dim3(grid), dim3(512), 0, stream, a);
+            else if (cout <= 32) hipLaunchKernelGGL((conv3x3_direct_kernel<9, 1, 32>), dim3(grid), dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((conv3x3_direct_kernel<9, 2, 40>), dim3(grid), dim3(512), 0, stream, a);
             VSC_CHECK_LAUNCH();
             return VSC_OK;
         }
