@@ -122,6 +122,17 @@ def test_conv2d_direct_3x3_matches_torch_and_the_gemm_path(dev, n, h, w, cin, co
     assert torch.allclose(got.cpu().permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)
     assert torch.allclose(got, gemm, atol=5e-6, rtol=1e-5)
     assert not torch.equal(got, torch.zeros_like(got))
+    # a channel window of a wider buffer at an offset that is not a multiple of 4 (scalar stores), other activations
+    for act in ("hard_swish", None):
+        wide = torch.full((n, h, w, cout + 7), 3.0, device=dev)
+        conv(x, act=act, residual=r, out=wide, coff=5)
+        _vsc_lib.set_option("VSC_CONV_DIRECT", "0")
+        try:
+            ref = conv(x, act=act, residual=r).clone()
+        finally:
+            _vsc_lib.set_option("VSC_CONV_DIRECT", None)
+        assert torch.allclose(wide[..., 5:5 + cout], ref, atol=5e-6, rtol=1e-5)
+        assert (wide[..., :5] == 3).all() and (wide[..., 5 + cout:] == 3).all()
 
 
 def test_depthwise_pool_scale_upsample(dev):
