@@ -301,7 +301,11 @@ int vsc_patchify_bf16(const float *frames_dev, uint16_t *patches_dev, int64_t n,
  * image token order; the cyclic shift and window partition are index math.  bias_dev f32
  * [heads, (2*window-1)^2]: the compact relative-position table 16*sigmoid(cpb_mlp(coords)),
  * bias(i, j) = table[(yi-yj+window-1)*(2*window-1) + xi-xj+window-1]; scale_dev f32 [heads] =
- * exp(min(logit_scale, ln 100)). */
+ * exp(min(logit_scale, ln 100)).
+ * Bounded form (optional, per head): cosine logits cannot exceed U = scale + max(table).  A caller that has subtracted U from a
+ * head's table and knows 2 scale + max(table) - min(table) <= 69 (so that no probability underflows) passes -scale for that
+ * head: the kernel then skips the row maximum of the softmax -- the same quotient, a sixth fewer vector instructions
+ * (vsc_swin_finalize does this for its own tables). */
 int vsc_window_attention_bf16(const uint16_t *qkv_dev, uint16_t *out_dev, const float *bias_dev,
                               const float *scale_dev, int32_t frames, int32_t res, int32_t window,
                               int32_t shift, int32_t heads, void *stream);

@@ -56,6 +56,17 @@ def test_window_attention(dev, frames, res, window, shift, heads):
     # q-hat / k-hat / P rounded to bf16, bf16 output
     torch.testing.assert_close(got, ref, rtol=2 ** -6, atol=2e-2)
     assert (got - ref).abs().mean() < 4e-3
+    # bounded form: the heads' upper bounds folded into their tables, no row maximum in the kernel -- the same softmax.  One
+    # head keeps a scale too large for the bound (it stays on the row maximum inside the same launch).
+    big = scale.clone()
+    big[0] = 60.0
+    for sc_ in (scale, big):
+        a = ops.window_attention_bf16(qkv.to(dev), table.to(dev), sc_.to(dev), frames, res, window, shift, heads).float().cpu()
+        b = ops.window_attention_bf16(qkv.to(dev), table.to(dev), sc_.to(dev), frames, res, window, shift, heads, bounded=True).float().cpu()
+        torch.testing.assert_close(b, a, rtol=2 ** -6, atol=1e-2)
+        assert (a - b).abs().mean() < 2e-3
+    torch.testing.assert_close(ops.window_attention_bf16(qkv.to(dev), table.to(dev), scale.to(dev), frames, res, window, shift, heads,
+                                                         bounded=True).float().cpu(), ref, rtol=2 ** -6, atol=2e-2)
 
 
 @pytest.mark.parametrize("rows,width", [(7, 64), (1000, 128), (33, 1024)])
@@ -147,6 +158,19 @@ def test_swin_fused_mlp_equals_two_gemm_path(dev):
         _lib.set_option("VSC_SWIN_FUSED_MLP", None)
         enc.set_profiling(False)
     assert np.abs(fused - plain).max() < 4e-4
+
+
+def test_swin_encoder_is_deterministic_at_full_chunks(dev):
+    """Run-to-run bit equality of Swin-V2-B at 256-frame chunks (fused MLP, fused PatchMerging, bounded softmax): the fused MLP once
+    published its weight chunks with a bare s_barrier -- no wait for the LDS-DMA that fills them -- and corrupted a few frames in
+    every other run (tools/micro/swin_determinism.py)."""
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    cfg = get_swin_config("swinv2_base_256")
+    enc = SwinHipEncoder(cfg, synth.swin_weights(9, cfg), max_batch=256, l2_normalize=True)
+    x = torch.from_numpy(synth.swin_frames(10, 300, cfg)).to(dev)
+    first = enc(x).clone()
+    for _ in range(5):
+        assert torch.equal(enc(x), first)
 
 
 @pytest.mark.parametrize("preset,frames", [("tiny_swin", 5), ("swinv2_base_256", 3)])

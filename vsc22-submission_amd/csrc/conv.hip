@@ -474,8 +474,10 @@ __global__ __launch_bounds__(512, NACC == 1 && CQ <= 5 ? 2 : 1) void conv3x3_dir
         wrow[a] = wl + (r < WR ? r : WR - 1) * WROW + hi * 16;
     }
     for (; t < p.ntiles; t += gridDim.x, buf ^= 1) {
-        // this wave's pieces of the tile's halo have landed; behind the barrier everyone's have (and, the first time, the
-        // weights are written), and every wave is done reading the other buffer
+        // this wave's pieces of the tile's halo have landed (explicit vmcnt wait: an LDS-DMA is tracked by the VM counter only and
+        // __syncthreads() compiles to a bare s_barrier); behind the barrier everyone's have (and, the first time, the weights
+        // are written), and every wave is done reading the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + gridDim.x < p.ntiles) stage(t + gridDim.x, buf ^ 1);
         const char *hb = halo + buf * HALO_BYTES + (wave * HW + l31) * (CQ * 16);

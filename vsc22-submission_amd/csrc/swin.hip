@@ -175,7 +175,13 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
     }
     __syncthreads();
 
-    const float sc = scale[head] * LOG2E;
+    // scale[head] < 0 (see vsc_window_attention_bf16): |scale| is the logit scale and the caller has subtracted the head's upper
+    // bound |scale| + max(bias) from its bias table -- cosine logits are bounded, so every shifted logit is <= 0 and, the caller
+    // guarantees, >= -100 log2 units: the softmax needs no row maximum (a v_max3 per pair of scores, two shuffles) and no
+    // subtraction (a v_pk_add per pair): a sixth of this kernel's vector instructions.  The same quotient either way.
+    const float scraw = scale[head];
+    const bool nomax = scraw < 0.f;   // workgroup-uniform
+    const float sc = fabsf(scraw) * LOG2E;
 
     // Only windows in the last window row / column of a shifted layer hold more than one mask region
     // (torch2scripts.py:236-254): every other workgroup runs the body without the mask compares/selects
@@ -185,8 +191,8 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
         for (int i = tid; i < 9 * N; i += NTHREADS) maskrow[i] = region[i % N] != i / N ? -100.0f * LOG2E : 0.f;
         __syncthreads();
     }
-    auto rows = [&](auto masked_c) {
-        constexpr bool MASKED = decltype(masked_c)::value;
+    auto rows = [&](auto masked_c, auto nomax_c) {
+        constexpr bool MASKED = decltype(masked_c)::value, NOMAX = decltype(nomax_c)::value;
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
             const int q = (wave * 2 + qi) * 16 + fr;
@@ -218,12 +224,16 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                 }
                 s[t][0] = (f32x2_t){z[0], z[1]} * sc2 + (f32x2_t){tb[0], tb[1]};  // v_pk_fma_f32
                 s[t][1] = (f32x2_t){z[2], z[3]} * sc2 + (f32x2_t){tb[2], tb[3]};
-                mx = fmaxf(fmaxf(mx, s[t][0][0]), s[t][0][1]);                    // v_max3_f32
-                mx = fmaxf(fmaxf(mx, s[t][1][0]), s[t][1][1]);
+                if (!NOMAX) {
+                    mx = fmaxf(fmaxf(mx, s[t][0][0]), s[t][0][1]);                // v_max3_f32
+                    mx = fmaxf(fmaxf(mx, s[t][1][0]), s[t][1][1]);
+                }
                 if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (!NOMAX) {
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            }
             const f32x2_t nmx = (f32x2_t){-mx, -mx};
             bf16x8_t pb[NT / 2];
 #pragma unroll
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                 f32x2_t e[4];
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    const f32x2_t d = s[2 * u + (h >> 1)][h & 1] + nmx;  // v_pk_add_f32
+                    const f32x2_t d = NOMAX ? s[2 * u + (h >> 1)][h & 1] : s[2 * u + (h >> 1)][h & 1] + nmx;  // v_pk_add_f32
                     e[h] = (ABL & 1) ? d : (f32x2_t){__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
                 }
                 union { uint32_t w[4]; bf16x8_t v; } pk;
@@ -267,10 +277,13 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
             if (!((ABL & 16) && inv != 12345.f)) *(uint4 *)orow = pk;
         }
     };
-    if (need_mask)
-        rows(std::true_type{});
-    else
-        rows(std::false_type{});
+    if (need_mask) {
+        if (nomax) rows(std::true_type{}, std::true_type{});
+        else rows(std::true_type{}, std::false_type{});
+    } else {
+        if (nomax) rows(std::false_type{}, std::true_type{});
+        else rows(std::false_type{}, std::false_type{});
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -322,10 +322,23 @@ extern "C" int vsc_swin_finalize(vsc_swin *e) {
             std::vector<float> sc(H);
             const std::vector<float> &ls = e->host_w.at(p + "attn.logit_scale");
             for (int i = 0; i < H; ++i) sc[i] = expf(fminf(ls[i], logf(100.0f)));  // clamp(max = ln(1/0.01)).exp(), :161
+            std::vector<float> pb = position_bias(e->host_w.at(p + "attn.cpb_mlp.0.weight"), e->host_w.at(p + "attn.cpb_mlp.0.bias"),
+                                                  e->host_w.at(p + "attn.cpb_mlp.2.weight"), W, c.pretrained_window_sizes[s], H);
+            // bounded softmax (vsc_window_attention_bf16): heads whose logits span <= 69 get their upper bound scale + max(bias)
+            // folded into the table and a negative scale
+            const size_t side2 = (size_t)(2 * W - 1) * (2 * W - 1);
+            for (int hh = 0; hh < H && !vsc_opt(OPT_SWIN_ROW_MAX); ++hh) {
+                float bmax = -INFINITY, bmin = INFINITY;
+                for (size_t i = 0; i < side2; ++i) {
+                    bmax = fmaxf(bmax, pb[hh * side2 + i]);
+                    bmin = fminf(bmin, pb[hh * side2 + i]);
+                }
+                if (!(2.0f * sc[hh] + (bmax - bmin) <= 69.0f)) continue;   // (also skips NaN / inf)
+                for (size_t i = 0; i < side2; ++i) pb[hh * side2 + i] -= bmax + sc[hh];
+                sc[hh] = -sc[hh];
+            }
             TRY(sw_upload_f32v(e, sc, &B.scale));
-            TRY(sw_upload_f32v(e, position_bias(e->host_w.at(p + "attn.cpb_mlp.0.weight"), e->host_w.at(p + "attn.cpb_mlp.0.bias"),
-                                                e->host_w.at(p + "attn.cpb_mlp.2.weight"), W,
-                                                c.pretrained_window_sizes[s], H), &B.bias));
+            TRY(sw_upload_f32v(e, pb, &B.bias));
             TRY(sw_upload_bf16(e, p + "attn.proj.weight", C, C, C, &B.proj_w));
             TRY(sw_upload_f32(e, p + "attn.proj.bias", &B.proj_b));
             TRY(sw_upload_f32(e, p + "norm1.weight", &B.n1_g));

@@ -123,6 +123,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
     for (int ch = 0; ch < NCH; ++ch) {
         // this wave's pieces of chunk ch have landed (and, the first time round, its bias rows are written); behind the barrier
         // every wave's have, and every wave is past its last read of the other slot
+        // (the explicit vmcnt wait is essential: an LDS-DMA is a pending LDS write that only the VM counter tracks, and
+        //  __syncthreads() compiles to a bare s_barrier here -- without it a wave can read a chunk whose pieces are still in flight)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(ABL & 16) || ch == 0) __syncthreads();
         if (ch + 1 < NCH && (!(ABL & 4) || ch == 0)) stage(ch + 1, (ch + 1) & 1);
         const char *w1s = ring + (ch & 1) * CHUNK, *w2s = w1s + W1B;

@@ -193,11 +193,18 @@ def video_pair_max(q, q_video, n_q_videos: int, r, r_video, n_r_videos: int, thr
         capacity = int(total.value)
 
 
-def window_attention_bf16(qkv, bias, scale, frames: int, res: int, window: int, shift: int, heads: int):
-    """Swin-V2 windowed cosine attention (head_dim 32) on image-ordered tokens."""
+def window_attention_bf16(qkv, bias, scale, frames: int, res: int, window: int, shift: int, heads: int, bounded: bool = False):
+    """Swin-V2 windowed cosine attention (head_dim 32) on image-ordered tokens.  bounded: fold every head's logit upper bound
+    scale + max(bias) into its table and pass -scale where the head's logits span <= 69 (vsc_hip.h: the kernel then skips the
+    softmax's row maximum), as vsc_swin_finalize does for its own tables."""
     lib = _lib.require_device()
     qkv = _dev(qkv, torch.bfloat16)
     bias, scale = _dev(bias, torch.float32), _dev(scale, torch.float32)
+    if bounded:
+        bmax, bmin = bias.max(dim=1).values, bias.min(dim=1).values
+        ok = (2 * scale + (bmax - bmin)) <= 69.0
+        bias = torch.where(ok[:, None], bias - (bmax + scale)[:, None], bias).contiguous()
+        scale = torch.where(ok, -scale, scale).contiguous()
     assert qkv.shape == (frames * res * res, 3 * heads * 32)
     assert bias.shape == (heads, (2 * window - 1) ** 2) and scale.shape == (heads,)   # compact table
     out = torch.empty((frames * res * res, heads * 32), dtype=torch.bfloat16, device=qkv.device)
