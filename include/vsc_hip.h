@@ -43,6 +43,9 @@ const char *vsc_version(void);
  * environment on its launch path.  Unknown names return VSC_ERR_INVALID.  Not a reference interface: the reference has no
  * counterpart. */
 int vsc_set_option(const char *name, const char *value);
+/* Current value of a switch (NULL when unset or unknown); the string stays valid for the life of the process.  For callers
+ * that change a switch temporarily and must restore what the environment or an enclosing scope had set. */
+const char *vsc_get_option(const char *name);
 
 /* ------------------------------------------------------------------------ *
  * Frame encoder: replaces `flat_features = model(flat_frames)` on the

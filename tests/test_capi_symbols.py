@@ -49,7 +49,11 @@ def test_option_table_is_read_once_and_set_through_the_api(lib, monkeypatch):
     _lib.set_option("VSC_KNN_PATH", "bf16")
     _lib.set_option("KNN_PATH", None)
     with _lib.option("VSC_GEMM_V4", "0"):
-        pass
+        assert _lib.get_option("GEMM_V4") == "0"
+        with _lib.option("VSC_GEMM_V4", "1"):          # nested: the inner exit restores the OUTER value, not "unset"
+            assert _lib.get_option("VSC_GEMM_V4") == "1"
+        assert _lib.get_option("VSC_GEMM_V4") == "0"
+    assert _lib.get_option("VSC_GEMM_V4") is None and _lib.get_option("VSC_NO_SUCH_SWITCH") is None
     assert lib.vsc_set_option(b"VSC_NO_SUCH_SWITCH", b"1") != 0
     assert b"unknown switch" in lib.vsc_last_error()
     assert lib.vsc_set_option(None, b"1") != 0

@@ -34,7 +34,7 @@ def _encoder(preset, seed, **kw):
     return cfg, w, HipEncoder(cfg, w, **kw)
 
 
-@pytest.mark.parametrize("preset", ["tiny", "tiny_clip", "vit_b16_224"])
+@pytest.mark.parametrize("preset", ["tiny", "tiny_clip", "vit_b16_224", "vit_v68"])
 def test_encoder_matches_golden(dev, preset, golden_dir):
     g = np.load(os.path.join(golden_dir, f"vit_{preset}.npz"))
     cfg, _, enc = _encoder(preset, int(g["weights_seed"]), max_batch=4)

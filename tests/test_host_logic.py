@@ -2,13 +2,14 @@
 bookkeeping, weight-name translation -- and that the product path refuses to run without
 the HIP device instead of falling back to anything."""
 import io
+import os
 
 import numpy as np
 import pytest
 import torch
 
 from vsc.index import VideoFeature, VideoIndex
-from vsc.metrics import CandidatePair, Dataset, format_video_id, micro_average_precision
+from vsc.metrics import CandidatePair, Dataset, average_precision, format_video_id, micro_average_precision
 from vsc.storage import load_features, same_value_ranges, store_features
 
 no_gpu = pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
@@ -94,6 +95,57 @@ def test_micro_ap():
     assert micro_average_precision(gt, preds[2:]) == 1.0
     with pytest.raises(AssertionError):
         micro_average_precision(gt + gt, preds)
+
+
+def _C(q, r, s):
+    return CandidatePair(format_video_id(q, Dataset.QUERIES), format_video_id(r, Dataset.REFS), s)
+
+
+def test_average_precision_reference_unit_vectors():
+    """DescriptorTrackTest.test_uap of the reference (train/train_v115/tests/test_metrics.py:215-240), as data."""
+    gt = [_C(1, 10, 1.0), _C(2, 11, 1.0)]
+    for want, preds in [(1.0, [_C(1, 10, 8.0), _C(2, 11, 4.0), _C(99, 99, 2.0)]),
+                        (np.mean([1, 2 / 3]), [_C(1, 10, 8.0), _C(2, 11, 4.0), _C(99, 99, 5.0)]),
+                        (np.mean([1, 0]), [_C(1, 10, 3.0), _C(2, 10, 2.0), _C(99, 99, 1.0)]),
+                        (np.mean([1 / 2, 0]), [_C(1, 10, 2.0), _C(2, 10, 3.0), _C(99, 99, 1.0)])]:
+        m = average_precision(gt, preds)
+        assert m.ap == pytest.approx(want, abs=1e-12) and m.simple_ap == pytest.approx(m.ap, abs=1e-12)
+        assert len(m.pr_curve.scores) == len(m.pr_curve.recalls) == len(m.pr_curve.precisions)
+    with pytest.raises(AssertionError):
+        average_precision(gt, [_C(1, 10, 1.0), _C(1, 10, 2.0)])
+
+
+def test_average_precision_matches_reference_outputs_under_ties():
+    """tests/golden/uap_reference.json holds outputs of the reference's own average_precision (gen_uap_golden.py):
+    `.ap` groups tied scores (sklearn) and is rescaled by predicted / actual positives; `.simple_ap` is tie-blind.
+    They differ by up to 1.5e-2 on these vectors — the reported number must be `.ap`."""
+    import json
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "uap_reference.json")))
+    assert any(abs(c["ap"] - c["simple_ap"]) > 1e-3 for c in cases)
+    for c in cases:
+        preds = [_C(a, b, s) for a, b, s in c["pred"]]
+        gt = [_C(a, b, 1.0) for a, b in c["gt"]]
+        m = average_precision(gt, preds)
+        assert m.ap == pytest.approx(c["ap"], abs=1e-12)
+        assert m.simple_ap == pytest.approx(c["simple_ap"], abs=1e-12)
+        assert float(np.sum(m.pr_curve.recalls)) == pytest.approx(c["curve_recalls_sum"], abs=1e-9)
+        assert float(np.sum(m.pr_curve.precisions)) == pytest.approx(c["curve_precisions_sum"], abs=1e-9)
+        assert micro_average_precision(gt, preds) == m.simple_ap
+        # order independence of the canonical number (ties are grouped, so shuffling cannot move it)
+        rng = np.random.default_rng(1)
+        perm = rng.permutation(len(preds))
+        assert average_precision(gt, [preds[i] for i in perm]).ap == pytest.approx(c["ap"], abs=1e-12)
+
+
+def test_tie_grouped_ap_equals_sklearn():
+    sk = pytest.importorskip("sklearn.metrics")
+    from vsc.metrics import _tie_grouped_ap
+    rng = np.random.default_rng(5)
+    for dec in (None, 2, 1, 0):
+        s = rng.random(500)
+        s = s if dec is None else np.round(s, dec)
+        y = (rng.random(500) < 0.2).astype(np.float64)
+        assert _tie_grouped_ap(y, s) == pytest.approx(sk.average_precision_score(y, s), abs=1e-12)
 
 
 def test_weight_name_translation_round_trip():
@@ -357,3 +409,7 @@ def test_matching_entry_derives_frames_per_video_from_timestamps():
     bad = VideoFeature(video_id="Q4", feature=np.zeros((5, 4), np.float32), timestamps=np.array([0, 1, 0, 1, 2], np.float32))
     with pytest.raises(ValueError, match="query_frames"):
         infer_matching.frames_per_video(bad)
+    # --query_frames covers the irregular video: it must be used, not re-derived; uncovered ones are counted
+    assert infer_matching.query_len_map([one, three, bad], {"Q4": 5}) == {"Q1": 7, "Q2": 7, "Q4": 5}
+    with pytest.raises(ValueError, match="query_frames"):
+        infer_matching.query_len_map([one, bad], {"Q1": 7})

@@ -23,7 +23,7 @@ def _run(preset, golden_dir):
     return g, tok.numpy(), desc.numpy(), desc_l2.numpy()
 
 
-@pytest.mark.parametrize("preset", ["tiny", "tiny_clip", "vit_b16_224"])
+@pytest.mark.parametrize("preset", ["tiny", "tiny_clip", "vit_b16_224", "vit_v68"])
 def test_oracle_matches_transformers_golden(preset, golden_dir):
     g, tok, desc, desc_l2 = _run(preset, golden_dir)
     # fp32 vs fp32, different op order: 2e-4 abs on O(1) activations

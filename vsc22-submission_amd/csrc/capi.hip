@@ -66,6 +66,16 @@ extern "C" int vsc_set_option(const char *name, const char *value) {
     return VSC_ERR_INVALID;
 }
 
+// current value of a switch (nullptr when unset or unknown): lets a caller save and restore around a temporary change
+extern "C" const char *vsc_get_option(const char *name) {
+    if (!name) return nullptr;
+    std::call_once(g_opt_once, opt_load_env);
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(name, g_opt_names[i]) || !strcmp(name, g_opt_names[i] + 4))
+            return g_opt_values[i].load(std::memory_order_acquire);
+    return nullptr;
+}
+
 extern "C" int vsc_gemm_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux,
                              void *out, int64_t m, int32_t n, int32_t k, int32_t epilogue,
                              int32_t tokens, void *stream) {

@@ -22,7 +22,8 @@ This script runs 1-5 from descriptor files:
 
 Model files are the reference's TorchScript checkpoints (their state dicts carry timm's parameter names) or plain
 `torch.save`d state dicts.  `--query_frames video_id,frames` gives the number of frames of each query video when the
-descriptor file holds several views per video (the reference's vid_feature_len_map, :155); default: every row is a frame.
+descriptor file holds several views per video (the reference's vid_feature_len_map, :155); videos it does not list get
+their frame count from the timestamps (rows / views, `frames_per_video`), which must then form whole views.
 """
 import argparse
 import collections
@@ -59,6 +60,14 @@ def frames_per_video(vf) -> int:
     return distinct
 
 
+def query_len_map(query_list, query_frames=None) -> dict:
+    """video_id -> frames per view.  --query_frames wins; only videos it does not cover are counted from their timestamps
+    (which raises for files whose rows do not form whole views)."""
+    query_frames = query_frames or {}
+    return {vf.video_id: int(query_frames[vf.video_id]) if vf.video_id in query_frames else frames_per_video(vf)
+            for vf in query_list}
+
+
 def run(query_list, score_norm_refs, refs, sn_refs, cls_models, refine_models, query_frames=None, candidates_csv=None,
         device="cuda"):
     """Steps 1-5 on loaded VideoFeature lists and HIP models -> rows [query_id, ref_id, query_start, query_end, ref_start,
@@ -78,9 +87,7 @@ def run(query_list, score_norm_refs, refs, sn_refs, cls_models, refine_models, q
     query_list, refs = [transform_features(x, normalize) for x in (query_list, refs)]             # :272-274
     query_map = {vf.video_id: vf.feature for vf in query_list}
     ref_map = {vf.video_id: vf.feature for vf in refs}
-    len_map = {vf.video_id: frames_per_video(vf) for vf in query_list}   # views share timestamps: best-view selection needs the frame count
-    if query_frames:
-        len_map.update(query_frames)
+    len_map = query_len_map(query_list, query_frames)   # views share timestamps: best-view selection needs the frame count
     cls_feature, cls_info = matching.generate_candidates_classfiy_feature(query_map, ref_map, search_res_list, len_map)   # :277-279
     cls_rows = matching.match_classify(cls_models, cls_feature, [(q, r) for q, r, _ in cls_info], device=device)       # :280
     best = {}

@@ -19,7 +19,7 @@ from typing import List
 from vsc.baseline.score_normalization import score_normalize
 from vsc.candidates import CandidateGeneration, MaxScoreAggregation
 from vsc.index import VideoFeature
-from vsc.metrics import CandidatePair, Dataset, Match, micro_average_precision
+from vsc.metrics import CandidatePair, Dataset, Match, average_precision, micro_average_precision  # noqa: F401
 from vsc.storage import load_features, store_features
 
 logger = logging.getLogger("sscd_baseline.py")
@@ -92,9 +92,10 @@ def main(args) -> None:
         Match.write_csv(matches, matches_file)
         logger.info("Matches: %s", matches_file)
     if args.ground_truth:
-        uap = micro_average_precision(read_ground_truth_pairs(args.ground_truth), candidates)
-        logger.info("Candidate uAP: %.4f", uap)
-        print(f"Candidate uAP: {uap:.4f}")
+        # the reference logs the canonical `.ap` (tied scores grouped), sscd_baseline.py:213-219
+        uap = average_precision(read_ground_truth_pairs(args.ground_truth), candidates)
+        logger.info("Candidate uAP: %.4f", uap.ap)
+        print(f"Candidate uAP: {uap.ap:.4f}")
 
 
 def build_parser() -> argparse.ArgumentParser:

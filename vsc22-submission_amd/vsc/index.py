@@ -83,6 +83,7 @@ class FlatIPBank:
         self.metric_type = metric
         self._chunks: list = []
         self._bank = None
+        self._bank_max_norm = None      # largest row norm of the bank (METRIC_L2 rounding bound), cached with the bank
         self.ntotal = 0
 
     @property
@@ -93,11 +94,11 @@ class FlatIPBank:
         x = np.ascontiguousarray(x, dtype=np.float32)
         assert x.ndim == 2 and x.shape[1] == self.d, f"expected [n,{self.d}], got {x.shape}"
         self._chunks.append(x)
-        self._bank = None
+        self._bank = self._bank_max_norm = None
         self.ntotal += x.shape[0]
 
     def reset(self) -> None:
-        self._chunks, self._bank, self.ntotal = [], None, 0
+        self._chunks, self._bank, self._bank_max_norm, self.ntotal = [], None, None, 0
 
     def _host_rows(self) -> np.ndarray:
         if len(self._chunks) > 1:
@@ -153,10 +154,11 @@ class FlatIPBank:
     def _l2_sweep_slack(self, x: np.ndarray) -> float:
         """Bound on |expanded form - exact squared distance| in the fp32 sweep: the chain 2 q.r - |r|^2 - |q|^2 has d + 2
         terms, each fmaf rounds to 2^-24 of a partial sum that never exceeds (|q| + |r|)^2."""
-        host = self._host_rows()
+        if self._bank_max_norm is None:                 # once per bank, not once per call (add() / reset() invalidate it)
+            host = self._host_rows()
+            self._bank_max_norm = float(np.sqrt(np.einsum("ij,ij->i", host, host, dtype=np.float64).max())) if len(host) else 0.0
         qn = float(np.sqrt(np.einsum("ij,ij->i", x, x, dtype=np.float64).max())) if len(x) else 0.0
-        rn = float(np.sqrt(np.einsum("ij,ij->i", host, host, dtype=np.float64).max())) if len(host) else 0.0
-        return (self.d + 3) * 2.0 ** -23 * (qn + rn) ** 2
+        return (self.d + 3) * 2.0 ** -23 * (qn + self._bank_max_norm) ** 2
 
     def range_search(self, x: np.ndarray, radius: float):
         """All (query row, ref row, score) with score > radius (inner product) / distance < radius (L2) -> three flat
@@ -285,6 +287,15 @@ class VideoIndex:
                 radius = self._radius_for(feats, want, D[:, kk - 1])
             if radius is not None:
                 rows, refs, scores = self.index.range_search(feats, radius)
+                if not sim:
+                    # _radius_for counted pairs of the expanded-form sweep; range_search re-filters on exact distances, so
+                    # borderline pairs can drop out again: widen by the rounding bound until `want` pairs are inside
+                    slack = max(self.index._l2_sweep_slack(np.asarray(feats, np.float32)), np.finfo(np.float32).tiny)
+                    for _ in range(40):
+                        if len(rows) >= want or not np.isfinite(np.float32(radius + slack)):
+                            break
+                        radius, slack = float(radius) + slack, 2.0 * slack
+                        rows, refs, scores = self.index.range_search(feats, radius)
                 order = np.lexsort((refs, rows, key(scores)))[:want]
         return [(int(rows[o]), int(refs[o]), float(scores[o])) for o in order]
 

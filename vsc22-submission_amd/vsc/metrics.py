@@ -1,6 +1,6 @@
 """The slice of the reference's vsc/metrics.py that the descriptor path touches:
 video-id formatting, candidate pairs, predicted matches (the rows of matches.csv) and the
-descriptor-track micro-AP (infer/vsc/metrics.py:21-95, 183-243, 423-455).  The matching-track
+descriptor-track micro-AP (infer/vsc/metrics.py:21-119, 183-243, 423-494).  The matching-track
 segment metric is out of scope of this path."""
 from __future__ import annotations
 
@@ -100,19 +100,94 @@ def candidate_pairs_from_matches(matches: Collection[Match]) -> List[CandidatePa
     return [CandidatePair(q, r, s) for (q, r), s in scores.items()]
 
 
-def micro_average_precision(ground_truth: Collection[CandidatePair],
-                            predictions: Collection[CandidatePair]) -> float:
-    """uAP over (query, ref) pairs: sum_i P(i) * correct(i) / |gt| with predictions in
-    descending score order (metrics.py:439-451, the `simple_ap`)."""
+@dataclasses.dataclass
+class PrecisionRecallCurve:
+    """Precision / recall / score at every correct prediction (metrics.py:96-112; plotting is out of scope)."""
+    precisions: np.ndarray
+    recalls: np.ndarray
+    scores: np.ndarray
+
+
+@dataclasses.dataclass
+class AveragePrecision:
+    """metrics.py:115-119: `ap` is the challenge's canonical number, `simple_ap` the tie-blind sum."""
+    ap: float
+    pr_curve: PrecisionRecallCurve
+    simple_ap: Optional[float] = None
+
+
+def _tie_grouped_ap(actual: np.ndarray, scores: np.ndarray) -> float:
+    """sklearn.metrics.average_precision_score(actual, scores) for binary labels: the precision / recall
+    curve has ONE point per distinct score (all predictions sharing a score enter together), and
+    AP = sum_n (R_n - R_{n-1}) P_n.  What drivendata_average_precision calls (metrics.py:481-485)."""
+    order = np.argsort(-scores, kind="mergesort")
+    s = scores[order]
+    y = actual[order].astype(np.float64)
+    last = np.r_[np.nonzero(np.diff(s))[0], len(s) - 1]      # last index of every tie group
+    tps = np.cumsum(y)[last]
+    fps = (1 + last) - tps
+    precision = tps / (tps + fps)
+    recall = tps / tps[-1]
+    return float(np.sum(np.diff(np.r_[0.0, recall]) * precision))
+
+
+def drivendata_average_precision(predicted, ground_truth) -> float:
+    """Canonical AP of the challenge backend (metrics.py:458-494): tie-grouped AP over the predicted
+    pairs, rescaled by predicted positives / ground-truth positives.  Takes the reference's data frames
+    (columns query_id, ref_id, score / query_id, ref_id)."""
+    scores = np.asarray(predicted["score"], dtype=np.float64)
+    if not np.isfinite(scores).all():
+        raise ValueError("Scores must be finite.")
+    gt_q, gt_r = list(ground_truth["query_id"]), list(ground_truth["ref_id"])
+    # a pair listed twice in the ground truth duplicates its prediction row in the reference's left merge
+    weight: dict = {}
+    for q, r in zip(gt_q, gt_r):
+        weight[(q, r)] = weight.get((q, r), 0) + 1
+    order = np.argsort(-scores, kind="mergesort")              # DataFrame.sort_values is not stable; ties are
+    keys = list(zip(predicted["query_id"], predicted["ref_id"]))  # grouped below, so their order is immaterial
+    rows_actual, rows_score = [], []
+    for i in order:
+        w = weight.get(keys[i], 0)
+        for _ in range(max(w, 1)):
+            rows_actual.append(1.0 if w else 0.0)
+            rows_score.append(scores[i])
+    actual = np.asarray(rows_actual, dtype=np.float64)
+    predicted_n_pos = int(actual.sum())
+    unadjusted = _tie_grouped_ap(actual, np.asarray(rows_score, dtype=np.float64)) if predicted_n_pos else 0.0
+    # rows with a blank ref_id only validate query ids (metrics.py:490-491)
+    actual_n_pos = int(sum(1 for r in gt_r if r is not None and r == r))
+    return unadjusted * (predicted_n_pos / actual_n_pos)
+
+
+def average_precision(ground_truth: Collection[CandidatePair],
+                      predictions: Collection[CandidatePair]) -> AveragePrecision:
+    """The descriptor-track uAP exactly as the reference reports it (metrics.py:423-455):
+    `.ap` = drivendata_average_precision (tied scores grouped, rescaled), `.simple_ap` =
+    sum_i P(i) correct(i) / |gt| over the descending-score list, `.pr_curve` at the correct predictions."""
     gt = {(p.query_id, p.ref_id) for p in ground_truth}
     if len(gt) != len(ground_truth):
         raise AssertionError("Duplicates detected in ground truth")
     seen = {(p.query_id, p.ref_id) for p in predictions}
     if len(seen) != len(predictions):
         raise AssertionError("Duplicates detected in predictions")
+    canonical = drivendata_average_precision(
+        predicted=CandidatePair.to_dataframe(predictions),
+        ground_truth=CandidatePair.to_dataframe(ground_truth))
     ranked = sorted(predictions, key=lambda p: p.score, reverse=True)
-    hit = np.array([(p.query_id, p.ref_id) in gt for p in ranked], dtype=np.float64)
-    if not len(hit) or not gt:
+    scores = np.array([p.score for p in ranked], dtype=np.float64)
+    correct = np.array([(p.query_id, p.ref_id) in gt for p in ranked], dtype=bool)
+    cum = np.cumsum(correct)
+    precision = cum / (np.arange(len(correct)) + 1)
+    recall = cum / len(gt)
+    simple = float(np.sum(precision * correct) / len(gt))
+    idx = np.nonzero(correct)[0]
+    return AveragePrecision(ap=canonical, simple_ap=simple,
+                            pr_curve=PrecisionRecallCurve(precision[idx], recall[idx], scores[idx]))
+
+
+def micro_average_precision(ground_truth: Collection[CandidatePair],
+                            predictions: Collection[CandidatePair]) -> float:
+    """`average_precision(...).simple_ap` (kept for callers of earlier rounds); 0.0 for empty inputs."""
+    if not len(predictions) or not len(ground_truth):
         return 0.0
-    precision = np.cumsum(hit) / (np.arange(len(hit)) + 1)
-    return float(np.sum(precision * hit) / len(gt))
+    return float(average_precision(ground_truth, predictions).simple_ap)

@@ -55,6 +55,7 @@ SIGNATURES = {
     "vsc_device_count": (c_int32, []),
     "vsc_version": (c_char_p, []),
     "vsc_set_option": (c_int32, [c_char_p, c_char_p]),
+    "vsc_get_option": (c_char_p, [c_char_p]),
     "vsc_encoder_create": (c_int32, [POINTER(EncoderConfigC), POINTER(c_void_p)]),
     "vsc_encoder_destroy": (None, [c_void_p]),
     "vsc_encoder_set_weight": (c_int32, [c_void_p, c_char_p, c_void_p, c_size_t]),
@@ -158,18 +159,26 @@ def set_option(name: str, value=None) -> None:
     check(load().vsc_set_option(name.encode(), None if value is None else str(value).encode()))
 
 
+def get_option(name: str):
+    """Current value of a switch (str) or None -- vsc_get_option."""
+    v = load().vsc_get_option(name.encode())
+    return None if v is None else v.decode()
+
+
 class option:
-    """with option("VSC_KNN_PATH", "bf16"): ...  -- the switch is cleared on exit."""
+    """with option("VSC_KNN_PATH", "bf16"): ...  -- on exit the switch returns to the value it had on entry (from the
+    environment at load, or from an enclosing `with option(...)`), not to "unset"."""
 
     def __init__(self, name: str, value):
-        self.name, self.value = name, value
+        self.name, self.value, self._saved = name, value, None
 
     def __enter__(self):
+        self._saved = get_option(self.name)
         set_option(self.name, self.value)
         return self
 
     def __exit__(self, *exc):
-        set_option(self.name, None)
+        set_option(self.name, self._saved)
         return False
 
 
