@@ -196,6 +196,59 @@ def cpu_baseline(cfg, weights, frames_np, budget_s=15.0):
             "kind": "port", "sample": f"{n} frames (bench frames, cycled), fp32 torch oracle, batches of 4, {dt:.1f} s"}
 
 
+def attention_mfma_busy(kernel_prefix, path_hint=""):
+    """MFMA-busy fraction of a kernel's launches from the committed PMC pass (tools/pmc_mfma_busy.py: SQ_VALU_MFMA_BUSY_CYCLES /
+    (GPU cycles x 1024 SIMDs); PMC needs rocprofv3, so it is not collected live) -> {"value", "source"} or None."""
+    for name in (f"r04_pmc_mfma_busy{path_hint}.json", "r02_pmc_mfma_busy.json"):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+            rows = [r for r in prof["kernels"] if r["kernel"].startswith(kernel_prefix) and r.get("mfma_busy") is not None]
+            if rows:
+                cyc = sum(r["gpu_cycles"] * r["launches"] for r in rows)
+                return {"value": round(sum(r["mfma_busy"] * r["gpu_cycles"] * r["launches"] for r in rows) / cyc, 4),
+                        "source": f"profiles/{name}"}
+        except (OSError, ValueError, KeyError, TypeError, ZeroDivisionError):
+            pass
+    return None
+
+
+def search_cpu_baseline(budget_s=12.0):
+    """The search leg's CPU baseline: oracle/knn_oracle.c (the restated faiss Flat index, OpenMP over queries) on the host
+    threads -- BASELINE.json configs[0]'s plumbing case (64 x 1k, top-10) and a bounded sample of configs[2]
+    (n queries x 1M refs x 512, top-100, n sized to ~budget_s)."""
+    from oracle import knn_oracle
+    ncpu = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncpu = max(1, min(ncpu, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    os.environ["OMP_NUM_THREADS"] = str(ncpu)   # read by libgomp when the oracle library is first loaded
+    rng = np.random.default_rng(3)
+    d = 512
+    r = rng.standard_normal((1000000, d), dtype=np.float32)
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    q = rng.standard_normal((4096, d), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    knn_oracle.knn_ip(q[:8], r[:1000], 10)          # load + warm
+    t0 = time.perf_counter()
+    reps = 200
+    for _ in range(reps):
+        knn_oracle.knn_ip(q[:64], r[:1000], 10)
+    small = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    knn_oracle.knn_ip(q[:2 * ncpu], r, 100)
+    probe = (time.perf_counter() - t0) / (2 * ncpu)
+    n = int(min(len(q), max(2 * ncpu, budget_s / max(probe, 1e-6)) // ncpu * ncpu))
+    t0 = time.perf_counter()
+    knn_oracle.knn_ip(q[:n], r, 100)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * 1e6 / dt / 1e6, 3), "unit": "Mpairs/s", "cores": ncpu, "kind": "port",
+            "sample": f"{n} queries x 1,000,000 refs x 512, top-100, oracle/knn_oracle.c (fmaf chains, OpenMP over queries), {dt:.1f} s",
+            "configs0_64x1k_top10": {"ms": round(small * 1e3, 3), "mpairs_per_s": round(64 * 1000 / small / 1e6, 2)}}
+
+
 def search_traffic():
     """HBM-side bytes per sweep-kernel launch from the committed PMC profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes over tools/knn_bench.py; reads = 2 x FETCH_SIZE on gfx950, see gemm_traffic).  -> (bytes, nq, nr) of
@@ -268,7 +321,14 @@ def bench_search(dev, args):
                             "hits": int(out[0][-1]), "path": {1: "exact fp32", 2: "bf16 pre-filter + exact re-score", 3: "pre-filter overflowed -> exact"}[last()]}
     except Exception as exc:  # noqa: BLE001 -- secondary numbers must not cost the primary line
         others["error"] = f"{type(exc).__name__}: {exc}"
-    return {"other_sweeps": others, "metric": "Mpairs/s (512-d exact inner-product top-k sweep, BASELINE.json configs[2])",
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            del D, I
+            cpu = search_cpu_baseline()
+        except Exception as exc:  # noqa: BLE001 -- a baseline must not cost the line
+            cpu = {"error": f"{type(exc).__name__}: {exc}"}
+    return {"other_sweeps": others, "cpu_baseline": cpu, "metric": "Mpairs/s (512-d exact inner-product top-k sweep, BASELINE.json configs[2])",
             "value": round(pairs / (ms * 1e-3) / 1e6, 1), "unit": "Mpairs/s", "nq": nq, "nr": nr,
             "k": k, "dtype": dtype, "ms_per_sweep": round(ms, 3), "path": {1: "exact fp32 sweep", 2: "bf16 pre-filter + exact re-score", 3: "pre-filter, some blocks redone exactly"}[path],
             "phases_ms": {"pack": round(float(phases[0]), 3), "sweep": round(sweep_ms, 3), "rescore": round(float(phases[2]), 3),
@@ -313,8 +373,24 @@ def bench_search_sharded(dev, args, dist, rank, world):
     pairs = float(world) * nq * (nr_local * world)
     return {"metric": "Mpairs/s (512-d exact top-k, bank all_gathered over RCCL, every rank sweeps its own queries)",
             "value": round(pairs / t / 1e6, 1), "unit": "Mpairs/s", "n_gpus": world, "nq_per_gpu": nq,
-            "nr_total": nr_local * world, "k": k, "dtype": "f32", "ms_per_sweep_incl_all_gather": round(t * 1e3, 3),
+            "nr_total": nr_local * world, "k": k, "dtype": "bf16 sweep / f32 re-score", "ms_per_sweep_incl_all_gather": round(t * 1e3, 3),
             "scaling": "weak", "all_gather_bytes_per_rank": nr_local * d * 4 * (world - 1)}
+
+
+def swin_traffic():
+    """Mean memory-side bytes per GEMM-class launch of the Swin step (gemm_ln_kernel, gemm_bf16_v*, swin_mlp_kernel) from the
+    committed PMC passes over `tools/swin_bench.py 256 3 256` (profiles/r04_pmc_swin.json; 2 x FETCH_SIZE + WRITE_SIZE as in
+    gemm_traffic) -> (bytes, launches, source) or None."""
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_swin.json")))["per_launch"]
+        tot, n = 0.0, 0
+        for key, v in prof.items():
+            if key.startswith(("gemm_ln_kernel", "gemm_bf16_v", "swin_mlp_kernel")) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                tot += v["launches"] * (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+                n += v["launches"]
+        return (tot / n, n, "profiles/r04_pmc_swin.json") if n else None
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def bench_swin(dev, args):
@@ -367,11 +443,14 @@ def bench_swin(dev, args):
         kernels[name] = {"ms_per_step": round(ms / psteps, 4), "launches_per_step": cnt // psteps, "avg_launch_us": round(ms / cnt * 1e3, 2)}
         if tf:
             kernels[name]["tflops"] = round(tf, 1)
+            kernels[name]["frac"] = round(tf / BF16_PEAK_TFLOPS, 4)
         all_ms += ms
         if is_gemm:
             gemm_ms += ms
             gemm_flop += flop * frames_prof
     gemm_tf = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms else 0.0
+    traffic = swin_traffic()
+    wbusy = attention_mfma_busy("window_attention_kernel", "_swin")
     return {"metric": "frames/s (Swin-V2-B 256x256 window-16 encode -> L2-normalised 512-d descriptors)",
             "value": round(b / dt, 1), "unit": "frames/s", "frames_per_step": b, "encoder_chunk": args.swin_batch, "lanes": 2,
             "ms_per_step": round(dt * 1e3, 3),
@@ -380,7 +459,10 @@ def bench_swin(dev, args):
             "roofline": {"bound": "mfma", "kernel": "all GEMM launches of the Swin-V2-B step (gemm_ln_kernel: proj / fc2 / merge / patch embedding with their "
                                                     "LayerNorms; gemm_bf16_v4 / v3 / v2: qkv, fc1)",
                          "achieved": round(gemm_tf, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tf / BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(gemm_tf / BF16_PEAK_TFLOPS, 4), "traffic": None if traffic is None else round(traffic[0]),
+                         "traffic_unit": None if traffic is None else f"memory-side bytes per GEMM-class launch, mean over {traffic[1]} launches "
+                                                                        f"({traffic[2]}: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
+                         "window_attention_mfma_busy": wbusy,
                          "gemm_ms_per_step": round(gemm_ms / psteps, 3), "all_kernels_ms_per_step": round(all_ms / psteps, 3),
                          "whole_model_frac": round(cfg.flops_per_frame() * b / dt / 1e12 / BF16_PEAK_TFLOPS, 4),
                          "note": "achieved = sum 2 M N K of the GEMM launches / sum of their HIP-event durations, taken in a separate loop of "
@@ -532,6 +614,14 @@ def main():
                      for k, v in prof.items() if v[1]}
         for k in fpf:
             per_class[k]["tflops"] = round(fpf[k] * args.batch * psteps / (prof[k][0] * 1e-3) / 1e12, 1)
+            per_class[k]["frac"] = round(per_class[k]["tflops"] / BF16_PEAK_TFLOPS, 4)
+        if prof.get("attention", (0, 0))[0] > 0:
+            # the two attention GEMMs (Q K^T and P V): 4 T^2 head_dim per head and frame; MFMA-busy share of the launch from the
+            # committed PMC pass (profiles/r04_pmc_mfma_busy.json, else the round-2 file)
+            att_flop = cfg.layers * 4.0 * cfg.tokens * cfg.tokens * cfg.width
+            tf = att_flop * args.batch * psteps / (prof["attention"][0] * 1e-3) / 1e12
+            per_class["attention"].update({"tflops": round(tf, 1), "frac": round(tf / BF16_PEAK_TFLOPS, 4),
+                                           "mfma_busy": attention_mfma_busy("attention_kernel")})
         traffic, algo_bytes, traffic_src = gemm_traffic(cfg, min(args.max_batch, args.batch))
         line = {
             "metric": "frames/s (ViT-B/16 224x224 encode -> L2-normalised 512-d descriptors)",

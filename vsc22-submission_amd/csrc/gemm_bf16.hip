@@ -946,8 +946,17 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8]
             ml64::wait_vmcnt<0>();   // the statistics are in L2 ...
             if (lane == 0) __hip_atomic_store(p.ex.xflags + blockIdx.x * 2 + wm, iter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag
         }
+        // Forward progress: the partner (blockIdx ^ 8) runs the row's other tile in the SAME round of a grid with one workgroup
+        // per CU on every CU (launch_v4 checks grid == CUs and whole tile pairs; launch_gemm_ln_bf16 checks the CU count), so it
+        // is resident and reaches its own publish without waiting for anybody.  Should that assumption ever break (a CU mask,
+        // a partitioned device) the wait is BOUNDED: ~2^21 polls of >= 128 cycles (>= 0.1 s against a tile time of 80 us), then
+        // a trap -- the launch fails with a HIP error at the next synchronisation instead of hanging the queue.
         const int *flag = p.ex.xflags + (blockIdx.x ^ 8) * 2 + wm;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < iter + 1) __builtin_amdgcn_s_sleep(2);
+        int polls = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < iter + 1) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++polls > (1 << 21)) __builtin_trap();
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             union { float2 f; unsigned long long u; } v;
@@ -1129,7 +1138,19 @@ int launch_v4(GemmArgs p, int cus, hipStream_t stream) {
     p.group_n = g < 1 ? 1 : (g > p.tiles_n ? p.tiles_n : g);
     p.skew = 0;
     p.skew_groups = 1;
-    if (const char *e = vsc_opt(OPT_GEMM_V4_SKEW)) {   // "cycles,groups" (diagnostic sweep)
+    constexpr bool pair_exchange = EPI == VSC_EPI_LN_RES_F32;
+    if (pair_exchange) {
+        // the row's two tiles (t, t ^ 1) must land on workgroups (b, b ^ 8) of the same round: N-groups spanning the whole row
+        // of tiles, no diagnostic regrouping, one workgroup on every CU, whole pairs per round
+        p.group_n = p.tiles_n;
+        int dev_cus = 0, dev = 0;
+        VSC_CHECK_HIP(hipGetDevice(&dev));
+        VSC_CHECK_HIP(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev));
+        VSC_REQUIRE(cus == dev_cus && cus == 256, "gemm LN_RES: the pair exchange needs one workgroup on each of 256 CUs (grid %d, device %d)", cus, dev_cus);
+        VSC_REQUIRE(p.tiles_n == 1 || (p.tiles_n == 2 && ((int64_t)p.tiles_m * p.tiles_n) % 16 == 0),
+                    "gemm LN_RES: %d x %d tiles do not form whole pairs per XCD round", p.tiles_m, p.tiles_n);
+    }
+    if (const char *e = pair_exchange ? nullptr : vsc_opt(OPT_GEMM_V4_SKEW)) {   // "cycles,groups" (diagnostic sweep)
         int cyc = 0, grp = 1;
         if (sscanf(e, "%d,%d", &cyc, &grp) == 2 && cyc >= 0 && grp >= 1) {
             p.skew = cyc;

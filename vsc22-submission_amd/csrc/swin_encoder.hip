@@ -53,6 +53,7 @@ struct vsc_swin {
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     int64_t ws_bytes = 0;
     size_t ws_sizes[9] = {0};
+    int64_t sub_frames = 0;     // frames per sub-chunk of the 512-wide stage and beyond (0 = whole chunk); VSC_SWIN_SUB overrides
     bool lanes_ready = false;   // second workspace + lane streams: made by the first call that has more than one chunk
     // per-launch HIP events (vsc_swin_set_profiling), as in encoder.hip
     bool profile = false;
@@ -241,14 +242,18 @@ static int swin_alloc_workspace(vsc_swin *e, int l) {
     vsc_swin::Workspace &w = e->ws[l];
     void **dst[] = {(void **)&w.patches, (void **)&w.x, (void **)&w.xb, (void **)&w.t, (void **)&w.qkv,
                     (void **)&w.att, (void **)&w.h, (void **)&w.merged, (void **)&w.pooled};
+    // idempotent per buffer: a call that failed part-way is resumed, not repeated (nothing is allocated or counted twice)
     for (int i = 0; i < 9; ++i) {
+        if (*dst[i]) continue;
         int rc = sw_alloc(e, e->ws_sizes[i], dst[i]);
         if (rc) return rc;
         e->ws_bytes += (int64_t)e->ws_sizes[i];
     }
-    int rc = sw_alloc(e, VSC_GEMM_LN_WS_BYTES, &w.lnws);
-    if (rc) return rc;
-    e->ws_bytes += (int64_t)VSC_GEMM_LN_WS_BYTES;
+    if (!w.lnws) {
+        int rc = sw_alloc(e, VSC_GEMM_LN_WS_BYTES, &w.lnws);
+        if (rc) return rc;
+        e->ws_bytes += (int64_t)VSC_GEMM_LN_WS_BYTES;
+    }
     return VSC_OK;
 }
 // The two lanes (second workspace, two internal streams, fork / join events) exist from the first call with more than one
@@ -258,10 +263,10 @@ static int swin_make_lanes(vsc_swin *e) {
     int rc = swin_alloc_workspace(e, 1);
     if (rc) return rc;
     for (int l = 0; l < 2; ++l) {
-        VSC_CHECK_HIP(hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking));
-        VSC_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join[l], hipEventDisableTiming));
+        if (!e->lane_stream[l]) VSC_CHECK_HIP(hipStreamCreateWithFlags(&e->lane_stream[l], hipStreamNonBlocking));
+        if (!e->ev_join[l]) VSC_CHECK_HIP(hipEventCreateWithFlags(&e->ev_join[l], hipEventDisableTiming));
     }
-    VSC_CHECK_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    if (!e->ev_fork) VSC_CHECK_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     e->lanes_ready = true;
     return VSC_OK;
 }
@@ -275,15 +280,27 @@ struct SwinProfScope {
         if (e->profile) e0 = rec();
     }
     ~SwinProfScope() {
-        if (e->profile) e->spans.push_back({cls, e0, rec()});
+        if (!e->profile || e0 == BAD) return;
+        const size_t e1 = rec();
+        if (e1 != BAD) e->spans.push_back({cls, e0, e1});
     }
+    static constexpr size_t BAD = ~(size_t)0;
+    // One event from the pool (recycled by get_profile / set_profiling).  A failed create / record, or a pool that has
+    // grown past MAX_EVENTS because nobody collects the profile, switches profiling off instead of recording garbage.
+    static constexpr size_t MAX_EVENTS = 1 << 16;
     size_t rec() {
         if (e->ev_used == e->ev_pool.size()) {
             hipEvent_t ev;
-            (void)hipEventCreate(&ev);
+            if (e->ev_pool.size() >= MAX_EVENTS || hipEventCreate(&ev) != hipSuccess) {
+                e->profile = false;
+                return BAD;
+            }
             e->ev_pool.push_back(ev);
         }
-        (void)hipEventRecord(e->ev_pool[e->ev_used], st);
+        if (hipEventRecord(e->ev_pool[e->ev_used], st) != hipSuccess) {
+            e->profile = false;
+            return BAD;
+        }
         return e->ev_used++;
     }
 };
@@ -383,15 +400,15 @@ extern "C" int64_t vsc_swin_workspace_bytes(const vsc_swin *e) { return e ? e->w
 // x_out = (x_in ? x_in : 0) + LayerNorm(A W^T + bias): one row-owning GEMM when a tile can hold the whole row
 // (widths 128/256/512), otherwise GEMM to fp32 scratch + the row kernel (width 1024: the last stage).
 static int gemm_ln(vsc_swin *e, vsc_swin::Workspace &ws, const uint16_t *a, const uint16_t *w, const float *bias, const float *g, const float *b,
-                   const float *x_in, int64_t m, int n, int k, hipStream_t st) {
+                   const float *x_in, float *x_out, uint16_t *xb_out, int64_t m, int n, int k, hipStream_t st) {
     const bool split = vsc_opt(OPT_SWIN_SPLIT_LN) != nullptr;
     const char *split_k_opt = vsc_opt(OPT_SWIN_SPLIT_K);
     const int split_k = split_k_opt ? atoi(split_k_opt) : 1 << 30;
     if (!split && k < split_k && gemm_ln_supported(n, k))
-        return launch_gemm_ln_bf16(a, w, bias, g, b, x_in, ws.x, ws.xb, m, n, k, e->cfg.ln_eps, st, ws.lnws);
+        return launch_gemm_ln_bf16(a, w, bias, g, b, x_in, x_out, xb_out, m, n, k, e->cfg.ln_eps, st, ws.lnws);
     int rc = launch_gemm_bf16(a, w, bias, nullptr, ws.t, m, n, k, VSC_EPI_F32, 0, st);
     if (rc) return rc;
-    return launch_ln_residual(ws.t, g, b, x_in, ws.x, ws.xb, m, n, e->cfg.ln_eps, st);
+    return launch_ln_residual(ws.t, g, b, x_in, x_out, xb_out, m, n, e->cfg.ln_eps, st);
 }
 
 // the chunks of one call; `fork`: alternate them over the two lanes.  Returns at the first failing launch (the caller joins
@@ -408,6 +425,8 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
     const bool unfused_mlp = fm && fm[0] == '0';
     const char *fg = vsc_opt(OPT_SWIN_FUSED_MERGE);   // diagnostic / test switch: 0 = PatchMerging as a gather kernel + GEMM
     const bool unfused_merge = fg && fg[0] == '0';
+    const char *so = vsc_opt(OPT_SWIN_SUB);
+    const int64_t sub_frames = so ? atoll(so) : e->sub_frames;
     int chunk = 0;
     for (int64_t off = 0; off < n; off += c.max_batch, ++chunk) {
         const int lane = fork ? (chunk & 1) : 0;
@@ -423,25 +442,35 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
                 TRY(launch_patchify_u8(frames_u8 + off * frame_elems, w.patches, B, c.channels, c.image_size, c.patch_size,
                                        e->kpad, mean, std, st));
         }
-        { PROF(VSC_SWIN_PROF_PATCH_EMBED); TRY(gemm_ln(e, w, w.patches, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, nullptr, M, c.embed_dim, e->kpad, st)); }
+        { PROF(VSC_SWIN_PROF_PATCH_EMBED); TRY(gemm_ln(e, w, w.patches, e->pe_w, e->pe_b, e->pe_g, e->pe_beta, nullptr, w.x, w.xb, M, c.embed_dim, e->kpad, st)); }
         for (int s = 0; s < c.stages; ++s) {
             const int C = e->dim(s), R = e->res(s), W = e->window(s), H = c.heads[s];
             const int pc = VSC_SWIN_PROF_STAGE0 + (s < 4 ? s : 3) * VSC_SWIN_PROF_PER_STAGE;
             M = B * R * R;
+            // Frames are independent, so a stage may walk its blocks over a SUB-chunk of the frames at a time (rows are frame-major:
+            // a sub-chunk is a row range of x / xb; qkv / att / h are reused from their start).  VSC_SWIN_SUB = frames per sub-chunk for
+            // the 512-wide stage and beyond: with few enough frames the stage's whole working set (x, xb, qkv, att, h) stays in the
+            // 256-MiB Infinity Cache across its 18 blocks instead of streaming through HBM once per launch.
+            const int64_t sub = (sub_frames > 0 && C >= 512 && sub_frames < B) ? sub_frames : B;
+            for (int64_t f0 = 0; f0 < B; f0 += sub) {
+            const int64_t Bs = (B - f0) < sub ? (B - f0) : sub, Ms = Bs * R * R;
+            float *x = w.x + f0 * R * R * C;
+            uint16_t *xb = w.xb + f0 * R * R * C;
             for (int b = 0; b < c.depths[s]; ++b) {
                 const SwinBlockW &K = e->stages[s].blocks[b];
-                { PROF(pc + VSC_SWIN_PROF_QKV); TRY(launch_gemm_bf16(w.xb, K.qkv_w, K.qkv_b, nullptr, w.qkv, M, 3 * C, C, VSC_EPI_BF16, 0, st)); }
-                { PROF(pc + VSC_SWIN_PROF_ATTENTION); TRY(launch_window_attention(w.qkv, w.att, K.bias, K.scale, (int)B, R, W, e->shift(s, b), H, st)); }
-                { PROF(pc + VSC_SWIN_PROF_PROJ_LN); TRY(gemm_ln(e, w, w.att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, w.x, M, C, C, st)); }
+                { PROF(pc + VSC_SWIN_PROF_QKV); TRY(launch_gemm_bf16(xb, K.qkv_w, K.qkv_b, nullptr, w.qkv, Ms, 3 * C, C, VSC_EPI_BF16, 0, st)); }
+                { PROF(pc + VSC_SWIN_PROF_ATTENTION); TRY(launch_window_attention(w.qkv, w.att, K.bias, K.scale, (int)Bs, R, W, e->shift(s, b), H, st)); }
+                { PROF(pc + VSC_SWIN_PROF_PROJ_LN); TRY(gemm_ln(e, w, w.att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, x, x, xb, Ms, C, C, st)); }
                 if (K.fc2_wp && !unfused_mlp) {
                     // both Linears, the GELU between them and the LayerNorm behind them in one kernel (swin_mlp.hip); its time is
                     // booked under fc2_ln, fc1 stays empty
                     PROF(pc + VSC_SWIN_PROF_FC2_LN);
-                    TRY(launch_swin_mlp(K.fc1_w, K.fc1_b, K.fc2_wp, K.fc2_b, K.n2_g, K.n2_b, w.x, w.xb, M, C, e->cfg.ln_eps, st));
+                    TRY(launch_swin_mlp(K.fc1_w, K.fc1_b, K.fc2_wp, K.fc2_b, K.n2_g, K.n2_b, x, xb, Ms, C, e->cfg.ln_eps, st));
                 } else {
-                    { PROF(pc + VSC_SWIN_PROF_FC1); TRY(launch_gemm_bf16(w.xb, K.fc1_w, K.fc1_b, nullptr, w.h, M, 4 * C, C, VSC_EPI_GELU_BF16, 0, st)); }
-                    { PROF(pc + VSC_SWIN_PROF_FC2_LN); TRY(gemm_ln(e, w, w.h, K.fc2_w, K.fc2_b, K.n2_g, K.n2_b, w.x, M, C, 4 * C, st)); }
+                    { PROF(pc + VSC_SWIN_PROF_FC1); TRY(launch_gemm_bf16(xb, K.fc1_w, K.fc1_b, nullptr, w.h, Ms, 4 * C, C, VSC_EPI_GELU_BF16, 0, st)); }
+                    { PROF(pc + VSC_SWIN_PROF_FC2_LN); TRY(gemm_ln(e, w, w.h, K.fc2_w, K.fc2_b, K.n2_g, K.n2_b, x, x, xb, Ms, C, 4 * C, st)); }
                 }
+            }
             }
             if (s + 1 < c.stages) {
                 PROF(pc + VSC_SWIN_PROF_MERGE);
@@ -456,7 +485,7 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
                     w.merged = t;
                 } else {
                     TRY(launch_merge_gather(w.xb, w.merged, B, R, C, st));
-                    TRY(gemm_ln(e, w, w.merged, e->stages[s].red_w, nullptr, e->stages[s].dn_g, e->stages[s].dn_b, nullptr,
+                    TRY(gemm_ln(e, w, w.merged, e->stages[s].red_w, nullptr, e->stages[s].dn_g, e->stages[s].dn_b, nullptr, w.x, w.xb,
                                 M / 4, 2 * C, 4 * C, st));
                 }
             }
