@@ -1,0 +1,75 @@
+"""Run-to-run bit equality of every kernel family that publishes LDS-DMA data through a barrier, at the sizes the bench runs.
+Parity tests compare values within a tolerance on a handful of frames; round 3's LDS-DMA publication bug (a bare s_barrier
+in front of freshly DMA'd weight chunks) passed all of them and corrupted a few frames in every other run at full chunk size.
+A race shows as a difference between two runs of the same call -- so every such kernel gets five repeats here."""
+import numpy as np
+import pytest
+import torch
+
+from tools import synth
+from vsc_hip.config import get_config
+
+pytestmark = pytest.mark.gpu
+
+REPEATS = 5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from vsc_hip import _lib
+    _lib.require_device()
+    return torch.device("cuda:0")
+
+
+def test_vit_encoder_two_lanes_full_chunks(dev):
+    """ViT-B/16 at the benchmarked configuration: 332-frame chunks on two lanes, persistent v4 GEMMs (LDS-DMA ring streaming
+    across tiles), attention, LayerNorm -- 700 frames = two full chunks + a ragged one."""
+    from vsc_hip.encoder import HipEncoder
+    cfg = get_config("vit_b16_224")
+    enc = HipEncoder(cfg, synth.encoder_weights(7, cfg), max_batch=332, l2_normalize=True, lanes=2)
+    base = torch.from_numpy(synth.frames(21, 20, cfg)).to(dev)
+    x = (base.repeat(35, 1, 1, 1) + 0.001 * torch.arange(700, device=dev).view(-1, 1, 1, 1)).contiguous()
+    first = enc(x).clone()
+    assert torch.isfinite(first).all()
+    for _ in range(REPEATS):
+        assert torch.equal(enc(x), first)
+    enc.close()
+
+
+def test_knn_prefilter_sweep_65536_x_1m(dev):
+    """vsc_knn_ip_f32 at 65 536 x 1M x 512, k = 100 (bf16 pre-filter sweep: the shared 256 x 256 x 64 LDS-DMA loop, candidate
+    lists, compactions, exact re-scoring).  The survivors' ORDER in the lists may differ between runs; the result may not."""
+    from vsc_hip import ops
+    g = torch.Generator(device=dev).manual_seed(4)
+    r = torch.randn(1000000, 512, generator=g, device=dev)
+    q = torch.randn(65536, 512, generator=g, device=dev)
+    ops.l2_normalize_(r)
+    ops.l2_normalize_(q)
+    D0, I0 = ops.knn_ip(q, r, 100)
+    D0, I0 = D0.clone(), I0.clone()
+    assert bool((D0[:, :-1] >= D0[:, 1:]).all()) and int(I0.min()) >= 0
+    for _ in range(REPEATS):
+        D, I = ops.knn_ip(q, r, 100)
+        assert torch.equal(D, D0) and torch.equal(I, I0)
+    del r, q
+    torch.cuda.empty_cache()
+
+
+def test_range_and_pair_max_sweeps_repeat(dev):
+    """The two other sweeps on the shared loop (fixed threshold): CSR of the range search and the video-pair table."""
+    from vsc_hip import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    r = torch.randn(400000, 512, generator=g, device=dev)
+    q = torch.randn(8192, 512, generator=g, device=dev)
+    ops.l2_normalize_(r)
+    ops.l2_normalize_(q)
+    qv = (torch.arange(8192, device=dev) // 32).int()
+    rv = (torch.arange(400000, device=dev) // 32).int()
+    first = [t.clone() for t in ops.range_search_ip(q, r, 0.15, capacity=1 << 22)]
+    firstp = [t.clone() for t in ops.video_pair_max(q, qv, 256, r, rv, 12500, 0.15, capacity=1 << 22)]
+    assert int(first[0][-1]) > 1000
+    for _ in range(REPEATS):
+        for a, b in zip(ops.range_search_ip(q, r, 0.15, capacity=1 << 22), first):
+            assert torch.equal(a, b)
+        for a, b in zip(ops.video_pair_max(q, qv, 256, r, rv, 12500, 0.15, capacity=1 << 22), firstp):
+            assert torch.equal(a, b)

@@ -2,6 +2,8 @@
 // final-LayerNorm + GeM/CLS pooling, the descriptor head and the L2 normalisation.
 // One wave (64 lanes) owns a row; rows are read as float4 per lane, reductions are
 // wave shuffles; nothing goes through LDS except the per-frame pooling combine.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -139,6 +141,93 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             pk.y = pack_bf16x2(y2, y3);
             *(uint2 *)((uint16_t *)out + row * width + col) = pk;
         }
+    }
+}
+
+// The same for widths <= 1024 (NV float4 per lane, compile-time) in at most 24 VGPRs.  Why 24: the persistent bf16 GEMMs hold
+// every CU with 8 waves of 232 VGPRs (plain / GELU / fp32-store write-outs), which leaves 48 of a SIMD's 512 registers per
+// lane unused -- two waves of a 24-register kernel.  A LayerNorm of the OTHER lane's chunk then runs beside the GEMM (it needs
+// no LDS, and it is bound by HBM while the GEMM's K loop is not) instead of waiting for the GEMM to leave the CUs: the
+// encoder's two lanes overlap a memory-bound kernel with a matrix-bound one.  One wave per workgroup so that any single free
+// slot can take one.  gamma / beta are fetched per 256-column round (not hoisted) to stay inside the budget.
+// sum over the 64 lanes without index registers: four DPP adds inside each row of 16 (as row16_sum of the GEMM write-out), then
+// the four row sums by v_readlane (__shfl_xor costs an address VGPR per butterfly step, kept live for the second reduction)
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+    auto dpp = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    x += dpp(x, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    x += dpp(x, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    x += dpp(x, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    x += dpp(x, std::integral_constant<int, 0x140>{});  // row_mirror
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// widths of exactly NV x 256 columns (768, 1024): no tails, no masks; every access is a buffer operation with ONE per-lane offset
+// register (the row base travels in the descriptor, the 256-column round in the instruction's scalar offset)
+template <bool OUT_F32, int NV>
+__global__ __launch_bounds__(64) void layernorm_light_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, void *__restrict__ out, float eps) {
+    constexpr int W = NV * 256;
+    const uint32_t off = threadIdx.x * 16u;
+    const int64_t row = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(x + row * W), 0, W * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)gamma, 0, W * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)beta, 0, W * 4, 0x00020000);
+    f32x4_t v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rx, off, i * 1024, 0));
+    // (the empty asm statements below keep the reductions sequential: left alone, the compiler packs them into v_pk_add_f32 /
+    //  interleaved chains whose operand copies and temporaries are a dozen registers -- this kernel's budget is 24)
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sum += v[i][r];
+            asm volatile("" : "+v"(sum));
+        }
+    const float mean = wave_sum_dpp(sum) * (1.0f / W);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float d;   // one temporary, dead after its statement: (x - mean)^2 accumulated in order
+            asm volatile("v_sub_f32 %1, %2, %3\n\tv_fmac_f32 %0, %1, %1" : "+v"(sq), "=&v"(d) : "v"(v[i][r]), "v"(mean));
+        }
+    const float rstd = rsqrtf(wave_sum_dpp(sq) * (1.0f / W) + eps);
+    const float shift = -mean * rstd;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(OUT_F32 ? (void *)((float *)out + row * W) : (void *)((uint16_t *)out + row * W), 0,
+                                                                        W * (OUT_F32 ? 4 : 2), 0x00020000);
+    // gamma / beta one round at a time, in place: their offset register is made to depend on rstd (and on the previous round)
+    // by an empty asm -- independent loads are otherwise all hoisted to the top of the kernel (36-44 registers)
+    uint32_t off_gb = off;
+    asm volatile("" : "+v"(off_gb) : "v"(rstd));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        f32x4_t y = v[i];
+        f32x4_t g = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rg, off_gb, i * 1024, 0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = fmaf(y[r], rstd, shift) * g[r];
+        asm volatile("" : "+v"(off_gb) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));   // gamma is dead: beta lands in its registers
+        g = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb, off_gb, i * 1024, 0));
+        y += g;
+        asm volatile("" : "+v"(off_gb) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
+        typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+        typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2_t;
+        if (OUT_F32) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, y), ro, off, i * 1024, 0);
+        } else {
+            u32x2_t pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+            uint32_t off_o;   // lane * 8, formed per round in a register that is free by now (as a value of the whole kernel it is the 25th)
+            asm volatile("v_lshrrev_b32 %0, 1, %1" : "=v"(off_o) : "v"(off_gb));
+            __builtin_amdgcn_raw_buffer_store_b64(pk, ro, off_o, i * 512, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -424,6 +513,19 @@ int launch_layernorm(const float *x, const float *g, const float *b, void *out, 
     VSC_REQUIRE(x && g && b && out && rows > 0, "layernorm: null/empty");
     VSC_REQUIRE(width % 4 == 0 && width <= MAXV * 256, "layernorm: width %d unsupported", width);
     VSC_REQUIRE((rows + 3) / 4 < (1ll << 31), "layernorm: too many rows");
+    const char *lt = vsc_opt(OPT_LN_LIGHT);   // diagnostic: 0 = the 50-register kernel for every width
+    if ((width == 768 || width == 1024) && rows < (1ll << 31) && !(lt && lt[0] == '0')) {
+        const dim3 grid1((unsigned)rows);
+        if (width == 768) {
+            if (out_f32) hipLaunchKernelGGL((layernorm_light_kernel<true, 3>), grid1, dim3(64), 0, stream, x, g, b, out, eps);
+            else hipLaunchKernelGGL((layernorm_light_kernel<false, 3>), grid1, dim3(64), 0, stream, x, g, b, out, eps);
+        } else {
+            if (out_f32) hipLaunchKernelGGL((layernorm_light_kernel<true, 4>), grid1, dim3(64), 0, stream, x, g, b, out, eps);
+            else hipLaunchKernelGGL((layernorm_light_kernel<false, 4>), grid1, dim3(64), 0, stream, x, g, b, out, eps);
+        }
+        VSC_CHECK_LAUNCH();
+        return VSC_OK;
+    }
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (out_f32)
         hipLaunchKernelGGL(layernorm_kernel<true>, grid, dim3(256), 0, stream, x, g, b, out, rows, width, eps);

@@ -779,9 +779,15 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
     const int fr = lane & 15, fq = lane >> 4;
     const int ncol0 = n0 + wn * 64;
     const int64_t mrow0 = m0 + wm * 128;
-    f32x4_t bz[4];
+    // (bf16 write-outs keep the wave's 16 bias values in registers; the fp32 ones re-read them from LDS per row group: the residual
+    //  variant then fits 232 VGPRs like the others, which leaves room on every SIMD for a light kernel of the other lane --
+    //  see layernorm_light_kernel)
+    f32x4_t bz[epi_bf16_out(EPI) ? 4 : 1];
+    if (epi_bf16_out(EPI)) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bz[j] = *(const f32x4_t *)(bias_lds + (wn * 64 + j * 16 + fq * 4) * 4);
+        for (int j = 0; j < 4; ++j) bz[j] = *(const f32x4_t *)(bias_lds + (wn * 64 + j * 16 + fq * 4) * 4);
+    }
+    const char *bias_lane = bias_lds + (wn * 64 + fq * 4) * 4;
     if (epi_bf16_out(EPI)) {
         // four passes of 32 rows: bias + activation + pack -> staging -> whole 128-byte row segments.  The activation of a
         // pass is VALU work between the store bursts of its neighbours (GELU: ~2 k cycles per pass), so the 128 KiB of a
@@ -831,20 +837,27 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
     } else {
         const int c = lane & 15, rq = lane >> 4;
         const int n = ncol0 + c * 4;
-        const int nc = n < p.n ? n : 0;
         // Residual rows are requested two passes ahead.  (Loads and stores share one in-order counter on gfx9 and the
         // compiler's waits count only the loads issued since, so with the stores of this read-modify-write loop in between
         // its vmcnt(n) forces more than the row it needs.  Hand-counted waits around untracked inline-asm loads were
         // measured: proj 114.6 -> 111.1 us, fc2 unchanged -- the write-out is bound by the fabric's read + write rate, not
         // by this latency -- and they need unconditional stores to keep the count exact on ragged tiles.  Not kept.)
+        //
+        // Addresses: ONE per-lane byte offset for the whole tile (row mrow0 + rq, column n) plus a wave-uniform scalar offset
+        // per 4-row step, through buffer descriptors over the whole [m, n] fp32 matrices (launcher: m n 4 < 2^32).  Rows past
+        // m lie past the descriptor's extent -- their loads return zeros and their stores are dropped by the hardware -- and
+        // lanes whose columns lie past n get an offset past every extent: no compares, no 64-bit address arithmetic and no
+        // per-row registers in the write-out (the residual variant: 250 -> 232 VGPRs).
+        const uint32_t row_bytes = (uint32_t)p.n * 4u;
+        const uint32_t extent = (uint32_t)((uint64_t)p.m * row_bytes);
+        const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)extent, 0x00020000);
+        const __amdgpu_buffer_rsrc_t aux_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.aux, 0, p.aux ? (int)extent : 0, 0x00020000);
+        const uint32_t off0 = n < p.n ? (uint32_t)(mrow0 + rq) * row_bytes + (uint32_t)n * 4u : 0xfffffff0u;
         f32x4_t ax[3][4];
         auto load_aux = [&](int i, f32x4_t (&dst)[4]) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                int64_t m = mrow0 + i * 16 + it * 4 + rq;
-                m = m < p.m ? m : p.m - 1;
-                dst[it] = *(const f32x4_t *)(p.aux + m * p.n + nc);
-            }
+            for (int it = 0; it < 4; ++it)
+                dst[it] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, off0, (uint32_t)(i * 16 + it * 4) * row_bytes, 0));
         };
         if (EPI == VSC_EPI_F32) {
             ml64::wait_vmcnt<0>();   // plain fp32 out: no residual loads to wait for (tile_p's `first` contract)
@@ -857,7 +870,7 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
             if (EPI != VSC_EPI_F32 && i + 2 < 8) load_aux(i + 2, ax[(i + 2) % 3]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *(f32x4_t *)(reg + fr * 256 + (((4 * j + fq) ^ fr) << 4)) = acc[i][j] + bz[j];
+                *(f32x4_t *)(reg + fr * 256 + (((4 * j + fq) ^ fr) << 4)) = acc[i][j] + *(const f32x4_t *)(bias_lane + j * 64);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -865,8 +878,8 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
                 const int row = it * 4 + rq;
                 f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ row) << 4));
                 if (EPI != VSC_EPI_F32) v += ax[i % 3][it];
-                const int64_t m = mrow0 + i * 16 + row;
-                if (m < p.m && n < p.n) *(f32x4_t *)((float *)p.out + m * p.n + n) = v;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc, off0,
+                                                       (uint32_t)(i * 16 + it * 4) * row_bytes, 0);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -952,8 +965,8 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8]
         // a partitioned device) the wait is BOUNDED: ~2^21 polls of >= 128 cycles (>= 0.1 s against a tile time of 80 us), then
         // a trap -- the launch fails with a HIP error at the next synchronisation instead of hanging the queue.
         const int *flag = p.ex.xflags + (blockIdx.x ^ 8) * 2 + wm;
-        int polls = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < iter + 1) {
+        int polls = 0;   // (the flag is read as a wave-uniform value, so the loop and its counter stay on the scalar side: no VGPR)
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < iter + 1) {
             __builtin_amdgcn_s_sleep(2);
             if (++polls > (1 << 21)) __builtin_trap();
         }
@@ -1201,8 +1214,10 @@ int launch_v34(GemmArgs p, hipStream_t stream) {
         }
         const int64_t a_span = (int64_t)p.tiles_m * 256 * p.k * 2, w_span = (int64_t)p.tiles_n * 256 * p.k * 2;
         // (K > 3072: the per-tile costs v4 removes are < 1 % of a tile and its lockstep costs ~3 % -- 8192^3 680 vs 701 us)
+        // fp32 write-outs address [m, n] by 32-bit byte offsets from the matrix origin, rows of the last (ragged) tile included
+        const bool out_span_ok = epi_bf16_out(EPI) || (int64_t)p.tiles_m * 256 * p.n * 4 < (1ll << 32);
         if (!off && p.k % 128 == 0 && p.k >= 128 && p.k <= 3072 && cus % 8 == 0 && (int64_t)p.tiles_m * p.tiles_n > cus &&
-            a_span < (1ll << 32) && w_span < (1ll << 32) && (EPI != VSC_EPI_RESADD_F32 || p.aux))
+            a_span < (1ll << 32) && w_span < (1ll << 32) && out_span_ok && (EPI != VSC_EPI_RESADD_F32 || p.aux))
         {
             int grid = cus;
             // diagnostic: persistent workgroups per launch (a multiple of 8).  Measured with two lanes, so that the two chunks' GEMMs run

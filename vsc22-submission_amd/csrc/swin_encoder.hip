@@ -53,7 +53,6 @@ struct vsc_swin {
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     int64_t ws_bytes = 0;
     size_t ws_sizes[9] = {0};
-    int64_t sub_frames = 0;     // frames per sub-chunk of the 512-wide stage and beyond (0 = whole chunk); VSC_SWIN_SUB overrides
     bool lanes_ready = false;   // second workspace + lane streams: made by the first call that has more than one chunk
     // per-launch HIP events (vsc_swin_set_profiling), as in encoder.hip
     bool profile = false;
@@ -425,8 +424,6 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
     const bool unfused_mlp = fm && fm[0] == '0';
     const char *fg = vsc_opt(OPT_SWIN_FUSED_MERGE);   // diagnostic / test switch: 0 = PatchMerging as a gather kernel + GEMM
     const bool unfused_merge = fg && fg[0] == '0';
-    const char *so = vsc_opt(OPT_SWIN_SUB);
-    const int64_t sub_frames = so ? atoll(so) : e->sub_frames;
     int chunk = 0;
     for (int64_t off = 0; off < n; off += c.max_batch, ++chunk) {
         const int lane = fork ? (chunk & 1) : 0;
@@ -447,15 +444,9 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
             const int C = e->dim(s), R = e->res(s), W = e->window(s), H = c.heads[s];
             const int pc = VSC_SWIN_PROF_STAGE0 + (s < 4 ? s : 3) * VSC_SWIN_PROF_PER_STAGE;
             M = B * R * R;
-            // Frames are independent, so a stage may walk its blocks over a SUB-chunk of the frames at a time (rows are frame-major:
-            // a sub-chunk is a row range of x / xb; qkv / att / h are reused from their start).  VSC_SWIN_SUB = frames per sub-chunk for
-            // the 512-wide stage and beyond: with few enough frames the stage's whole working set (x, xb, qkv, att, h) stays in the
-            // 256-MiB Infinity Cache across its 18 blocks instead of streaming through HBM once per launch.
-            const int64_t sub = (sub_frames > 0 && C >= 512 && sub_frames < B) ? sub_frames : B;
-            for (int64_t f0 = 0; f0 < B; f0 += sub) {
-            const int64_t Bs = (B - f0) < sub ? (B - f0) : sub, Ms = Bs * R * R;
-            float *x = w.x + f0 * R * R * C;
-            uint16_t *xb = w.xb + f0 * R * R * C;
+            const int64_t Bs = B, Ms = M;
+            float *x = w.x;
+            uint16_t *xb = w.xb;
             for (int b = 0; b < c.depths[s]; ++b) {
                 const SwinBlockW &K = e->stages[s].blocks[b];
                 { PROF(pc + VSC_SWIN_PROF_QKV); TRY(launch_gemm_bf16(xb, K.qkv_w, K.qkv_b, nullptr, w.qkv, Ms, 3 * C, C, VSC_EPI_BF16, 0, st)); }
@@ -470,7 +461,6 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
                     { PROF(pc + VSC_SWIN_PROF_FC1); TRY(launch_gemm_bf16(xb, K.fc1_w, K.fc1_b, nullptr, w.h, Ms, 4 * C, C, VSC_EPI_GELU_BF16, 0, st)); }
                     { PROF(pc + VSC_SWIN_PROF_FC2_LN); TRY(gemm_ln(e, w, w.h, K.fc2_w, K.fc2_b, K.n2_g, K.n2_b, x, x, xb, Ms, C, 4 * C, st)); }
                 }
-            }
             }
             if (s + 1 < c.stages) {
                 PROF(pc + VSC_SWIN_PROF_MERGE);
