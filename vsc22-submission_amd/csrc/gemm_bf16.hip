@@ -993,14 +993,21 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8]
     const int c = lane & 15, rq = lane >> 4;
     const int n = ncol0 + c * 4;
     const f32x4_t gm = *(const f32x4_t *)(p.ex.gamma + n), bt = *(const f32x4_t *)(p.ex.beta + n);
+    // addresses as in epilogue_small's fp32 path: one per-lane byte offset for the tile, a scalar offset per 4-row step, buffer
+    // descriptors over [m, n] (rows past m: loads return zeros, stores are dropped); the bf16 shadow at half the offsets
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+    typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2_t;
+    const uint32_t row_bytes = (uint32_t)p.n * 4u;
+    const uint32_t extent = (uint32_t)((uint64_t)p.m * row_bytes);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)extent, 0x00020000);
+    const __amdgpu_buffer_rsrc_t aux_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.aux, 0, p.aux ? (int)extent : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xb_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.ex.xb, 0, (int)(extent >> 1), 0x00020000);
+    const uint32_t off0 = (uint32_t)(mrow0 + rq) * row_bytes + (uint32_t)n * 4u;
     f32x4_t ax[3][4];
     auto load_aux = [&](int i, f32x4_t (&dst)[4]) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            int64_t m = mrow0 + i * 16 + it * 4 + rq;
-            m = m < p.m ? m : p.m - 1;
-            dst[it] = *(const f32x4_t *)(p.aux + m * p.n + n);
-        }
+        for (int it = 0; it < 4; ++it)
+            dst[it] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(aux_rsrc, off0, (uint32_t)(i * 16 + it * 4) * row_bytes, 0));
     };
     const bool res = p.aux != nullptr;
     if (res) {
@@ -1020,14 +1027,10 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8]
             f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ row) << 4));
             v = v * gm + bt;
             if (res) v += ax[i % 3][it];
-            const int64_t m = mrow0 + i * 16 + row;
-            if (m < p.m) {
-                *(f32x4_t *)((float *)p.out + m * p.n + n) = v;
-                uint2 pk;
-                pk.x = pack_bf16x2(v[0], v[1]);
-                pk.y = pack_bf16x2(v[2], v[3]);
-                *(uint2 *)(p.ex.xb + m * p.n + n) = pk;
-            }
+            const uint32_t soff = (uint32_t)(i * 16 + it * 4) * row_bytes;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), out_rsrc, off0, soff, 0);
+            const u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            __builtin_amdgcn_raw_buffer_store_b64(pk, xb_rsrc, off0 >> 1, soff >> 1, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1159,7 +1162,8 @@ int launch_v4(GemmArgs p, int cus, hipStream_t stream) {
         int dev_cus = 0, dev = 0;
         VSC_CHECK_HIP(hipGetDevice(&dev));
         VSC_CHECK_HIP(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev));
-        VSC_REQUIRE(cus == dev_cus && cus == 256, "gemm LN_RES: the pair exchange needs one workgroup on each of 256 CUs (grid %d, device %d)", cus, dev_cus);
+        // (grid < CUs -- the VSC_GEMM_V4_GRID diagnostic -- keeps every workgroup resident as well; the exchange slots are sized for 256)
+        VSC_REQUIRE(cus <= dev_cus && cus <= 256 && cus % 16 == 0, "gemm LN_RES: the pair exchange needs every workgroup resident, in whole pairs per XCD (grid %d, device %d CUs)", cus, dev_cus);
         VSC_REQUIRE(p.tiles_n == 1 || (p.tiles_n == 2 && ((int64_t)p.tiles_m * p.tiles_n) % 16 == 0),
                     "gemm LN_RES: %d x %d tiles do not form whole pairs per XCD round", p.tiles_m, p.tiles_n);
     }
@@ -1726,13 +1730,14 @@ int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias,
             if (dev >= 0 && dev < 16) cus_of[dev] = cus;
         }
         const bool shape_ok = (n == 256 || (n == 512 && tiles_m % 8 == 0)) && k % 128 == 0 && k >= 128 && k <= 3072 && cus == 256 &&
-                              tiles_m * tiles_n > cus && tiles_m * 256 * k * 2 < (1ll << 32) && dev >= 0 && dev < 16;
-        // Where it pays (tools/micro/gemm_ln_ab.py, 256 Swin-V2-B frames): only the long-K launches.  With K <= 1024 the call is
-        // bound by its bytes whichever kernel runs it -- x read + x written + bf16 shadow + A: 805 MB in 165 us (N = 256, K = 256),
-        // 402 MB in 100 us (N = 512, K = 512) = 4-4.9 TB/s -- and the row-owning tiles' two rounds of workgroups de-phase their
-        // write-outs for free (s2 proj 99 vs 110 us here); at N = 512, K = 2048 the K loop matters: 196 -> 177 us.
-        // VSC_GEMM_LN_V4=1 forces the persistent kernel on every shape it supports (tests), 0 switches it off.
-        const bool pays = n == 512 && k >= 1536;
+                              tiles_m * tiles_n > cus && tiles_m * 256 * k * 2 < (1ll << 32) && tiles_m * 256 * n * 4 < (1ll << 32) &&
+                              dev >= 0 && dev < 16;
+        // Where it pays (tools/micro/gemm_ln_ab.py, 256 Swin-V2-B frames; round 4, with the write-out on buffer operations and no
+        // spill left): N = 512 from K = 512 on -- s2 proj 96 vs 100 us, s2 fc2 166 vs 195, the un-gathered merge shape 114 vs
+        // 128; at N = 256 the short-K launch ties (s1 proj 168 vs 168: bound by its bytes whichever kernel runs it) and stays
+        // on the row-owning tile.  VSC_GEMM_LN_V4=1 forces the persistent kernel on every shape it supports (tests), 0
+        // switches it off.
+        const bool pays = n == 512 && k >= 512;
         if (shape_ok && merge_res == 0 && !(opt && opt[0] == '0') && (pays || (opt && opt[0] == '1'))) {
             static void *dev_ws[16] = {};   // callers without a workspace of their own: one call at a time per device
             if (!pair_ws) {
@@ -1748,7 +1753,12 @@ int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias,
             p.ex.xch = (float *)pair_ws;
             p.ex.xflags = (int *)((char *)pair_ws + 2 * 256 * 256 * 2 * 4);
             if (tiles_n == 2) VSC_CHECK_HIP(hipMemsetAsync(p.ex.xflags, 0, 256 * 2 * 4, stream));
-            return launch_v4<VSC_EPI_LN_RES_F32>(p, cus, stream);
+            int grid = cus;
+            if (const char *e = vsc_opt(OPT_GEMM_V4_GRID)) {   // diagnostic, as in launch_v34
+                const int g = atoi(e);
+                if (g >= 16 && g <= cus && g % 16 == 0 && tiles_m * tiles_n >= g) grid = g;
+            }
+            return launch_v4<VSC_EPI_LN_RES_F32>(p, grid, stream);
         }
     }
     GemmLnArgs p{a, w, bias, gamma, beta, x_in, x_out, xb_out, m, n, k, eps};
