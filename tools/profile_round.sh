@@ -3,7 +3,7 @@
 # summary of the same command at 3 steps, and separate --pmc passes (FETCH_SIZE / WRITE_SIZE) for the encoder GEMMs and the
 # similarity sweep.  Outputs under gpurun_out/<tag>/; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -20,6 +20,17 @@ for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && rocprofv3 --pmc $c -d "$OUT/pmc_$c" -o enc --output-format csv -- python $OLDPWD/bench.py $SHORT > /dev/null 2> "$OUT/pmc_$c.err")
   (cd /tmp && timeout 600 rocprofv3 --pmc $c -d "$OUT/pmcknn_$c" -o knn --output-format csv -- python $OLDPWD/tools/knn_bench.py 8192 1000000 100 1 > /dev/null 2> "$OUT/pmcknn_$c.err")
 done
+# Swin: memory-side bytes per launch (swin.roofline.traffic of the bench line) -- the same command as the kernel-trace pass
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && timeout 600 rocprofv3 --pmc $c -d "$OUT/pmcswin_$c" -o swin --output-format csv -- python $OLDPWD/tools/swin_bench.py 256 3 256 > /dev/null 2> "$OUT/pmcswin_$c.err")
+done
+python tools/pmc_summarize.py "$OUT/pmc_swin.json" "$OUT/pmcswin_FETCH_SIZE" "$OUT/pmcswin_WRITE_SIZE" > "$OUT/pmc_swin_summary.txt" 2>&1
+# matrix-pipe busy share per kernel (attention / window attention / GEMMs): one pass of three SQ / GRBM counters each
+MF="GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"
+(cd /tmp && timeout 600 rocprofv3 --pmc $MF -d "$OUT/pmc_mfma" -o enc --output-format csv -- python $OLDPWD/bench.py $SHORT > /dev/null 2> "$OUT/pmc_mfma.err")
+python tools/pmc_mfma_busy.py "$OUT/pmc_mfma_busy.json" "$OUT/pmc_mfma" "rocprofv3 --pmc $MF -- python bench.py $SHORT" > "$OUT/pmc_mfma_busy.txt" 2>&1
+(cd /tmp && timeout 600 rocprofv3 --pmc $MF -d "$OUT/pmc_mfma_swin" -o swin --output-format csv -- python $OLDPWD/tools/swin_bench.py 256 3 256 > /dev/null 2> "$OUT/pmc_mfma_swin.err")
+python tools/pmc_mfma_busy.py "$OUT/pmc_mfma_busy_swin.json" "$OUT/pmc_mfma_swin" "rocprofv3 --pmc $MF -- python tools/swin_bench.py 256 3 256" > "$OUT/pmc_mfma_busy_swin.txt" 2>&1
 python tools/pmc_summarize.py "$OUT/pmc_per_launch.json" "$OUT/pmc_FETCH_SIZE" "$OUT/pmc_WRITE_SIZE" > "$OUT/pmc_summary.txt" 2>&1
 python tools/pmc_summarize.py "$OUT/pmc_knn.json" "$OUT/pmcknn_FETCH_SIZE" "$OUT/pmcknn_WRITE_SIZE" > "$OUT/pmc_knn_summary.txt" 2>&1
 find "$OUT" -name "*.db" | while read f; do python profiles/summarize_rocpd.py "$f" > "${f%.db}_summary.txt" 2>&1; done

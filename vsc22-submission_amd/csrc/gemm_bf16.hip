@@ -794,6 +794,11 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
         // workgroup's tile leave spread over the write-out instead of in one burst behind it.
         const int c = lane & 7;
         const int n = ncol0 + c * 8;
+        // stores through a buffer descriptor over [m, n] bf16: one per-lane offset for the tile + a scalar offset per 8-row step;
+        // rows past m are past the extent (dropped), lanes past n get an offset past every extent (launcher: m n 2 < 2^32)
+        const uint32_t row_bytes_h = (uint32_t)p.n * 2u;
+        const __amdgpu_buffer_rsrc_t outh_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(uint32_t)((uint64_t)p.m * row_bytes_h), 0x00020000);
+        const uint32_t offh = n < p.n ? (uint32_t)(mrow0 + (lane >> 3)) * row_bytes_h + (uint32_t)n * 2u : 0xfffffff0u;
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
 #pragma unroll
@@ -830,8 +835,9 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int64_t m = mrow0 + pass * 32 + it * 8 + (lane >> 3);
-                if (m < p.m && n < p.n) *(uint4 *)((uint16_t *)p.out + m * p.n + n) = d[it];
+                typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+                const u32x4_t dv = {d[it].x, d[it].y, d[it].z, d[it].w};
+                __builtin_amdgcn_raw_buffer_store_b128(dv, outh_rsrc, offh, (uint32_t)(pass * 32 + it * 8) * row_bytes_h, 0);
             }
         }
     } else {
@@ -1219,7 +1225,7 @@ int launch_v34(GemmArgs p, hipStream_t stream) {
         const int64_t a_span = (int64_t)p.tiles_m * 256 * p.k * 2, w_span = (int64_t)p.tiles_n * 256 * p.k * 2;
         // (K > 3072: the per-tile costs v4 removes are < 1 % of a tile and its lockstep costs ~3 % -- 8192^3 680 vs 701 us)
         // fp32 write-outs address [m, n] by 32-bit byte offsets from the matrix origin, rows of the last (ragged) tile included
-        const bool out_span_ok = epi_bf16_out(EPI) || (int64_t)p.tiles_m * 256 * p.n * 4 < (1ll << 32);
+        const bool out_span_ok = (int64_t)p.tiles_m * 256 * p.n * (epi_bf16_out(EPI) ? 2 : 4) < (1ll << 32);
         if (!off && p.k % 128 == 0 && p.k >= 128 && p.k <= 3072 && cus % 8 == 0 && (int64_t)p.tiles_m * p.tiles_n > cus &&
             a_span < (1ll << 32) && w_span < (1ll << 32) && out_span_ok && (EPI != VSC_EPI_RESADD_F32 || p.aux))
         {
