@@ -129,7 +129,7 @@ int vsc_encoder_get_profile(vsc_encoder *enc, double ms_out[VSC_PROF_CLASSES],
  * patch embed + norm, stages of res-post-norm blocks with windowed cosine attention and continuous
  * relative position bias, patch merging, final norm, GeM(p) over tokens, output_proj).
  * Weight names are the reference's state-dict names ("layers.2.blocks.5.attn.qkv.weight" ...).
- * Supported: head_dim 32, window 16 or 8 (after clipping to the feature map), mlp_ratio 4.
+ * Supported: head_dim 32, window 8, 12, 16 or 24 (after clipping to the feature map; 8 and 16 run the tuned kernel), mlp_ratio 4.
  * ------------------------------------------------------------------------ */
 typedef struct vsc_swin vsc_swin;
 

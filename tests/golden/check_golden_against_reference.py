@@ -150,6 +150,7 @@ def check_vsm(preset: str) -> float:
 
 
 CHECKS = [("swin", check_swin, "tiny_swin"), ("swin", check_swin, "tiny_swin_w8"), ("swin", check_swin, "swinv2_base_256"),
+          ("swin", check_swin, "tiny_swin_w24"), ("swin", check_swin, "swinv2_large_384"),
           ("clip", check_clip, "tiny_clip"), ("sscd", check_sscd, "vit_v68"), ("vsm", check_vsm, "tiny_vsm")]
 
 

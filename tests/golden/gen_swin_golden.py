@@ -83,3 +83,5 @@ if __name__ == "__main__":
     gen("tiny_swin", 3)
     gen("tiny_swin_w8", 3)
     gen("swinv2_base_256", 2)
+    gen("tiny_swin_w24", 2)
+    gen("swinv2_large_384", 1)

@@ -13,7 +13,7 @@ import _reference_classes as refc  # noqa: E402
 pytestmark = pytest.mark.skipif(not refc.available(), reason="/root/reference absent (GPU box)")
 
 
-@pytest.mark.parametrize("kind,preset", [("swin", "tiny_swin"), ("swin", "tiny_swin_w8"), ("swin", "swinv2_base_256"),
+@pytest.mark.parametrize("kind,preset", [("swin", "tiny_swin"), ("swin", "tiny_swin_w8"), ("swin", "swinv2_base_256"), ("swin", "tiny_swin_w24"),
                                          ("clip", "tiny_clip"), ("sscd", "vit_v68"), ("vsm", "tiny_vsm")])
 def test_fixture_equals_reference_class_output(kind, preset):
     import check_golden_against_reference as chk

@@ -28,7 +28,10 @@ def _rand(seed, shape, std=1.0):
 
 
 @pytest.mark.parametrize("frames,res,window,shift,heads", [(2, 32, 16, 0, 2), (2, 32, 16, 8, 2), (1, 16, 16, 0, 4),
-                                                           (3, 16, 8, 4, 2), (2, 8, 8, 0, 4), (1, 64, 16, 8, 4)])
+                                                           (3, 16, 8, 4, 2), (2, 8, 8, 0, 4), (1, 64, 16, 8, 4),
+                                                           # windows of BASELINE.json configs[4] (Swin-V2-L at 384): 24, clipped to 12
+                                                           (2, 48, 24, 12, 2), (1, 48, 24, 0, 3), (1, 24, 24, 0, 4), (2, 12, 12, 0, 3),
+                                                           (1, 24, 12, 6, 2)])
 def test_window_attention(dev, frames, res, window, shift, heads):
     from vsc_hip import ops
     c, n = heads * 32, window * window
@@ -213,7 +216,7 @@ def test_merge_gather_bit_exact(dev):
     assert torch.equal(out.view(torch.int16), ref.contiguous().view(torch.int16))
 
 
-@pytest.mark.parametrize("preset", ["tiny_swin", "tiny_swin_w8", "swinv2_base_256"])
+@pytest.mark.parametrize("preset", ["tiny_swin", "tiny_swin_w8", "swinv2_base_256", "tiny_swin_w24", "swinv2_large_384"])
 def test_swin_encoder_matches_golden(dev, preset, golden_dir):
     from vsc_hip.swin_encoder import SwinHipEncoder
     g = np.load(os.path.join(golden_dir, f"swin_{preset}.npz"))

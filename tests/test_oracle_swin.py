@@ -11,7 +11,7 @@ from tools import synth
 from vsc_hip.swin_config import get_swin_config
 
 
-@pytest.mark.parametrize("preset", ["tiny_swin", "tiny_swin_w8", "swinv2_base_256"])
+@pytest.mark.parametrize("preset", ["tiny_swin", "tiny_swin_w8", "swinv2_base_256", "tiny_swin_w24"])
 def test_swin_oracle_matches_transformers_golden(preset, golden_dir):
     g = np.load(os.path.join(golden_dir, f"swin_{preset}.npz"))
     cfg = get_swin_config(preset)

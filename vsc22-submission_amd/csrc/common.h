@@ -79,6 +79,19 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
     return *(uint32_t *)&b;
 }
 
+// ---- 16-byte stores through a buffer descriptor with a scalar offset ---------------------------------------------------
+// buffer_store_dwordx4 with an SGPR soffset: on gfx950 the instruction is still reading its four data registers when the next
+// instruction issues, and a VALU write to one of them in that slot reaches memory instead of the value stored (measured: the
+// persistent GEMM's GELU write-out stored garbage in the first dword of a row segment whenever the next pass's v_med3 reused the
+// register right behind the store -- ~1 % of the tiles, different ones every run; tools/micro/gemm_determinism.py).  The
+// compiler's hazard recognizer pads this store-data hazard only for stores WITHOUT a register soffset.  Hence: the data stays
+// live through one s_nop 1 (two wait states) behind every such store.  8-byte stores are not affected.
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int vsc_u32x4_t;
+__device__ __forceinline__ void buffer_store_b128_soff(vsc_u32x4_t data, __amdgpu_buffer_rsrc_t rsrc, uint32_t voffset, uint32_t soffset) {
+    __builtin_amdgcn_raw_buffer_store_b128(data, rsrc, voffset, soffset, 0);
+    asm volatile("s_nop 1" : : "v"(data));
+}
+
 // ---- wave reductions (64 lanes) --------------------------------------------------
 __device__ inline float wave_sum(float v) {
 #pragma unroll

@@ -217,10 +217,9 @@ __global__ __launch_bounds__(64) void layernorm_light_kernel(const float *__rest
         g = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rb, off_gb, i * 1024, 0));
         y += g;
         asm volatile("" : "+v"(off_gb) : "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
-        typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
-        typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2_t;
+            typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2_t;
         if (OUT_F32) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, y), ro, off, i * 1024, 0);
+            buffer_store_b128_soff(__builtin_bit_cast(vsc_u32x4_t, y), ro, off, i * 1024);
         } else {
             u32x2_t pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
             uint32_t off_o;   // lane * 8, formed per round in a register that is free by now (as a value of the whole kernel it is the 25th)

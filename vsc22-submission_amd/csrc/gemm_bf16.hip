@@ -835,9 +835,13 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
-                const u32x4_t dv = {d[it].x, d[it].y, d[it].z, d[it].w};
-                __builtin_amdgcn_raw_buffer_store_b128(dv, outh_rsrc, offh, (uint32_t)(pass * 32 + it * 8) * row_bytes_h, 0);
+#ifdef VSC_BF16_GLOBAL_STORE
+                const int64_t m = mrow0 + pass * 32 + it * 8 + (lane >> 3);
+                if (m < p.m && n < p.n) *(uint4 *)((uint16_t *)p.out + m * p.n + n) = d[it];
+#else
+                            const u32x4_t dv = {d[it].x, d[it].y, d[it].z, d[it].w};
+                buffer_store_b128_soff(dv, outh_rsrc, offh, (uint32_t)(pass * 32 + it * 8) * row_bytes_h);
+#endif
             }
         }
     } else {
@@ -884,8 +888,7 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
                 const int row = it * 4 + rq;
                 f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ row) << 4));
                 if (EPI != VSC_EPI_F32) v += ax[i % 3][it];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int, v), out_rsrc, off0,
-                                                       (uint32_t)(i * 16 + it * 4) * row_bytes, 0);
+                buffer_store_b128_soff(__builtin_bit_cast(vsc_u32x4_t, v), out_rsrc, off0, (uint32_t)(i * 16 + it * 4) * row_bytes);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1001,7 +1004,6 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8]
     const f32x4_t gm = *(const f32x4_t *)(p.ex.gamma + n), bt = *(const f32x4_t *)(p.ex.beta + n);
     // addresses as in epilogue_small's fp32 path: one per-lane byte offset for the tile, a scalar offset per 4-row step, buffer
     // descriptors over [m, n] (rows past m: loads return zeros, stores are dropped); the bf16 shadow at half the offsets
-    typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
     typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2_t;
     const uint32_t row_bytes = (uint32_t)p.n * 4u;
     const uint32_t extent = (uint32_t)((uint64_t)p.m * row_bytes);
@@ -1034,7 +1036,7 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8]
             v = v * gm + bt;
             if (res) v += ax[i % 3][it];
             const uint32_t soff = (uint32_t)(i * 16 + it * 4) * row_bytes;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), out_rsrc, off0, soff, 0);
+            buffer_store_b128_soff(__builtin_bit_cast(vsc_u32x4_t, v), out_rsrc, off0, soff);
             const u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             __builtin_amdgcn_raw_buffer_store_b64(pk, xb_rsrc, off0 >> 1, soff >> 1, 0);
         }

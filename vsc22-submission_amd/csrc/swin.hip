@@ -287,6 +287,168 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// The same attention for the window sizes the reference's own models do not use but BASELINE.json's configs[4] names
+// (Swin-V2-L at 384 x 384: window 24, clipped to 12 in the last stage): 576- / 144-token windows.  Written for coverage,
+// not tuned like the 8 / 16 kernel above: the bias is gathered per score from the plain (2w-1)^2 table, shift masks are
+// compares, the row maximum is always taken (scale < 0 -- see vsc_window_attention_bf16 -- only says the caller folded a
+// bound into the table: subtracting the row maximum as well is the same quotient), V^T keeps the plain key order.
+// MFMA operand layouts, k-slot permutation of P and the ones-operand row sum are those of the kernel above.
+template <int WS>
+__global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
+    const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, const float *__restrict__ bias,
+    const float *__restrict__ scale, int res, int shift, int heads) {
+    constexpr int N = WS * WS, NT = N / 16, NTP = (NT + 1) & ~1, NP = NTP * 16;   // keys padded to whole 32-key PV steps
+    constexpr int NTHREADS = 256, NWAVES = 4;   // one wave per SIMD: a 576-key score row is 144 registers of a lane (up to 512 are its own)
+    constexpr int SIDE = 2 * WS - 1, VSTRIDE = NP * 2 + 32;
+    static_assert(N % 16 == 0 && WS % 4 == 0, "whole 16-key tiles; a lane's 4 keys stay inside one window row");
+    extern __shared__ __attribute__((aligned(16))) char wsmem[];
+    char *klds = wsmem;                                       // [NP][32] bf16, 64-B rows, chunk ^= (-(row >> 2)) & 3
+    char *vt = klds + NP * 64;                                // [32][VSTRIDE]
+    int *rowmap = (int *)(vt + HD * VSTRIDE);                 // image token of window token i
+    float *tbl = (float *)(rowmap + N);                       // this head's bias table * log2 e
+    unsigned char *region = (unsigned char *)(tbl + SIDE * SIDE);
+    const float LOG2E = 1.44269504088896340736f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwx = res / WS, nw = nwx * nwx;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = b % heads; b /= heads;
+    const int win = b % nw, frame = b / nw;
+    const int wh = win / nwx, wwx = win - wh * nwx;
+    const int C = heads * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const uint16_t *base = qkv + (int64_t)frame * res * res * ld + head * HD;
+    for (int i = tid; i < N; i += NTHREADS) {
+        const int wy = i / WS, wx = i - wy * WS;
+        const int sy = wh * WS + wy, sx = wwx * WS + wx;
+        int y = sy + shift, x = sx + shift;
+        y = y >= res ? y - res : y;
+        x = x >= res ? x - res : x;
+        rowmap[i] = y * res + x;
+        const int hr = sy < res - WS ? 0 : (sy < res - shift ? 1 : 2);
+        const int wr = sx < res - WS ? 0 : (sx < res - shift ? 1 : 2);
+        region[i] = (unsigned char)(3 * hr + wr);
+    }
+    for (int i = tid; i < SIDE * SIDE; i += NTHREADS) tbl[i] = bias[(int64_t)head * SIDE * SIDE + i] * LOG2E;
+    __syncthreads();
+    // K-hat (4 threads per key row) and V^T (task = 4 keys x 8 dims); keys past N are zero rows / zero columns
+    for (int e = tid; e < NP * 4; e += NTHREADS) {
+        const int i = e >> 2, c = e & 3;
+        bf16x8_t raw = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+        if (i < N) raw = *(const bf16x8_t *)(base + C + rowmap[i] * ld + c * 8);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+        float ss = sumsq8(raw);
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
+        uint4 pk;
+        pk.x = pack_bf16x2(v[0] * inv, v[1] * inv);
+        pk.y = pack_bf16x2(v[2] * inv, v[3] * inv);
+        pk.z = pack_bf16x2(v[4] * inv, v[5] * inv);
+        pk.w = pack_bf16x2(v[6] * inv, v[7] * inv);
+        *(uint4 *)(klds + i * 64 + ((c ^ ((-(i >> 2)) & 3)) << 4)) = pk;
+    }
+    for (int e = tid; e < (NP / 4) * 4; e += NTHREADS) {
+        const int kg = e >> 2, c8 = e & 3;
+        bf16x8_t r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r[i] = (bf16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+            if (kg * 4 + i < N) r[i] = *(const bf16x8_t *)(base + 2 * C + rowmap[kg * 4 + i] * ld + c8 * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint2 pk;
+            pk.x = (uint32_t)(uint16_t)r[0][j] | ((uint32_t)(uint16_t)r[1][j] << 16);
+            pk.y = (uint32_t)(uint16_t)r[2][j] | ((uint32_t)(uint16_t)r[3][j] << 16);
+            *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + kg * 8) = pk;
+        }
+    }
+    __syncthreads();
+    const float sc = fabsf(scale[head]) * LOG2E;
+    const bool need_mask = shift > 0 && (wh == nwx - 1 || wwx == nwx - 1);
+    const int fr = lane & 15, g = lane >> 4;
+    for (int qt = wave; qt < NT; qt += NWAVES) {
+        const int q = qt * 16 + fr;
+        const int qrow = rowmap[q];
+        bf16x8_t qf;
+        {
+            const bf16x8_t raw = *(const bf16x8_t *)(base + qrow * ld + g * 8);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+            float ss = sumsq8(raw);
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
+            union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pk.w[j] = pack_bf16x2(v[2 * j] * inv, v[2 * j + 1] * inv);
+            qf = pk.v;
+        }
+        const int yq = q / WS, xq = q - yq * WS, rq = region[q];
+        const float *lt = tbl + (yq + WS - 1) * SIDE + xq + WS - 1;   // bias(q, key j) = lt[-(yj * SIDE + xj)]
+        float s[NTP][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int krow = t * 16 + fr;
+            const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
+            f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);
+            const int j0 = t * 16 + g * 4, yj = j0 / WS, xj = j0 - yj * WS;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = fmaf(z[r], sc, lt[-(yj * SIDE + xj + r)]);
+                if (need_mask && region[j0 + r] != rq) v += -100.0f * LOG2E;
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = NT; t < NTP; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = -INFINITY;   // the padding tile: probability 0
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+        f32x4_t o[2], osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NTP / 2; ++u) {
+            union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float *sv = s[2 * u + (h >> 1)] + 2 * (h & 1);
+                pk.w[h] = pack_bf16x2(__builtin_amdgcn_exp2f(sv[0] - mx), __builtin_amdgcn_exp2f(sv[1] - mx));
+            }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const char *vrow = vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 4 * g) * 2;
+                union { uint2 h[2]; bf16x8_t v; } vf;
+                vf.h[0] = *(const uint2 *)vrow;            // keys 32 u + 4 g .. + 3       (k slots j < 4)
+                vf.h[1] = *(const uint2 *)(vrow + 32);     // keys 32 u + 16 + 4 g .. + 3  (k slots j >= 4)
+                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk.v, o[ct], 0, 0, 0);
+            }
+            osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pk.v, osum, 0, 0, 0);
+            if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        const float inv = __builtin_amdgcn_rcpf(osum[0]);
+        uint16_t *orow = out + ((int64_t)frame * res * res + qrow) * C + head * HD + g * 4;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {   // o[ct][r] = context[query fr][dim ct * 16 + 4 g + r]
+            uint2 pk;
+            pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
+            pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
+            *(uint2 *)(orow + ct * 16) = pk;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // y = LayerNorm(t) * gamma + beta;  x = (x_in ? x_in : 0) + y;  writes x (fp32) and its bf16
 // shadow.  One wave per row, row in registers (two-pass statistics).
 constexpr int MAXV = 8;
@@ -382,8 +544,25 @@ int launch_window_attention(const uint16_t *qkv, uint16_t *out, const float *bia
     else if (ws == 8)
         hipLaunchKernelGGL(window_attention_kernel<4>, dim3((unsigned)grid), dim3(128), 0, stream, qkv, out, bias,
                            scale, res, ws, shift, heads);
-    else
-        VSC_REQUIRE(false, "window_attention: window %d unsupported (8 or 16)", ws);
+    else if (ws == 24 || ws == 12) {
+        auto smem_of = [](int w) {
+            const int n = w * w, np = ((n / 16 + 1) & ~1) * 16, side = 2 * w - 1;
+            return np * 64 + HD * (np * 2 + 32) + n * 4 + side * side * 4 + n + 16;
+        };
+        const int smem = smem_of(ws);
+        static bool attr_set[16][2] = {};
+        int dev = 0;
+        VSC_CHECK_HIP(hipGetDevice(&dev));
+        const int wi = ws == 24;
+        if (dev < 0 || dev >= 16 || !attr_set[dev][wi]) {
+            if (wi) VSC_CHECK_HIP(hipFuncSetAttribute((const void *)window_attention_wide_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            else VSC_CHECK_HIP(hipFuncSetAttribute((const void *)window_attention_wide_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            if (dev >= 0 && dev < 16) attr_set[dev][wi] = true;
+        }
+        if (wi) hipLaunchKernelGGL(window_attention_wide_kernel<24>, dim3((unsigned)grid), dim3(256), smem, stream, qkv, out, bias, scale, res, shift, heads);
+        else hipLaunchKernelGGL(window_attention_wide_kernel<12>, dim3((unsigned)grid), dim3(256), smem, stream, qkv, out, bias, scale, res, shift, heads);
+    } else
+        VSC_REQUIRE(false, "window_attention: window %d unsupported (8, 12, 16 or 24)", ws);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }

@@ -162,8 +162,8 @@ extern "C" int vsc_swin_create(const vsc_swin_config *cfg, vsc_swin **out) {
             return VSC_ERR_INVALID;
         }
         const int w = e->window(s);
-        if (!((w == 8 || w == 16) && e->res(s) % w == 0) || c.depths[s] < 1) {
-            vsc_set_error("swin: stage %d window %d on a %d x %d map unsupported (8 or 16)", s, w, e->res(s), e->res(s));
+        if (!((w == 8 || w == 16 || w == 12 || w == 24) && e->res(s) % w == 0) || c.depths[s] < 1) {
+            vsc_set_error("swin: stage %d window %d on a %d x %d map unsupported (8, 12, 16 or 24)", s, w, e->res(s), e->res(s));
             delete e;
             return VSC_ERR_INVALID;
         }

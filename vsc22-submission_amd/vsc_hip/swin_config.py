@@ -65,6 +65,14 @@ SWIN_PRESETS = {
     # parity-test sizes: 256-token shifted windows then one full 256-token window
     "tiny_swin": SwinConfig(name="tiny_swin", image_size=128, embed_dim=64, depths=(2, 2), heads=(2, 4),
                             window_size=16, pretrained_window_sizes=(12, 6), out_dim=64),
+    # BASELINE.json configs[4] names a Swin-L 384 backbone; the reference ships none (its models are the swinv2_base_256 above).
+    # This is Microsoft's Swin-V2-L at 384 (window 24, embed 192, heads 6/12/24/48) under the reference's head: 576-token
+    # windows, clipped to 12 x 12 in the last stage.
+    "swinv2_large_384": SwinConfig(name="swinv2_large_384", image_size=384, embed_dim=192, depths=(2, 2, 18, 2),
+                                   heads=(6, 12, 24, 48), window_size=24, pretrained_window_sizes=(12, 12, 12, 6)),
+    # parity-test size for those windows: 576-token shifted windows (2 x 2 of them), one full 24 x 24 window, a clipped 12 x 12 one
+    "tiny_swin_w24": SwinConfig(name="tiny_swin_w24", image_size=192, embed_dim=64, depths=(2, 2, 2), heads=(2, 4, 8),
+                                window_size=24, pretrained_window_sizes=(12, 12, 6), out_dim=64),
     # 64-token shifted windows, then a clipped 8x8 window
     "tiny_swin_w8": SwinConfig(name="tiny_swin_w8", image_size=64, embed_dim=64, depths=(2, 2), heads=(2, 4),
                                window_size=8, pretrained_window_sizes=(0, 0), out_dim=64),
