@@ -835,13 +835,8 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-#ifdef VSC_BF16_GLOBAL_STORE
-                const int64_t m = mrow0 + pass * 32 + it * 8 + (lane >> 3);
-                if (m < p.m && n < p.n) *(uint4 *)((uint16_t *)p.out + m * p.n + n) = d[it];
-#else
-                            const u32x4_t dv = {d[it].x, d[it].y, d[it].z, d[it].w};
+                const vsc_u32x4_t dv = {d[it].x, d[it].y, d[it].z, d[it].w};
                 buffer_store_b128_soff(dv, outh_rsrc, offh, (uint32_t)(pass * 32 + it * 8) * row_bytes_h);
-#endif
             }
         }
     } else {
