@@ -150,7 +150,7 @@ def gemm_traffic(cfg, chunk):
             "4": chunk * (t - 1) * cfg.patch_dim * 2 + cfg.patch_dim * d * 2 + chunk * (t - 1) * d * 4}
     n = sum(launches.values())
     algorithmic = sum(launches[k] * algo[k] for k in launches) / n
-    for name, prefix in (("r03_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")), ("r02_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")),
+    for name, prefix in (("r04_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")), ("r03_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")), ("r02_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")),
                          ("r01_pmc_per_launch_v2.json", ("gemm_bf16_v2_kernel<",))):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))["per_launch"]
@@ -254,12 +254,12 @@ def search_traffic():
     separate passes over tools/knn_bench.py; reads = 2 x FETCH_SIZE on gfx950, see gemm_traffic).  -> (bytes, nq, nr) of
     the profiled launch, or None."""
     try:
-        name = "r03_pmc_knn.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_knn.json")) else "r02_pmc_knn.json"
+        name = next(n for n in ("r04_pmc_knn.json", "r03_pmc_knn.json", "r02_pmc_knn.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         prof = json.load(open(os.path.join(ROOT, "profiles", name)))
         key = prof.get("sweep_kernel_key") or next(k for k in prof["per_launch"] if k.startswith("knn_sweep_bf16_kernel"))
         v = prof["per_launch"][key]
         # tools/profile_round.sh profiles `tools/knn_bench.py 8192 1000000 100 1`
-        return (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024, prof.get("nq", 8192), prof.get("nr", 1000000)
+        return (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024, prof.get("nq", 8192), prof.get("nr", 1000000), name
     except (OSError, KeyError, ValueError, StopIteration):
         return None
 
@@ -338,7 +338,7 @@ def bench_search(dev, args):
                          "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
                          "traffic": None if traffic is None else round(traffic[0]),
                          "traffic_note": None if traffic is None else
-                         f"memory-side bytes of one sweep launch at nq={traffic[1]}, nr={traffic[2]} (profiles/r03_pmc_knn.json, else r02_); "
+                         f"memory-side bytes of one sweep launch at nq={traffic[1]}, nr={traffic[2]} (profiles/{traffic[3]}); "
                          f"algorithmic operand bytes of that launch: {(traffic[1] + traffic[2]) * d * 2}",
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "achieved = 2 nq nr d / HIP-event time of the sweep kernel alone (vsc_knn_last_profile); value covers the whole call "
