@@ -287,6 +287,181 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Unshifted 16 x 16 windows (every block of the 512- and 1024-wide stages, every other block of the first two): the same
+// attention with the softmax STREAMED over pairs of key tiles instead of held as a 256-key row per lane.  The kernel above is
+// bound by its residency -- 128 VGPRs and 62 KiB of LDS allow two workgroups per CU, each of which loads, computes and stores in
+// turn -- not by any pipe (PMC: matrix pipe 17 % busy; its VALU / LDS work adds up to half the launch).  Without shift there are
+// no masks (9 KiB of mask rows gone: 52 KiB), and with the bounded softmax (scale < 0: every logit <= 0, no row maximum) a
+// probability can be packed and fed to the PV MFMA as soon as its score exists: no score row, ~70 VGPRs, THREE workgroups per
+// CU.  Heads whose logit span is too large for the bound (scale >= 0) take a first pass over the key tiles for the row maximum
+// (scores recomputed: MFMAs are not what this kernel lacks).  Layouts, operand order and the ones-operand row sum as above.
+__global__ __launch_bounds__(512, 6) void window_attention_stream_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out,
+                                                                         const float *__restrict__ bias, const float *__restrict__ scale,
+                                                                         int res, int heads) {
+    constexpr int NT = 16, N = 256, NTHREADS = 512, WS = 16, SIDE = 31;
+    constexpr int VSTRIDE = N * 2 + 32, TSTRIDE = 36, TCOPY = SIDE * TSTRIDE;
+    __shared__ __attribute__((aligned(16))) char smem[N * 64 + HD * VSTRIDE + N * 4 + 4 * TCOPY * 4];
+    char *klds = smem;
+    char *vt = smem + N * 64;
+    int *rowmap = (int *)(smem + N * 64 + HD * VSTRIDE);
+    float *tbl = (float *)(smem + N * 64 + HD * VSTRIDE + N * 4);
+    const float LOG2E = 1.44269504088896340736f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwx = res / WS, nw = nwx * nwx;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = b % heads; b /= heads;
+    const int win = b % nw, frame = b / nw;
+    const int wh = win / nwx, wwx = win - wh * nwx;
+    const int C = heads * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const uint16_t *base = qkv + (int64_t)frame * res * res * ld + head * HD;
+    for (int i = tid; i < N; i += NTHREADS) rowmap[i] = (wh * WS + (i >> 4)) * res + wwx * WS + (i & 15);
+    for (int i = tid; i < SIDE * SIDE; i += NTHREADS) {
+        const float v = bias[(int64_t)head * SIDE * SIDE + i] * LOG2E;
+        const int at = (i / SIDE) * TSTRIDE + (SIDE - 1 - i % SIDE);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tbl[c * TCOPY + at + c] = v;
+    }
+    __syncthreads();
+    const int fr = lane & 15, g = lane >> 4;
+    bf16x8_t qf[2];
+    int qrow[2];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        const int q = (wave * 2 + qi) * 16 + fr;
+        qrow[qi] = rowmap[q];
+        const bf16x8_t raw = *(const bf16x8_t *)(base + qrow[qi] * ld + g * 8);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+        float ss = sumsq8(raw);
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
+        union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk.w[j] = pack_bf16x2(v[2 * j] * inv, v[2 * j + 1] * inv);
+        qf[qi] = pk.v;
+    }
+    {   // K-hat: 4 threads per key row, two rows per thread
+        bf16x8_t kraw[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + it * NTHREADS;
+            kraw[it] = *(const bf16x8_t *)(base + C + rowmap[e >> 2] * ld + (e & 3) * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + it * NTHREADS;
+            const int i = e >> 2, c = e & 3;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)kraw[it][j]);
+            float ss = sumsq8(kraw[it]);
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
+            uint4 pk;
+            pk.x = pack_bf16x2(v[0] * inv, v[1] * inv);
+            pk.y = pack_bf16x2(v[2] * inv, v[3] * inv);
+            pk.z = pack_bf16x2(v[4] * inv, v[5] * inv);
+            pk.w = pack_bf16x2(v[6] * inv, v[7] * inv);
+            *(uint4 *)(klds + i * 64 + ((c ^ ((-(i >> 2)) & 3)) << 4)) = pk;
+        }
+    }
+    if (tid < (N / 4) * 4) {   // V^T: task = (4 keys) x (8 dims), consumption order inside each 32-key block (see the kernel above)
+        const int e = tid;
+        const int blk = e >> 6, c8 = (e >> 4) & 3, kg = blk * 16 + (e & 15);
+        const int slot = (kg & ~7) | ((kg & 3) << 1) | ((kg >> 2) & 1);
+        bf16x8_t r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *(const bf16x8_t *)(base + 2 * C + rowmap[kg * 4 + i] * ld + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint2 pk;
+            pk.x = (uint32_t)(uint16_t)r[0][j] | ((uint32_t)(uint16_t)r[1][j] << 16);
+            pk.y = (uint32_t)(uint16_t)r[2][j] | ((uint32_t)(uint16_t)r[3][j] << 16);
+            const int d = c8 * 8 + j;
+            *(uint2 *)(vt + (16 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3)) * VSTRIDE + slot * 8) = pk;
+        }
+    }
+    __syncthreads();
+    const float scraw = scale[head];
+    const bool nomax = scraw < 0.f;   // workgroup-uniform
+    const float sc = fabsf(scraw) * LOG2E;
+    const f32x2_t sc2 = (f32x2_t){sc, sc};
+    const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    auto rows = [&](auto nomax_c) {
+        constexpr bool NOMAX = decltype(nomax_c)::value;
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            const int q = (wave * 2 + qi) * 16 + fr;
+            const int tcopy = (q + 1) & 3;
+            const float *lt = tbl + tcopy * (TCOPY + 1) + (q / WS + WS - 1) * TSTRIDE + WS - 1 - (q % WS);
+            auto scores = [&](int t, f32x2_t (&s)[2]) {   // the 4 logits (log2 units) of this lane for key tile t
+                const int krow = t * 16 + fr;
+                const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
+                f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi], z, 0, 0, 0);
+                const int j0 = t * 16 + g * 4;
+                const f32x4_t b4 = *(const f32x4_t *)(lt - (j0 / WS) * TSTRIDE + (j0 % WS));
+                s[0] = (f32x2_t){z[0], z[1]} * sc2 + (f32x2_t){b4[0], b4[1]};
+                s[1] = (f32x2_t){z[2], z[3]} * sc2 + (f32x2_t){b4[2], b4[3]};
+            };
+            float nmx = 0.f;
+            if (!NOMAX) {   // unbounded head: the row maximum first
+                float mx = -INFINITY;
+#pragma unroll 4
+                for (int t = 0; t < NT; ++t) {
+                    f32x2_t s[2];
+                    scores(t, s);
+                    mx = fmaxf(fmaxf(mx, s[0][0]), s[0][1]);
+                    mx = fmaxf(fmaxf(mx, s[1][0]), s[1][1]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                nmx = -mx;
+            }
+            const f32x2_t nm2 = (f32x2_t){nmx, nmx};
+            f32x4_t o[2], osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < NT / 2; ++u) {
+                union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x2_t s[2];
+                    scores(2 * u + h, s);
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        const f32x2_t d = NOMAX ? s[x] : s[x] + nm2;
+                        pk.w[2 * h + x] = pack_bf16x2(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
+                    }
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const bf16x8_t vf = *(const bf16x8_t *)(vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 8 * g) * 2);
+                    o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pk.v, o[ct], 0, 0, 0);
+                }
+                osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pk.v, osum, 0, 0, 0);
+                if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            const float inv = __builtin_amdgcn_rcpf(osum[0]);
+            uint16_t *orow = out + ((int64_t)frame * res * res + qrow[qi]) * C + head * HD + g * 8;
+            uint4 pk;
+            pk.x = pack_bf16x2(o[0][0] * inv, o[0][1] * inv);
+            pk.y = pack_bf16x2(o[0][2] * inv, o[0][3] * inv);
+            pk.z = pack_bf16x2(o[1][0] * inv, o[1][1] * inv);
+            pk.w = pack_bf16x2(o[1][2] * inv, o[1][3] * inv);
+            *(uint4 *)orow = pk;
+        }
+    };
+    if (nomax) rows(std::true_type{});
+    else rows(std::false_type{});
+}
+
+// ------------------------------------------------------------------------------------------
 // The same attention for the window sizes the reference's own models do not use but BASELINE.json's configs[4] names
 // (Swin-V2-L at 384 x 384: window 24, clipped to 12 in the last stage): 576- / 144-token windows.  Written for coverage,
 // not tuned like the 8 / 16 kernel above: the bias is gathered per score from the plain (2w-1)^2 table, shift masks are
@@ -538,7 +713,10 @@ int launch_window_attention(const uint16_t *qkv, uint16_t *out, const float *bia
             switch (atoi(e)) { VSC_WABL_CASE(1) VSC_WABL_CASE(2) VSC_WABL_CASE(3) VSC_WABL_CASE(8) VSC_WABL_CASE(16) VSC_WABL_CASE(24) VSC_WABL_CASE(27) default: break; }
         }
 #endif
-    if (ws == 16)
+    const char *so = vsc_opt(OPT_WATTN_STREAM);   // diagnostic: 0 = the row-in-registers kernel for unshifted windows as well
+    if (ws == 16 && shift == 0 && !(so && so[0] == '0'))
+        hipLaunchKernelGGL(window_attention_stream_kernel, dim3((unsigned)grid), dim3(512), 0, stream, qkv, out, bias, scale, res, heads);
+    else if (ws == 16)
         hipLaunchKernelGGL(window_attention_kernel<16>, dim3((unsigned)grid), dim3(512), 0, stream, qkv, out, bias,
                            scale, res, ws, shift, heads);
     else if (ws == 8)
