@@ -231,3 +231,16 @@ def test_l2_normalize(dev):
     ref = knn_oracle.l2_normalize(x)
     np.testing.assert_allclose(out, ref, rtol=0, atol=1e-6)  # only the reduction order differs
     assert not out[17].any()
+
+
+@pytest.mark.parametrize("frames,tokens,heads", [(3, 197, 12), (2, 145, 4), (5, 50, 2), (2, 256, 3)])
+def test_attention_lds_dma_kernel_is_bit_identical(dev, frames, tokens, heads):
+    """VSC_ATTN_DMA=1: the persistent attention kernel (K / V by LDS-DMA into a double buffer, V row-major read with
+    ds_read_b64_tr_b16) against the default one: the same MFMAs on the same operands in the same order -> identical bits."""
+    from vsc_hip import _lib, ops
+    g = torch.Generator().manual_seed(frames * 1000 + tokens)
+    qkv = (torch.randn(frames * tokens, 3 * heads * 64, generator=g) * 0.8).to(torch.bfloat16).to(dev)
+    ref = ops.attention_bf16(qkv, frames, tokens, heads).clone()
+    with _lib.option("VSC_ATTN_DMA", "1"):
+        for _ in range(3):
+            assert torch.equal(ops.attention_bf16(qkv, frames, tokens, heads), ref)

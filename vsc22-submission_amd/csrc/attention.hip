@@ -275,6 +275,182 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same attention as a PERSISTENT kernel fed by LDS-DMA (round 4): one 16-wave workgroup per CU walks the (frame, head) items;
+// K and V of item i + 1 travel HBM -> LDS by buffer_load ... lds (no registers) into the second half of a double buffer while
+// item i is computed, so a CU computes all the time instead of alternating two workgroups between a load and a compute phase
+// (the kernel above moves 3 TB/s and keeps the matrix pipe 22 % busy: it is bound by that alternation, not by a pipe).
+//   * LDS-DMA writes lane-linear images, so V cannot be transposed on the way as above.  It is stored ROW-major like K
+//     ([key][64] bf16, 128-byte rows) and the PV operand V^T[dim][key] is read with ds_read_b64_tr_b16: each lane reads the
+//     8 bytes V[key0 + ((l >> 2) & 3)][dim0 + 4 (l & 3) .. + 3] and receives V[key0 .. key0 + 3][dim0 + (l & 15)] -- 4 consecutive
+//     keys of its own head dim (semantics measured with tools/micro/tr_b16_probe.hip: lane l of a 16-lane group gets element
+//     l & 3 of the pieces read by lanes (l >> 2) + 4 j, j = 0..3).  Two reads (keys 32 u + 4 g .. and 32 u + 16 + 4 g ..) make
+//     the 8 k-slots of a lane, in exactly the slot -> key order the packed P uses.
+//   * swizzles (applied to the DMA's SOURCE address, and again on the read): K 16-byte chunk c -> c ^ ((row >> 1) & 7) as in
+//     the GEMM tiles; V 32-byte chunk c -> c ^ ((row >> 1) & 3): the 8 rows x 32 bytes a 32-lane half reads in one
+//     transpose-read then cover all 64 banks once.
+//   * one 16-query tile per wave (tokens <= 256: 13 of the 16 waves at 197 tokens), Q fragments of the next item requested
+//     during the current one; rows past the last token lie past the DMA descriptors' extent and arrive as zeros.
+// Scores, softmax, P packing, ones-operand row sum and the write-out are those of the kernel above.
+template <int KT>
+__global__ __launch_bounds__(1024) void attention_dma_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, int tokens,
+                                                             int heads, int total) {
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+    typedef __attribute__((address_space(3))) s16x4_t *ldstr_t;
+    constexpr int TP = KT * 32, OP_BYTES = TP * 128, PIECES = TP / 8;   // one operand of one item: TP rows of 128 B = PIECES KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];         // [2 buffers][K | V] + 16 x 2 KiB write-out staging
+    char *ost = smem + 4 * OP_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int width = heads * DH;
+    const int64_t ld = 3 * (int64_t)width;
+    const uint32_t ld_bytes = (uint32_t)ld * 2u;
+    const int fr = lane & 15, g = lane >> 4;
+    const int qtiles = (tokens + 15) >> 4;
+    const float scale = 0.125f * 1.44269504088896340736f;
+    auto q_of = [&](int item) { return qkv + (int64_t)(item / heads) * tokens * ld + (item % heads) * DH; };
+    const uint32_t op_extent = (uint32_t)(tokens - 1) * ld_bytes + 128u;
+
+    auto stage = [&](int item, int buf) {
+        const uint16_t *kp = q_of(item) + width;
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)kp, 0, (int)op_extent, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(kp + width), 0, (int)op_extent, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < (2 * PIECES + 15) / 16; ++j) {
+            const int pc = wave + 16 * j;            // wave-uniform
+            if (pc >= 2 * PIECES) break;
+            const int op = pc >= PIECES, pp = pc - op * PIECES;
+            const int row = pp * 8 + (lane >> 3), chunk = lane & 7;
+            const int src = op ? ((((chunk >> 1) ^ ((row >> 1) & 3)) << 1) | (chunk & 1)) : (chunk ^ ((row >> 1) & 7));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(op ? rv : rk, (lptr_t)(smem + (buf * 2 + op) * OP_BYTES + pp * 1024), 16,
+                                                     (uint32_t)row * ld_bytes + (uint32_t)src * 16u, 0, 0, 0);
+        }
+    };
+    auto load_q = [&](int item, bf16x8_t (&qf)[2]) {
+        const uint16_t *qptr = q_of(item);
+        int qrow = wave * 16 + fr;
+        qrow = qrow < tokens ? qrow : tokens - 1;
+        qf[0] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8);
+        qf[1] = *(const bf16x8_t *)(qptr + qrow * ld + g * 8 + 32);
+    };
+    // per-lane part of the transpose-read address: row 4 g + r4 of a 32-key block, its 32-byte chunk swizzle, 8-byte column group
+    const int r4 = (lane >> 2) & 3, sw = (2 * g + (r4 >> 1)) & 3;
+    const uint32_t vlane = (uint32_t)(4 * g + r4) * 128u + (uint32_t)(lane & 3) * 8u;
+
+    auto compute = [&](int item, const char *klds, const char *vlds, const bf16x8_t (&qf)[2]) {
+        const int frame = item / heads, head = item - frame * heads;
+        const int qt = wave;
+        f32x4_t s[2 * KT];
+#pragma unroll
+        for (int t = 0; t < 2 * KT; ++t) {
+            s[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            const int krow = t * 16 + fr;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 128 + (((g + 4 * kk) ^ ((krow >> 1) & 7)) << 4));
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+            }
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2 * KT; ++t) {
+            if (t >= 2 * KT - 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (t * 16 + g * 4 + r >= tokens) s[t][r] = -INFINITY;
+            }
+            mx = max3(max3(mx, s[t][0], s[t][1]), s[t][2], s[t][3]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mxs = mx * scale;
+        const f32x2_t sc2 = (f32x2_t){scale, scale}, nm2 = (f32x2_t){-mxs, -mxs};
+        bf16x8_t pb[KT];
+#pragma unroll
+        for (int u = 0; u < KT; ++u) {
+            float e[8];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const f32x4_t &sv = s[2 * u + (h >> 1)];
+                const f32x2_t d = (f32x2_t){sv[2 * (h & 1)], sv[2 * (h & 1) + 1]} * sc2 + nm2;
+                e[2 * h] = __builtin_amdgcn_exp2f(d[0]);
+                e[2 * h + 1] = __builtin_amdgcn_exp2f(d[1]);
+            }
+            union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pk.w[r] = pack_bf16x2(e[2 * r], e[2 * r + 1]);
+            pb[u] = pk.v;
+        }
+        const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+        f32x4_t osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        f32x4_t o[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) o[ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < KT; ++u) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const char *va = vlds + vlane + ((ct ^ sw) << 5) + u * 4096;
+                union { s16x4_t h[2]; bf16x8_t v; } vf;
+                vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ldstr_t)va);            // keys 32 u + 4 g .. + 3
+                vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ldstr_t)(va + 2048));   // keys 32 u + 16 + 4 g .. + 3
+                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
+            }
+            osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[u], osum, 0, 0, 0);
+            if (u & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        const float inv = __builtin_amdgcn_rcpf(osum[0]);
+        char *reg = ost + wave * 2048;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            uint2 pk;
+            pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
+            pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
+            const int chunk = 2 * ct + (g >> 1);
+            *(uint2 *)(reg + fr * 128 + ((chunk ^ (fr & 7)) << 4) + ((g ^ (fr >> 3)) & 1) * 8) = pk;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int c = lane & 7;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            uint4 d = *(const uint4 *)(reg + row * 128 + ((c ^ (row & 7)) << 4));
+            if (it & 1) d = make_uint4(d.z, d.w, d.x, d.y);
+            const int q = qt * 16 + row;
+            if (q < tokens) *(uint4 *)(out + ((int64_t)frame * tokens + q) * width + head * DH + c * 8) = d;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    int item = blockIdx.x;
+    if (item >= total) return;
+    bf16x8_t qf[2];
+    stage(item, 0);
+    load_q(item, qf);
+    for (int it = 0;; ++it) {
+        const int nxt = item + (int)gridDim.x;
+        const bool more = nxt < total;    // workgroup-uniform
+        // this wave's DMA pieces of `item` have landed (and nothing of the previous item's write-out is in flight); the barrier
+        // publishes every wave's pieces and tells that every wave is done with the buffer the next stage() overwrites
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        bf16x8_t qn[2];
+        if (more) {
+            stage(nxt, (it + 1) & 1);
+            load_q(nxt, qn);
+        }
+        if (wave < qtiles) compute(item, smem + (it & 1) * 2 * OP_BYTES, smem + ((it & 1) * 2 + 1) * OP_BYTES, qf);
+        if (!more) break;
+        qf[0] = qn[0];
+        qf[1] = qn[1];
+        item = nxt;
+    }
+}
+
 template <int KT>
 int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int heads,
               hipStream_t stream) {
@@ -309,6 +485,25 @@ int launch_kt(const uint16_t *qkv, uint16_t *out, int frames, int tokens, int he
         }
 #endif
     const int total = frames * heads;
+    // Persistent LDS-DMA form (attention_dma_kernel; one query tile per wave: tokens <= 256, two K/V buffers + staging within 160 KiB:
+    // KT <= 8): opt-in by VSC_ATTN_DMA=1.  Bit-identical results; measured 110 us per launch against 103 us for the kernel below in the
+    // ViT-B step (four alternating runs, same box) -- with all loads off the critical path the item time is the compute phase's
+    // instruction stream (MFMA + softmax VALU + LDS issue add up on a SIMD), which 13 waves side by side do not shorten.
+    if constexpr (KT <= 8) {
+        const char *dm = vsc_opt(OPT_ATTN_DMA);
+        if (tokens <= 256 && dm && dm[0] == '1') {
+            constexpr int smem_dma = 4 * TP * 128 + 16 * 2048;
+            static bool dma_attr[16] = {};
+            if (dev >= 16 || !dma_attr[dev]) {
+                VSC_CHECK_HIP(hipFuncSetAttribute((const void *)attention_dma_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_dma));
+                if (dev < 16) dma_attr[dev] = true;
+            }
+            const int grid = total < ncu ? total : ncu;
+            hipLaunchKernelGGL((attention_dma_kernel<KT>), dim3(grid), dim3(1024), smem_dma, stream, qkv, out, tokens, heads, total);
+            VSC_CHECK_LAUNCH();
+            return VSC_OK;
+        }
+    }
     // items per workgroup: 1.  Two (the second one's K / V rows requested into registers before the first is computed) were
     // measured again on this kernel (tools/micro/attn_ni.py): 166 VGPRs, i.e. one resident workgroup per CU, or capped at
     // 128 VGPRs 120 bytes of scratch -- 160 us per launch against 110-119.  VSC_ATTN_NI=2 keeps the variant reachable.
