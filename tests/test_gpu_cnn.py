@@ -137,6 +137,42 @@ def test_conv2d_direct_3x3_matches_torch_and_the_gemm_path(dev, n, h, w, cin, co
         assert (wide[..., :5] == 3).all() and (wide[..., 5 + cout:] == 3).all()
 
 
+@pytest.mark.parametrize("n,h,w,cout,res,act", [
+    (2, 128, 128, 256, True, "relu"),      # whole tiles, the Bottleneck's last convolution with its residual
+    (3, 113, 97, 256, True, "relu"),       # 32 883 pixels: a ragged last tile (rows past the end are dropped by the descriptor)
+    (2, 130, 127, 256, False, None),       # the downsample convolution: no residual, no activation
+    (1, 200, 170, 128, True, "hard_swish"),   # four of the eight waves own channels
+])
+def test_conv2d_1x1_expansion_stream_kernel(dev, n, h, w, cout, res, act):
+    """conv1x1_expand64_kernel (pixels as the MFMA row operand, weights in registers, input tiles by LDS-DMA) against torch
+    and against the tile kernel it replaces for 64 -> 128..256 1 x 1 layers (VSC_CONV_EXPAND=0): same ascending-k chains per
+    output, bias and residual added in the same order -> identical bits."""
+    from vsc_hip import cnn
+    rng = np.random.RandomState(cout + h)
+    sd = {"c.weight": torch.from_numpy((rng.randn(cout, 64, 1, 1) / 8).astype(np.float32)),
+          "c.bias": torch.from_numpy(rng.randn(cout).astype(np.float32) * 0.1)}
+    x = torch.from_numpy(rng.randn(n, h, w, 64).astype(np.float32)).to(dev)
+    r = torch.from_numpy(rng.randn(n, h, w, cout).astype(np.float32)).to(dev) if res else None
+    conv = cnn.Conv(sd, "c", None, 1, dev)
+    got = conv(x, act=act, residual=r).clone()
+    _vsc_lib.set_option("VSC_CONV_EXPAND", "0")
+    try:
+        tile = conv(x, act=act, residual=r).clone()
+    finally:
+        _vsc_lib.set_option("VSC_CONV_EXPAND", None)
+    want = F.conv2d(x.cpu().permute(0, 3, 1, 2), sd["c.weight"], sd["c.bias"])
+    if res:
+        want = want + r.cpu().permute(0, 3, 1, 2)
+    want = {"relu": F.relu, "hard_swish": F.hardswish, None: lambda v: v}[act](want)
+    assert torch.allclose(got.cpu().permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)
+    assert torch.equal(got.view(torch.int32), tile.view(torch.int32))
+    for _ in range(3):
+        assert torch.equal(conv(x, act=act, residual=r), got)
+    wide = torch.full((n, h, w, cout + 8), 3.0, device=dev)   # a channel window of a wider buffer
+    conv(x, act=act, residual=r, out=wide, coff=4)
+    assert torch.equal(wide[..., 4:4 + cout], got) and (wide[..., :4] == 3).all() and (wide[..., 4 + cout:] == 3).all()
+
+
 def test_depthwise_pool_scale_upsample(dev):
     from vsc_hip import cnn
     rng = np.random.RandomState(0)

@@ -192,9 +192,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmArgs p) {
 // Narrow variant for the thin layers (HRNet's 18- / 36- / 72-wide branches, the SE and head convolutions): 32 output
 // channels x 256 pixels per workgroup, wave w owns pixels [64 w, 64 w + 64) as two 32 x 32 accumulators.  An 18-channel
 // layer fills 56 % of this tile against 14 % of the 128-row one.  Same packed operands, same ascending-k chains.
-constexpr int NARROW_C = 32, NARROW_P = 256;
+constexpr int NARROW_C = 32;
 constexpr int NARROW_W_BYTES = 4096;                         // 32 weight rows x 32 floats
-constexpr int NARROW_STAGE = NARROW_W_BYTES + 2 * TILE_BYTES;   // W | P0 | P1 = 36 KiB: two workgroups per CU
+constexpr int narrow_stage(int nt) { return NARROW_W_BYTES + nt * TILE_BYTES; }   // W | P0 [| P1]: 36 KiB at 256 pixels (two workgroups per CU)
 
 // IMPLICIT: the patch operand is gathered from the input feature map while it is staged (no materialised im2col matrix:
 // the pack pass and the GEMM's read of its output were 616 MB each way for one 3 x 3 layer of HRNet's 224 x 224 branch, and
@@ -203,8 +203,12 @@ constexpr int NARROW_STAGE = NARROW_W_BYTES + 2 * TILE_BYTES;   // W | P0 | P1 =
 // zero line when the tap falls into the padding or k >= K.  The pixel part of the address is decoded once per tile
 // (divisions), the tap part comes from a per-workgroup LDS table indexed by the chunk.  Same values in the same LDS image as
 // the packed path: results are bit-identical.
-template <bool IMPLICIT, int STAGES, int NW>   // NW waves: 4 (wave = 64 pixels, two accumulators) or 8 (wave = 32 pixels, one)
-__global__ __launch_bounds__(NW * 64, 1) void conv_gemm_narrow_kernel(ConvGemmArgs p) {
+// NT = 128-pixel tiles per workgroup.  NT = 1 (four waves, 32 pixels each; 44 KiB of LDS: three workgroups per CU) is for the layers
+// whose tile list at 256 pixels does not fill the chip or fills it in 1.x rounds -- HRNet's 72 @ 56 x 56 (588 tiles on 512 slots:
+// a second round for 76 of them) and 144 @ 28 x 28 (245 tiles) branches.
+template <bool IMPLICIT, int STAGES, int NW, int NT = 2>   // NW waves: 4 (wave = 64 pixels, two accumulators) or 8 (wave = 32 pixels, one)
+__global__ __launch_bounds__(NW * 64, NT == 1 ? (STAGES == 3 ? 2 : 3) : 1) void conv_gemm_narrow_kernel(ConvGemmArgs p) {
+    constexpr int NARROW_STAGE = narrow_stage(NT), NARROW_P = NT * 128;
     __shared__ __attribute__((aligned(16))) char lds[STAGES * NARROW_STAGE + (IMPLICIT ? IM2COL_TABLE : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -225,12 +229,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_gemm_narrow_kernel(ConvGemmAr
     constexpr int PJ = 16 / NW;   // 1-KiB pieces of a 128-row pixel tile per wave
     // this lane's patch rows of a tile (2 pixel halves x 4 pieces): element offset of x[img, iy0, ix0, 0] and (iy0 << 16) | ix0
     struct Rows {
-        int64_t pbase[2][PJ];
-        int pyx[2][PJ];
+        int64_t pbase[NT][PJ];
+        int pyx[NT][PJ];
     };
     auto decode = [&](int64_t p0, Rows &rw) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int j = 0; j < PJ; ++j) {
                 const int r = (j * NW + wave) * 8 + (lane >> 3);
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_gemm_narrow_kernel(ConvGemmAr
         }
         if (!IMPLICIT) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < PJ; ++j) {
                     const int piece = j * NW + wave;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_gemm_narrow_kernel(ConvGemmAr
                 }
         } else {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < PJ; ++j) {
                     const int piece = j * NW + wave;
@@ -325,16 +329,19 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_gemm_narrow_kernel(ConvGemmAr
             stage_next();
             ++beyond;
         }
-    if (STAGES == 3 && NW == 4 && beyond == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    constexpr int LOADS = 1 + NT * PJ;   // LDS-DMA instructions per wave and stage when every wave also stages weights (NW == 4)
+    if (STAGES == 3 && NW == 4 && beyond == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0;
     for (int64_t vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
         int64_t c0, p0;
         origin(vt, c0, p0);
-        f32x16_t acc[8 / NW];
+        constexpr int NB = 4 * NT / NW;                              // 32-pixel accumulators per wave
+        constexpr int WPT = NW / NT;                                 // waves per 128-pixel tile
+        f32x16_t acc[NB];
 #pragma unroll
-        for (int b = 0; b < 8 / NW; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
         for (int ks = 0; ks < nks; ++ks) {
@@ -343,8 +350,6 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_gemm_narrow_kernel(ConvGemmAr
                 ++beyond;
             }
             const char *wt = lds + cur * NARROW_STAGE;
-            constexpr int NB = 8 / NW;                                   // 32-pixel accumulators per wave
-            constexpr int WPT = NW / 2;                                  // waves per 128-pixel tile
             const char *pt = wt + NARROW_W_BYTES + (wave / WPT) * TILE_BYTES;
             const int prow = (wave % WPT) * (32 * NB);
 #pragma unroll
@@ -360,16 +365,16 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_gemm_narrow_kernel(ConvGemmAr
             }
             // the next stage must have landed; the ones behind it may stay in flight (loads complete in order, and the epilogue's
             // stores, which sit in the same queue, only make the count more conservative)
-            if (STAGES == 3 && NW == 4 && beyond == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            if (STAGES == 3 && NW == 4 && beyond == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             cur = cur + 1 == STAGES ? 0 : cur + 1;
             --beyond;
         }
-        // acc[b][reg] = <w[c0 + 8*(reg>>2) + 4*hi + (reg&3)], patch[p0 + wave*(256/NW) + b*32 + l31]>
+        // acc[b][reg] = <w[c0 + 8*(reg>>2) + 4*hi + (reg&3)], patch[p0 + wave*(NARROW_P/NW) + b*32 + l31]>
 #pragma unroll
-        for (int b = 0; b < 8 / NW; ++b) {
-            const int64_t pix = p0 + wave * (256 / NW) + b * 32 + l31;
+        for (int b = 0; b < NB; ++b) {
+            const int64_t pix = p0 + wave * (NARROW_P / NW) + b * 32 + l31;
             if (pix >= p.rows) continue;
             float *orow = p.out + pix * p.ldo;
             const float *rrow = p.res ? p.res + pix * p.ldr : nullptr;
@@ -549,6 +554,111 @@ __global__ __launch_bounds__(512, NACC == 1 && CQ <= 5 ? 2 : 1) void conv3x3_dir
                         if (co + r < p.cout) orow[co + r] = v[r];
                 }
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 1 x 1 expansion from 64 channels (HRNet layer1: 64 -> 256 at 224 x 224 with the 256-wide residual, 4 + 1 calls per pass, 12 % of
+// it on the 128 x 128 tile kernel: two K-steps per tile, a serial load -> multiply -> scattered 16-byte epilogue per workgroup,
+// 1.7 TB/s).  The layer is a stream: 64 floats in, cout out (+ cout of residual) per pixel, 26 GF of products under 1.85 GB.
+//   * persistent workgroups of 8 waves, one per CU; a tile = 128 pixels x all channels; wave w owns channels 32 w .. 32 w + 31 and
+//     keeps its 32 x 64 weights in 32 VGPRs for the whole kernel;
+//   * the tile's 128 x 64 input is brought in by LDS-DMA (32 KiB, two buffers: tile t + 1 lands under tile t's MFMAs), rows
+//     256 B with the 16-byte chunk index xor-ed with the row (conflict-free ds_read_b128 over consecutive pixels);
+//   * PIXELS are the MFMA row operand and channels the column operand: a lane owns one channel and the accumulator registers
+//     walk over pixels, so every store / residual load instruction covers two full 128-byte lines (32 consecutive channels of
+//     one pixel per lane half) -- no transposition, no partial lines;
+//   * the residual of tile t is requested before its MFMAs; the stores of tile t are not waited for until tile t + 1's MFMAs
+//     are done.
+struct ExpandArgs {
+    const float *x, *wp, *bias, *res;
+    float *out;
+    int64_t rows, ntiles;
+    int cout, ldo, ldr, act;
+};
+
+__global__ __launch_bounds__(512, 1) void conv1x1_expand64_kernel(ExpandArgs p) {
+    constexpr int CIN = 64, TP = 128, BUF = TP * CIN * 4;
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bool active = wave * 32 < p.cout;   // wave-uniform: waves past cout only help with the staging
+    const int ch = wave * 32 + l31;
+    // weights of this lane's channel: chunk 2 pr + hi of the packed row (k = 8 pr + 4 hi .. + 3), as in lds_frag()'s pairing
+    f32x4_t wf[8];
+#pragma unroll
+    for (int pr = 0; pr < 8; ++pr)
+        wf[pr] = active ? *(const f32x4_t *)(p.wp + (int64_t)ch * CIN + (2 * pr + hi) * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const float bias = active && p.bias ? p.bias[ch] : 0.f;
+    // residual / output through buffer descriptors: one per-lane offset (pixel 4 hi, channel ch) + a wave-uniform pixel offset per
+    // accumulator register; pixels past the last row fall outside the descriptor (loads give 0, stores are dropped)
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)(p.rows * p.ldo * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), 0, (int)(p.rows * (p.res ? p.ldr : p.ldo) * 4), 0x00020000);
+    const uint32_t ovoff = (uint32_t)(4 * hi * p.ldo + ch) * 4u, rvoff = (uint32_t)(4 * hi * p.ldr + ch) * 4u;
+    auto stage = [&](int64_t t, int b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = j * 8 + wave;                 // 1 KiB = 4 rows
+            const int r = piece * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (r & 15);
+            int64_t gr = t * TP + r;
+            gr = gr > p.rows - 1 ? p.rows - 1 : gr;
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.x + gr * CIN + c * 4), (lptr_t)(lds + b * BUF + piece * 1024), 16, 0, 0);
+        }
+    };
+    int64_t t = blockIdx.x;
+    if (t >= p.ntiles) return;
+    stage(t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (; t < p.ntiles; t += gridDim.x, buf ^= 1) {
+        if (t + gridDim.x < p.ntiles) stage(t + gridDim.x, buf ^ 1);
+        const int64_t p0 = t * TP;
+        // residual: rs[blk][reg] belongs to pixel p0 + 32 blk + 8 (reg >> 2) + 4 hi + (reg & 3), channel ch
+        float rs[4][16];
+        if (p.res && active) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const uint32_t soff = (uint32_t)(p0 + blk * 32 + 8 * (reg >> 2) + (reg & 3)) * (uint32_t)(p.ldr * 4);
+                    rs[blk][reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, rvoff, soff, 0));
+                }
+        }
+        f32x16_t acc[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
+        if (active) {
+            const char *xb = lds + buf * BUF;
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr)
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    const int row = blk * 32 + l31;
+                    const f32x4_t af = *(const f32x4_t *)(xb + row * 256 + (((2 * pr + hi) ^ (row & 15)) << 4));
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k4], wf[pr][k4], acc[blk], 0, 0, 0);
+                }
+        }
+        // the next tile's input and this tile's residual have landed; behind the barrier every wave is done with `buf`
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const uint32_t soff = (uint32_t)(p0 + blk * 32 + 8 * (reg >> 2) + (reg & 3)) * (uint32_t)(p.ldo * 4);
+                    float v = acc[blk][reg] + bias;
+                    if (p.res) v += rs[blk][reg];
+                    v = activate(v, p.act);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, ovoff, soff, 0);
+                }
         }
     }
 }
@@ -777,9 +887,26 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
             return VSC_OK;
         }
     }
+    // 1 x 1 expansion from 64 channels: the streaming kernel (conv1x1_expand64_kernel)
+    {
+        const char *ee = vsc_opt(OPT_CONV_EXPAND);   // diagnostic / test switch: 0 = the tile kernels
+        const bool expand = !(ee && ee[0] == '0') && kh == 1 && kw == 1 && stride == 1 && pad == 0 && cin == 64 && ldx == 64 && cout >= 128 &&
+                            cout <= 256 && (cout & 31) == 0 && rows >= 128 * 256 && rows * (int64_t)ldo * 4 < (1ll << 31) &&
+                            (!res_dev || rows * (int64_t)ldr * 4 < (1ll << 31)) && (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0;
+        if (expand) {
+            static int cus_expand[16] = {};
+            if (!cus_expand[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_expand[dev], hipDeviceAttributeMultiprocessorCount, dev));
+            ExpandArgs a{x_dev, w_packed_dev, bias_dev, res_dev, out_dev, rows, (rows + 127) / 128, cout, ldo, ldr, act};
+            const unsigned grid = (unsigned)(a.ntiles < cus_expand[dev] ? a.ntiles : cus_expand[dev]);
+            hipLaunchKernelGGL(conv1x1_expand64_kernel, dim3(grid), dim3(512), 0, stream, a);
+            VSC_CHECK_LAUNCH();
+            return VSC_OK;
+        }
+    }
     // 1 x 1, stride 1, dense rows of a multiple of 32 channels: the input IS the patch matrix
     const bool in_place = kh == 1 && kw == 1 && stride == 1 && pad == 0 && ldx == cin && (cin % KS) == 0 && (((uintptr_t)x_dev) & 15) == 0;
-    const bool narrow = cout <= 80;   // <= 3 channel tiles of 32: the thin layers (see conv_gemm_narrow_kernel)
+    const char *nm = vsc_opt(OPT_CONV_NARROW_MAX);
+    const bool narrow = cout <= (nm ? atoi(nm) : 160);   // <= 3 channel tiles of 32: the thin layers (see conv_gemm_narrow_kernel)
     // patches gathered inside the GEMM's staging (narrow kernel): 4-channel chunks, table-sized K, 16-bit image coordinates
     const char *imp_env = vsc_opt(OPT_CONV_IMPLICIT);   // diagnostic / test switch, read per call
     const bool no_implicit = imp_env && imp_env[0] == '0';
@@ -824,24 +951,34 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
                            h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k, kpad);
     }
     VSC_CHECK_LAUNCH();
-    const int tiles_c = narrow ? (cout + NARROW_C - 1) / NARROW_C : (cout + TR - 1) / TR;
-    const int64_t tiles_p = narrow ? (rows + NARROW_P - 1) / NARROW_P : (rows + TQ - 1) / TQ;
-    VSC_REQUIRE(tiles_p * tiles_c < (1ll << 31), "conv2d: grid too large");
-    ConvGemmArgs a{w_packed_dev, in_place ? x_dev : (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c, tiles_p,
-                   x_dev, g_zero_line[dev], h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k, 0};
-    if (const char *e = vsc_opt(OPT_CONV_REMAP)) a.no_remap = e[0] == '0';
     static int cus_of[16] = {};
     if (!cus_of[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev));
     const char *pe = vsc_opt(OPT_CONV_PERSIST);   // diagnostic: 0 = one tile per workgroup
     const char *se = vsc_opt(OPT_CONV_STAGES);    // diagnostic: 3 = three LDS stages, one workgroup per CU
     const char *we = vsc_opt(OPT_CONV_WAVES);     // diagnostic: 4 = four waves per workgroup
+    const char *te = vsc_opt(OPT_CONV_NARROW_NT); // diagnostic: 1 / 2 = 128- / 256-pixel tiles for every narrow layer
     const int stages = se && se[0] == '3' ? 3 : 2;
     const int nw = we && we[0] == '4' ? 4 : 8;
-    const int64_t resident = (stages == 2 ? 2ll : 1ll) * cus_of[dev];   // 76 KiB (2 stages) / 112 KiB (3 stages) of LDS per workgroup
+    const int tiles_c = narrow ? (cout + NARROW_C - 1) / NARROW_C : (cout + TR - 1) / TR;
+    // 128-pixel tiles (four waves, three workgroups per CU) when the 256-pixel list gives the chip's 2 x CUs slots fewer than four
+    // tiles each: the list then ends in a mostly empty round, or does not fill the first one
+    const bool small = narrow && nw == 8 &&
+                       (te ? te[0] == '1' : ((rows + 255) / 256) * tiles_c < 8ll * cus_of[dev]);
+    const int narrow_p = small ? 128 : 256;
+    const int64_t tiles_p = narrow ? (rows + narrow_p - 1) / narrow_p : (rows + TQ - 1) / TQ;
+    VSC_REQUIRE(tiles_p * tiles_c < (1ll << 31), "conv2d: grid too large");
+    ConvGemmArgs a{w_packed_dev, in_place ? x_dev : (const float *)s.ptr, bias_dev, res_dev, out_dev, rows, cout, kpad, ldo, ldr, act, tiles_c, tiles_p,
+                   x_dev, g_zero_line[dev], h, w, cin, ldx, kh, kw, stride, pad, ho, wo, k, 0};
+    if (const char *e = vsc_opt(OPT_CONV_REMAP)) a.no_remap = e[0] == '0';
+    const int64_t resident = (small ? (stages == 3 ? 2ll : 3ll) : stages == 2 ? 2ll : 1ll) * cus_of[dev];   // LDS per workgroup: 44 / 64 KiB (128 pixels), 76 / 112 KiB
     const unsigned ngrid = (unsigned)((pe && pe[0] == '0') || tiles_p * tiles_c < resident ? tiles_p * tiles_c : resident);
     if (narrow) {
 #define VSC_NARROW(I, S, W) hipLaunchKernelGGL((conv_gemm_narrow_kernel<I, S, W>), dim3(ngrid), dim3(W * 64), 0, stream, a)
-        if (implicit) { if (stages == 3) VSC_NARROW(true, 3, 4); else if (nw == 4) VSC_NARROW(true, 2, 4); else VSC_NARROW(true, 2, 8); }
+        if (small && stages == 3) { if (implicit) hipLaunchKernelGGL((conv_gemm_narrow_kernel<true, 3, 4, 1>), dim3(ngrid), dim3(256), 0, stream, a);
+                                    else hipLaunchKernelGGL((conv_gemm_narrow_kernel<false, 3, 4, 1>), dim3(ngrid), dim3(256), 0, stream, a); }
+        else if (small) { if (implicit) hipLaunchKernelGGL((conv_gemm_narrow_kernel<true, 2, 4, 1>), dim3(ngrid), dim3(256), 0, stream, a);
+                          else hipLaunchKernelGGL((conv_gemm_narrow_kernel<false, 2, 4, 1>), dim3(ngrid), dim3(256), 0, stream, a); }
+        else if (implicit) { if (stages == 3) VSC_NARROW(true, 3, 4); else if (nw == 4) VSC_NARROW(true, 2, 4); else VSC_NARROW(true, 2, 8); }
         else { if (stages == 3) VSC_NARROW(false, 3, 4); else if (nw == 4) VSC_NARROW(false, 2, 4); else VSC_NARROW(false, 2, 8); }
 #undef VSC_NARROW
     } else {
