@@ -373,6 +373,13 @@ int vsc_channel_scale_f32(float *x_dev, const float *scale_dev, int64_t n, int32
  * nn.Upsample(scale_factor, 'nearest') fused with the sum of an HRNet fuse layer or with torch.cat along channels. */
 int vsc_upsample_add_f32(const float *src_dev, int64_t n, int32_t h, int32_t w, int32_t c, int32_t factor, float *out_dev,
                          int32_t ldo, int32_t coff, int32_t accumulate, int32_t act, void *stream);
+/* One HRNet fuse node in one pass (timm HighResolutionModule.forward: y = relu(sum_j fuse_layers[i][j](x[j])), the sum taken in
+ * order of j): out[n, y, x, ch] = act(((base[n, y, x, ch] + up(src0)) + up(src1)) + up(src2)), up = nearest upsampling by a
+ * power-of-two factor, absent sources null.  base [n, h, w, ldb >= c] may be null or alias out [n, h, w, ldo >= c]; srcK
+ * [n, h / factorK, w / factorK, c] dense.  c, ldb, ldo multiples of 4, operands 16-byte aligned. */
+int vsc_upsample_sum_f32(const float *base_dev, int32_t ldb, const float *src0_dev, int32_t factor0, const float *src1_dev,
+                         int32_t factor1, const float *src2_dev, int32_t factor2, int64_t n, int32_t h, int32_t w, int32_t c,
+                         int32_t act, float *out_dev, int32_t ldo, void *stream);
 
 /* fp32 multi-head self-attention for short sequences: out[t, h*dh:(h+1)*dh] = softmax(q k^T / sqrt(dh)) v per head, qkv
  * [tokens, 3 * heads * head_dim] float32 as q | k | v column blocks.  Used by the video-score head (BERT encoder over <= 258

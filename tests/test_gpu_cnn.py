@@ -192,6 +192,35 @@ def test_depthwise_pool_scale_upsample(dev):
     assert torch.equal(out, want)
 
 
+def test_upsample_sum_is_the_chain_of_upsample_adds(dev):
+    """vsc_upsample_sum_f32 (one pass per HRNet fuse node) adds its terms in the order of the separate passes: identical bits."""
+    from vsc_hip import cnn
+    rng = np.random.RandomState(5)
+    n, h, w, c = 2, 16, 24, 20
+    base = torch.from_numpy(rng.randn(n, h, w, c).astype(np.float32)).to(dev)
+    terms = [(torch.from_numpy(rng.randn(n, h // f, w // f, c).astype(np.float32)).to(dev), f) for f in (1, 2, 8)]
+    for nterms in (0, 1, 2, 3):
+        for with_base in (True, False):
+            if not with_base and nterms == 0:
+                continue
+            for act in ("relu", None):
+                want = base.clone() if with_base else torch.zeros_like(base)
+                for t, f in terms[:nterms]:
+                    want = want + F.interpolate(t.permute(0, 3, 1, 2), scale_factor=f, mode="nearest").permute(0, 2, 3, 1)
+                if act:
+                    want = F.relu(want)
+                got = cnn.upsample_sum(base if with_base else None, terms[:nterms], torch.empty_like(base), act)
+                assert torch.equal(got, want), (nterms, with_base, act)
+    inplace = base.clone()   # base aliasing the output
+    cnn.upsample_sum(inplace, terms, inplace, "relu")
+    assert torch.equal(inplace, cnn.upsample_sum(base, terms, torch.empty_like(base), "relu"))
+    # the concat path (a channel window of a wider buffer) now runs on the same kernel
+    wide = torch.full((n, h, w, 48), 2.0, device=dev)
+    cnn.upsample_into(terms[1][0], wide, 2, 8, True, None)
+    assert torch.equal(wide[..., 8:28], 2.0 + F.interpolate(terms[1][0].permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1))
+    assert (wide[..., :8] == 2).all() and (wide[..., 28:] == 2).all()
+
+
 def test_mobilenetv3_classifier_matches_oracle(dev):
     from oracle import cnn_oracle
     from vsc_hip import cnn

@@ -773,6 +773,39 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restri
     }
 }
 
+// The same on 16-byte chunks, with up to three upsampled terms in one pass (an HRNet fuse node is y_i + sum_j up(conv(y_j)); as
+// three read-modify-write passes over the 64-MB branch-0 map plus a clone it cost 1.5 ms per refinement pass):
+//   out[n, y, x, coff + ch] = act(((base[n, y, x, ch] + up_f0(s0)) + up_f1(s1)) + up_f2(s2))      (terms added in this order)
+// base may be null (0) or the output window itself.  One workgroup row per output image row: the only per-thread division is by
+// the chunk count.  Factors are powers of two (shifts).
+struct UpsampleSumArgs {
+    const float *base, *src[3];
+    float *out;
+    int shift[3], nsrc;
+    int h, w, c4, ldb, ldo, act;
+};
+__global__ __launch_bounds__(256) void upsample_sum4_kernel(UpsampleSumArgs p) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= p.w * p.c4) return;
+    const int ox = e / p.c4, q = e - ox * p.c4;
+    const int64_t row = blockIdx.y;
+    const int oy = (int)(row % p.h);
+    const int64_t img = row / p.h;
+    const int64_t pix = row * p.w + ox;
+    f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (p.base) v = *(const f32x4_t *)(p.base + pix * p.ldb + q * 4);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (k < p.nsrc) {
+            const int sh = p.shift[k];
+            const f32x4_t t = *(const f32x4_t *)(p.src[k] + ((img * (p.h >> sh) + (oy >> sh)) * (p.w >> sh) + (ox >> sh)) * (p.c4 * 4) + q * 4);
+            v[0] += t[0], v[1] += t[1], v[2] += t[2], v[3] += t[3];
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = activate(v[r], p.act);
+    *(f32x4_t *)(p.out + pix * p.ldo + q * 4) = v;
+}
+
 // softmax(q k^T / sqrt(dh)) v for one (head, query) pair per workgroup, all in fp32 (the video-score head: <= 258 tokens,
 // one video at a time -- 0.1 GFLOP per layer, latency- not throughput-bound).  qkv [tokens, 3 * heads * dh] as q | k | v.
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restrict__ qkv, float *__restrict__ out, int tokens,
@@ -960,10 +993,12 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     const int stages = se && se[0] == '3' ? 3 : 2;
     const int nw = we && we[0] == '4' ? 4 : 8;
     const int tiles_c = narrow ? (cout + NARROW_C - 1) / NARROW_C : (cout + TR - 1) / TR;
-    // 128-pixel tiles (four waves, three workgroups per CU) when the 256-pixel list gives the chip's 2 x CUs slots fewer than four
-    // tiles each: the list then ends in a mostly empty round, or does not fill the first one
+    // 128-pixel tiles (four waves, three workgroups per CU) when the 256-pixel list spills a partial second round over the chip's
+    // 2 x CUs slots (72 @ 56 x 56: 588 tiles, 100 -> 95 us) or leaves most CUs without a workgroup (144 -> 20 @ 28 x 28: 49 tiles,
+    // 18 -> 13 us); measured worse for lists of 245 / 392 (one round either way) and >= 1568 tiles
+    const int64_t tiles256 = ((rows + 255) / 256) * tiles_c;
     const bool small = narrow && nw == 8 &&
-                       (te ? te[0] == '1' : ((rows + 255) / 256) * tiles_c < 8ll * cus_of[dev]);
+                       (te ? te[0] == '1' : ((tiles256 > 2ll * cus_of[dev] && tiles256 < 4ll * cus_of[dev]) || 2 * tiles256 <= cus_of[dev]));
     const int narrow_p = small ? 128 : 256;
     const int64_t tiles_p = narrow ? (rows + narrow_p - 1) / narrow_p : (rows + TQ - 1) / TQ;
     VSC_REQUIRE(tiles_p * tiles_c < (1ll << 31), "conv2d: grid too large");
@@ -1033,12 +1068,43 @@ extern "C" int vsc_channel_scale_f32(float *x_dev, const float *scale_dev, int64
     return VSC_OK;
 }
 
+extern "C" int vsc_upsample_sum_f32(const float *base_dev, int32_t ldb, const float *src0_dev, int32_t factor0, const float *src1_dev,
+                                    int32_t factor1, const float *src2_dev, int32_t factor2, int64_t n, int32_t h, int32_t w, int32_t c,
+                                    int32_t act, float *out_dev, int32_t ldo, void *stream_) {
+    VSC_REQUIRE(out_dev && n > 0 && h > 0 && w > 0 && c > 0 && ldo >= c && (!base_dev || ldb >= c), "upsample_sum: bad arguments");
+    VSC_REQUIRE(act >= VSC_ACT_NONE && act <= VSC_ACT_GELU, "upsample_sum: unknown activation %d", act);
+    VSC_REQUIRE((c & 3) == 0 && (ldo & 3) == 0 && (!base_dev || (ldb & 3) == 0), "upsample_sum: channel counts / row pitches must be multiples of 4");
+    VSC_REQUIRE(n * h < (1ll << 31) && (int64_t)w * c < (1ll << 31), "upsample_sum: grid too large");
+    UpsampleSumArgs a{};
+    a.base = base_dev, a.out = out_dev, a.h = h, a.w = w, a.c4 = c / 4, a.ldb = ldb, a.ldo = ldo, a.act = act;
+    const float *srcs[3] = {src0_dev, src1_dev, src2_dev};
+    const int factors[3] = {factor0, factor1, factor2};
+    uintptr_t align = (uintptr_t)out_dev | (uintptr_t)base_dev;
+    for (int k = 0; k < 3; ++k) {
+        if (!srcs[k]) continue;
+        const int f = factors[k];
+        VSC_REQUIRE(f >= 1 && (f & (f - 1)) == 0 && h % f == 0 && w % f == 0, "upsample_sum: factor %d must be a power of two dividing %d x %d", f, h, w);
+        a.src[a.nsrc] = srcs[k];
+        a.shift[a.nsrc++] = __builtin_ctz((unsigned)f);
+        align |= (uintptr_t)srcs[k];
+    }
+    VSC_REQUIRE((align & 15) == 0, "upsample_sum: operands must be 16-byte aligned");
+    VSC_REQUIRE(a.base || a.nsrc, "upsample_sum: nothing to sum");
+    hipLaunchKernelGGL(upsample_sum4_kernel, dim3((unsigned)((w * a.c4 + 255) / 256), (unsigned)(n * h)), dim3(256), 0, (hipStream_t)stream_, a);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
 extern "C" int vsc_upsample_add_f32(const float *src_dev, int64_t n, int32_t h, int32_t w, int32_t c, int32_t factor,
                                     float *out_dev, int32_t ldo, int32_t coff, int32_t accumulate, int32_t act, void *stream_) {
     VSC_REQUIRE(src_dev && out_dev && n > 0 && h > 0 && w > 0 && c > 0 && factor >= 1, "upsample_add: bad arguments");
     VSC_REQUIRE(h % factor == 0 && w % factor == 0, "upsample_add: %d x %d is not a multiple of the factor %d", h, w, factor);
     VSC_REQUIRE(ldo >= coff + c && coff >= 0, "upsample_add: channel window outside the output row");
     VSC_REQUIRE(act >= VSC_ACT_NONE && act <= VSC_ACT_GELU, "upsample_add: unknown activation %d", act);
+    if ((factor & (factor - 1)) == 0 && (c & 3) == 0 && (ldo & 3) == 0 && (coff & 3) == 0 && (((uintptr_t)src_dev | (uintptr_t)out_dev) & 15) == 0 &&
+        n * h < (1ll << 31) && (int64_t)w * c < (1ll << 31))
+        return vsc_upsample_sum_f32(accumulate ? out_dev + coff : nullptr, ldo, src_dev, factor, nullptr, 0, nullptr, 0, n, h, w, c, act,
+                                    out_dev + coff, ldo, stream_);
     const int64_t total = n * h * w * c;
     hipLaunchKernelGGL(upsample_add_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream_, src_dev, out_dev, total, h,
                        w, c, factor, ldo, coff, accumulate, act);

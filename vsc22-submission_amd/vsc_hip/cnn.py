@@ -137,6 +137,24 @@ def upsample_into(src, out, factor=1, coff=0, accumulate=False, act=None):
     return out
 
 
+def upsample_sum(base, terms, out, act=None):
+    """out = act(((base + up(t0)) + up(t1)) + up(t2)): one HRNet fuse node; terms = [(tensor [n, h / f, w / f, c], f), ...] (<= 3),
+    base [n, h, w, c] or None, may be `out` itself."""
+    lib = _lib.require_device()
+    n, h, w, c = out.shape
+    assert len(terms) <= 3 and out.is_contiguous() and (base is None or (base.shape == out.shape and base.is_contiguous()))
+    args = []
+    for k in range(3):
+        if k < len(terms):
+            t, f = terms[k]
+            assert t.shape == (n, h // f, w // f, c) and t.is_contiguous()
+            args += [ptr(t), f]
+        else:
+            args += [None, 0]
+    check(lib.vsc_upsample_sum_f32(ptr(base), c, *args, n, h, w, c, ACT[act], ptr(out), c, current_stream()))
+    return out
+
+
 class SqueezeExcite:
     def __init__(self, sd, p, device):
         self.reduce = Conv(sd, p + ".conv_reduce", None, device=device)
@@ -247,28 +265,29 @@ class _HrModule:
             ys.append(y)
         outs = []
         for i in range(self.nbr):
-            # summation order of the reference: j = 0 .. nbr-1; the running sum lives in `acc`, ReLU with the last term
+            # summation order of the reference: j = 0 .. nbr-1, ReLU after the last term.  The terms j < i end in a convolution
+            # (the running sum is its residual); y_i and the upsampled terms j > i are added in ONE pass (vsc_upsample_sum_f32)
             acc = None
-            for j in range(self.nbr):
+            for j in range(i):
+                chain = self.fuse[i, j]
+                t = ys[j]
+                for conv in chain[:-1]:
+                    t = conv(t, act="relu")
                 last = j == self.nbr - 1
-                if j == i:
-                    if acc is None:
-                        acc = ys[j].clone()
-                    else:
-                        upsample_into(ys[j], acc, 1, 0, True, "relu" if last else None)
-                elif j > i:
-                    t = self.fuse[i, j](ys[j])
-                    upsample_into(t, acc, 2 ** (j - i), 0, True, "relu" if last else None)   # acc exists: j > i >= 0
-                else:
-                    chain = self.fuse[i, j]
-                    t = ys[j]
-                    for k, conv in enumerate(chain[:-1]):
-                        t = conv(t, act="relu")
-                    if acc is None:
-                        acc = chain[-1](t)
-                    else:   # the sum so far is the residual of the last convolution of the chain
-                        acc = chain[-1](t, residual=acc, act="relu" if last else None)
-            outs.append(acc)
+                acc = chain[-1](t) if acc is None else chain[-1](t, residual=acc, act="relu" if last else None)
+            terms = [(ys[i], 1)] + [(self.fuse[i, j](ys[j]), 2 ** (j - i)) for j in range(i + 1, self.nbr)]
+            if acc is None:
+                base, terms = terms[0][0], terms[1:]
+            else:
+                base = acc
+            out = torch.empty_like(ys[i])
+            while True:   # three upsampled terms per pass (hrnet_w18 has at most three)
+                upsample_sum(base, terms[:3], out, "relu" if len(terms) <= 3 else None)
+                terms = terms[3:]
+                if not terms:
+                    break
+                base = out
+            outs.append(out)
         return outs
 
 
