@@ -136,14 +136,18 @@ struct GemmExtra {
     uint16_t *xb = nullptr;          // RESADD_STATS: bf16 copy of out [m, n]
     float *stats = nullptr;          // RESADD_STATS: [n / 64][m][2]
     const float *rowstats = nullptr; // LNF: [m][2] = (mean, rstd)
+    const float *slices = nullptr;   // LNF: the [nslices][m][2] (mean, M2) partials RESADD_STATS wrote; given (with eps), the persistent kernel merges
+    int nslices = 0;                 //      them per tile itself, other kernels get them merged into rowstats (then a scratch buffer) first
     const float *colsum = nullptr;   // LNF: [n]
     const float *gamma = nullptr, *beta = nullptr;   // LN_RES: [n]
     float eps = 0.f;                 // LN_RES
     float *xch = nullptr;            // LN_RES, N = 512: [2][256 workgroups][256 rows][2] partial row statistics
-    int *xflags = nullptr;           // LN_RES, N = 512: [256 workgroups][2] tiles published (zeroed before the launch)
+    int *xflags = nullptr;           // LN_RES, N = 512: [256 workgroups][2] tiles published, counting up across launches from `epoch`
+    int epoch = 0;
 };
 // bytes of the pair-exchange workspace of launch_gemm_ln_bf16 (one per stream that may run it)
 constexpr size_t VSC_GEMM_LN_WS_BYTES = 2 * 256 * 256 * 2 * 4 + 256 * 2 * 4;
+void gemm_ln_workspace_forget(const void *ws);   // call before freeing a workspace that was passed to launch_gemm_ln_bf16
 int launch_gemm_bf16_ex(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux, void *out, int64_t m,
                         int n, int k, int epilogue, int tokens, const GemmExtra &ex, hipStream_t stream);
 int launch_ln_stats_merge(const float *stats, float *rowstats, int64_t rows, int slices, int width, float eps,

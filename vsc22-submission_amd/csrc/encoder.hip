@@ -397,7 +397,10 @@ static int encoder_forward_impl(vsc_encoder *e, const float *frames, const uint8
         GemmExtra emit, take;
         emit.xb = w.xb;
         emit.stats = w.stats;
-        take.rowstats = w.rowstats;
+        take.rowstats = w.rowstats;   // scratch: where the GEMM launcher merges the partials when its kernel cannot (launch_v34)
+        take.slices = w.stats;
+        take.nslices = D / 64;
+        take.eps = c.ln_eps;
         for (int l = 0; l < c.layers; ++l) {
             const LayerW &L = e->layers[l];
             if (fold && l > 0) {
@@ -411,14 +414,9 @@ static int encoder_forward_impl(vsc_encoder *e, const float *frames, const uint8
             { ProfScope _ps(e, VSC_PROF_ATTENTION, st); TRY(launch_attention_bf16(w.qkv, w.y, (int)B, T, c.heads, st)); }
             if (fold) {
                 { ProfScope _ps(e, VSC_PROF_GEMM_PROJ, st); TRY(launch_gemm_bf16_ex(w.y, L.proj_w, L.proj_b, w.x, w.x, M, D, D, VSC_EPI_RESADD_STATS_F32, 0, emit, st)); }
-                { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_ln_stats_merge(w.stats, w.rowstats, M, D / 64, D, c.ln_eps, st)); }
                 take.colsum = L.fc1_cs;
                 { ProfScope _ps(e, VSC_PROF_GEMM_FC1, st); TRY(launch_gemm_bf16_ex(w.xb, L.fc1_wf, L.fc1_bf, nullptr, w.h, M, c.mlp_dim, D, act_lnf, 0, take, st)); }
                 { ProfScope _ps(e, VSC_PROF_GEMM_FC2, st); TRY(launch_gemm_bf16_ex(w.h, L.fc2_w, L.fc2_b, w.x, w.x, M, D, c.mlp_dim, l + 1 < c.layers ? VSC_EPI_RESADD_STATS_F32 : VSC_EPI_RESADD_F32, 0, emit, st)); }
-                if (l + 1 < c.layers) {
-                    ProfScope _ps(e, VSC_PROF_LAYERNORM, st);
-                    TRY(launch_ln_stats_merge(w.stats, w.rowstats, M, D / 64, D, c.ln_eps, st));
-                }
             } else {
                 { ProfScope _ps(e, VSC_PROF_GEMM_PROJ, st); TRY(launch_gemm_bf16(w.y, L.proj_w, L.proj_b, w.x, w.x, M, D, D, VSC_EPI_RESADD_F32, 0, st)); }
                 { ProfScope _ps(e, VSC_PROF_LAYERNORM, st); TRY(launch_layernorm(w.x, L.ln2_g, L.ln2_b, w.y, M, D, c.ln_eps, 0, st)); }

@@ -24,6 +24,9 @@
 
 #include <type_traits>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 #include "gelu_poly.h"
 #include "mainloop64.h"
@@ -766,7 +769,7 @@ int launch_v3(GemmArgs p, hipStream_t stream) {
 // Serves the plain, GELU and residual epilogues; K % 128 == 0 (an even number of K-tiles), K >= 256.
 constexpr bool epi_v4(int e) {
     return e == VSC_EPI_BF16 || e == VSC_EPI_GELU_BF16 || e == VSC_EPI_QGELU_BF16 || e == VSC_EPI_RESADD_F32 || e == VSC_EPI_F32 ||
-           e == VSC_EPI_LN_RES_F32;
+           e == VSC_EPI_LN_RES_F32 || epi_lnf(e) || e == VSC_EPI_RESADD_STATS_F32;
 }
 
 #ifdef VSC_GEMM_TIMING
@@ -775,7 +778,7 @@ static __device__ unsigned long long g_v4_t_mid[16];   // (per-wave scratch of t
 // write-out of one wave's 128 x 64 tile through its 4 KiB of staging; bias: this tile's 256 floats in LDS
 template <int EPI>
 __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)[8][4], char *reg, const char *bias_lds,
-                                               int lane, int wm, int wn, int64_t m0, int n0) {
+                                               int lane, int wm, int wn, int64_t m0, int n0, const char *rs_lds = nullptr) {
     const int fr = lane & 15, fq = lane >> 4;
     const int ncol0 = n0 + wn * 64;
     const int64_t mrow0 = m0 + wm * 128;
@@ -799,13 +802,32 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
         const uint32_t row_bytes_h = (uint32_t)p.n * 2u;
         const __amdgpu_buffer_rsrc_t outh_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)(uint32_t)((uint64_t)p.m * row_bytes_h), 0x00020000);
         const uint32_t offh = n < p.n ? (uint32_t)(mrow0 + (lane >> 3)) * row_bytes_h + (uint32_t)n * 2u : 0xfffffff0u;
+        // LayerNorm folding: the column sums of the lane's 16 columns (behind the bias in this tile's epilogue constants) for the
+        // whole tile, (mean, rstd) of a pass's two rows at its start -- one LDS round trip per pass, not one per value
+        f32x4_t cs[epi_lnf(EPI) ? 4 : 1];
+        if (epi_lnf(EPI)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[j] = *(const f32x4_t *)(bias_lds + 1024 + (wn * 64 + j * 16 + fq * 4) * 4);
+        }
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
+            float2 rs[2];
+            if (epi_lnf(EPI)) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) rs[ii] = *(const float2 *)(rs_lds + (wm * 128 + (pass * 2 + ii) * 16 + fr) * 8);
+            }
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    f32x4_t v = acc[pass * 2 + ii][j] + bz[j];
+                    f32x4_t v;
+                    if (epi_lnf(EPI)) {
+                        // LayerNorm folding: v = rstd_row (acc - mean_row colsum) + bias'
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaf(fmaf(-rs[ii].x, cs[j][r], acc[pass * 2 + ii][j][r]), rs[ii].y, bz[j][r]);
+                    } else {
+                        v = acc[pass * 2 + ii][j] + bz[j];
+                    }
                     if (epi_gelu(EPI)) gelu4(v);
                     else if (epi_qgelu(EPI)) {
 #pragma unroll
@@ -858,6 +880,14 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
         const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)extent, 0x00020000);
         const __amdgpu_buffer_rsrc_t aux_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.aux, 0, p.aux ? (int)extent : 0, 0x00020000);
         const uint32_t off0 = n < p.n ? (uint32_t)(mrow0 + rq) * row_bytes + (uint32_t)n * 4u : 0xfffffff0u;
+        // RESADD_STATS (LayerNorm folding): the bf16 shadow of the new x at half the offsets, and (mean, M2) of every row's
+        // 64-column slice into stats[slice][m] (lane c == 0 of the row's 16; rows past m fall outside the descriptor)
+        typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2_t;
+        constexpr bool STATS = EPI == VSC_EPI_RESADD_STATS_F32;
+        const __amdgpu_buffer_rsrc_t xb_rsrc = __builtin_amdgcn_make_buffer_rsrc(STATS ? (void *)p.ex.xb : p.out, 0, (int)(extent >> 1), 0x00020000);
+        const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            STATS ? (void *)(p.ex.stats + (int64_t)(ncol0 >> 6) * p.m * 2) : p.out, 0, (int)((uint32_t)p.m * 8u), 0x00020000);
+        const uint32_t st_off = (c == 0 && ncol0 < p.n) ? (uint32_t)(mrow0 + rq) * 8u : 0xfffffff0u;
         f32x4_t ax[3][4];
         auto load_aux = [&](int i, f32x4_t (&dst)[4]) {
 #pragma unroll
@@ -884,6 +914,16 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
                 f32x4_t v = *(const f32x4_t *)(reg + row * 256 + ((c ^ row) << 4));
                 if (EPI != VSC_EPI_F32) v += ax[i % 3][it];
                 buffer_store_b128_soff(__builtin_bit_cast(vsc_u32x4_t, v), out_rsrc, off0, (uint32_t)(i * 16 + it * 4) * row_bytes);
+                if (STATS) {
+                    const u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(pk, xb_rsrc, off0 >> 1, ((uint32_t)(i * 16 + it * 4) * row_bytes) >> 1, 0);
+                    // two passes on the registers, as the one-tile kernel (epilogue_via_lds)
+                    const float mean = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
+                    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                    const float m2 = row16_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                    const u32x2_t sv = {__builtin_bit_cast(unsigned, mean), __builtin_bit_cast(unsigned, m2)};
+                    __builtin_amdgcn_raw_buffer_store_b64(sv, st_rsrc, st_off, (uint32_t)(i * 16 + it * 4) * 8u, 0);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -961,7 +1001,7 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8]
                 }
             }
             ml64::wait_vmcnt<0>();   // the statistics are in L2 ...
-            if (lane == 0) __hip_atomic_store(p.ex.xflags + blockIdx.x * 2 + wm, iter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag
+            if (lane == 0) __hip_atomic_store(p.ex.xflags + blockIdx.x * 2 + wm, p.ex.epoch + iter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag
         }
         // Forward progress: the partner (blockIdx ^ 8) runs the row's other tile in the SAME round of a grid with one workgroup
         // per CU on every CU (launch_v4 checks grid == CUs and whole tile pairs; launch_gemm_ln_bf16 checks the CU count), so it
@@ -970,7 +1010,8 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8]
         // a trap -- the launch fails with a HIP error at the next synchronisation instead of hanging the queue.
         const int *flag = p.ex.xflags + (blockIdx.x ^ 8) * 2 + wm;
         int polls = 0;   // (the flag is read as a wave-uniform value, so the loop and its counter stay on the scalar side: no VGPR)
-        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < iter + 1) {
+        // (flags count up across launches -- p.ex.epoch is this launch's base -- so nothing has to be zeroed between launches)
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - (p.ex.epoch + iter + 1) < 0) {
             __builtin_amdgcn_s_sleep(2);
             if (++polls > (1 << 21)) __builtin_trap();
         }
@@ -1060,16 +1101,42 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs p) {
         tm = rem / width;
         tn = first + (rem - tm * width);
     };
-    char *ext = lds2 + ml64::RING_BYTES;   // 2 x 1 KiB: the bias of this tile / of the next one
+    // epilogue constants behind the ring: the bias of this tile / of the next one (2 x 1 KiB); with LayerNorm folding 2 x (bias |
+    // column sums), then (mean, rstd) of the current tile's 256 rows (2 KiB) and, when the kernel merges the statistics itself,
+    // the [nslices][256] (mean, M2) partials of those rows (2 KiB per slice)
+    constexpr int EXT = epi_lnf(EPI) ? 2048 : 1024;
+    char *ext = lds2 + ml64::RING_BYTES;
+    char *rs_lds = ext + 2 * EXT, *sl_lds = rs_lds + 2048;
+    const int nsl = epi_lnf(EPI) ? p.ex.nslices : 0;   // > 0: merge in the kernel
     const __amdgpu_buffer_rsrc_t bias_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.bias, 0, p.bias ? p.n * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(epi_lnf(EPI) ? p.ex.colsum : p.bias), 0, epi_lnf(EPI) ? p.n * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(epi_lnf(EPI) ? (nsl ? p.ex.slices : p.ex.rowstats) : p.bias), 0, epi_lnf(EPI) ? (int)((uint32_t)p.m * 8u * (uint32_t)(nsl ? nsl : 1)) : 0, 0x00020000);
     auto stage_bias = [&](int buf, int n0) {   // waves 0-3, one 256-byte piece each (zeros without a bias / past n)
         if (wave < 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(bias_rsrc, (lptr_t)(ext + buf * 1024 + wave * 256), 4,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(bias_rsrc, (lptr_t)(ext + buf * EXT + wave * 256), 4,
                                                      (n0 + wave * 64 + lane) * 4, 0, 0, 0);
+        else if (epi_lnf(EPI))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(cs_rsrc, (lptr_t)(ext + buf * EXT + 1024 + (wave - 4) * 256), 4,
+                                                     (n0 + (wave - 4) * 64 + lane) * 4, 0, 0, 0);
+    };
+    // row statistics of the tile about to be multiplied (single buffer: its previous readers are behind the tile-end barrier):
+    // (mean, rstd) of rows m0 .. m0 + 255, or their nslices partials (1-KiB pieces of 128 rows; rows past m read zeros or the next
+    // slice's rows -- their outputs are never stored)
+    auto stage_rows = [&](int64_t m0) {
+        if (!epi_lnf(EPI)) return;
+        if (nsl == 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rsrc, (lptr_t)(rs_lds + wave * 256), 4, (uint32_t)m0 * 8u + (wave * 64 + lane) * 4, 0, 0, 0);
+        } else {
+            for (int q = wave; q < 2 * nsl; q += 8)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rsrc, (lptr_t)(sl_lds + q * 1024), 16,
+                                                         (uint32_t)(((int64_t)(q >> 1) * p.m + m0 + (q & 1) * 128) * 8) + lane * 16, 0, 0, 0);
+        }
     };
     int vt = blockIdx.x, tm, tn;
     tile_of(vt, tm, tn);
     stage_bias(0, tn * 256);
+    stage_rows((int64_t)tm * 256);
     ml64::Ctx c;
     ml64::init_whole(c, p.a, p.k, p.m, p.w, p.k, p.n, (int64_t)tm * 256, (int64_t)tn * 256, lds2, wave, lane);
     // Start skew.  All workgroups of a persistent launch run in lockstep (same start, same tile times), so the 32 CUs of an
@@ -1105,7 +1172,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs p) {
                 asm volatile("" : "+v"(acc[ii][j]));   // real zeros in real registers: folded into the first MFMAs' C operand, the
                                                        // first K-tile gets a register assignment of its own and the kernel spills
             }
-        if (!last) stage_bias((i + 1) & 1, tn2 * 256);   // a tile ahead: landed long before the write-out that reads it
+        if (!last) stage_bias((i + 1) & 1, tn2 * 256);
+        if (i > 0) stage_rows((int64_t)tm * 256);   // a tile ahead: landed long before the write-out that reads it
 #ifdef VSC_GEMM_TIMING
         if (rec && i < 6) tb[1 + i * 5] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1118,9 +1186,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs p) {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         if constexpr (EPI == VSC_EPI_LN_RES_F32)
-            epilogue_ln(p, acc, lds2 + 6 * ml64::UNIT_BYTES, reg, ext + (i & 1) * 1024, lane_e, wm, wn, (int64_t)tm * 256, tn * 256, i);
+            epilogue_ln(p, acc, lds2 + 6 * ml64::UNIT_BYTES, reg, ext + (i & 1) * EXT, lane_e, wm, wn, (int64_t)tm * 256, tn * 256, i);
         else
-            epilogue_small<EPI>(p, acc, reg, ext + (i & 1) * 1024, lane_e, wm, wn, (int64_t)tm * 256, tn * 256);
+        {
+            if (epi_lnf(EPI) && nsl) {
+                // (mean, M2) of the row's 64-column slices -> (mean, rstd) of the row (Chan, equal counts), one row per thread of waves
+                // 0-3; every wave's pieces have landed (counted waits + barriers of the K loop behind them)
+                if (tid < 256) {
+                    float mean = 0.f, m2 = 0.f;
+                    for (int sl = 0; sl < nsl; ++sl) mean += *(const float *)(sl_lds + sl * 2048 + tid * 8);
+                    mean /= (float)nsl;
+                    for (int sl = 0; sl < nsl; ++sl) {
+                        const float2 v = *(const float2 *)(sl_lds + sl * 2048 + tid * 8);
+                        const float d = v.x - mean;
+                        m2 += v.y + 64.0f * d * d;
+                    }
+                    *(float2 *)(rs_lds + tid * 8) = make_float2(mean, rsqrtf(m2 / (float)p.k + p.ex.eps));
+                }
+                __syncthreads();
+            }
+            epilogue_small<EPI>(p, acc, reg, ext + (i & 1) * EXT, lane_e, wm, wn, (int64_t)tm * 256, tn * 256, rs_lds);
+        }
 #ifdef VSC_GEMM_TIMING
         if (rec && i < 6) {
             tb[3 + i * 5] = g_v4_t_mid[wave];
@@ -1141,13 +1227,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs p) {
 
 template <int EPI>
 int launch_v4(GemmArgs p, int cus, hipStream_t stream) {
-    constexpr int smem = ml64::RING_BYTES + 2048;
+    constexpr int smem_max = ml64::RING_BYTES + (epi_lnf(EPI) ? 2 * 2048 + 2048 + 12 * 2048 : 2048);
+    const int smem = ml64::RING_BYTES + (epi_lnf(EPI) ? 2 * 2048 + 2048 + p.ex.nslices * 2048 : 2048);
     auto kern = gemm_bf16_v4_kernel<EPI>;
     static bool attr_set[16] = {};
     int dev = 0;
     VSC_CHECK_HIP(hipGetDevice(&dev));
     if (dev >= 16 || !attr_set[dev]) {
-        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max));
         if (dev < 16) attr_set[dev] = true;
     }
     // groups of 4 N-tiles; of 3 where that divides the row of tiles and 4 does not (qkv: 9 = 3 + 3 + 3 instead of 4 + 4 + 1:
@@ -1224,7 +1311,8 @@ int launch_v34(GemmArgs p, hipStream_t stream) {
         // fp32 write-outs address [m, n] by 32-bit byte offsets from the matrix origin, rows of the last (ragged) tile included
         const bool out_span_ok = (int64_t)p.tiles_m * 256 * p.n * (epi_bf16_out(EPI) ? 2 : 4) < (1ll << 32);
         if (!off && p.k % 128 == 0 && p.k >= 128 && p.k <= 3072 && cus % 8 == 0 && (int64_t)p.tiles_m * p.tiles_n > cus &&
-            a_span < (1ll << 32) && w_span < (1ll << 32) && out_span_ok && (EPI != VSC_EPI_RESADD_F32 || p.aux))
+            a_span < (1ll << 32) && w_span < (1ll << 32) && out_span_ok && (EPI != VSC_EPI_RESADD_F32 || p.aux) &&
+            (!epi_lnf(EPI) || p.m * 8 < (1ll << 32)))
         {
             int grid = cus;
             // diagnostic: persistent workgroups per launch (a multiple of 8).  Measured with two lanes, so that the two chunks' GEMMs run
@@ -1233,8 +1321,25 @@ int launch_v34(GemmArgs p, hipStream_t stream) {
                 const int g = atoi(e);
                 if (g >= 8 && g <= cus && g % 8 == 0) grid = g;
             }
+            if constexpr (epi_lnf(EPI)) {
+                // statistics given as slice partials: merged per tile inside the kernel when they fit behind the ring (<= 12 slices)
+                if (p.ex.slices && p.ex.nslices > 12) {
+                    int rc = launch_ln_stats_merge(p.ex.slices, const_cast<float *>(p.ex.rowstats), p.m, p.ex.nslices, p.k, p.ex.eps, stream);
+                    if (rc) return rc;
+                    p.ex.nslices = 0;
+                } else if (!p.ex.slices) {
+                    p.ex.nslices = 0;
+                }
+            }
             return launch_v4<EPI>(p, grid, stream);
         }
+    }
+    if constexpr (epi_lnf(EPI)) {
+        if (p.ex.slices) {
+            int rc = launch_ln_stats_merge(p.ex.slices, const_cast<float *>(p.ex.rowstats), p.m, p.ex.nslices, p.k, p.ex.eps, stream);
+            if (rc) return rc;
+        }
+        p.ex.nslices = 0;
     }
     return launch_v3<EPI>(p, stream);
 }
@@ -1645,7 +1750,8 @@ int launch_gemm_bf16_ex(const uint16_t *a, const uint16_t *w, const float *bias,
         if (epilogue == VSC_EPI_RESADD_STATS_F32)
             VSC_REQUIRE(aux && ex.xb && ex.stats, "gemm: RESADD_STATS needs residual, xb and stats");
         else
-            VSC_REQUIRE(ex.rowstats && ex.colsum && bias, "gemm: LNF needs rowstats, colsum and the folded bias");
+            VSC_REQUIRE(ex.rowstats && ex.colsum && bias && (!ex.slices || (ex.nslices * 64 == k && ex.eps > 0.f)),
+                        "gemm: LNF needs rowstats, colsum and the folded bias (and K / 64 slices + eps when given partials)");
     }
     const bool v2 = fused || (!force_v1 && m >= 1024 && k % 32 == 0 && n % 8 == 0 && (fills || force_v2));
     if (epilogue == VSC_EPI_RESADD_F32) VSC_REQUIRE(aux, "gemm: RESADD needs the residual pointer");
@@ -1663,10 +1769,10 @@ int launch_gemm_bf16_ex(const uint16_t *a, const uint16_t *w, const float *bias,
             case VSC_EPI_RESADD_F32: return launch_v2_pick<VSC_EPI_RESADD_F32>(p, stream);
             case VSC_EPI_PATCH_F32: return launch_v2_pick<VSC_EPI_PATCH_F32>(p, stream);
             case VSC_EPI_F32: return launch_v2_pick<VSC_EPI_F32>(p, stream);
-            case VSC_EPI_LNF_BF16: return p.k % 64 == 0 ? launch_v3<VSC_EPI_LNF_BF16>(p, stream) : launch_v2<VSC_EPI_LNF_BF16, 2, 4, 8, 4, 4>(p, stream);
-            case VSC_EPI_LNF_GELU_BF16: return p.k % 64 == 0 ? launch_v3<VSC_EPI_LNF_GELU_BF16>(p, stream) : launch_v2<VSC_EPI_LNF_GELU_BF16, 2, 4, 8, 4, 4>(p, stream);
-            case VSC_EPI_LNF_QGELU_BF16: return p.k % 64 == 0 ? launch_v3<VSC_EPI_LNF_QGELU_BF16>(p, stream) : launch_v2<VSC_EPI_LNF_QGELU_BF16, 2, 4, 8, 4, 4>(p, stream);
-            case VSC_EPI_RESADD_STATS_F32: return p.k % 64 == 0 ? launch_v3<VSC_EPI_RESADD_STATS_F32>(p, stream) : launch_v2<VSC_EPI_RESADD_STATS_F32, 2, 4, 8, 4, 4>(p, stream);
+            case VSC_EPI_LNF_BF16: return p.k % 64 == 0 ? launch_v34<VSC_EPI_LNF_BF16>(p, stream) : launch_v2<VSC_EPI_LNF_BF16, 2, 4, 8, 4, 4>(p, stream);
+            case VSC_EPI_LNF_GELU_BF16: return p.k % 64 == 0 ? launch_v34<VSC_EPI_LNF_GELU_BF16>(p, stream) : launch_v2<VSC_EPI_LNF_GELU_BF16, 2, 4, 8, 4, 4>(p, stream);
+            case VSC_EPI_LNF_QGELU_BF16: return p.k % 64 == 0 ? launch_v34<VSC_EPI_LNF_QGELU_BF16>(p, stream) : launch_v2<VSC_EPI_LNF_QGELU_BF16, 2, 4, 8, 4, 4>(p, stream);
+            case VSC_EPI_RESADD_STATS_F32: return p.k % 64 == 0 ? launch_v34<VSC_EPI_RESADD_STATS_F32>(p, stream) : launch_v2<VSC_EPI_RESADD_STATS_F32, 2, 4, 8, 4, 4>(p, stream);
             default: VSC_REQUIRE(false, "gemm: unknown epilogue %d", epilogue);
         }
     }
@@ -1706,6 +1812,14 @@ int launch_ln_stats_merge(const float *stats, float *rowstats, int64_t rows, int
                        slices, width, eps);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
+}
+
+// pair-exchange workspaces seen so far -> the value their flags have reached (see launch_gemm_ln_bf16)
+static std::mutex g_ln_ws_mutex;
+static std::unordered_map<const void *, int> g_ln_ws_epoch;
+void gemm_ln_workspace_forget(const void *ws) {   // before the owner frees it: a later allocation at this address starts from zeroed flags
+    std::lock_guard<std::mutex> lock(g_ln_ws_mutex);
+    g_ln_ws_epoch.erase(ws);
 }
 
 int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias, const float *gamma,
@@ -1755,11 +1869,28 @@ int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias,
             p.ex.eps = eps;
             p.ex.xch = (float *)pair_ws;
             p.ex.xflags = (int *)((char *)pair_ws + 2 * 256 * 256 * 2 * 4);
-            if (tiles_n == 2) VSC_CHECK_HIP(hipMemsetAsync(p.ex.xflags, 0, 256 * 2 * 4, stream));
             int grid = cus;
             if (const char *e = vsc_opt(OPT_GEMM_V4_GRID)) {   // diagnostic, as in launch_v34
                 const int g = atoi(e);
                 if (g >= 16 && g <= cus && g % 16 == 0 && tiles_m * tiles_n >= g) grid = g;
+            }
+            if (tiles_n == 2) {
+                // the flags of a workspace count up from launch to launch (zeroed once, when the workspace is first seen): no memset
+                // node between the GEMMs of a block.  One launch advances them by its tiles per workgroup.
+                std::lock_guard<std::mutex> lock(g_ln_ws_mutex);
+                auto it = g_ln_ws_epoch.find(pair_ws);
+                if (it == g_ln_ws_epoch.end()) {
+                    VSC_CHECK_HIP(hipMemsetAsync(p.ex.xflags, 0, 256 * 2 * 4, stream));
+                    it = g_ln_ws_epoch.emplace(pair_ws, 0).first;
+                }
+                p.ex.epoch = it->second;
+                const int per_wg = (int)((tiles_m * tiles_n + grid - 1) / grid);
+                it->second = (it->second + per_wg + 1) & 0x3fffffff;
+                if (it->second < p.ex.epoch) {   // wrapped (after ~10^8 launches): start over from zeroed flags
+                    VSC_CHECK_HIP(hipMemsetAsync(p.ex.xflags, 0, 256 * 2 * 4, stream));
+                    p.ex.epoch = 0;
+                    it->second = per_wg + 1;
+                }
             }
             return launch_v4<VSC_EPI_LN_RES_F32>(p, grid, stream);
         }

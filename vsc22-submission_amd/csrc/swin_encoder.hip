@@ -213,6 +213,8 @@ extern "C" int vsc_swin_create(const vsc_swin_config *cfg, vsc_swin **out) {
 
 extern "C" void vsc_swin_destroy(vsc_swin *e) {
     if (!e) return;
+    for (int l = 0; l < 2; ++l)
+        if (e->ws[l].lnws) gemm_ln_workspace_forget(e->ws[l].lnws);   // its flag counters die with the buffer
     for (void *p : e->allocs) (void)hipFree(p);
     for (int l = 0; l < 2; ++l) {
         if (e->lane_stream[l]) (void)hipStreamDestroy(e->lane_stream[l]);
