@@ -173,6 +173,35 @@ def test_conv2d_1x1_expansion_stream_kernel(dev, n, h, w, cout, res, act):
     assert torch.equal(wide[..., 4:4 + cout], got) and (wide[..., :4] == 3).all() and (wide[..., 4 + cout:] == 3).all()
 
 
+@pytest.mark.parametrize("n,h,w,cout,stride,act", [
+    (3, 160, 160, 16, 2, "hard_swish"),     # the classifier's stem at its resolution
+    (2, 37, 53, 16, 2, "relu"),             # odd sizes: the last band of output rows is ragged
+    (2, 18, 22, 32, 1, None),               # stride 1, eight channel quads
+    (1, 5, 4, 8, 2, "relu"),                # an image smaller than one band
+])
+def test_conv2d_stem_direct_kernel(dev, n, h, w, cout, stride, act):
+    """conv_stem3_kernel (3 input channels, 3 x 3; input rows in LDS, weights in registers) against torch and, bit for bit, against
+    the patch-matrix GEMM path (VSC_CONV_STEM=0): the same fmaf chain in ascending k."""
+    from vsc_hip import cnn
+    rng = np.random.RandomState(h + cout)
+    sd = {"c.weight": torch.from_numpy((rng.randn(cout, 3, 3, 3) / 5).astype(np.float32)), "c.bias": torch.from_numpy(rng.randn(cout).astype(np.float32) * 0.1)}
+    x = torch.from_numpy(rng.randn(n, h, w, 3).astype(np.float32)).to(dev)
+    conv = cnn.Conv(sd, "c", None, stride, dev)
+    got = conv(x, act=act).clone()
+    _vsc_lib.set_option("VSC_CONV_STEM", "0")
+    try:
+        gemm = conv(x, act=act).clone()
+    finally:
+        _vsc_lib.set_option("VSC_CONV_STEM", None)
+    want = F.conv2d(x.cpu().permute(0, 3, 1, 2), sd["c.weight"], sd["c.bias"], stride=stride, padding=1)
+    want = {"relu": F.relu, "hard_swish": F.hardswish, None: lambda v: v}[act](want)
+    assert torch.allclose(got.cpu().permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)
+    assert torch.equal(got.view(torch.int32), gemm.view(torch.int32))
+    wide = torch.full(got.shape[:3] + (cout + 8,), 3.0, device=dev)
+    conv(x, act=act, out=wide, coff=4)
+    assert torch.equal(wide[..., 4:4 + cout], got) and (wide[..., :4] == 3).all() and (wide[..., 4 + cout:] == 3).all()
+
+
 def test_depthwise_pool_scale_upsample(dev):
     from vsc_hip import cnn
     rng = np.random.RandomState(0)
@@ -182,6 +211,22 @@ def test_depthwise_pool_scale_upsample(dev):
         want = F.hardswish(F.conv2d(x, sd["d.weight"], None, stride=stride, padding=k // 2, groups=c))
         got = cnn.DwConv(sd, "d", None, stride, dev)(x.permute(0, 2, 3, 1).contiguous().to(dev), act="hard_swish")
         assert torch.allclose(got.cpu().permute(0, 3, 1, 2), want, atol=1e-5)
+    # small maps (the classifier's 5 x 5 / 10 x 10 stages): dwconv_small_kernel (channel slabs, the image in LDS) against torch and,
+    # bit for bit, against the row kernel (VSC_DWCONV_SMALL=0); 9 images per workgroup column, a partial last slab (240 = 3 x 64 + 48)
+    for c, k, stride, hh, ww, nimg in ((576, 5, 1, 5, 5, 40), (240, 5, 1, 10, 10, 19), (288, 5, 2, 10, 10, 7), (16, 3, 1, 6, 7, 3), (120, 5, 1, 10, 10, 2100)):
+        sd = {"d.weight": torch.from_numpy(rng.randn(c, 1, k, k).astype(np.float32) * 0.2), "d.bias": torch.from_numpy(rng.randn(c).astype(np.float32))}
+        x = torch.from_numpy(rng.randn(nimg, hh, ww, c).astype(np.float32)).to(dev)
+        dw = cnn.DwConv(sd, "d", None, stride, dev)
+        got = dw(x, act="hard_swish").clone()
+        _vsc_lib.set_option("VSC_DWCONV_SMALL", "0")
+        try:
+            rows = dw(x, act="hard_swish").clone()
+        finally:
+            _vsc_lib.set_option("VSC_DWCONV_SMALL", None)
+        assert torch.equal(got.view(torch.int32), rows.view(torch.int32)), (c, k, stride)
+        if nimg < 100:
+            want = F.hardswish(F.conv2d(x.cpu().permute(0, 3, 1, 2), sd["d.weight"], sd["d.bias"], stride=stride, padding=k // 2, groups=c))
+            assert torch.allclose(got.cpu().permute(0, 3, 1, 2), want, atol=1e-5)
     x = torch.from_numpy(rng.randn(3, 6, 5, 70).astype(np.float32)).to(dev)
     assert torch.allclose(cnn.avgpool(x).reshape(3, 70), x.mean((1, 2)), atol=1e-6)
     src = torch.from_numpy(rng.randn(2, 3, 4, 18).astype(np.float32)).to(dev)

@@ -663,6 +663,60 @@ __global__ __launch_bounds__(512, 1) void conv1x1_expand64_kernel(ExpandArgs p) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Stem of the classifier: 3 x 3 convolution from 3 input channels (K = 27) to <= 32 channels at 160 x 160, stride 2.  On the GEMM
+// path it materialises a [pixels, 32] patch matrix (1.7 GB written and read for 0.6 GB of input; 1229 us).  Direct form: a thread
+// owns one output pixel -- its 27 inputs in registers (neighbouring threads' patches overlap: L1 hits), all COUT channels, the
+// weights through scalar loads (uniform addresses: v_fmac with an SGPR operand, no LDS) -- and writes COUT x 4 contiguous bytes.
+// One fmaf chain per output over k = (i, j, ci) in the order the matrix path multiplies a 32-float slab (k, k + 4 alternating per
+// chunk pair), then the bias; padding taps multiply zeros there too: identical bits.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_stem3_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
+                                                         float *__restrict__ out, int64_t total, int h, int w, int kpad, int stride, int pad,
+                                                         int ho, int wo, int ldo, int act) {
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= total) return;
+    const int ox = (int)(pix % wo);
+    const int64_t t = pix / wo;
+    const int oy = (int)(t % ho);
+    const int64_t img = t / ho;
+    const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
+    float xv[27];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int iy = iy0 + i, ix = ix0 + j;
+            const bool ok = iy >= 0 && iy < h && ix >= 0 && ix < w;
+            const float *src = x + ((img * h + (ok ? iy : 0)) * (int64_t)w + (ok ? ix : 0)) * 3;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) xv[(i * 3 + j) * 3 + ci] = ok ? src[ci] : 0.f;
+        }
+    float *o = out + pix * ldo;
+    // the weights through the constant address space: uniform addresses become s_load (rows of 27 consecutive floats), the products
+    // v_fmac with an SGPR operand -- one channel's chain at a time, so at most a few rows of weights are live in SGPRs
+    const __attribute__((address_space(4))) float *wc = (const __attribute__((address_space(4))) float *)wp;
+#pragma unroll
+    for (int cq = 0; cq < COUT / 4; ++cq) {
+        f32x4_t a;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float acc = 0.f;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                // the matrix path's order inside a 32-float slab: MFMA t of chunk pair pr multiplies k = 8 pr + t, then 8 pr + 4 + t
+                const int k = (s >> 3) * 8 + ((s & 7) >> 1) + (s & 1) * 4;
+                if (k < 27) acc = fmaf(xv[k], wc[(cq * 4 + q) * kpad + k], acc);
+            }
+            a[q] = acc;
+        }
+        if (bias) a += *(const f32x4_t *)(bias + cq * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = activate(a[q], act);
+        *(f32x4_t *)(o + cq * 4) = a;
+    }
+}
+
 // depthwise: one thread per (pixel, channel); w [c, kh * kw]
 __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
                                                      const float *__restrict__ bias, float *__restrict__ out, int64_t total,
@@ -731,6 +785,61 @@ __global__ __launch_bounds__(256) void dwconv_rows_kernel(const float *__restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[r] = activate(a[r], act);
         *(f32x4_t *)(orow + (int64_t)ox * c + c4 * 4) = a;
+    }
+}
+
+// Depthwise layers on SMALL maps (the classifier's 5 x 5 and 10 x 10 stages: 576 / 240 / 288 / 144 / 120 channels, 5 x 5 taps).  The
+// row kernel above restages the whole [taps][c] weight table per output image row -- 57.6 KB for 3 outputs per thread at 576 x 5 x 5:
+// 783 us for 236 MB (0.3 TB/s).  Here a workgroup owns a 64-channel slab: its weights (taps x 64) are staged once, then it walks over
+// images, bringing each image's slab (h w x 64 floats <= 25.6 KB) into LDS once and computing every output of it from LDS -- the
+// input is read from memory exactly once, in 256-byte runs.  Same taps in the same order per channel: identical bits.
+constexpr int DW_SLAB = 64;   // channels per workgroup (16 chunks of 4)
+__global__ __launch_bounds__(256) void dwconv_small_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
+                                                           const float *__restrict__ bias, float *__restrict__ out, int n, int h, int w,
+                                                           int c, int kh, int kw, int stride, int pad, int ho, int wo, int act) {
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    const int taps = kh * kw;
+    float *wt = dw_lds;                       // [taps][64]
+    float *xs = dw_lds + taps * DW_SLAB;      // [h w][64]
+    const int c0 = blockIdx.x * DW_SLAB;
+    const int cs = c - c0 < DW_SLAB ? c - c0 : DW_SLAB;   // channels of this slab (a multiple of 4)
+    for (int e = threadIdx.x; e < taps * DW_SLAB; e += 256) {
+        const int tp = e >> 6, ch = e & 63;
+        wt[e] = ch < cs ? wgt[(int64_t)(c0 + ch) * taps + tp] : 0.f;
+    }
+    const int q = threadIdx.x & 15;           // this thread's chunk of the slab, for staging and for its outputs
+    const bool qok = q * 4 < cs;
+    f32x4_t bz = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (bias && qok) bz = *(const f32x4_t *)(bias + c0 + q * 4);
+    const int hw = h * w, howo = ho * wo;
+    for (int img = blockIdx.y; img < n; img += gridDim.y) {
+        const float *ximg = x + (int64_t)img * hw * c + c0;
+        __syncthreads();   // the previous image's readers are done (and, the first time, the weights are written)
+        for (int pix = threadIdx.x >> 4; pix < hw; pix += 16)
+            if (qok) *(f32x4_t *)(xs + pix * DW_SLAB + q * 4) = *(const f32x4_t *)(ximg + (int64_t)pix * c + q * 4);
+        __syncthreads();
+        float *oimg = out + (int64_t)img * howo * c + c0;
+        for (int op = threadIdx.x >> 4; op < howo; op += 16) {
+            const int oy = op / wo, ox = op - oy * wo;
+            const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
+            f32x4_t a = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < kh; ++i) {
+                const int iy = iy0 + i;
+                if (iy < 0 || iy >= h) continue;
+                for (int j = 0; j < kw; ++j) {
+                    const int ix = ix0 + j;
+                    if (ix < 0 || ix >= w) continue;
+                    const f32x4_t xv = *(const f32x4_t *)(xs + (iy * w + ix) * DW_SLAB + q * 4);
+                    const f32x4_t wv = *(const f32x4_t *)(wt + (i * kw + j) * DW_SLAB + q * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = fmaf(xv[r], wv[r], a[r]);
+                }
+            }
+            a += bz;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = activate(a[r], act);
+            if (qok) *(f32x4_t *)(oimg + (int64_t)op * c + q * 4) = a;
+        }
     }
 }
 
@@ -920,6 +1029,20 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
             return VSC_OK;
         }
     }
+    // 3 -> 8 / 16 / 32 channels, 3 x 3: the direct stem kernel (conv_stem3_kernel)
+    {
+        const char *se = vsc_opt(OPT_CONV_STEM);   // diagnostic / test switch: 0 = the GEMM path
+        const bool stem = !(se && se[0] == '0') && cin == 3 && ldx == 3 && kh == 3 && kw == 3 && (cout == 8 || cout == 16 || cout == 32) && !res_dev &&
+                          (ldo & 3) == 0 && (((uintptr_t)out_dev | (uintptr_t)(bias_dev ? bias_dev : out_dev)) & 15) == 0 && rows < (1ll << 31) * 256;
+        if (stem) {
+            const dim3 grid((unsigned)((rows + 255) / 256));
+#define VSC_STEM(C) hipLaunchKernelGGL(conv_stem3_kernel<C>, grid, dim3(256), 0, stream, x_dev, w_packed_dev, bias_dev, out_dev, rows, h, w, kpad, stride, pad, ho, wo, ldo, act)
+            if (cout == 8) VSC_STEM(8); else if (cout == 16) VSC_STEM(16); else VSC_STEM(32);
+#undef VSC_STEM
+            VSC_CHECK_LAUNCH();
+            return VSC_OK;
+        }
+    }
     // 1 x 1 expansion from 64 channels: the streaming kernel (conv1x1_expand64_kernel)
     {
         const char *ee = vsc_opt(OPT_CONV_EXPAND);   // diagnostic / test switch: 0 = the tile kernels
@@ -1034,7 +1157,16 @@ extern "C" int vsc_dwconv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_
     const int64_t total = n * ho * wo * c;
     const size_t wbytes = (size_t)kh * kw * c * 4;
     const bool aligned = ((((uintptr_t)x_dev) | ((uintptr_t)out_dev) | (bias_dev ? (uintptr_t)bias_dev : 0)) & 15) == 0;
-    if ((c & 3) == 0 && aligned && wbytes <= 64 * 1024 && n * ho < (1ll << 31)) {
+    const size_t small_bytes = ((size_t)kh * kw + (size_t)h * w) * DW_SLAB * 4;
+    const char *se = vsc_opt(OPT_DWCONV_SMALL);   // diagnostic / test switch: 0 = the row kernel
+    if ((c & 3) == 0 && aligned && small_bytes <= 40 * 1024 && n < (1ll << 31) && !(se && se[0] == '0')) {
+        // small maps: a workgroup per (64-channel slab, image group), about eight workgroups per CU in flight
+        const int slabs = (c + DW_SLAB - 1) / DW_SLAB;
+        int64_t gy = 2048 / slabs;
+        gy = gy < 1 ? 1 : (gy > n ? n : gy);
+        hipLaunchKernelGGL(dwconv_small_kernel, dim3(slabs, (unsigned)gy), dim3(256), small_bytes, (hipStream_t)stream_, x_dev, w_dev, bias_dev,
+                           out_dev, (int)n, h, w, c, kh, kw, stride, pad, ho, wo, act);
+    } else if ((c & 3) == 0 && aligned && wbytes <= 64 * 1024 && n * ho < (1ll << 31)) {
         static bool attr_set[16] = {};
         int dev = 0;
         VSC_CHECK_HIP(hipGetDevice(&dev));
