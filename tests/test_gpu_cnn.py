@@ -173,6 +173,40 @@ def test_conv2d_1x1_expansion_stream_kernel(dev, n, h, w, cout, res, act):
     assert torch.equal(wide[..., 4:4 + cout], got) and (wide[..., :4] == 3).all() and (wide[..., 4 + cout:] == 3).all()
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,res,act", [
+    (48, 40, 40, 16, 72, False, "relu"),          # the classifier's first expansion: 3 channel blocks, the last one 8 wide
+    (150, 20, 20, 24, 88, False, "relu"),         # cin % 8 == 4: a pixel's pad chunk reads the next pixel (zero weights)
+    (400, 10, 10, 40, 240, False, "hard_swish"),
+    (401, 10, 10, 48, 288, False, "hard_swish"),  # two channel groups of 256 (grid.y), ragged last tile
+    (1400, 5, 5, 96, 576, False, "hard_swish"),   # three groups, 128-pixel tiles
+    (350, 10, 10, 88, 176, True, None),           # with a residual
+])
+def test_conv2d_pointwise_stream_kernel(dev, n, h, w, cin, cout, res, act):
+    """conv1x1_stream_kernel (any cin % 4 == 0 up to 96, all output channels of a pixel tile in one workgroup) against torch and,
+    bit for bit, against the tile kernels (VSC_CONV_EXPAND=0)."""
+    from vsc_hip import cnn
+    rng = np.random.RandomState(cin + cout)
+    sd = {"c.weight": torch.from_numpy((rng.randn(cout, cin, 1, 1) / np.sqrt(cin)).astype(np.float32)),
+          "c.bias": torch.from_numpy(rng.randn(cout).astype(np.float32) * 0.1)}
+    x = torch.from_numpy(rng.randn(n, h, w, cin).astype(np.float32)).to(dev)
+    r = torch.from_numpy(rng.randn(n, h, w, cout).astype(np.float32)).to(dev) if res else None
+    conv = cnn.Conv(sd, "c", None, 1, dev)
+    got = conv(x, act=act, residual=r).clone()
+    _vsc_lib.set_option("VSC_CONV_EXPAND", "0")
+    try:
+        tile = conv(x, act=act, residual=r).clone()
+    finally:
+        _vsc_lib.set_option("VSC_CONV_EXPAND", None)
+    want = F.conv2d(x.cpu().permute(0, 3, 1, 2), sd["c.weight"], sd["c.bias"])
+    if res:
+        want = want + r.cpu().permute(0, 3, 1, 2)
+    want = {"relu": F.relu, "hard_swish": F.hardswish, None: lambda v: v}[act](want)
+    assert torch.allclose(got.cpu().permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)
+    assert torch.equal(got.view(torch.int32), tile.view(torch.int32))
+    for _ in range(3):
+        assert torch.equal(conv(x, act=act, residual=r), got)
+
+
 @pytest.mark.parametrize("n,h,w,cout,stride,act", [
     (3, 160, 160, 16, 2, "hard_swish"),     # the classifier's stem at its resolution
     (2, 37, 53, 16, 2, "relu"),             # odd sizes: the last band of output rows is ragged

@@ -664,6 +664,97 @@ __global__ __launch_bounds__(512, 1) void conv1x1_expand64_kernel(ExpandArgs p) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The same streaming form for the classifier's pointwise layers with few input channels (16 -> 72, 24 -> 88 / 96, 40 -> 120 / 240,
+// 48 -> 144 / 288, 96 -> 576: on the 32-channel x 256-pixel tile kernel every channel tile re-gathers the pixels and writes 16-byte
+// pieces of 288..2304-byte rows at its own time: 1.1-2.0 TB/s).  CP = chunk pairs per pixel (input channels rounded up to 8);
+// a tile = TP pixels x the workgroup's 128 channels (grid.y groups: all of a pixel's channels are written within one tile time); weights of a wave's 32 channels in CP x 4 VGPRs; a pixel's pad chunk (cin % 8 == 4) reads the next pixel's
+// first channels -- finite values against zero weights.  The k order is the tile kernels' (chunk pairs of 32-float slabs): same bits.
+template <int CP>
+__global__ __launch_bounds__(256, CP <= 3 ? 4 : 3) void conv1x1_stream_kernel(ExpandArgs p, int cin, int kpad) {
+    // four waves = 128 channels per workgroup, 128- / 64-pixel tiles: 16-48 KiB of LDS and <= 128 / 168 VGPRs, so three or four
+    // workgroups share a CU.  The K loop of these layers is a few MFMAs; what a tile costs is the round trip of its input and the
+    // drain of its stores, and only other workgroups' tiles can fill that time (one 8-wave workgroup per CU: 16 -> 72 at 2.0 TB/s)
+    constexpr int PITCH = 32 * CP;                       // bytes per pixel in LDS
+    constexpr int TP = CP <= 6 ? 128 : 64, NB = TP / 32, BUF = TP * PITCH;
+    constexpr int PIECES = BUF / 1024;                   // 1-KiB LDS-DMA pieces per tile
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ch = (blockIdx.y * 4 + wave) * 32 + l31;
+    const bool active = (blockIdx.y * 4 + wave) * 32 < p.cout;   // wave-uniform
+    const bool mine = ch < p.cout;                                // this lane's channel exists
+    f32x4_t wf[CP];
+#pragma unroll
+    for (int pr = 0; pr < CP; ++pr)
+        wf[pr] = mine ? *(const f32x4_t *)(p.wp + (int64_t)ch * kpad + (2 * pr + hi) * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const float bias = mine && p.bias ? p.bias[ch] : 0.f;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)(p.rows * cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)(p.rows * p.ldo * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), 0, (int)(p.rows * (p.res ? p.ldr : p.ldo) * 4), 0x00020000);
+    const uint32_t ovoff = mine ? (uint32_t)(4 * hi * p.ldo + ch) * 4u : 0xfffffff0u, rvoff = mine ? (uint32_t)(4 * hi * p.ldr + ch) * 4u : 0xfffffff0u;
+    auto stage = [&](int64_t t, int b) {
+#pragma unroll
+        for (int j = 0; j < (PIECES + 3) / 4; ++j) {
+            const int piece = j * 4 + wave;
+            if (piece >= PIECES) break;   // wave-uniform
+            const int o = piece * 1024 + lane * 16;
+            const int r = o / PITCH, cb = o - r * PITCH;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(lds + b * BUF + piece * 1024), 16,
+                                                     (uint32_t)((t * TP + r) * cin * 4 + cb), 0, 0, 0);
+        }
+    };
+    int64_t t = blockIdx.x;
+    if (t >= p.ntiles) return;
+    stage(t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (; t < p.ntiles; t += gridDim.x, buf ^= 1) {
+        if (t + gridDim.x < p.ntiles) stage(t + gridDim.x, buf ^ 1);
+        const int64_t p0 = t * TP;
+        f32x16_t acc[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[blk][r] = 0.f;
+        if (active) {
+            const char *xb = lds + buf * BUF;
+#pragma unroll
+            for (int pr = 0; pr < CP; ++pr)
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) {
+                    const f32x4_t af = *(const f32x4_t *)(xb + (blk * 32 + l31) * PITCH + (2 * pr + hi) * 16);
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k4], wf[pr][k4], acc[blk], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile's input has landed (and the previous tile's stores are out)
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                float rs[16];
+                if (p.res) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        rs[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rrsrc, rvoff, (uint32_t)(p0 + blk * 32 + 8 * (reg >> 2) + (reg & 3)) * (uint32_t)(p.ldr * 4), 0));
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float v = acc[blk][reg] + bias;
+                    if (p.res) v += rs[reg];
+                    v = activate(v, p.act);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orsrc, ovoff,
+                                                          (uint32_t)(p0 + blk * 32 + 8 * (reg >> 2) + (reg & 3)) * (uint32_t)(p.ldo * 4), 0);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Stem of the classifier: 3 x 3 convolution from 3 input channels (K = 27) to <= 32 channels at 160 x 160, stride 2.  On the GEMM
 // path it materialises a [pixels, 32] patch matrix (1.7 GB written and read for 0.6 GB of input; 1229 us).  Direct form: a thread
 // owns one output pixel -- its 27 inputs in registers (neighbouring threads' patches overlap: L1 hits), all COUT channels, the
@@ -1055,6 +1146,31 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
             ExpandArgs a{x_dev, w_packed_dev, bias_dev, res_dev, out_dev, rows, (rows + 127) / 128, cout, ldo, ldr, act};
             const unsigned grid = (unsigned)(a.ntiles < cus_expand[dev] ? a.ntiles : cus_expand[dev]);
             hipLaunchKernelGGL(conv1x1_expand64_kernel, dim3(grid), dim3(512), 0, stream, a);
+            VSC_CHECK_LAUNCH();
+            return VSC_OK;
+        }
+    }
+    // pointwise layers with <= 96 input channels and >= 2 x as many outputs on many pixels: the streaming kernel for any cin % 4 == 0
+    {
+        const char *ee = vsc_opt(OPT_CONV_EXPAND);
+        const char *nm2 = vsc_opt(OPT_CONV_STREAM_MIN_COUT);   // diagnostic: smallest cout taken (default 2 cin)
+        const int cp = (cin + 7) / 8;
+        const bool strm = !(ee && ee[0] == '0') && kh == 1 && kw == 1 && stride == 1 && pad == 0 && ldx == cin && (cin & 3) == 0 && cin >= 16 && cin <= 96 &&
+                          cout >= (nm2 ? atoi(nm2) : 2 * cin) && rows >= 128 * 256 && rows * (int64_t)ldo * 4 < (1ll << 31) && rows * (int64_t)cin * 4 < (1ll << 31) &&
+                          (!res_dev || rows * (int64_t)ldr * 4 < (1ll << 31)) && (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 &&
+                          (cp == 2 || cp == 3 || cp == 5 || cp == 6 || cp == 11 || cp == 12);
+        if (strm) {
+            static int cus_strm[16] = {};
+            if (!cus_strm[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_strm[dev], hipDeviceAttributeMultiprocessorCount, dev));
+            const int tp = cp <= 6 ? 128 : 64, groups = (cout + 127) / 128;
+            ExpandArgs a{x_dev, w_packed_dev, bias_dev, res_dev, out_dev, rows, (rows + tp - 1) / tp, cout, ldo, ldr, act};
+            const int resident = cus_strm[dev] * (cp <= 3 ? 4 : 3);
+            const int per = resident / groups > 0 ? resident / groups : 1;
+            const dim3 grid((unsigned)(a.ntiles < per ? a.ntiles : per), groups);
+#define VSC_STRM(C) hipLaunchKernelGGL(conv1x1_stream_kernel<C>, grid, dim3(256), 0, stream, a, cin, kpad)
+            switch (cp) { case 2: VSC_STRM(2); break; case 3: VSC_STRM(3); break; case 5: VSC_STRM(5); break; case 6: VSC_STRM(6); break;
+                          case 11: VSC_STRM(11); break; default: VSC_STRM(12); }
+#undef VSC_STRM
             VSC_CHECK_LAUNCH();
             return VSC_OK;
         }
