@@ -109,18 +109,26 @@ def test_conv2d_direct_3x3_matches_torch_and_the_gemm_path(dev, n, h, w, cin, co
     x = torch.from_numpy(rng.randn(n, h, w, cin).astype(np.float32)).to(dev)
     r = torch.from_numpy(rng.randn(n, h, w, cout).astype(np.float32)).to(dev) if res else None
     conv = cnn.Conv(sd, "c", None, 1, dev)
-    got = conv(x, act="relu", residual=r).clone()
+    got = conv(x, act="relu", residual=r).clone()   # 20 -> <= 20 channels: the split-bf16 kernel (conv3x3_direct_x3_kernel); else the fp32 one
+    _vsc_lib.set_option("VSC_CONV_X3", "0")
+    try:
+        f32 = conv(x, act="relu", residual=r).clone()   # conv3x3_direct_kernel on the fp32 matrix pipe
+    finally:
+        _vsc_lib.set_option("VSC_CONV_X3", None)
     _vsc_lib.set_option("VSC_CONV_DIRECT", "0")
     try:
         gemm = conv(x, act="relu", residual=r).clone()
     finally:
         _vsc_lib.set_option("VSC_CONV_DIRECT", None)
-    want = F.conv2d(x.cpu().permute(0, 3, 1, 2), sd["c.weight"], sd["c.bias"], padding=1)
+    want = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), sd["c.weight"].double(), sd["c.bias"].double(), padding=1)
     if res:
-        want = want + r.cpu().permute(0, 3, 1, 2)
+        want = want + r.double().cpu().permute(0, 3, 1, 2)
     want = F.relu(want)
-    assert torch.allclose(got.cpu().permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)
-    assert torch.allclose(got, gemm, atol=5e-6, rtol=1e-5)
+    assert torch.allclose(got.double().cpu().permute(0, 3, 1, 2), want, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(got, gemm, atol=5e-6, rtol=1e-5) and torch.allclose(f32, gemm, atol=5e-6, rtol=1e-5)
+    # the split-bf16 products (x1 w1 + x1 w2 + x2 w1 + x1 w3 + x3 w1 + x2 w2, fp32 accumulation) are as close to float64 as the fp32 pipe's
+    e_x3, e_f32 = float((got.double().cpu().permute(0, 3, 1, 2) - want).abs().max()), float((f32.double().cpu().permute(0, 3, 1, 2) - want).abs().max())
+    assert e_x3 < 2.0 * e_f32 + 1e-6, (e_x3, e_f32)
     assert not torch.equal(got, torch.zeros_like(got))
     for _ in range(3):   # run-to-run bit equality (the halo tiles arrive by LDS-DMA: a missing wait shows up as flicker)
         assert torch.equal(conv(x, act="relu", residual=r), got)

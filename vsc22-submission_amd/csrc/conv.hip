@@ -427,6 +427,7 @@ struct DirectArgs {
     int tiles_x, tiles_y;
     int64_t ntiles;
     unsigned xbytes;
+    int cin4;   // input channels / 4 (the split-bf16 kernel pads them to chunk pairs itself)
 };
 
 // NACC accumulators per wave (32 output channels each), WR weight rows kept in LDS (>= cout; a lane whose channel row does not
@@ -808,6 +809,188 @@ __global__ __launch_bounds__(256) void conv_stem3_kernel(const float *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The direct 3 x 3 convolution on the bf16 matrix pipe with fp32-level accuracy (split operands): every fp32 value is written as
+// x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (24 significant bits together), likewise the
+// weights, and a product is taken as x1 w1 + x1 w2 + x2 w1 + x1 w3 + x3 w1 + x2 w2 -- the dropped terms are below 2^-24 |x w|, the
+// size of an fp32 rounding -- on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 6 instructions of 16 cycles per 16 x 16 x 32
+// block against 16 fp32 instructions of 64 cycles per 32 x 32 x 32: 2.7 x the fp32 pipe's rate on the same products.
+//   * halo tile and weights live in LDS as three bf16 planes each; the split happens on the way in (the halo passes through
+//     registers: 6 VALU instructions per value, each value then feeds 9 taps x cout products);
+//   * M = output channels (NRT tiles of 16), N = pixels (a wave = one output row of 32 = two tiles), K = (tap, channel) flattened in
+//     4-channel chunks, 8 chunks per MFMA; a lane's two chunks may come from different taps (two 8-byte halo reads);
+//   * a lane ends up with 4 consecutive channels of one pixel: 16-byte residual loads and stores;
+//   * 78 KiB of LDS (one halo buffer): two workgroups per CU; the next tile's halo is loaded into registers before the MFMAs and
+//     split into LDS after them.
+__device__ __forceinline__ void split_bf16x3(f32x4_t v, uint2 &p1, uint2 &p2, uint2 &p3) {
+    auto hi = [](uint32_t pk, int i) { return __builtin_bit_cast(float, i ? (pk & 0xffff0000u) : (pk << 16)); };
+    p1.x = pack_bf16x2(v[0], v[1]);
+    p1.y = pack_bf16x2(v[2], v[3]);
+    const float r0 = v[0] - hi(p1.x, 0), r1 = v[1] - hi(p1.x, 1), r2 = v[2] - hi(p1.y, 0), r3 = v[3] - hi(p1.y, 1);
+    p2.x = pack_bf16x2(r0, r1);
+    p2.y = pack_bf16x2(r2, r3);
+    p3.x = pack_bf16x2(r0 - hi(p2.x, 0), r1 - hi(p2.x, 1));
+    p3.y = pack_bf16x2(r2 - hi(p2.y, 0), r3 - hi(p2.y, 1));
+}
+
+// CP = 8-channel chunk pairs per pixel (input channels rounded up to 8: 20 -> 24, 36 -> 40), WR = weight rows kept in LDS (>= cout),
+// NRT = 16-row tiles of output channels.
+template <int CP, int WR, int NRT>
+__global__ __launch_bounds__(512, 4) void conv3x3_direct_x3_kernel(DirectArgs p) {
+    constexpr int TH = 8, TW = 32, HW = TW + 2, HH = TH + 2, HPIX = HW * HH;
+    constexpr int NPAIR = 9 * CP, NBLK = (NPAIR + 3) / 4;              // chunk pairs of K (8 channels of one tap), MFMA blocks of 4 pairs
+    constexpr int PIXB = CP * 16, PLANE = HPIX * PIXB;                 // halo: bytes per pixel and per plane
+    constexpr int WROWB = NBLK * 64 + 16, WPLANE = WR * WROWB;         // weights: bytes per row (16 B of padding: conflict-free b128 reads) and per plane
+    constexpr int ITEMS = (HPIX * CP + 511) / 512;
+    __shared__ __attribute__((aligned(16))) char lds[3 * WPLANE + 3 * PLANE];
+    char *wl = lds, *halo = lds + 3 * WPLANE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, g = lane >> 4;
+    const int cin4 = p.kpad;   // (unused name guard)
+    (void)cin4;
+    const int cq_real = p.cin4;   // real 4-channel chunks per pixel (5 for 20 channels)
+    // ---- weights: row r, pair q = (tap, 8 channels) of the packed fp32 row (k = tap cin + ci) -> three planes; zeros past cin / K
+    for (int e = tid; e < WR * NBLK * 8; e += 512) {
+        const int r = e / (NBLK * 8), hc = e - r * (NBLK * 8);          // hc: half-chunk index = 2 pair + half
+        const int pair = hc >> 1, tap = pair / CP, cq = (pair - tap * CP) * 2 + (hc & 1);
+        f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (r < p.cout && pair < NPAIR && cq < cq_real) v = *(const f32x4_t *)(p.wp + (int64_t)r * p.kpad + (tap * cq_real + cq) * 4);
+        uint2 w1, w2, w3;
+        split_bf16x3(v, w1, w2, w3);
+        *(uint2 *)(wl + r * WROWB + hc * 8) = w1;
+        *(uint2 *)(wl + WPLANE + r * WROWB + hc * 8) = w2;
+        *(uint2 *)(wl + 2 * WPLANE + r * WROWB + hc * 8) = w3;
+    }
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.xbytes, 0x00020000);
+    // this thread's halo items (pixel, pair): position inside the halo and byte offset relative to the tile's first halo pixel
+    int hyx[ITEMS], rel[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = j * 512 + tid;
+        const int pix = e / CP, pr = e - pix * CP;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        hyx[j] = pix < HPIX ? (hy << 16) | hx : -1;
+        rel[j] = ((hy * p.w + hx) * p.ldx + pr * 8) * 4;
+    }
+    f32x4_t nxt[ITEMS][2];
+    auto fetch = [&](int64_t t) {   // the halo of tile t into registers (pixels outside the image: past the descriptor, zeros)
+        const int tx = (int)(t % p.tiles_x);
+        const int64_t t2 = t / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y), img = (int)(t2 / p.tiles_y);
+        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+        const int base = (((img * p.h + iy0) * p.w + ix0) * p.ldx) * 4;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int iy = iy0 + (hyx[j] >> 16), ix = ix0 + (hyx[j] & 0xffff);
+            const bool ok = hyx[j] >= 0 && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+            const int pr = (j * 512 + tid) % CP;
+            const unsigned v0 = ok ? (unsigned)(base + rel[j]) : 0x80000000u;
+            const unsigned v1 = ok && pr * 2 + 1 < cq_real ? v0 + 16u : 0x80000000u;   // the pair's second half past cin: zeros
+            nxt[j][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, v0, 0, 0));
+            nxt[j][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, v1, 0, 0));
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int e = j * 512 + tid;
+            if (e >= HPIX * CP) break;
+            uint2 a1, a2, a3, b1, b2, b3;
+            split_bf16x3(nxt[j][0], a1, a2, a3);
+            split_bf16x3(nxt[j][1], b1, b2, b3);
+            *(uint4 *)(halo + e * 16) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+            *(uint4 *)(halo + PLANE + e * 16) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+            *(uint4 *)(halo + 2 * PLANE + e * 16) = make_uint4(a3.x, a3.y, b3.x, b3.y);
+        }
+    };
+    // halo byte offset of this lane group's pair in every MFMA block (pair q -> tap q / CP, channels 8 (q % CP) ..); the pad pairs of
+    // the last block re-read the last real one (their weights are zero)
+    int offx[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        int q = 4 * b + g;
+        q = q < NPAIR ? q : NPAIR - 1;
+        const int tap = q / CP, pr = q - tap * CP;
+        offx[b] = ((tap / 3) * HW + tap % 3) * PIXB + pr * 16;
+    }
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)((int64_t)p.n * p.h * p.w * p.ldo * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), 0, (int)((int64_t)p.n * p.h * p.w * (p.res ? p.ldr : p.ldo) * 4), 0x00020000);
+    int64_t t = blockIdx.x;
+    if (t >= p.ntiles) return;
+    fetch(t);
+    int wrow[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+        const int r = rt * 16 + lc;
+        wrow[rt] = (r < WR ? r : WR - 1) * WROWB + g * 16;
+    }
+    for (; t < p.ntiles; t += gridDim.x) {
+        __syncthreads();   // every wave is done reading the halo of the previous tile
+        deposit();
+        __syncthreads();
+        if (t + gridDim.x < p.ntiles) fetch(t + gridDim.x);
+        const int tx = (int)(t % p.tiles_x);
+        const int64_t t2 = t / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y);
+        const int img = (int)(t2 / p.tiles_y);
+        const int oy = ty * TH + wave;
+        f32x4_t acc[NRT][2];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) acc[rt][pt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const char *hb = halo + (wave * HW + lc) * PIXB;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            bf16x8_t xo[3][2], wo[3][NRT];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) xo[pl][pt] = *(const bf16x8_t *)(hb + offx[b] + pl * PLANE + pt * 16 * PIXB);
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt) wo[pl][rt] = *(const bf16x8_t *)(wl + wrow[rt] + pl * WPLANE + b * 64);
+            }
+            constexpr int TW_[6] = {1, 2, 0, 1, 0, 0}, TX_[6] = {1, 0, 2, 0, 1, 0};   // (w plane, x plane), smallest terms first
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+                        acc[rt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[TW_[term]][rt], xo[TX_[term]][pt], acc[rt][pt], 0, 0, 0);
+        }
+        // a lane holds channels 16 rt + 4 g .. + 3 of pixel (oy, tx TW + 16 pt + lc): 16-byte residual loads and stores through buffer
+        // descriptors (pixels / channel groups that do not exist: an offset past the extent)
+        const bool vec = ((p.ldo | p.ldr) & 3) == 0;
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int ox = tx * TW + pt * 16 + lc, co = rt * 16 + 4 * g;
+                const bool ok = oy < p.h && ox < p.w && co < p.cout;
+                const int pix = (img * p.h + oy) * p.w + ox;
+                f32x4_t v = acc[rt][pt];
+                if (vec && co + 3 < p.cout) {
+                    const unsigned ro = ok ? (unsigned)((pix * p.ldr + co) * 4) : 0x80000000u, oo = ok ? (unsigned)((pix * p.ldo + co) * 4) : 0x80000000u;
+                    if (p.bias) v += *(const f32x4_t *)(p.bias + co);
+                    if (p.res) v += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ro, 0, 0));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = activate(v[r], p.act);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vsc_u32x4_t, v), orsrc, oo, 0, 0);
+                } else if (ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (co + r < p.cout) {
+                            float s = v[r] + (p.bias ? p.bias[co + r] : 0.f);
+                            if (p.res) s += p.res[(int64_t)pix * p.ldr + co + r];
+                            p.out[(int64_t)pix * p.ldo + co + r] = activate(s, p.act);
+                        }
+                }
+            }
+    }
+}
+
 // depthwise: one thread per (pixel, channel); w [c, kh * kw]
 __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
                                                      const float *__restrict__ bias, float *__restrict__ out, int64_t total,
@@ -1105,14 +1288,16 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
                             (!res_dev || ldr >= cout);
         if (direct) {
             DirectArgs a{x_dev, w_packed_dev, bias_dev, res_dev, out_dev, (int)n, h, w, ldx, cout, kpad, ldo, ldr, act,
-                         (w + 31) / 32, (h + 7) / 8, 0, (unsigned)xbytes};
+                         (w + 31) / 32, (h + 7) / 8, 0, (unsigned)xbytes, cin / 4};
             a.ntiles = (int64_t)a.tiles_x * a.tiles_y * n;
             static int cus_direct[16] = {};
             if (!cus_direct[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_direct[dev], hipDeviceAttributeMultiprocessorCount, dev));
             const bool two = cin == 20 && cout <= 32;   // workgroups per CU (LDS)
             const int64_t resident = (two ? 2ll : 1ll) * cus_direct[dev];
             const unsigned grid = (unsigned)(a.ntiles < resident ? a.ntiles : resident);
-            if (cin == 20 && cout <= 32) hipLaunchKernelGGL((conv3x3_direct_kernel<5, 1, 32>), dim3(grid), dim3(512), 0, stream, a);
+            const char *x3 = vsc_opt(OPT_CONV_X3);   // diagnostic / test switch: 0 = the fp32-pipe kernels everywhere
+            if (!(x3 && x3[0] == '0') && cin == 20 && cout <= 20 && n * (int64_t)h * w * (ldo > ldr ? ldo : ldr) * 4 < (1ll << 31)) hipLaunchKernelGGL((conv3x3_direct_x3_kernel<3, 20, 2>), dim3(grid), dim3(512), 0, stream, a);
+            else if (cin == 20 && cout <= 32) hipLaunchKernelGGL((conv3x3_direct_kernel<5, 1, 32>), dim3(grid), dim3(512), 0, stream, a);
             else if (cin == 20) hipLaunchKernelGGL((conv3x3_direct_kernel<5, 2, 40>), dim3(grid), dim3(512), 0, stream, a);
             else if (cout <= 32) hipLaunchKernelGGL((conv3x3_direct_kernel<9, 1, 32>), dim3(grid), dim3(512), 0, stream, a);
             else hipLaunchKernelGGL((conv3x3_direct_kernel<9, 2, 40>), dim3(grid), dim3(512), 0, stream, a);
