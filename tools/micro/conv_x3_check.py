@@ -3,12 +3,13 @@ sys.path.insert(0, "/root/repo/vsc22-submission_amd"); sys.path.insert(0, "/root
 import numpy as np, torch, torch.nn.functional as F
 from vsc_hip import cnn, _lib
 dev = torch.device("cuda:0")
-for (n, h, w, cin, cout, res) in [(2, 16, 32, 20, 18, True), (3, 21, 45, 20, 20, True), (1, 5, 3, 20, 18, False), (16, 56, 56, 20, 18, True), (1, 8, 33, 20, 32, False), (16, 224, 224, 20, 20, True)]:
+for (n, h, w, cin, cout, res) in [(2, 19, 40, 36, 36, True), (16, 28, 28, 36, 36, True), (16, 112, 112, 36, 36, True), (2, 16, 32, 20, 18, True), (3, 21, 45, 20, 20, True), (1, 5, 3, 20, 18, False), (16, 56, 56, 20, 18, True), (1, 8, 33, 20, 32, False), (16, 224, 224, 20, 20, True)]:
     rng = np.random.RandomState(cin + h)
     sd = {"c.weight": torch.from_numpy((rng.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)).astype(np.float32)), "c.bias": torch.from_numpy(rng.randn(cout).astype(np.float32) * 0.1)}
     x = torch.from_numpy(rng.randn(n, h, w, cin).astype(np.float32)).to(dev)
     r = torch.from_numpy(rng.randn(n, h, w, cout).astype(np.float32)).to(dev) if res else None
     conv = cnn.Conv(sd, "c", None, 1, dev)
+    _lib.set_option("VSC_CONV_X3", "0")
     ref = conv(x, act="relu", residual=r).clone()
     _lib.set_option("VSC_CONV_X3", "1")
     got = conv(x, act="relu", residual=r).clone()
@@ -17,11 +18,12 @@ for (n, h, w, cin, cout, res) in [(2, 16, 32, 20, 18, True), (3, 21, 45, 20, 20,
     for it in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); conv(x, act="relu", residual=r); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
-    _lib.set_option("VSC_CONV_X3", None)
+    _lib.set_option("VSC_CONV_X3", "0")
     t0 = []
     for it in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); conv(x, act="relu", residual=r); e1.record(); torch.cuda.synchronize(); t0.append(e0.elapsed_time(e1) * 1e3)
+    _lib.set_option("VSC_CONV_X3", None)
     want = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), sd["c.weight"].double(), sd["c.bias"].double(), padding=1)
     if res: want = want + r.double().cpu().permute(0, 3, 1, 2)
     want = F.relu(want).permute(0, 2, 3, 1)

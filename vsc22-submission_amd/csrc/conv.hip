@@ -834,10 +834,12 @@ __device__ __forceinline__ void split_bf16x3(f32x4_t v, uint2 &p1, uint2 &p2, ui
 }
 
 // CP = 8-channel chunk pairs per pixel (input channels rounded up to 8: 20 -> 24, 36 -> 40), WR = weight rows kept in LDS (>= cout),
-// NRT = 16-row tiles of output channels.
-template <int CP, int WR, int NRT>
-__global__ __launch_bounds__(512, 4) void conv3x3_direct_x3_kernel(DirectArgs p) {
-    constexpr int TH = 8, TW = 32, HW = TW + 2, HH = TH + 2, HPIX = HW * HH;
+// NRT = 16-row tiles of output channels, NPT = 16-pixel tiles per wave: 2 -> a wave is an output row of an 8 x 32 tile (20 channels:
+// 77 KiB, two workgroups per CU); 1 -> a wave is half a row of a 4 x 32 tile (36 channels: the three weight planes alone are 85
+// KiB, the smaller halo keeps the workgroup at 134 KiB).
+template <int CP, int WR, int NRT, int NPT>
+__global__ __launch_bounds__(512, NPT == 2 ? 4 : 2) void conv3x3_direct_x3_kernel(DirectArgs p) {
+    constexpr int TH = 4 * NPT, TW = 32, HW = TW + 2, HH = TH + 2, HPIX = HW * HH;
     constexpr int NPAIR = 9 * CP, NBLK = (NPAIR + 3) / 4;              // chunk pairs of K (8 channels of one tap), MFMA blocks of 4 pairs
     constexpr int PIXB = CP * 16, PLANE = HPIX * PIXB;                 // halo: bytes per pixel and per plane
     constexpr int WROWB = NBLK * 64 + 16, WPLANE = WR * WROWB;         // weights: bytes per row (16 B of padding: conflict-free b128 reads) and per plane
@@ -934,20 +936,21 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_x3_kernel(DirectArgs p)
         const int64_t t2 = t / p.tiles_x;
         const int ty = (int)(t2 % p.tiles_y);
         const int img = (int)(t2 / p.tiles_y);
-        const int oy = ty * TH + wave;
-        f32x4_t acc[NRT][2];
+        const int wrow_ = NPT == 2 ? wave : wave >> 1, px0 = NPT == 2 ? 0 : (wave & 1) * 16;   // this wave's output row and first pixel in the tile
+        const int oy = ty * TH + wrow_;
+        f32x4_t acc[NRT][NPT];
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt) acc[rt][pt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        const char *hb = halo + (wave * HW + lc) * PIXB;
+            for (int pt = 0; pt < NPT; ++pt) acc[rt][pt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const char *hb = halo + (wrow_ * HW + px0 + lc) * PIXB;
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
-            bf16x8_t xo[3][2], wo[3][NRT];
+            bf16x8_t xo[3][NPT], wo[3][NRT];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt) xo[pl][pt] = *(const bf16x8_t *)(hb + offx[b] + pl * PLANE + pt * 16 * PIXB);
+                for (int pt = 0; pt < NPT; ++pt) xo[pl][pt] = *(const bf16x8_t *)(hb + offx[b] + pl * PLANE + pt * 16 * PIXB);
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt) wo[pl][rt] = *(const bf16x8_t *)(wl + wrow[rt] + pl * WPLANE + b * 64);
             }
@@ -957,17 +960,17 @@ __global__ __launch_bounds__(512, 4) void conv3x3_direct_x3_kernel(DirectArgs p)
 #pragma unroll
                 for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
+                    for (int pt = 0; pt < NPT; ++pt)
                         acc[rt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[TW_[term]][rt], xo[TX_[term]][pt], acc[rt][pt], 0, 0, 0);
         }
-        // a lane holds channels 16 rt + 4 g .. + 3 of pixel (oy, tx TW + 16 pt + lc): 16-byte residual loads and stores through buffer
+        // a lane holds channels 16 rt + 4 g .. + 3 of pixel (oy, tx TW + px0 + 16 pt + lc): 16-byte residual loads and stores through buffer
         // descriptors (pixels / channel groups that do not exist: an offset past the extent)
         const bool vec = ((p.ldo | p.ldr) & 3) == 0;
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                const int ox = tx * TW + pt * 16 + lc, co = rt * 16 + 4 * g;
+            for (int pt = 0; pt < NPT; ++pt) {
+                const int ox = tx * TW + px0 + pt * 16 + lc, co = rt * 16 + 4 * g;
                 const bool ok = oy < p.h && ox < p.w && co < p.cout;
                 const int pix = (img * p.h + oy) * p.w + ox;
                 f32x4_t v = acc[rt][pt];
@@ -1296,7 +1299,16 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
             const int64_t resident = (two ? 2ll : 1ll) * cus_direct[dev];
             const unsigned grid = (unsigned)(a.ntiles < resident ? a.ntiles : resident);
             const char *x3 = vsc_opt(OPT_CONV_X3);   // diagnostic / test switch: 0 = the fp32-pipe kernels everywhere
-            if (!(x3 && x3[0] == '0') && cin == 20 && cout <= 20 && n * (int64_t)h * w * (ldo > ldr ? ldo : ldr) * 4 < (1ll << 31)) hipLaunchKernelGGL((conv3x3_direct_x3_kernel<3, 20, 2>), dim3(grid), dim3(512), 0, stream, a);
+            if (!(x3 && x3[0] == '0') && cin == 36 && cout <= 36 && n * (int64_t)h * w * (ldo > ldr ? ldo : ldr) * 4 < (1ll << 31)) {
+                DirectArgs b = a;   // 4 x 32 tiles, one workgroup per CU
+                b.tiles_y = (h + 3) / 4;
+                b.ntiles = (int64_t)b.tiles_x * b.tiles_y * n;
+                const unsigned g36 = (unsigned)(b.ntiles < cus_direct[dev] ? b.ntiles : cus_direct[dev]);
+                hipLaunchKernelGGL((conv3x3_direct_x3_kernel<5, 36, 3, 1>), dim3(g36), dim3(512), 0, stream, b);
+                VSC_CHECK_LAUNCH();
+                return VSC_OK;
+            }
+            if (!(x3 && x3[0] == '0') && cin == 20 && cout <= 20 && n * (int64_t)h * w * (ldo > ldr ? ldo : ldr) * 4 < (1ll << 31)) hipLaunchKernelGGL((conv3x3_direct_x3_kernel<3, 20, 2, 2>), dim3(grid), dim3(512), 0, stream, a);
             else if (cin == 20 && cout <= 32) hipLaunchKernelGGL((conv3x3_direct_kernel<5, 1, 32>), dim3(grid), dim3(512), 0, stream, a);
             else if (cin == 20) hipLaunchKernelGGL((conv3x3_direct_kernel<5, 2, 40>), dim3(grid), dim3(512), 0, stream, a);
             else if (cout <= 32) hipLaunchKernelGGL((conv3x3_direct_kernel<9, 1, 32>), dim3(grid), dim3(512), 0, stream, a);
