@@ -499,7 +499,8 @@ def bench_matching(dev, args):
     ref = cnn.HRNetRefineHip(cnn_synth.hrnet_refine_state(3), dev)
     xr = cnn_synth.similarity_maps(4, 16, 224, 224).to(dev)
     dtr, fr = run(ref, xr, 5)
-    return {"dtype": "f32", "peak_tflops": F32_MFMA_PEAK_TFLOPS,
+    return {"dtype": "f32 (HRNet's thin 3 x 3 layers: bf16 pipe on split operands x = x1 + x2 + x3, six products, fp32 accumulation -- fp32-level error)",
+            "peak_tflops": F32_MFMA_PEAK_TFLOPS,
             "classifier": {"model": "mobilenetv3_small_100, 2 classes", "batch": list(xc.shape), "ms": round(dtc * 1e3, 2),
                            "maps_per_s": round(xc.shape[0] / dtc, 0), "gflop_per_map": round(fc / xc.shape[0] / 1e9, 4),
                            "tflops": round(fc / dtc / 1e12, 2), "frac_of_f32_mfma_peak": round(fc / dtc / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},
@@ -507,7 +508,8 @@ def bench_matching(dev, args):
                         "maps_per_s": round(xr.shape[0] / dtr, 1), "gflop_per_map": round(fr / xr.shape[0] / 1e9, 3),
                         "tflops": round(fr / dtr / 1e12, 2), "frac_of_f32_mfma_peak": round(fr / dtr / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},
             "note": "whole-network wall time per batch, inputs resident in HBM; FLOPs = 2 x MACs of every convolution call "
-                    "(depthwise included); parity of these networks is unpinned (DESIGN.md section 3)"}
+                    "(depthwise included), each counted once whatever pipe ran it: frac_of_f32_mfma_peak prices the network against the fp32 matrix pipe; "
+                    "parity of these networks is unpinned (DESIGN.md section 3)"}
 
 
 def main():

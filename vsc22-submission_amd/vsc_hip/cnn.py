@@ -4,7 +4,9 @@
 A model is built once from the reference's state dict (timm parameter names): every Conv+BatchNorm pair is folded into
 one weight / bias, permuted to (cout, kh, kw, cin) and packed for the fp32 MFMA tiles (vsc_conv_pack_weight_f32).  The
 forward pass is a sequence of C-ABI calls on NHWC float32 buffers -- vsc_conv2d_f32 (residual and activation fused),
-vsc_dwconv2d_f32, vsc_global_avgpool_f32, vsc_channel_scale_f32, vsc_upsample_add_f32.  torch provides device memory only.
+vsc_dwconv2d_f32, vsc_global_avgpool_f32, vsc_channel_scale_f32, vsc_upsample_add_f32 / vsc_upsample_sum_f32.  torch provides
+device memory only.  (Which kernel a layer runs on -- fp32 matrix tiles, the streaming pointwise kernels, the direct 3 x 3 kernels on
+fp32 or on split-bf16 operands -- is vsc_conv2d_f32's choice by shape: csrc/conv.hip)
 """
 from __future__ import annotations
 
