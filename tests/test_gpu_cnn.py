@@ -244,6 +244,42 @@ def test_conv2d_stem_direct_kernel(dev, n, h, w, cout, stride, act):
     assert torch.equal(wide[..., 4:4 + cout], got) and (wide[..., :4] == 3).all() and (wide[..., 4 + cout:] == 3).all()
 
 
+@pytest.mark.parametrize("n,h,w,cout,res,act", [
+    (4, 128, 128, 64, False, "relu"),       # whole 4 x 32 tiles
+    (3, 150, 171, 48, True, "relu"),        # ragged tiles in both directions, 48 of the 64 weight rows exist, residual
+    (5, 118, 113, 64, True, None),
+])
+def test_conv2d_3x3_tap_streaming_split_bf16_kernel(dev, n, h, w, cout, res, act):
+    """conv3x3_tap_x3_kernel (64 input channels: halo tile resident as three bf16 planes, weights streamed and split per tap) against
+    float64 and against the fp32-pipe path (VSC_CONV_X3=0): as close to float64 as the fp32 pipe, run to run identical."""
+    from vsc_hip import cnn
+    rng = np.random.RandomState(h + cout)
+    sd = {"c.weight": torch.from_numpy((rng.randn(cout, 64, 3, 3) / 24).astype(np.float32)), "c.bias": torch.from_numpy(rng.randn(cout).astype(np.float32) * 0.1)}
+    x = torch.from_numpy(rng.randn(n, h, w, 64).astype(np.float32)).to(dev)
+    r = torch.from_numpy(rng.randn(n, h, w, cout).astype(np.float32)).to(dev) if res else None
+    conv = cnn.Conv(sd, "c", None, 1, dev)
+    got = conv(x, act=act, residual=r).clone()
+    _vsc_lib.set_option("VSC_CONV_X3", "0")
+    try:
+        f32 = conv(x, act=act, residual=r).clone()
+    finally:
+        _vsc_lib.set_option("VSC_CONV_X3", None)
+    want = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), sd["c.weight"].double(), sd["c.bias"].double(), padding=1)
+    if res:
+        want = want + r.double().cpu().permute(0, 3, 1, 2)
+    if act:
+        want = F.relu(want)
+    e_x3 = float((got.double().cpu().permute(0, 3, 1, 2) - want).abs().max())
+    e_f32 = float((f32.double().cpu().permute(0, 3, 1, 2) - want).abs().max())
+    assert e_x3 < 2e-5 and e_x3 < 2.0 * e_f32 + 1e-6, (e_x3, e_f32)
+    assert not torch.equal(got, f32)                       # the split-bf16 kernel really ran
+    for _ in range(3):
+        assert torch.equal(conv(x, act=act, residual=r), got)
+    wide = torch.full((n, h, w, cout + 8), 3.0, device=dev)
+    conv(x, act=act, residual=r, out=wide, coff=4)
+    assert torch.equal(wide[..., 4:4 + cout], got) and (wide[..., :4] == 3).all() and (wide[..., 4 + cout:] == 3).all()
+
+
 def test_depthwise_pool_scale_upsample(dev):
     from vsc_hip import cnn
     rng = np.random.RandomState(0)

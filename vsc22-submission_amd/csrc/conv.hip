@@ -994,6 +994,167 @@ __global__ __launch_bounds__(512, NPT == 2 ? 4 : 2) void conv3x3_direct_x3_kerne
     }
 }
 
+// The same arithmetic for layers whose weights do not fit LDS as three planes (64 -> 64 at 224 x 224: 221 KB): the weights are
+// streamed PER TAP -- the tap's [cout][cin] slab is read from the packed fp32 rows into registers while the previous tap is
+// multiplied, split, and written into the other of two 28-KiB plane buffers -- under a resident halo tile (4 x 32 outputs, 78 KiB as
+// three planes).  A wave = (output row, 16-pixel tile), all NRT row tiles of output channels.  cin = 8 CP (a multiple of 32 here: a
+// tap is CP / 4 whole MFMA blocks).
+template <int CP, int NRT>
+__global__ __launch_bounds__(512, 2) void conv3x3_tap_x3_kernel(DirectArgs p) {
+    static_assert(CP % 4 == 0, "a tap must be whole 32-channel MFMA blocks");
+    constexpr int TH = 4, TW = 32, HW = TW + 2, HH = TH + 2, HPIX = HW * HH;
+    constexpr int BPT = CP / 4;                                         // MFMA blocks per tap
+    constexpr int PIXB = CP * 16, PLANE = HPIX * PIXB;
+    constexpr int WR = NRT * 16, WROWB = BPT * 64 + 16, WPLANE = WR * WROWB, WBUF = 3 * WPLANE;
+    constexpr int ITEMS = (HPIX * CP + 511) / 512;                      // halo chunk pairs per thread
+    constexpr int WITEMS = (WR * CP * 2 + 511) / 512;                   // weight 4-float chunks of one tap per thread
+    __shared__ __attribute__((aligned(16))) char lds[2 * WBUF + 3 * PLANE];
+    char *wl = lds, *halo = lds + 2 * WBUF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)p.xbytes, 0x00020000);
+    int hyx[ITEMS], rel[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = j * 512 + tid;
+        const int pix = e / CP, pr = e - pix * CP;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        hyx[j] = pix < HPIX ? (hy << 16) | hx : -1;
+        rel[j] = ((hy * p.w + hx) * p.ldx + pr * 8) * 4;
+    }
+    // weights of tap `tap`: this thread's chunks (row r, 4 channels cq) -> registers; deposit: split into buffer b
+    f32x4_t wreg[WITEMS];
+    auto wfetch = [&](int tap) {
+#pragma unroll
+        for (int j = 0; j < WITEMS; ++j) {
+            const int e = j * 512 + tid;
+            const int r = e / (2 * CP), cq = e - r * (2 * CP);
+            wreg[j] = (e < WR * 2 * CP && r < p.cout) ? *(const f32x4_t *)(p.wp + (int64_t)r * p.kpad + (tap * 2 * CP + cq) * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto wdeposit = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < WITEMS; ++j) {
+            const int e = j * 512 + tid;
+            if (e >= WR * 2 * CP) break;
+            const int r = e / (2 * CP), cq = e - r * (2 * CP);
+            uint2 w1, w2, w3;
+            split_bf16x3(wreg[j], w1, w2, w3);
+            char *dst = wl + b * WBUF + r * WROWB + cq * 8;
+            *(uint2 *)dst = w1;
+            *(uint2 *)(dst + WPLANE) = w2;
+            *(uint2 *)(dst + 2 * WPLANE) = w3;
+        }
+    };
+    f32x4_t nxt[ITEMS][2];
+    auto fetch = [&](int64_t t) {
+        const int tx = (int)(t % p.tiles_x);
+        const int64_t t2 = t / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y), img = (int)(t2 / p.tiles_y);
+        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+        const int base = (((img * p.h + iy0) * p.w + ix0) * p.ldx) * 4;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int iy = iy0 + (hyx[j] >> 16), ix = ix0 + (hyx[j] & 0xffff);
+            const bool ok = hyx[j] >= 0 && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+            const unsigned v0 = ok ? (unsigned)(base + rel[j]) : 0x80000000u;
+            nxt[j][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, v0, 0, 0));
+            nxt[j][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? v0 + 16u : 0x80000000u, 0, 0));
+        }
+    };
+    auto deposit = [&]() {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int e = j * 512 + tid;
+            if (e >= HPIX * CP) break;
+            uint2 a1, a2, a3, b1, b2, b3;
+            split_bf16x3(nxt[j][0], a1, a2, a3);
+            split_bf16x3(nxt[j][1], b1, b2, b3);
+            *(uint4 *)(halo + e * 16) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+            *(uint4 *)(halo + PLANE + e * 16) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+            *(uint4 *)(halo + 2 * PLANE + e * 16) = make_uint4(a3.x, a3.y, b3.x, b3.y);
+        }
+    };
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.out, 0, (int)((int64_t)p.n * p.h * p.w * p.ldo * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), 0, (int)((int64_t)p.n * p.h * p.w * (p.res ? p.ldr : p.ldo) * 4), 0x00020000);
+    int64_t t = blockIdx.x;
+    if (t >= p.ntiles) return;
+    fetch(t);
+    wfetch(0);
+    const int wrow_ = wave >> 1, px0 = (wave & 1) * 16;
+    const int woff = lc * WROWB + g * 16;
+    const int hoff = (wrow_ * HW + px0 + lc) * PIXB + g * 16;
+    for (; t < p.ntiles; t += gridDim.x) {
+        __syncthreads();   // every wave is done with the previous tile's halo and with weight buffer 0 (tap 8 lives in it)
+        deposit();
+        wdeposit(0);
+        wfetch(1);
+        __syncthreads();
+        if (t + gridDim.x < p.ntiles) fetch(t + gridDim.x);
+        const int tx = (int)(t % p.tiles_x);
+        const int64_t t2 = t / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y);
+        const int img = (int)(t2 / p.tiles_y);
+        const int oy = ty * TH + wrow_;
+        f32x4_t acc[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) acc[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const char *wb = wl + (tap & 1) * WBUF + woff;
+            const char *hb = halo + hoff + ((tap / 3) * HW + tap % 3) * PIXB;
+#pragma unroll
+            for (int b = 0; b < BPT; ++b) {
+                bf16x8_t xo[3], wo[3][NRT];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    xo[pl] = *(const bf16x8_t *)(hb + pl * PLANE + b * 64);
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt) wo[pl][rt] = *(const bf16x8_t *)(wb + pl * WPLANE + rt * 16 * WROWB + b * 64);
+                }
+                constexpr int TW_[6] = {1, 2, 0, 1, 0, 0}, TX_[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt)
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[TW_[term]][rt], xo[TX_[term]], acc[rt], 0, 0, 0);
+            }
+            if (tap < 8) {
+                // the next tap's weights go into the other buffer (its readers -- tap - 1 -- are behind the previous barrier), then the
+                // tap after that is requested
+                wdeposit((tap + 1) & 1);
+                wfetch(tap + 2 < 9 ? tap + 2 : 0);   // tap 0 again: the next tile's first
+                __syncthreads();
+            }
+        }
+        const bool vec = ((p.ldo | p.ldr) & 3) == 0;
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int ox = tx * TW + px0 + lc, co = rt * 16 + 4 * g;
+            const bool ok = oy < p.h && ox < p.w && co < p.cout;
+            const int pix = (img * p.h + oy) * p.w + ox;
+            f32x4_t v = acc[rt];
+            if (vec && co + 3 < p.cout) {
+                const unsigned ro = ok ? (unsigned)((pix * p.ldr + co) * 4) : 0x80000000u, oo = ok ? (unsigned)((pix * p.ldo + co) * 4) : 0x80000000u;
+                if (p.bias) v += *(const f32x4_t *)(p.bias + co);
+                if (p.res) v += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, ro, 0, 0));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = activate(v[r], p.act);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vsc_u32x4_t, v), orsrc, oo, 0, 0);
+            } else if (ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < p.cout) {
+                        float sx = v[r] + (p.bias ? p.bias[co + r] : 0.f);
+                        if (p.res) sx += p.res[(int64_t)pix * p.ldr + co + r];
+                        p.out[(int64_t)pix * p.ldo + co + r] = activate(sx, p.act);
+                    }
+            }
+        }
+    }
+}
+
 // depthwise: one thread per (pixel, channel); w [c, kh * kw]
 __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
                                                      const float *__restrict__ bias, float *__restrict__ out, int64_t total,
@@ -1286,6 +1447,21 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     {
         const char *de = vsc_opt(OPT_CONV_DIRECT);   // diagnostic / test switch: 0 = the implicit-GEMM path
         const int64_t xbytes = n * (int64_t)h * w * ldx * 4;
+        const char *x3e = vsc_opt(OPT_CONV_X3);
+        const bool tap_x3 = !(de && de[0] == '0') && !(x3e && x3e[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cin == 64 && ldx == 64 && cout <= 64 &&
+                            (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 && xbytes < (1ll << 31) && (!res_dev || ldr >= cout) &&
+                            n * (int64_t)h * w * (ldo > ldr ? ldo : ldr) * 4 < (1ll << 31) && n * (int64_t)h * w >= 65536;
+        if (tap_x3) {
+            DirectArgs a{x_dev, w_packed_dev, bias_dev, res_dev, out_dev, (int)n, h, w, ldx, cout, kpad, ldo, ldr, act,
+                         (w + 31) / 32, (h + 3) / 4, 0, (unsigned)xbytes, cin / 4};
+            a.ntiles = (int64_t)a.tiles_x * a.tiles_y * n;
+            static int cus_tap[16] = {};
+            if (!cus_tap[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_tap[dev], hipDeviceAttributeMultiprocessorCount, dev));
+            const unsigned grid = (unsigned)(a.ntiles < cus_tap[dev] ? a.ntiles : cus_tap[dev]);
+            hipLaunchKernelGGL((conv3x3_tap_x3_kernel<8, 4>), dim3(grid), dim3(512), 0, stream, a);
+            VSC_CHECK_LAUNCH();
+            return VSC_OK;
+        }
         const bool direct = !(de && de[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cout <= 40 && (cin == 20 || cin == 36) &&
                             (ldx & 3) == 0 && (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 && xbytes < (1ll << 31) &&
                             (!res_dev || ldr >= cout);
