@@ -280,6 +280,43 @@ def test_conv2d_3x3_tap_streaming_split_bf16_kernel(dev, n, h, w, cout, res, act
     assert torch.equal(wide[..., 4:4 + cout], got) and (wide[..., :4] == 3).all() and (wide[..., 4 + cout:] == 3).all()
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,res,act", [
+    (16, 56, 56, 72, 72, True, "relu"),       # HRNet's third branch
+    (7, 61, 45, 72, 72, False, "relu"),       # ragged last pixel tile, images change inside tiles
+    (16, 28, 28, 144, 144, True, "relu"),     # fourth branch: two channel groups of 80 rows
+    (5, 47, 39, 144, 72, False, None),
+])
+def test_conv2d_3x3_split_bf16_implicit_gemm(dev, n, h, w, cin, cout, res, act):
+    """conv_x3_gemm_kernel (both operands split into three bf16 planes once per call, implicit GEMM with LDS-DMA gathers, six MFMAs
+    per block) against float64 and the fp32-pipe path (VSC_CONV_X3=0)."""
+    from vsc_hip import cnn
+    rng = np.random.RandomState(h + cout)
+    sd = {"c.weight": torch.from_numpy((rng.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)), "c.bias": torch.from_numpy(rng.randn(cout).astype(np.float32) * 0.1)}
+    x = torch.from_numpy(rng.randn(n, h, w, cin).astype(np.float32)).to(dev)
+    r = torch.from_numpy(rng.randn(n, h, w, cout).astype(np.float32)).to(dev) if res else None
+    conv = cnn.Conv(sd, "c", None, 1, dev)
+    got = conv(x, act=act, residual=r).clone()
+    _vsc_lib.set_option("VSC_CONV_X3", "0")
+    try:
+        f32 = conv(x, act=act, residual=r).clone()
+    finally:
+        _vsc_lib.set_option("VSC_CONV_X3", None)
+    want = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), sd["c.weight"].double(), sd["c.bias"].double(), padding=1)
+    if res:
+        want = want + r.double().cpu().permute(0, 3, 1, 2)
+    if act:
+        want = F.relu(want)
+    e_x3 = float((got.double().cpu().permute(0, 3, 1, 2) - want).abs().max())
+    e_f32 = float((f32.double().cpu().permute(0, 3, 1, 2) - want).abs().max())
+    assert e_x3 < 2e-5 and e_x3 < 2.0 * e_f32 + 1e-6, (e_x3, e_f32)
+    assert not torch.equal(got, f32)
+    for _ in range(3):
+        assert torch.equal(conv(x, act=act, residual=r), got)
+    wide = torch.full((n, h, w, cout + 7), 3.0, device=dev)   # a window at an offset that is not a multiple of 4: scalar stores
+    conv(x, act=act, residual=r, out=wide, coff=5)
+    assert torch.equal(wide[..., 5:5 + cout], got) and (wide[..., :5] == 3).all() and (wide[..., 5 + cout:] == 3).all()
+
+
 def test_depthwise_pool_scale_upsample(dev):
     from vsc_hip import cnn
     rng = np.random.RandomState(0)

@@ -1155,6 +1155,171 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tap_x3_kernel(DirectArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Split-bf16 IMPLICIT GEMM for the wide 3 x 3 layers on small maps (72 @ 56 x 56, 144 @ 28 x 28): their weights do not fit LDS as
+// planes, and streamed per tap under a small halo tile they cost more than the fp32 tile kernel.  Here both operands
+// are split ONCE per call into bf16 planes in the per-device scratch (the activations of these layers are 7-14 MB) and the product
+// is the narrow kernel's implicit GEMM on plain bf16 data: out[pixel, co] = sum_k patch[pixel, k] w[co, k], k = (tap, ci) flattened,
+// a K-step = 32 k = four 8-channel chunks gathered by LDS-DMA (16 bytes = one chunk of one plane; a tap outside the image or k >= K
+// points past the buffer descriptor: zeros), six MFMAs per 16 x 16 x 32 block.  128 pixels x up to 80 channels per workgroup, two
+// 39-KiB stages: two workgroups per CU.  Wave = (32 pixels, half of the row tiles).
+__global__ __launch_bounds__(256) void split_planes_kernel(const float *__restrict__ x, char *__restrict__ dst, int64_t chunks, int64_t plane_bytes) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < chunks; e += (int64_t)gridDim.x * 256) {
+        uint2 a, b, c;
+        split_bf16x3(*(const f32x4_t *)(x + e * 4), a, b, c);
+        *(uint2 *)(dst + e * 8) = a;
+        *(uint2 *)(dst + plane_bytes + e * 8) = b;
+        *(uint2 *)(dst + 2 * plane_bytes + e * 8) = c;
+    }
+}
+
+// packed fp32 rows [cout][kpad] (k = (tap, ci)) -> planes [3][wr][kp] bf16, zero rows past cout, zero columns past K
+__global__ __launch_bounds__(256) void split_weight_rows_kernel(const float *__restrict__ wp, char *__restrict__ dst, int cout, int kpad, int k, int wr, int kp) {
+    const int per_row = kp / 4;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < wr * per_row; e += gridDim.x * 256) {
+        const int r = e / per_row, c4 = e - r * per_row;
+        f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (r < cout && c4 * 4 < k) v = *(const f32x4_t *)(wp + (int64_t)r * kpad + c4 * 4);   // (K is a multiple of 8 here: whole chunks)
+        uint2 a, b, c;
+        split_bf16x3(v, a, b, c);
+        const size_t plane = (size_t)wr * kp * 2;
+        *(uint2 *)(dst + (size_t)e * 8) = a;
+        *(uint2 *)(dst + plane + (size_t)e * 8) = b;
+        *(uint2 *)(dst + 2 * plane + (size_t)e * 8) = c;
+    }
+}
+
+struct X3GemmArgs {
+    const char *xpl, *wpl;      // activation planes [3][rows_in][cin] bf16, weight planes [3][wr_total][kp] bf16
+    const float *bias, *res;
+    float *out;
+    int64_t rows;               // output pixels
+    int n, h, w, cin, cout, ldo, ldr, act;
+    int nks, kp, chunks_per_tap, wr_total;
+    unsigned xplane_bytes, wplane_bytes;
+};
+
+template <int NRT>   // 16-row tiles of output channels per workgroup (grid.y channel groups of NRT x 16 rows); the two wave groups take
+                      // tiles 0 .. NRTG - 1 and NRTG .. NRT - 1
+__global__ __launch_bounds__(512, 4) void conv_x3_gemm_kernel(X3GemmArgs p) {
+    constexpr int TP = 128, WRG = NRT * 16, NRTG = (NRT + 1) / 2;
+    constexpr int STAGE = 3 * (WRG + TP) * 64;   // W planes | P planes, 64-byte rows, chunk ^= (row >> 2) & 3
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, g = lane >> 4;
+    const int64_t p0 = (int64_t)blockIdx.x * TP;
+    const int r0 = blockIdx.y * WRG;   // first weight row of this workgroup
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.xpl, 0, (int)(3u * p.xplane_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.wpl, 0, (int)(3u * p.wplane_bytes), 0x00020000);
+    // this lane's gather row: pixel p0 + 16 wave + (lane >> 2), stored chunk lane & 3 holding source chunk (lane & 3) ^ ((row >> 2) & 3)
+    const int prow = wave * 16 + (lane >> 2);
+    const int pch = (lane & 3) ^ ((prow >> 2) & 3);
+    int64_t pix = p0 + prow;
+    const bool pin = pix < p.rows;
+    pix = pin ? pix : p.rows - 1;
+    const int img = (int)(pix / (p.h * p.w));
+    const int rem = (int)(pix - (int64_t)img * p.h * p.w);
+    const int oy = rem / p.w, ox = rem - oy * p.w;
+    // weights: waves 0 .. WRG / 16 - 1 stage 16 rows each
+    const int wrow = wave * 16 + (lane >> 2);
+    const int wch = (lane & 3) ^ ((wrow >> 2) & 3);
+    const bool wstager = wave * 16 < WRG;
+    auto stage = [&](int ks, int b) {
+        char *st = lds + b * STAGE;
+        {
+            const int kc = ks * 4 + pch;                       // 8-channel chunk of K
+            const int tap = kc / p.chunks_per_tap, c8 = kc - tap * p.chunks_per_tap;
+            const int i = tap / 3, j = tap - i * 3;
+            const int iy = oy + i - 1, ix = ox + j - 1;
+            const bool ok = pin && tap < 9 && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+            const unsigned voff = ok ? (unsigned)((((img * p.h + iy) * p.w + ix) * p.cin + c8 * 8) * 2) : 0x80000000u;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(st + 3 * WRG * 64 + pl * TP * 64 + wave * 1024), 16, voff, pl * p.xplane_bytes, 0, 0);
+        }
+        if (wstager) {
+            const unsigned voff = (unsigned)(((r0 + wrow) * p.kp + (ks * 4 + wch) * 8) * 2);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lptr_t)(st + pl * WRG * 64 + wave * 1024), 16, voff, pl * p.wplane_bytes, 0, 0);
+        }
+    };
+    const int pg = wave & 3, rg = wave >> 2;   // this wave: pixels 32 pg .. + 31, row tiles rg NRTG .. (nrt of them)
+    const int nrt = NRT - rg * NRTG < NRTG ? NRT - rg * NRTG : NRTG;   // wave-uniform
+    f32x4_t acc[NRTG][2];
+#pragma unroll
+    for (int rt = 0; rt < NRTG; ++rt)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) acc[rt][pt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // operand rows of this lane: weights row 16 (rg NRTG + rt) + lc, pixels 32 pg + 16 pt + lc; chunk g of the K-step
+    int wofs[NRTG], pofs[2];
+#pragma unroll
+    for (int rt = 0; rt < NRTG; ++rt) {
+        const int r = (rg * NRTG + (rt < nrt ? rt : 0)) * 16 + lc;
+        wofs[rt] = r * 64 + ((g ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+        const int r = pg * 32 + pt * 16 + lc;
+        pofs[pt] = 3 * WRG * 64 + r * 64 + ((g ^ ((r >> 2) & 3)) << 4);
+    }
+    int cur = 0;
+    for (int ks = 0; ks < p.nks; ++ks) {
+        if (ks + 1 < p.nks) stage(ks + 1, cur ^ 1);
+        const char *st = lds + cur * STAGE;
+        bf16x8_t xo[3][2], wo[3][NRTG];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) xo[pl][pt] = *(const bf16x8_t *)(st + pofs[pt] + pl * TP * 64);
+#pragma unroll
+            for (int rt = 0; rt < NRTG; ++rt) wo[pl][rt] = *(const bf16x8_t *)(st + wofs[rt] + pl * WRG * 64);
+        }
+        constexpr int TW_[6] = {1, 2, 0, 1, 0, 0}, TX_[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int rt = 0; rt < NRTG; ++rt)
+                if (rt < nrt) {
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+                        acc[rt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wo[TW_[term]][rt], xo[TX_[term]][pt], acc[rt][pt], 0, 0, 0);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    const bool vec = ((p.ldo | p.ldr) & 3) == 0;
+#pragma unroll
+    for (int rt = 0; rt < NRTG; ++rt)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const int64_t px = p0 + pg * 32 + pt * 16 + lc;
+            const int co = r0 + (rg * NRTG + rt) * 16 + 4 * g;
+            if (rt >= nrt || px >= p.rows || co >= p.cout) continue;
+            f32x4_t v = acc[rt][pt];
+            if (vec && co + 3 < p.cout) {
+                if (p.bias) v += *(const f32x4_t *)(p.bias + co);
+                if (p.res) v += *(const f32x4_t *)(p.res + px * p.ldr + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = activate(v[r], p.act);
+                *(f32x4_t *)(p.out + px * p.ldo + co) = v;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < p.cout) {
+                        float sx = v[r] + (p.bias ? p.bias[co + r] : 0.f);
+                        if (p.res) sx += p.res[px * p.ldr + co + r];
+                        p.out[px * p.ldo + co + r] = activate(sx, p.act);
+                    }
+            }
+        }
+}
+
 // depthwise: one thread per (pixel, channel); w [c, kh * kw]
 __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
                                                      const float *__restrict__ bias, float *__restrict__ out, int64_t total,
@@ -1408,6 +1573,7 @@ struct Scratch {
 Scratch g_patch[16];   // per device, grow-only: the packed patch matrix of the convolution in flight
 std::mutex g_conv_mutex;
 float *g_zero_line[16] = {};   // per device: 256 bytes of zeros (implicit gathering points padding taps at it)
+Scratch g_x3[16];               // per device, grow-only: split-bf16 planes (activations | weights) of the implicit GEMM in flight
 
 inline int blocks_for(int64_t items) {
     int64_t b = (items + 255) / 256;
@@ -1451,6 +1617,43 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
         const bool tap_x3 = !(de && de[0] == '0') && !(x3e && x3e[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cin == 64 && ldx == 64 && cout <= 64 &&
                             (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 && xbytes < (1ll << 31) && (!res_dev || ldr >= cout) &&
                             n * (int64_t)h * w * (ldo > ldr ? ldo : ldr) * 4 < (1ll << 31) && n * (int64_t)h * w >= 65536;
+        // wide 3 x 3 layers on small maps: both operands split into planes once, implicit GEMM on the bf16 pipe (conv_x3_gemm_kernel)
+        const int64_t in_elems = n * (int64_t)h * w * cin;
+        const bool x3gemm = !(de && de[0] == '0') && !(x3e && x3e[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (cin == 72 || cin == 144) &&
+                            ldx == cin && cout >= 48 && cout <= 160 && (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 && in_elems * 6 < (1ll << 31) &&
+                            in_elems <= (16ll << 20) && (!res_dev || ldr >= cout) && n * (int64_t)h * w >= 8192 && n * (int64_t)h * w < (1ll << 31);
+        if (x3gemm) {
+            const int k = 9 * cin, nks = (k + 31) / 32, kp = nks * 32;
+            const int groups = (cout + 79) / 80, wr_total = groups * 80;   // channel groups of 80 rows (grid.y)
+            const size_t xplane = (size_t)in_elems * 2, wplane = (size_t)wr_total * kp * 2;
+            const size_t xbytes3 = (3 * xplane + 255) / 256 * 256, need = xbytes3 + 3 * wplane;
+            std::lock_guard<std::mutex> scratch_lock(g_conv_mutex);   // one plane scratch per device: one stream at a time (vsc_hip.h)
+            Scratch &sx = g_x3[dev];
+            if (sx.bytes < need) {
+                if (sx.ptr) {
+                    VSC_CHECK_HIP(hipDeviceSynchronize());
+                    VSC_CHECK_HIP(hipFree(sx.ptr));
+                    sx.ptr = nullptr;
+                    sx.bytes = 0;
+                }
+                hipError_t e = hipMalloc(&sx.ptr, need);
+                if (e != hipSuccess) {
+                    sx.ptr = nullptr;
+                    vsc_set_error("conv2d: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+                    return VSC_ERR_NOMEM;
+                }
+                sx.bytes = need;
+            }
+            char *xpl = (char *)sx.ptr, *wpl = xpl + xbytes3;
+            hipLaunchKernelGGL(split_planes_kernel, dim3(blocks_for(in_elems / 4)), dim3(256), 0, stream, x_dev, xpl, in_elems / 4, (int64_t)xplane);
+            hipLaunchKernelGGL(split_weight_rows_kernel, dim3(blocks_for((int64_t)wr_total * kp / 4)), dim3(256), 0, stream, w_packed_dev, wpl, cout, kpad, k, wr_total, kp);
+            X3GemmArgs a{xpl, wpl, bias_dev, res_dev, out_dev, n * (int64_t)h * w, (int)n, h, w, cin, cout, ldo, ldr, act, nks, kp, cin / 8, wr_total,
+                         (unsigned)xplane, (unsigned)wplane};
+            const dim3 grid((unsigned)((a.rows + 127) / 128), groups);
+            hipLaunchKernelGGL((conv_x3_gemm_kernel<5>), grid, dim3(512), 0, stream, a);
+            VSC_CHECK_LAUNCH();
+            return VSC_OK;
+        }
         if (tap_x3) {
             DirectArgs a{x_dev, w_packed_dev, bias_dev, res_dev, out_dev, (int)n, h, w, ldx, cout, kpad, ldo, ldr, act,
                          (w + 31) / 32, (h + 3) / 4, 0, (unsigned)xbytes, cin / 4};
