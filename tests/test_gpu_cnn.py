@@ -244,18 +244,20 @@ def test_conv2d_stem_direct_kernel(dev, n, h, w, cout, stride, act):
     assert torch.equal(wide[..., 4:4 + cout], got) and (wide[..., :4] == 3).all() and (wide[..., 4 + cout:] == 3).all()
 
 
-@pytest.mark.parametrize("n,h,w,cout,res,act", [
-    (4, 128, 128, 64, False, "relu"),       # whole 4 x 32 tiles
-    (3, 150, 171, 48, True, "relu"),        # ragged tiles in both directions, 48 of the 64 weight rows exist, residual
-    (5, 118, 113, 64, True, None),
+@pytest.mark.parametrize("n,h,w,cin,cout,res,act", [
+    (4, 128, 128, 64, 64, False, "relu"),       # whole 4 x 32 tiles
+    (3, 150, 171, 64, 48, True, "relu"),        # ragged tiles in both directions, 48 of the 64 weight rows exist, residual
+    (5, 118, 113, 64, 64, True, None),
+    (3, 150, 171, 256, 20, False, "relu"),      # HRNet's transition from the 256-wide stem: four 64-channel passes per tile
+    (2, 224, 224, 256, 20, True, None),
 ])
-def test_conv2d_3x3_tap_streaming_split_bf16_kernel(dev, n, h, w, cout, res, act):
+def test_conv2d_3x3_tap_streaming_split_bf16_kernel(dev, n, h, w, cin, cout, res, act):
     """conv3x3_tap_x3_kernel (64 input channels: halo tile resident as three bf16 planes, weights streamed and split per tap) against
     float64 and against the fp32-pipe path (VSC_CONV_X3=0): as close to float64 as the fp32 pipe, run to run identical."""
     from vsc_hip import cnn
     rng = np.random.RandomState(h + cout)
-    sd = {"c.weight": torch.from_numpy((rng.randn(cout, 64, 3, 3) / 24).astype(np.float32)), "c.bias": torch.from_numpy(rng.randn(cout).astype(np.float32) * 0.1)}
-    x = torch.from_numpy(rng.randn(n, h, w, 64).astype(np.float32)).to(dev)
+    sd = {"c.weight": torch.from_numpy((rng.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)), "c.bias": torch.from_numpy(rng.randn(cout).astype(np.float32) * 0.1)}
+    x = torch.from_numpy(rng.randn(n, h, w, cin).astype(np.float32)).to(dev)
     r = torch.from_numpy(rng.randn(n, h, w, cout).astype(np.float32)).to(dev) if res else None
     conv = cnn.Conv(sd, "c", None, 1, dev)
     got = conv(x, act=act, residual=r).clone()

@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo/vsc22-submission_amd"); sys.path.insert(0, "/root
 import numpy as np, torch, torch.nn.functional as F
 from vsc_hip import cnn, _lib
 dev = torch.device("cuda:0")
-for (n, h, w, cin, cout, res) in [(16, 56, 56, 72, 72, True), (7, 61, 45, 72, 72, False), (16, 28, 28, 144, 144, True), (4, 128, 128, 64, 64, False), (3, 150, 171, 64, 48, True), (16, 224, 224, 64, 64, False), (2, 19, 40, 36, 36, True), (16, 28, 28, 36, 36, True), (16, 112, 112, 36, 36, True), (2, 16, 32, 20, 18, True), (3, 21, 45, 20, 20, True), (1, 5, 3, 20, 18, False), (16, 56, 56, 20, 18, True), (1, 8, 33, 20, 32, False), (16, 224, 224, 20, 20, True)]:
+for (n, h, w, cin, cout, res) in [(16, 224, 224, 256, 20, False), (3, 150, 171, 256, 20, False), (16, 56, 56, 72, 72, True), (7, 61, 45, 72, 72, False), (16, 28, 28, 144, 144, True), (4, 128, 128, 64, 64, False), (3, 150, 171, 64, 48, True), (16, 224, 224, 64, 64, False), (2, 19, 40, 36, 36, True), (16, 28, 28, 36, 36, True), (16, 112, 112, 36, 36, True), (2, 16, 32, 20, 18, True), (3, 21, 45, 20, 20, True), (1, 5, 3, 20, 18, False), (16, 56, 56, 20, 18, True), (1, 8, 33, 20, 32, False), (16, 224, 224, 20, 20, True)]:
     rng = np.random.RandomState(cin + h)
     sd = {"c.weight": torch.from_numpy((rng.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)).astype(np.float32)), "c.bias": torch.from_numpy(rng.randn(cout).astype(np.float32) * 0.1)}
     x = torch.from_numpy(rng.randn(n, h, w, cin).astype(np.float32)).to(dev)

@@ -997,9 +997,10 @@ __global__ __launch_bounds__(512, NPT == 2 ? 4 : 2) void conv3x3_direct_x3_kerne
 // The same arithmetic for layers whose weights do not fit LDS as three planes (64 -> 64 at 224 x 224: 221 KB): the weights are
 // streamed PER TAP -- the tap's [cout][cin] slab is read from the packed fp32 rows into registers while the previous tap is
 // multiplied, split, and written into the other of two 28-KiB plane buffers -- under a resident halo tile (4 x 32 outputs, 78 KiB as
-// three planes).  A wave = (output row, 16-pixel tile), all NRT row tiles of output channels.  cin = 8 CP (a multiple of 32 here: a
-// tap is CP / 4 whole MFMA blocks).
-template <int CP, int NRT>
+// three planes).  A wave = (output row, 16-pixel tile), all NRT row tiles of output channels.  8 CP channels per pass (a multiple
+// of 32: a tap is CP / 4 whole MFMA blocks); wider inputs (256 -> 20: NCC = 4) take NCC passes over the tile, one per 8 CP-channel
+// slice of the input, the accumulators staying in registers.
+template <int CP, int NRT, int NCC>
 __global__ __launch_bounds__(512, 2) void conv3x3_tap_x3_kernel(DirectArgs p) {
     static_assert(CP % 4 == 0, "a tap must be whole 32-channel MFMA blocks");
     constexpr int TH = 4, TW = 32, HW = TW + 2, HH = TH + 2, HPIX = HW * HH;
@@ -1025,12 +1026,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tap_x3_kernel(DirectArgs p) {
     }
     // weights of tap `tap`: this thread's chunks (row r, 4 channels cq) -> registers; deposit: split into buffer b
     f32x4_t wreg[WITEMS];
-    auto wfetch = [&](int tap) {
+    auto wfetch = [&](int tap, int cc) {
 #pragma unroll
         for (int j = 0; j < WITEMS; ++j) {
             const int e = j * 512 + tid;
             const int r = e / (2 * CP), cq = e - r * (2 * CP);
-            wreg[j] = (e < WR * 2 * CP && r < p.cout) ? *(const f32x4_t *)(p.wp + (int64_t)r * p.kpad + (tap * 2 * CP + cq) * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            wreg[j] = (e < WR * 2 * CP && r < p.cout) ? *(const f32x4_t *)(p.wp + (int64_t)r * p.kpad + ((tap * NCC + cc) * 2 * CP + cq) * 4) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto wdeposit = [&](int b) {
@@ -1048,12 +1049,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tap_x3_kernel(DirectArgs p) {
         }
     };
     f32x4_t nxt[ITEMS][2];
-    auto fetch = [&](int64_t t) {
+    auto fetch = [&](int64_t t, int cc) {   // the halo of tile t, input channels 8 CP cc ..
         const int tx = (int)(t % p.tiles_x);
         const int64_t t2 = t / p.tiles_x;
         const int ty = (int)(t2 % p.tiles_y), img = (int)(t2 / p.tiles_y);
         const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
-        const int base = (((img * p.h + iy0) * p.w + ix0) * p.ldx) * 4;
+        const int base = (((img * p.h + iy0) * p.w + ix0) * p.ldx + cc * 8 * CP) * 4;
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int iy = iy0 + (hyx[j] >> 16), ix = ix0 + (hyx[j] & 0xffff);
@@ -1080,26 +1081,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tap_x3_kernel(DirectArgs p) {
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(p.res ? p.res : p.out), 0, (int)((int64_t)p.n * p.h * p.w * (p.res ? p.ldr : p.ldo) * 4), 0x00020000);
     int64_t t = blockIdx.x;
     if (t >= p.ntiles) return;
-    fetch(t);
-    wfetch(0);
+    fetch(t, 0);
+    wfetch(0, 0);
     const int wrow_ = wave >> 1, px0 = (wave & 1) * 16;
     const int woff = lc * WROWB + g * 16;
     const int hoff = (wrow_ * HW + px0 + lc) * PIXB + g * 16;
-    for (; t < p.ntiles; t += gridDim.x) {
-        __syncthreads();   // every wave is done with the previous tile's halo and with weight buffer 0 (tap 8 lives in it)
+    f32x4_t acc[NRT];
+    for (int cc = 0; t < p.ntiles;) {
+        const int ncc = cc + 1 < NCC ? cc + 1 : 0;                  // the pass after this one: the next channel slice of the tile, or
+        const int64_t nt = cc + 1 < NCC ? t : t + gridDim.x;        // slice 0 of the workgroup's next tile
+        __syncthreads();   // every wave is done with the previous pass's halo and with weight buffer 0 (tap 8 lives in it)
         deposit();
         wdeposit(0);
-        wfetch(1);
+        wfetch(1, cc);
         __syncthreads();
-        if (t + gridDim.x < p.ntiles) fetch(t + gridDim.x);
+        if (nt < p.ntiles) fetch(nt, ncc);
         const int tx = (int)(t % p.tiles_x);
         const int64_t t2 = t / p.tiles_x;
         const int ty = (int)(t2 % p.tiles_y);
         const int img = (int)(t2 / p.tiles_y);
         const int oy = ty * TH + wrow_;
-        f32x4_t acc[NRT];
+        if (cc == 0) {
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) acc[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < NRT; ++rt) acc[rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const char *wb = wl + (tap & 1) * WBUF + woff;
@@ -1124,10 +1129,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tap_x3_kernel(DirectArgs p) {
                 // the next tap's weights go into the other buffer (its readers -- tap - 1 -- are behind the previous barrier), then the
                 // tap after that is requested
                 wdeposit((tap + 1) & 1);
-                wfetch(tap + 2 < 9 ? tap + 2 : 0);   // tap 0 again: the next tile's first
+                if (tap + 2 < 9) wfetch(tap + 2, cc);
+                else wfetch(0, ncc);   // tap 0 again: the next pass's first
                 __syncthreads();
             }
         }
+        const int cc_done = cc;
+        const int64_t t_done = t;
+        (void)t_done;
+        cc = ncc;
+        t = nt;
+        if (cc_done + 1 < NCC) continue;   // more channel slices of this tile to go
         const bool vec = ((p.ldo | p.ldr) & 3) == 0;
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) {
@@ -1614,7 +1626,7 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
         const char *de = vsc_opt(OPT_CONV_DIRECT);   // diagnostic / test switch: 0 = the implicit-GEMM path
         const int64_t xbytes = n * (int64_t)h * w * ldx * 4;
         const char *x3e = vsc_opt(OPT_CONV_X3);
-        const bool tap_x3 = !(de && de[0] == '0') && !(x3e && x3e[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cin == 64 && ldx == 64 && cout <= 64 &&
+        const bool tap_x3 = !(de && de[0] == '0') && !(x3e && x3e[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && ((cin == 64 && cout <= 64) || (cin == 256 && cout <= 32)) && ldx == cin &&
                             (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 && xbytes < (1ll << 31) && (!res_dev || ldr >= cout) &&
                             n * (int64_t)h * w * (ldo > ldr ? ldo : ldr) * 4 < (1ll << 31) && n * (int64_t)h * w >= 65536;
         // wide 3 x 3 layers on small maps: both operands split into planes once, implicit GEMM on the bf16 pipe (conv_x3_gemm_kernel)
@@ -1661,7 +1673,8 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
             static int cus_tap[16] = {};
             if (!cus_tap[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_tap[dev], hipDeviceAttributeMultiprocessorCount, dev));
             const unsigned grid = (unsigned)(a.ntiles < cus_tap[dev] ? a.ntiles : cus_tap[dev]);
-            hipLaunchKernelGGL((conv3x3_tap_x3_kernel<8, 4>), dim3(grid), dim3(512), 0, stream, a);
+            if (cin == 256) hipLaunchKernelGGL((conv3x3_tap_x3_kernel<8, 2, 4>), dim3(grid), dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((conv3x3_tap_x3_kernel<8, 4, 1>), dim3(grid), dim3(512), 0, stream, a);
             VSC_CHECK_LAUNCH();
             return VSC_OK;
         }
