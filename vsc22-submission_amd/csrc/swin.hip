@@ -624,6 +624,200 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// 24 x 24 windows (Swin-V2-L at 384: 44 % of its encoder time on the kernel above, which keeps a 576-key score row in 144
+// registers of a lane and therefore runs four waves per CU, gathers the bias per score and reads the shift regions per key):
+// the streamed softmax of window_attention_stream_kernel for wide windows, shifted ones included.
+//   * a probability is packed and fed to the PV MFMA as soon as its score exists (bounded heads: scale < 0, every unmasked logit
+//     <= 0; the others take a first pass over the key tiles for the row maximum, scores recomputed): ~100 VGPRs, TWELVE waves
+//     per workgroup -- 36 query tiles, three per wave;
+//   * the bias of a lane's 4 consecutive keys is one ds_read_b128 from a column-reversed table kept in four copies shifted by
+//     0..3 floats (the copy is picked by the query's column so that the read is aligned), as in the 16 x 16 kernels;
+//   * shift masks: the regions of a lane's 4 keys are one 4-byte read, compared byte-wise with the query's region, only in the
+//     windows that touch the wrapped edge.
+// K-hat / V^T staging, MFMA operand layouts, the k-slot order of P and the ones-operand row sum are those of the kernel above.
+template <int WS>
+__global__ __launch_bounds__(768, 3) void window_attention_wide_stream_kernel(
+    const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, const float *__restrict__ bias,
+    const float *__restrict__ scale, int res, int shift, int heads) {
+    constexpr int N = WS * WS, NT = N / 16, NTHREADS = 768, NWAVES = 12, QPW = NT / NWAVES;
+    constexpr int SIDE = 2 * WS - 1, VSTRIDE = N * 2 + 32, TSTRIDE = (SIDE + 3 + 3) & ~3, TCOPY = SIDE * TSTRIDE;
+    static_assert(N % 32 == 0 && NT % NWAVES == 0 && WS % 4 == 0, "whole 32-key PV steps, whole query tiles per wave, a lane's 4 keys inside one window row");
+    extern __shared__ __attribute__((aligned(16))) char wsmem[];
+    char *klds = wsmem;                                       // [N][32] bf16, 64-B rows, chunk ^= (-(row >> 2)) & 3
+    char *vt = klds + N * 64;                                 // [32][VSTRIDE]
+    int *rowmap = (int *)(vt + HD * VSTRIDE);                 // image token of window token i
+    unsigned char *region = (unsigned char *)(rowmap + N);    // shift region of window token i (N bytes, 4-byte aligned)
+    float *tbl = (float *)(region + N);                       // 4 x [SIDE][TSTRIDE] column-reversed bias * log2 e, copy c shifted by c
+    const float LOG2E = 1.44269504088896340736f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwx = res / WS, nw = nwx * nwx;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int head = b % heads; b /= heads;
+    const int win = b % nw, frame = b / nw;
+    const int wh = win / nwx, wwx = win - wh * nwx;
+    const int C = heads * HD;
+    const int64_t ld = 3 * (int64_t)C;
+    const uint16_t *base = qkv + (int64_t)frame * res * res * ld + head * HD;
+    for (int i = tid; i < N; i += NTHREADS) {
+        const int wy = i / WS, wx = i - wy * WS;
+        const int sy = wh * WS + wy, sx = wwx * WS + wx;
+        int y = sy + shift, x = sx + shift;
+        y = y >= res ? y - res : y;
+        x = x >= res ? x - res : x;
+        rowmap[i] = y * res + x;
+        const int hr = sy < res - WS ? 0 : (sy < res - shift ? 1 : 2);
+        const int wr = sx < res - WS ? 0 : (sx < res - shift ? 1 : 2);
+        region[i] = (unsigned char)(3 * hr + wr);
+    }
+    for (int i = tid; i < SIDE * SIDE; i += NTHREADS) {
+        const float v = bias[(int64_t)head * SIDE * SIDE + i] * LOG2E;
+        const int at = (i / SIDE) * TSTRIDE + (SIDE - 1 - i % SIDE);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tbl[c * TCOPY + at + c] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < N * 4; e += NTHREADS) {   // K-hat: 4 threads per key row
+        const int i = e >> 2, c = e & 3;
+        const bf16x8_t raw = *(const bf16x8_t *)(base + C + rowmap[i] * ld + c * 8);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+        float ss = sumsq8(raw);
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
+        uint4 pk;
+        pk.x = pack_bf16x2(v[0] * inv, v[1] * inv);
+        pk.y = pack_bf16x2(v[2] * inv, v[3] * inv);
+        pk.z = pack_bf16x2(v[4] * inv, v[5] * inv);
+        pk.w = pack_bf16x2(v[6] * inv, v[7] * inv);
+        *(uint4 *)(klds + i * 64 + ((c ^ ((-(i >> 2)) & 3)) << 4)) = pk;
+    }
+    for (int e = tid; e < (N / 4) * 4; e += NTHREADS) {   // V^T: task = 4 keys x 8 dims, plain key order
+        const int kg = e >> 2, c8 = e & 3;
+        bf16x8_t r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = *(const bf16x8_t *)(base + 2 * C + rowmap[kg * 4 + i] * ld + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint2 pk;
+            pk.x = (uint32_t)(uint16_t)r[0][j] | ((uint32_t)(uint16_t)r[1][j] << 16);
+            pk.y = (uint32_t)(uint16_t)r[2][j] | ((uint32_t)(uint16_t)r[3][j] << 16);
+            *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + kg * 8) = pk;
+        }
+    }
+    __syncthreads();
+    const float scraw = scale[head];
+    const bool need_mask = shift > 0 && (wh == nwx - 1 || wwx == nwx - 1);   // workgroup-uniform
+    const bool nomax = scraw < 0.f;                                          // workgroup-uniform
+    const float sc = fabsf(scraw) * LOG2E;
+    const f32x2_t sc2 = (f32x2_t){sc, sc};
+    const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const int fr = lane & 15, g = lane >> 4;
+    auto rows = [&](auto nomax_c, auto mask_c) {
+        constexpr bool NOMAX = decltype(nomax_c)::value, MASK = decltype(mask_c)::value;
+#pragma unroll 1
+        for (int qi = 0; qi < QPW; ++qi) {
+            const int q = (wave * QPW + qi) * 16 + fr;
+            const int qrow = rowmap[q];
+            bf16x8_t qf;
+            {
+                const bf16x8_t raw = *(const bf16x8_t *)(base + qrow * ld + g * 8);
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+                float ss = sumsq8(raw);
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
+                union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk.w[j] = pack_bf16x2(v[2 * j] * inv, v[2 * j + 1] * inv);
+                qf = pk.v;
+            }
+            const int tcopy = (q + 1) & 3;
+            const float *lt = tbl + tcopy * (TCOPY + 1) + (q / WS + WS - 1) * TSTRIDE + WS - 1 - (q % WS);
+            const uint32_t rq4 = 0x01010101u * region[q];
+            auto scores = [&](int t, f32x2_t (&sv)[2]) {   // the 4 logits (log2 units) of this lane for key tile t
+                const int krow = t * 16 + fr;
+                const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
+                f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);
+                const int a = t * 4 + g, yj = a / (WS / 4), xj = (a - yj * (WS / 4)) * 4;   // keys j0 = 16 t + 4 g .. + 3 = (yj, xj ..)
+                const f32x4_t b4 = *(const f32x4_t *)(lt - yj * TSTRIDE + xj);
+                sv[0] = (f32x2_t){z[0], z[1]} * sc2 + (f32x2_t){b4[0], b4[1]};
+                sv[1] = (f32x2_t){z[2], z[3]} * sc2 + (f32x2_t){b4[2], b4[3]};
+                if (MASK) {
+                    const uint32_t df = *(const uint32_t *)(region + a * 4) ^ rq4;   // a byte is non-zero where the regions differ
+                    const float m = -100.0f * LOG2E;
+                    sv[0][0] += (df & 0x000000ffu) ? m : 0.f;
+                    sv[0][1] += (df & 0x0000ff00u) ? m : 0.f;
+                    sv[1][0] += (df & 0x00ff0000u) ? m : 0.f;
+                    sv[1][1] += (df & 0xff000000u) ? m : 0.f;
+                }
+            };
+            float nmx = 0.f;
+            if (!NOMAX) {
+                float mx = -INFINITY;
+#pragma unroll 4
+                for (int t = 0; t < NT; ++t) {
+                    f32x2_t sv[2];
+                    scores(t, sv);
+                    mx = fmaxf(fmaxf(mx, sv[0][0]), sv[0][1]);
+                    mx = fmaxf(fmaxf(mx, sv[1][0]), sv[1][1]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                nmx = -mx;
+            }
+            const f32x2_t nm2 = (f32x2_t){nmx, nmx};
+            f32x4_t o[2], osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+            for (int u = 0; u < NT / 2; ++u) {
+                union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x2_t sv[2];
+                    scores(2 * u + h, sv);
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        const f32x2_t d = NOMAX ? sv[x] : sv[x] + nm2;
+                        pk.w[2 * h + x] = pack_bf16x2(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
+                    }
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const char *vrow = vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 4 * g) * 2;
+                    union { uint2 h[2]; bf16x8_t v; } vf;
+                    vf.h[0] = *(const uint2 *)vrow;            // keys 32 u + 4 g .. + 3       (k slots j < 4)
+                    vf.h[1] = *(const uint2 *)(vrow + 32);     // keys 32 u + 16 + 4 g .. + 3  (k slots j >= 4)
+                    o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk.v, o[ct], 0, 0, 0);
+                }
+                osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pk.v, osum, 0, 0, 0);
+            }
+            const float inv = __builtin_amdgcn_rcpf(osum[0]);
+            uint16_t *orow = out + ((int64_t)frame * res * res + qrow) * C + head * HD + g * 4;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {   // o[ct][r] = context[query fr][dim ct * 16 + 4 g + r]
+                uint2 pk;
+                pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
+                pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
+                *(uint2 *)(orow + ct * 16) = pk;
+            }
+        }
+    };
+    if (nomax) {
+        if (need_mask) rows(std::true_type{}, std::true_type{});
+        else rows(std::true_type{}, std::false_type{});
+    } else {
+        if (need_mask) rows(std::false_type{}, std::true_type{});
+        else rows(std::false_type{}, std::false_type{});
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // y = LayerNorm(t) * gamma + beta;  x = (x_in ? x_in : 0) + y;  writes x (fp32) and its bf16
 // shadow.  One wave per row, row in registers (two-pass statistics).
 constexpr int MAXV = 8;
@@ -722,7 +916,18 @@ int launch_window_attention(const uint16_t *qkv, uint16_t *out, const float *bia
     else if (ws == 8)
         hipLaunchKernelGGL(window_attention_kernel<4>, dim3((unsigned)grid), dim3(128), 0, stream, qkv, out, bias,
                            scale, res, ws, shift, heads);
-    else if (ws == 24 || ws == 12) {
+    else if (ws == 24 && !(so && so[0] == '0')) {
+        constexpr int n = 576, side = 47, tstride = (side + 3 + 3) & ~3;
+        constexpr int smem = n * 64 + HD * (n * 2 + 32) + n * 4 + n + (4 * side * tstride + 4) * 4;
+        static bool attr_set[16] = {};
+        int dev = 0;
+        VSC_CHECK_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+            VSC_CHECK_HIP(hipFuncSetAttribute((const void *)window_attention_wide_stream_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            if (dev >= 0 && dev < 16) attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL(window_attention_wide_stream_kernel<24>, dim3((unsigned)grid), dim3(768), smem, stream, qkv, out, bias, scale, res, shift, heads);
+    } else if (ws == 24 || ws == 12) {
         auto smem_of = [](int w) {
             const int n = w * w, np = ((n / 16 + 1) & ~1) * 16, side = 2 * w - 1;
             return np * 64 + HD * (np * 2 + 32) + n * 4 + side * side * 4 + n + 16;
