@@ -635,11 +635,11 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
 //   * shift masks: the regions of a lane's 4 keys are one 4-byte read, compared byte-wise with the query's region, only in the
 //     windows that touch the wrapped edge.
 // K-hat / V^T staging, MFMA operand layouts, the k-slot order of P and the ones-operand row sum are those of the kernel above.
-template <int WS>
-__global__ __launch_bounds__(768, 3) void window_attention_wide_stream_kernel(
+template <int WS, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_attention_wide_stream_kernel(
     const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, const float *__restrict__ bias,
     const float *__restrict__ scale, int res, int shift, int heads) {
-    constexpr int N = WS * WS, NT = N / 16, NTHREADS = 768, NWAVES = 12, QPW = NT / NWAVES;
+    constexpr int N = WS * WS, NT = N / 16, NTHREADS = NWAVES * 64, QPW = NT / NWAVES;
     constexpr int SIDE = 2 * WS - 1, VSTRIDE = N * 2 + 32, TSTRIDE = (SIDE + 3 + 3) & ~3, TCOPY = SIDE * TSTRIDE;
     static_assert(N % 32 == 0 && NT % NWAVES == 0 && WS % 4 == 0, "whole 32-key PV steps, whole query tiles per wave, a lane's 4 keys inside one window row");
     extern __shared__ __attribute__((aligned(16))) char wsmem[];
@@ -910,7 +910,11 @@ int launch_window_attention(const uint16_t *qkv, uint16_t *out, const float *bia
     const char *so = vsc_opt(OPT_WATTN_STREAM);   // diagnostic: 0 = the row-in-registers kernel for unshifted windows as well
     if (ws == 16 && shift == 0 && !(so && so[0] == '0'))
         hipLaunchKernelGGL(window_attention_stream_kernel, dim3((unsigned)grid), dim3(512), 0, stream, qkv, out, bias, scale, res, heads);
-    else if (ws == 16)
+    else if (ws == 16 && !(so && so[0] == '0')) {   // shifted 16 x 16 windows: the streamed kernel with masks (eight waves, 52 KiB: three workgroups per CU)
+        constexpr int n = 256, side = 31, tstride = (side + 3 + 3) & ~3;
+        constexpr int smem = n * 64 + HD * (n * 2 + 32) + n * 4 + n + (4 * side * tstride + 4) * 4;
+        hipLaunchKernelGGL((window_attention_wide_stream_kernel<16, 8>), dim3((unsigned)grid), dim3(512), smem, stream, qkv, out, bias, scale, res, shift, heads);
+    } else if (ws == 16)
         hipLaunchKernelGGL(window_attention_kernel<16>, dim3((unsigned)grid), dim3(512), 0, stream, qkv, out, bias,
                            scale, res, ws, shift, heads);
     else if (ws == 8)
@@ -923,10 +927,10 @@ int launch_window_attention(const uint16_t *qkv, uint16_t *out, const float *bia
         int dev = 0;
         VSC_CHECK_HIP(hipGetDevice(&dev));
         if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-            VSC_CHECK_HIP(hipFuncSetAttribute((const void *)window_attention_wide_stream_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            VSC_CHECK_HIP(hipFuncSetAttribute((const void *)window_attention_wide_stream_kernel<24, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             if (dev >= 0 && dev < 16) attr_set[dev] = true;
         }
-        hipLaunchKernelGGL(window_attention_wide_stream_kernel<24>, dim3((unsigned)grid), dim3(768), smem, stream, qkv, out, bias, scale, res, shift, heads);
+        hipLaunchKernelGGL((window_attention_wide_stream_kernel<24, 12>), dim3((unsigned)grid), dim3(768), smem, stream, qkv, out, bias, scale, res, shift, heads);
     } else if (ws == 24 || ws == 12) {
         auto smem_of = [](int w) {
             const int n = w * w, np = ((n / 16 + 1) & ~1) * 16, side = 2 * w - 1;
