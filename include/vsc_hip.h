@@ -373,6 +373,12 @@ int vsc_dwconv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t w, int32_
 int vsc_global_avgpool_f32(const float *x_dev, int64_t n, int32_t hw, int32_t c, float *out_dev, void *stream);
 /* x[n, hw, c] *= scale[n, c] (squeeze-excite gate) */
 int vsc_channel_scale_f32(float *x_dev, const float *scale_dev, int64_t n, int32_t hw, int32_t c, void *stream);
+/* One squeeze-excite block in place (timm SqueezeExcite: x * gate_fn(conv_expand(act(conv_reduce(x.mean((2, 3)))))), as one launch for
+ * maps whose image fits LDS ((hw c + 2 c + cr) * 4 <= 150 KiB; larger ones: vsc_global_avgpool_f32 + vsc_conv2d_f32 x 2 +
+ * vsc_channel_scale_f32): x[n, hw, c] *= act2(W2 act1(W1 mean_hw(x) + b1) + b2), W1 [cr, c] / W2 [c, cr] as packed by
+ * vsc_conv_pack_weight_f32 (1 x 1 kernels), biases may be null.  c a multiple of 4. */
+int vsc_se_block_f32(float *x_dev, int64_t n, int32_t hw, int32_t c, const float *w1_packed_dev, const float *b1_dev, int32_t cr,
+                     const float *w2_packed_dev, const float *b2_dev, int32_t act1, int32_t act2, void *stream);
 /* out[n, y, x, coff + ch] = act((accumulate ? out : 0) + src[n, y / factor, x / factor, ch]) for the h x w output grid:
  * nn.Upsample(scale_factor, 'nearest') fused with the sum of an HRNet fuse layer or with torch.cat along channels. */
 int vsc_upsample_add_f32(const float *src_dev, int64_t n, int32_t h, int32_t w, int32_t c, int32_t factor, float *out_dev,

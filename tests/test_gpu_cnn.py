@@ -383,6 +383,32 @@ def test_upsample_sum_is_the_chain_of_upsample_adds(dev):
     assert (wide[..., :8] == 2).all() and (wide[..., 28:] == 2).all()
 
 
+def test_squeeze_excite_one_launch_equals_the_four_launch_form(dev):
+    """vsc_se_block_f32 (image in LDS: mean, two Linears, scale, one read and one write of x) against avgpool + two convolutions +
+    channel_scale on the same weights: same arithmetic in another summation order."""
+    from vsc_hip import cnn
+    rng = np.random.RandomState(9)
+    for n, h, w, c, cr in ((37, 10, 10, 120, 32), (5, 10, 10, 144, 40), (3, 40, 40, 16, 8), (2, 7, 9, 96, 24)):
+        sd = {"s.conv_reduce.weight": torch.from_numpy((rng.randn(cr, c, 1, 1) / np.sqrt(c)).astype(np.float32)),
+              "s.conv_reduce.bias": torch.from_numpy(rng.randn(cr).astype(np.float32) * 0.1),
+              "s.conv_expand.weight": torch.from_numpy((rng.randn(c, cr, 1, 1) / np.sqrt(cr)).astype(np.float32)),
+              "s.conv_expand.bias": torch.from_numpy(rng.randn(c).astype(np.float32) * 0.1)}
+        se = cnn.SqueezeExcite(sd, "s", dev)
+        x = torch.from_numpy(rng.randn(n, h, w, c).astype(np.float32)).to(dev)
+        got = se(x.clone())
+        cnn.SqueezeExcite.FUSED = False
+        try:
+            ref = se(x.clone())
+        finally:
+            cnn.SqueezeExcite.FUSED = True
+        xt = x.cpu().permute(0, 3, 1, 2)
+        gate = F.hardsigmoid(F.conv2d(F.relu(F.conv2d(xt.mean((2, 3), keepdim=True), sd["s.conv_reduce.weight"], sd["s.conv_reduce.bias"])),
+                                      sd["s.conv_expand.weight"], sd["s.conv_expand.bias"]))
+        assert torch.allclose(got.cpu().permute(0, 3, 1, 2), xt * gate, atol=1e-5, rtol=1e-5), (c, cr)
+        assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5) and not torch.equal(got, x)
+        assert torch.equal(se(x.clone()), got)
+
+
 def test_mobilenetv3_classifier_matches_oracle(dev):
     from oracle import cnn_oracle
     from vsc_hip import cnn

@@ -1481,6 +1481,54 @@ __global__ __launch_bounds__(256) void channel_scale_kernel(float *__restrict__ 
     }
 }
 
+// One squeeze-excite block per launch for maps that fit LDS (every SE of the classifier: <= 100 KB per image): a workgroup brings one
+// image in (16-byte loads), takes the channel means from LDS, runs the gate's two small Linears (a wave per output row, lanes over the
+// input, 6-step shuffle reduction; weights straight from their packed rows, L2-resident), scales the image in LDS and writes it back:
+// x is read once and written once where avgpool + two convolution launches + channel_scale read it twice and wrote it once.
+//   gate = act2(W2 act1(W1 mean_hw(x) + b1) + b2),  x *= gate
+__global__ __launch_bounds__(512) void se_block_kernel(float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1, int kpad1,
+                                                       const float *__restrict__ w2, const float *__restrict__ b2, int kpad2, int hw, int c, int cr,
+                                                       int act1, int act2) {
+    extern __shared__ __attribute__((aligned(16))) float se_lds[];
+    float *img = se_lds;                       // [hw][c]
+    float *pooled = se_lds + hw * c;           // [c]
+    float *hidden = pooled + c;                // [cr]
+    float *gate = hidden + cr;                 // [c]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *xi = x + (int64_t)blockIdx.x * hw * c;
+    const int n4 = hw * c / 4;
+    for (int e = tid; e < n4; e += 512) *(f32x4_t *)(img + e * 4) = *(const f32x4_t *)(xi + e * 4);
+    __syncthreads();
+    const float inv = 1.0f / (float)hw;
+    for (int ch = tid; ch < c; ch += 512) {
+        float sacc = 0.f;
+        for (int pz = 0; pz < hw; ++pz) sacc += img[pz * c + ch];
+        pooled[ch] = sacc * inv;
+    }
+    __syncthreads();
+    for (int j = wave; j < cr; j += 8) {
+        float sacc = 0.f;
+        for (int k = lane; k < c; k += 64) sacc = fmaf(w1[(int64_t)j * kpad1 + k], pooled[k], sacc);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        if (lane == 0) hidden[j] = activate(sacc + (b1 ? b1[j] : 0.f), act1);
+    }
+    __syncthreads();
+    for (int ch = wave; ch < c; ch += 8) {
+        float sacc = 0.f;
+        for (int k = lane; k < cr; k += 64) sacc = fmaf(w2[(int64_t)ch * kpad2 + k], hidden[k], sacc);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sacc += __shfl_xor(sacc, m, 64);
+        if (lane == 0) gate[ch] = activate(sacc + (b2 ? b2[ch] : 0.f), act2);
+    }
+    __syncthreads();
+    const int c4 = c / 4;
+    for (int e = tid; e < n4; e += 512) {
+        const int q = e % c4;
+        *(f32x4_t *)(xi + e * 4) = *(const f32x4_t *)(img + e * 4) * *(const f32x4_t *)(gate + q * 4);
+    }
+}
+
 // out[n, y, x, coff + ch] (op)= src[n, y / f, x / f, ch]   (nearest upsample by f >= 1); accumulate ? += : =; then act
 __global__ __launch_bounds__(256) void upsample_add_kernel(const float *__restrict__ src, float *__restrict__ out, int64_t total,
                                                            int h, int w, int c, int f, int ldo, int coff, int accumulate, int act) {
@@ -1901,6 +1949,27 @@ extern "C" int vsc_channel_scale_f32(float *x_dev, const float *scale_dev, int64
     VSC_REQUIRE(x_dev && scale_dev && n > 0 && hw > 0 && c > 0, "channel_scale: bad arguments");
     const int64_t total = n * hw * c;
     hipLaunchKernelGGL(channel_scale_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream_, x_dev, scale_dev, total, hw, c);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+extern "C" int vsc_se_block_f32(float *x_dev, int64_t n, int32_t hw, int32_t c, const float *w1_packed_dev, const float *b1_dev, int32_t cr,
+                                const float *w2_packed_dev, const float *b2_dev, int32_t act1, int32_t act2, void *stream_) {
+    VSC_REQUIRE(x_dev && w1_packed_dev && w2_packed_dev && n > 0 && n < (1ll << 31) && hw > 0 && c > 0 && cr > 0, "se_block: bad arguments");
+    VSC_REQUIRE(act1 >= VSC_ACT_NONE && act1 <= VSC_ACT_GELU && act2 >= VSC_ACT_NONE && act2 <= VSC_ACT_GELU, "se_block: unknown activation");
+    VSC_REQUIRE((c & 3) == 0 && (((uintptr_t)x_dev) & 15) == 0, "se_block: channels must be a multiple of 4 and x 16-byte aligned");
+    const size_t lds = ((size_t)hw * c + 2 * c + cr) * 4;
+    VSC_REQUIRE(lds <= 150 * 1024, "se_block: a %d x %d map does not fit LDS (%zu bytes): use avgpool + conv2d + channel_scale", hw, c, lds);
+    static bool attr_set[16] = {};
+    int dev = 0;
+    VSC_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)se_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    const int kpad1 = vsc_conv_packed_k(c, 1, 1), kpad2 = vsc_conv_packed_k(cr, 1, 1);
+    hipLaunchKernelGGL(se_block_kernel, dim3((unsigned)n), dim3(512), lds, (hipStream_t)stream_, x_dev, w1_packed_dev, b1_dev, kpad1, w2_packed_dev, b2_dev,
+                       kpad2, hw, c, cr, act1, act2);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }

@@ -104,6 +104,7 @@ SIGNATURES = {
     "vsc_channel_scale_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "vsc_upsample_add_f32": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32,
                                        c_int32, c_int32, c_void_p]),
+    "vsc_se_block_f32": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "vsc_upsample_sum_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32,
                                        c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "vsc_attention_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),

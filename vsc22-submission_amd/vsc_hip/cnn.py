@@ -162,9 +162,18 @@ class SqueezeExcite:
         self.reduce = Conv(sd, p + ".conv_reduce", None, device=device)
         self.expand = Conv(sd, p + ".conv_expand", None, device=device)
 
+    FUSED = True   # one launch per block where the image fits LDS (vsc_se_block_f32); False: avgpool + two convolutions + scale
+
     def __call__(self, x):
         lib = _lib.require_device()
         n, h, w, c = x.shape
+        cr = self.reduce.cout
+        # (the gate's Linears are re-read per image there: beyond ~8 k weights per matrix -- 240 x 64, 576 x 144 -- the batched GEMMs of the
+        #  four-launch form win: 599 vs 160 us at 576 channels, 54 vs 121 us at 96)
+        if self.FUSED and c % 4 == 0 and c * cr <= 8192 and (h * w * c + 2 * c + cr) * 4 <= 150 * 1024:
+            check(lib.vsc_se_block_f32(ptr(x), n, h * w, c, ptr(self.reduce.w), ptr(self.reduce.b), cr, ptr(self.expand.w), ptr(self.expand.b),
+                                       ACT["relu"], ACT["hard_sigmoid"], current_stream()))
+            return x
         gate = self.expand(self.reduce(avgpool(x), act="relu"), act="hard_sigmoid")
         check(lib.vsc_channel_scale_f32(ptr(x), ptr(gate), n, h * w, c, current_stream()))
         return x
