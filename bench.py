@@ -438,6 +438,8 @@ def bench_swin(dev, args):
                 flop = per_block * cfg.depths[st]
                 if kind == "fc2_ln" and f"s{st}.fc1" not in prof:   # fused MLP kernel (swin_mlp.hip): both Linears in this class
                     flop *= 2
+                    if f"s{st}.proj_ln" not in prof:                # ... and the projection in front of them (PROJ form)
+                        flop += 2.0 * T * C * C * cfg.depths[st]
             is_gemm = kind != "attention"
         tf = flop * frames_prof / (ms * 1e-3) / 1e12 if flop and ms else None
         kernels[name] = {"ms_per_step": round(ms / psteps, 4), "launches_per_step": cnt // psteps, "avg_launch_us": round(ms / cnt * 1e3, 2)}

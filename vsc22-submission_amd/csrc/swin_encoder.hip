@@ -424,6 +424,8 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
 #define PROF(cls) SwinProfScope _ps(e, (cls), st)
     const char *fm = vsc_opt(OPT_SWIN_FUSED_MLP);   // diagnostic / test switch: 0 = fc1 and fc2 as two GEMM launches
     const bool unfused_mlp = fm && fm[0] == '0';
+    const char *fp = vsc_opt(OPT_SWIN_FUSED_PROJ);   // diagnostic / test switch: 0 = proj + LayerNorm as their own launch
+    const bool unfused_proj = fp && fp[0] == '0';
     const char *fg = vsc_opt(OPT_SWIN_FUSED_MERGE);   // diagnostic / test switch: 0 = PatchMerging as a gather kernel + GEMM
     const bool unfused_merge = fg && fg[0] == '0';
     int chunk = 0;
@@ -453,6 +455,14 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
                 const SwinBlockW &K = e->stages[s].blocks[b];
                 { PROF(pc + VSC_SWIN_PROF_QKV); TRY(launch_gemm_bf16(xb, K.qkv_w, K.qkv_b, nullptr, w.qkv, Ms, 3 * C, C, VSC_EPI_BF16, 0, st)); }
                 { PROF(pc + VSC_SWIN_PROF_ATTENTION); TRY(launch_window_attention(w.qkv, w.att, K.bias, K.scale, (int)Bs, R, W, e->shift(s, b), H, st)); }
+                if (K.fc2_wp && !unfused_mlp && !unfused_proj && swin_proj_mlp_supported(C)) {
+                    // the whole second half of the block -- proj, LayerNorm, residual, MLP, LayerNorm, residual -- in one kernel; its time
+                    // is booked under fc2_ln, proj_ln and fc1 stay empty
+                    PROF(pc + VSC_SWIN_PROF_FC2_LN);
+                    TRY(launch_swin_proj_mlp(w.att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, K.fc1_w, K.fc1_b, K.fc2_wp, K.fc2_b, K.n2_g, K.n2_b, x, xb,
+                                             Ms, C, e->cfg.ln_eps, st));
+                    continue;
+                }
                 { PROF(pc + VSC_SWIN_PROF_PROJ_LN); TRY(gemm_ln(e, w, w.att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, x, x, xb, Ms, C, C, st)); }
                 if (K.fc2_wp && !unfused_mlp) {
                     // both Linears, the GELU between them and the LayerNorm behind them in one kernel (swin_mlp.hip); its time is

@@ -41,6 +41,11 @@ struct MlpArgs {
     uint16_t *xb;          // [m, C] its bf16 shadow: the MLP's input, replaced by the shadow of the new x
     int64_t m;
     float eps;
+    // PROJ (swin_mlp_kernel<C, NW, ABL, true>): the attention projection and its LayerNorm in front, in the same kernel --
+    //     x1 = x + LayerNorm(att Wp^T + bp) * gamma1 + beta1;  then the MLP block on x1 (its shadow never leaves the registers)
+    const uint16_t *att;   // [m, C] attention output
+    const uint16_t *wp;    // [C, C]
+    const float *bp, *gamma1, *beta1;   // [C]
 };
 
 // Empty volatile asm through which every element of a step's results passes: the step's arithmetic cannot be sunk below it nor
@@ -62,7 +67,12 @@ __device__ __forceinline__ int w2_swz(int row) { return ((row >> 1) & 1) | (((ro
 // 35, everything else 100.  Measured and dropped: four waves per workgroup so that two workgroups share a CU and one
 // computes while the other moves its rows -- 710 us, no gain (and 882 us when the launch bounds let the compiler spread to one
 // workgroup per CU): the two pipes do not overlap in this instruction mix whichever waves issue them.
-template <int C, int NW, int ABL = 0>
+// PROJ: the block's first half fused in front (round 4): a wave multiplies its rows of the attention output by Wp (C x C, resident in
+// LDS beside the ring), normalises, adds x -- the accumulator layout of that product is the layout of GEMM 2's, so the LayerNorm code
+// is shared, and its bf16 shadow (8 consecutive columns per lane and column pair) IS the B operand of GEMM 1: x1 and its shadow
+// never go to memory (1.6 of the 3.2 GB the two launches moved at 256 frames of stage 0), the residual of the second LayerNorm is
+// taken from the registers.
+template <int C, int NW, int ABL = 0, bool PROJ = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpArgs p) {
 #define MFMA(a, b, c) ((ABL & 2) ? (c) + (f32x4_t){(float)(a)[0], (float)(b)[0], 0.f, 0.f} : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0))
     constexpr int RW = C == 128 ? 32 : 16, MT = RW / 16, R = NW * RW;
@@ -72,6 +82,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
     char *ring = lds;                          // 2 x CHUNK
     float *b1s = (float *)(lds + 2 * CHUNK);   // [H]
     float *b2s = b1s + H, *gs = b2s + C, *bs = gs + C;
+    float *bps = bs + C, *g1s = bps + C, *be1s = g1s + C;   // PROJ: bp, gamma1, beta1
+    char *wps = (char *)(be1s + C);                         // PROJ: Wp [C][C] bf16, 2 C-byte rows, chunk ^= row & 15
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, quad = lane >> 4;
@@ -106,12 +118,104 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
     }
     // ---- this wave's rows of xb as B operands of GEMM 1: xf[mt][ks] = xb[row0 + 16 mt + fr][32 ks + 8 quad .. + 7]
     bf16x8_t xf[MT][KS1];
+    f32x4_t xres[PROJ ? MT : 1][PROJ ? JO : 1];   // PROJ: x1 (fp32), the residual of the second LayerNorm
+    // LayerNorm of the wave's rows of `acc` (+ bias), times gamma, plus beta, plus the residual rows `res`: y[mt][jo] in acc's layout
+    // -- lane (fr, quad) holds, of row fr, the columns 32 p + 8 quad + 4 t + r in [mt][2 p + t][r]
+    auto layer_norm = [&](f32x4_t (&acc)[MT][JO], const float *bias_s, const float *gamma_s, const float *beta_s, auto &&emit) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int64_t row = row0 + mt * 16 + fr;
-        row = row < p.m ? row : p.m - 1;
+        for (int mt = 0; mt < MT; ++mt) {
+            float sum = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) xf[mt][ks] = *(const bf16x8_t *)(p.xb + row * C + ks * 32 + quad * 8);
+            for (int jo = 0; jo < JO; ++jo) {
+                acc[mt][jo] += *(const f32x4_t *)(bias_s + 32 * (jo >> 1) + 8 * quad + 4 * (jo & 1));
+                sum += (acc[mt][jo][0] + acc[mt][jo][1]) + (acc[mt][jo][2] + acc[mt][jo][3]);
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * (1.0f / C);
+            float sq = 0.f;
+#pragma unroll
+            for (int jo = 0; jo < JO; ++jo) {
+                acc[mt][jo] -= (f32x4_t){mean, mean, mean, mean};
+                sq += (acc[mt][jo][0] * acc[mt][jo][0] + acc[mt][jo][1] * acc[mt][jo][1]) +
+                      (acc[mt][jo][2] * acc[mt][jo][2] + acc[mt][jo][3] * acc[mt][jo][3]);
+            }
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            const float rstd = rsqrtf(sq * (1.0f / C) + p.eps);
+#pragma unroll
+            for (int pp = 0; pp < JO / 2; ++pp) {
+                const int col = 32 * pp + 8 * quad;
+                f32x4_t nrm[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4_t g4 = *(const f32x4_t *)(gamma_s + col + 4 * t), b4 = *(const f32x4_t *)(beta_s + col + 4 * t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) nrm[t][r] = acc[mt][2 * pp + t][r] * rstd * g4[r] + b4[r];
+                }
+                emit(mt, pp, col, nrm, rstd);
+            }
+        }
+    };
+    if (!PROJ) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int64_t row = row0 + mt * 16 + fr;
+            row = row < p.m ? row : p.m - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) xf[mt][ks] = *(const bf16x8_t *)(p.xb + row * C + ks * 32 + quad * 8);
+        }
+    } else {
+        // Wp into LDS (2 C-byte rows, chunk ^= row & 15), the wave's attention rows and residual rows into registers
+#pragma unroll
+        for (int qq = 0; qq < C * C * 2 / 1024 / NW; ++qq) {
+            const int q = qq * NW + wave;
+            const int off = q * 1024 + lane * 16;
+            const int row = off / (2 * C), cp = (off % (2 * C)) >> 4;
+            const int c = cp ^ (row & 15);
+            __builtin_amdgcn_global_load_lds((gptr_t)(p.wp + (int64_t)row * C + c * 8), (lptr_t)(wps + q * 1024), 16, 0, 0);
+        }
+        for (int i = tid; i < C; i += NW * 64) {
+            bps[i] = p.bp[i];
+            g1s[i] = p.gamma1[i];
+            be1s[i] = p.beta1[i];
+        }
+        bf16x8_t af[MT][KS1];
+        f32x4_t xin1[MT][JO];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            int64_t row = row0 + mt * 16 + fr;
+            row = row < p.m ? row : p.m - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) af[mt][ks] = *(const bf16x8_t *)(p.att + row * C + ks * 32 + quad * 8);
+#pragma unroll
+            for (int jo = 0; jo < JO; ++jo) xin1[mt][jo] = *(const f32x4_t *)(p.x + row * C + 32 * (jo >> 1) + 8 * quad + 4 * (jo & 1));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the MLP's first weight chunk, issued above, is waited for here as well)
+        __syncthreads();
+        f32x4_t pacc[MT][JO];
+#pragma unroll
+        for (int jo = 0; jo < JO; ++jo) {
+            const int n = 32 * (jo >> 1) + 8 * (fr >> 2) + 4 * (jo & 1) + (fr & 3);   // Wp row = output column (GEMM 2's row order)
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const bf16x8_t wf = *(const bf16x8_t *)(wps + n * (2 * C) + (((4 * ks + quad) ^ (n & 15)) << 4));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    pacc[mt][jo] = MFMA(wf, af[mt][ks], (ks == 0 ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : pacc[mt][jo]));
+            }
+        }
+        layer_norm(pacc, bps, g1s, be1s, [&](int mt, int pp, int col, f32x4_t (&nrm)[2], float) {
+            (void)col;
+            union { uint32_t w[4]; bf16x8_t v; } pk;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                xres[mt][2 * pp + t] = xin1[mt][2 * pp + t] + nrm[t];
+                pk.w[2 * t] = pack_bf16x2(xres[mt][2 * pp + t][0], xres[mt][2 * pp + t][1]);
+                pk.w[2 * t + 1] = pack_bf16x2(xres[mt][2 * pp + t][2], xres[mt][2 * pp + t][3]);
+            }
+            xf[mt][pp] = pk.v;   // columns 32 pp + 8 quad .. + 7 of row fr: GEMM 1's B operand of k-step pp
+        });
     }
     f32x4_t oacc[MT][JO];
 #pragma unroll
@@ -274,62 +378,57 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
     // ---- LayerNorm of the wave's rows + residual + shadow.  Lane (fr, quad) holds, of row fr, the columns
     //      32 p + 8 quad + 4 t + r (p = 0 .. C/32 - 1, t = 0, 1) in oacc[mt][2 p + t][r].
     // The residual rows are requested first, all of them, and arrive under the statistics (requested where they are used,
-    // between the stores of the same rows, every 16-byte piece was its own memory round trip).
-    f32x4_t xin[MT][JO];
+    // between the stores of the same rows, every 16-byte piece was its own memory round trip); PROJ: they are xres.
+    f32x4_t xin[PROJ ? 1 : MT][PROJ ? 1 : JO];
+    if (!PROJ) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int64_t row = row0 + mt * 16 + fr;
-        row = row < p.m ? row : p.m - 1;
+        for (int mt = 0; mt < MT; ++mt) {
+            int64_t row = row0 + mt * 16 + fr;
+            row = row < p.m ? row : p.m - 1;
 #pragma unroll
-        for (int jo = 0; jo < JO; ++jo)
-            xin[mt][jo] = (ABL & 8) ? (f32x4_t){1.f, 2.f, 3.f, 4.f} : *(const f32x4_t *)(p.x + row * C + 32 * (jo >> 1) + 8 * quad + 4 * (jo & 1));
+            for (int jo = 0; jo < JO; ++jo)
+                xin[mt][jo] = (ABL & 8) ? (f32x4_t){1.f, 2.f, 3.f, 4.f} : *(const f32x4_t *)(p.x + row * C + 32 * (jo >> 1) + 8 * quad + 4 * (jo & 1));
+        }
     }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    layer_norm(oacc, b2s, gs, bs, [&](int mt, int pp, int col, f32x4_t (&nrm)[2], float rstd) {
         const int64_t row = row0 + mt * 16 + fr;
-        float sum = 0.f;
-#pragma unroll
-        for (int jo = 0; jo < JO; ++jo) {
-            oacc[mt][jo] += *(const f32x4_t *)(b2s + 32 * (jo >> 1) + 8 * quad + 4 * (jo & 1));
-            sum += (oacc[mt][jo][0] + oacc[mt][jo][1]) + (oacc[mt][jo][2] + oacc[mt][jo][3]);
-        }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float mean = sum * (1.0f / C);
-        float sq = 0.f;
-#pragma unroll
-        for (int jo = 0; jo < JO; ++jo) {
-            oacc[mt][jo] -= (f32x4_t){mean, mean, mean, mean};
-            sq += (oacc[mt][jo][0] * oacc[mt][jo][0] + oacc[mt][jo][1] * oacc[mt][jo][1]) +
-                  (oacc[mt][jo][2] * oacc[mt][jo][2] + oacc[mt][jo][3] * oacc[mt][jo][3]);
-        }
-        sq += __shfl_xor(sq, 16, 64);
-        sq += __shfl_xor(sq, 32, 64);
-        const float rstd = rsqrtf(sq * (1.0f / C) + p.eps);
         if (row < p.m && !((ABL & 8) && rstd != 12345.f)) {
             float *xr = p.x + row * C;
             uint16_t *xbr = p.xb + row * C;
+            f32x4_t y[2];
 #pragma unroll
-            for (int pp = 0; pp < JO / 2; ++pp) {
-                const int col = 32 * pp + 8 * quad;
-                f32x4_t y[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const f32x4_t g4 = *(const f32x4_t *)(gs + col + 4 * t), b4 = *(const f32x4_t *)(bs + col + 4 * t);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) y[t][r] = xin[mt][2 * pp + t][r] + (oacc[mt][2 * pp + t][r] * rstd * g4[r] + b4[r]);
-                    *(f32x4_t *)(xr + col + 4 * t) = y[t];
-                }
-                uint4 pk;
-                pk.x = pack_bf16x2(y[0][0], y[0][1]);
-                pk.y = pack_bf16x2(y[0][2], y[0][3]);
-                pk.z = pack_bf16x2(y[1][0], y[1][1]);
-                pk.w = pack_bf16x2(y[1][2], y[1][3]);
-                *(uint4 *)(xbr + col) = pk;
+            for (int t = 0; t < 2; ++t) {
+                y[t] = (PROJ ? xres[mt][2 * pp + t] : xin[mt][2 * pp + t]) + nrm[t];
+                *(f32x4_t *)(xr + col + 4 * t) = y[t];
             }
+            uint4 pk;
+            pk.x = pack_bf16x2(y[0][0], y[0][1]);
+            pk.y = pack_bf16x2(y[0][2], y[0][3]);
+            pk.z = pack_bf16x2(y[1][0], y[1][1]);
+            pk.w = pack_bf16x2(y[1][2], y[1][3]);
+            *(uint4 *)(xbr + col) = pk;
         }
-    }
+    });
 #undef MFMA
+}
+
+template <int C>
+int launch_proj_c(const MlpArgs &a, hipStream_t stream) {
+    constexpr int NW = 8, R = NW * (C == 128 ? 32 : 16);
+    constexpr int smem = 2 * (2 * 64 * C * 2) + (4 * C + 3 * C + 3 * C) * 4 + C * C * 2;
+    static_assert(smem <= 160 * 1024, "Wp does not fit beside the ring");
+    static bool attr_set[16] = {};
+    int dev = 0;
+    VSC_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 16 || !attr_set[dev]) {
+        VSC_CHECK_HIP(hipFuncSetAttribute((const void *)swin_mlp_kernel<C, NW, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        if (dev < 16) attr_set[dev] = true;
+    }
+    const int64_t grid = (a.m + R - 1) / R;
+    VSC_REQUIRE(grid < (1ll << 31), "swin_mlp: grid too large");
+    hipLaunchKernelGGL((swin_mlp_kernel<C, NW, 0, true>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, a);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
 }
 
 template <int C>
@@ -376,6 +475,19 @@ int launch_swin_mlp(const uint16_t *w1, const float *b1, const uint16_t *w2p, co
                     float *x, uint16_t *xb, int64_t m, int c, float eps, hipStream_t stream) {
     VSC_REQUIRE(w1 && b1 && w2p && b2 && gamma && beta && x && xb && m > 0, "swin_mlp: null/empty");
     VSC_REQUIRE(swin_mlp_supported(c), "swin_mlp: width %d unsupported (128 or 256)", c);
-    const MlpArgs a{w1, b1, w2p, b2, gamma, beta, x, xb, m, eps};
+    const MlpArgs a{w1, b1, w2p, b2, gamma, beta, x, xb, m, eps, nullptr, nullptr, nullptr, nullptr, nullptr};
     return c == 128 ? launch_c<128>(a, stream) : launch_c<256>(a, stream);
 }
+
+bool swin_proj_mlp_supported(int c) { return c == 128; }
+
+// proj + LayerNorm + residual + the MLP block of one Swin-V2 block in one launch (swin_mlp_kernel<..., PROJ>): x, xb updated in place
+int launch_swin_proj_mlp(const uint16_t *att, const uint16_t *wp, const float *bp, const float *gamma1, const float *beta1, const uint16_t *w1,
+                         const float *b1, const uint16_t *w2p, const float *b2, const float *gamma2, const float *beta2, float *x, uint16_t *xb,
+                         int64_t m, int c, float eps, hipStream_t stream) {
+    VSC_REQUIRE(att && wp && bp && gamma1 && beta1 && w1 && b1 && w2p && b2 && gamma2 && beta2 && x && xb && m > 0, "swin_proj_mlp: null/empty");
+    VSC_REQUIRE(swin_proj_mlp_supported(c), "swin_proj_mlp: width %d unsupported (128)", c);
+    const MlpArgs a{w1, b1, w2p, b2, gamma2, beta2, x, xb, m, eps, att, wp, bp, gamma1, beta1};
+    return launch_proj_c<128>(a, stream);
+}
+
