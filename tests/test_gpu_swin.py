@@ -303,7 +303,7 @@ def test_swin_profiling_classes(dev):
     assert prof["patchify"][1] == chunks and prof["pool_head"][1] == chunks
     for s in range(cfg.stages):
         fused_mlp = cfg.dim(s) in (128, 256)     # one kernel for the whole MLP, booked under fc2_ln
-        fused_proj = cfg.dim(s) == 128           # ... with proj + LayerNorm in front of it as well
+        fused_proj = fused_mlp                   # ... with proj + LayerNorm in front of it as well
         for kind in ("qkv", "attention", "proj_ln", "fc1", "fc2_ln"):
             ms, n = prof.get(f"s{s}.{kind}", (0.0, 0))
             if (kind == "fc1" and fused_mlp) or (kind == "proj_ln" and fused_proj):

@@ -83,7 +83,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
     float *b1s = (float *)(lds + 2 * CHUNK);   // [H]
     float *b2s = b1s + H, *gs = b2s + C, *bs = gs + C;
     float *bps = bs + C, *g1s = bps + C, *be1s = g1s + C;   // PROJ: bp, gamma1, beta1
-    char *wps = (char *)(be1s + C);                         // PROJ: Wp [C][C] bf16, 2 C-byte rows, chunk ^= row & 15
+    // PROJ: Wp [C][C] bf16, 2 C-byte rows, chunk ^= row & 15 -- beside the ring at C = 128 (32 KiB); at C = 256 it is as large as the ring
+    // (128 KiB) and lives IN it until the projection is done, the MLP's first weight chunk being requested only then
+    constexpr bool WP_IN_RING = PROJ && C * C * 2 > 32 * 1024;
+    char *wps = WP_IN_RING ? ring : (char *)(be1s + C);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, quad = lane >> 4;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
             __builtin_amdgcn_global_load_lds((gptr_t)(p.w2p + (int64_t)row * H + ch * HC + c * 8), (lptr_t)(dst + W1B + q * 1024), 16, 0, 0);
         }
     };
-    stage(0, 0);
+    if (!WP_IN_RING) stage(0, 0);
     for (int i = tid; i < H; i += NW * 64) b1s[i] = p.b1[i];
     for (int i = tid; i < C; i += NW * 64) {
         b2s[i] = p.b2[i];
@@ -204,6 +207,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
                 for (int mt = 0; mt < MT; ++mt)
                     pacc[mt][jo] = MFMA(wf, af[mt][ks], (ks == 0 ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : pacc[mt][jo]));
             }
+        }
+        if (WP_IN_RING) {
+            __syncthreads();   // every wave is done reading Wp: the ring is the MLP's from here on
+            stage(0, 0);
         }
         layer_norm(pacc, bps, g1s, be1s, [&](int mt, int pp, int col, f32x4_t (&nrm)[2], float) {
             (void)col;
@@ -415,8 +422,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
 template <int C>
 int launch_proj_c(const MlpArgs &a, hipStream_t stream) {
     constexpr int NW = 8, R = NW * (C == 128 ? 32 : 16);
-    constexpr int smem = 2 * (2 * 64 * C * 2) + (4 * C + 3 * C + 3 * C) * 4 + C * C * 2;
-    static_assert(smem <= 160 * 1024, "Wp does not fit beside the ring");
+    constexpr int smem = 2 * (2 * 64 * C * 2) + (4 * C + 3 * C + 3 * C) * 4 + (C * C * 2 > 32 * 1024 ? 0 : C * C * 2);
+    static_assert(smem <= 160 * 1024 && C * C * 2 <= 2 * (2 * 64 * C * 2), "Wp fits neither beside the ring nor in it");
     static bool attr_set[16] = {};
     int dev = 0;
     VSC_CHECK_HIP(hipGetDevice(&dev));
@@ -479,15 +486,15 @@ int launch_swin_mlp(const uint16_t *w1, const float *b1, const uint16_t *w2p, co
     return c == 128 ? launch_c<128>(a, stream) : launch_c<256>(a, stream);
 }
 
-bool swin_proj_mlp_supported(int c) { return c == 128; }
+bool swin_proj_mlp_supported(int c) { return c == 128 || c == 256; }
 
 // proj + LayerNorm + residual + the MLP block of one Swin-V2 block in one launch (swin_mlp_kernel<..., PROJ>): x, xb updated in place
 int launch_swin_proj_mlp(const uint16_t *att, const uint16_t *wp, const float *bp, const float *gamma1, const float *beta1, const uint16_t *w1,
                          const float *b1, const uint16_t *w2p, const float *b2, const float *gamma2, const float *beta2, float *x, uint16_t *xb,
                          int64_t m, int c, float eps, hipStream_t stream) {
     VSC_REQUIRE(att && wp && bp && gamma1 && beta1 && w1 && b1 && w2p && b2 && gamma2 && beta2 && x && xb && m > 0, "swin_proj_mlp: null/empty");
-    VSC_REQUIRE(swin_proj_mlp_supported(c), "swin_proj_mlp: width %d unsupported (128)", c);
+    VSC_REQUIRE(swin_proj_mlp_supported(c), "swin_proj_mlp: width %d unsupported (128, 256)", c);
     const MlpArgs a{w1, b1, w2p, b2, gamma2, beta2, x, xb, m, eps, att, wp, bp, gamma1, beta1};
-    return launch_proj_c<128>(a, stream);
+    return c == 128 ? launch_proj_c<128>(a, stream) : launch_proj_c<256>(a, stream);
 }
 
