@@ -443,6 +443,21 @@ def test_hrnet_refine_matches_oracle(dev, n, h, w):
     assert float((got - want).abs().max()) < 1e-4            # probability map (tier bound 1e-3)
 
 
+def test_hrnet_fuse0_per_source_equals_the_concatenated_form(dev):
+    """fuse.0 applied per source at the source's resolution and summed (a 1 x 1 convolution commutes with nearest upsampling)
+    against the convolution over the materialised 336-channel concatenation: the same products, partial sums in source order."""
+    from vsc_hip import cnn
+    net = cnn.HRNetRefineHip(cnn_synth.hrnet_refine_state(7), dev)
+    x = cnn_synth.similarity_maps(8, 2, 64, 96).to(dev)
+    a = net(x)
+    cnn.HRNetRefineHip.SPLIT_FUSE0 = False
+    try:
+        b = net(x)
+    finally:
+        cnn.HRNetRefineHip.SPLIT_FUSE0 = True
+    assert a.shape == b.shape and float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max())) and not torch.equal(a, b)
+
+
 def test_match_classify_and_refine_entry_points(dev):
     """src.matching.match_classify / match_refine (infer_matching.py:158-204) end to end on synthetic candidates: datasets,
     batching, model averaging, transposed pass, crop to the valid h x w -- against the oracle's restatement of the same steps,

@@ -305,6 +305,8 @@ class _HrModule:
 class HRNetRefineHip:
     """HRnet (train/models.py:20-47): x [n, 3, h, w] on the GPU (h, w multiples of 8) -> logits [n, 2, h, w]."""
 
+    SPLIT_FUSE0 = True   # fuse.0 per source at the source's resolution (False: over the materialised 336-channel concatenation)
+
     def __init__(self, state_dict: dict, device="cuda"):
         sd = {k[len("model."):]: v for k, v in state_dict.items() if k.startswith("model.")}
         self.conv1 = Conv(sd, "conv1", "bn1", 1, device)   # stride 2 in timm, set to 1 by the reference (models.py:25-26)
@@ -325,6 +327,16 @@ class HRNetRefineHip:
             real += list(range(off, off + wd))
             off += wd + (-wd % 4)
         self.fuse0 = Conv(state_dict, "fuse.0", None, 1, device, pad4=True, cin_map=(real, off))
+        # fuse.0 is a 1 x 1 convolution over torch.cat of nearest-upsampled features, and a 1 x 1 convolution commutes with nearest
+        # upsampling: conv(cat_s up(x_s)) = sum_s up(conv_s(x_s)) with conv_s = the weight columns of source s.  Per source at its OWN
+        # resolution (the 72- / 144-wide branches at 1/16 and 1/64 of the pixels), no 336-channel tensor (1.08 GB written and read):
+        # 1.08 -> 0.45 ms per pass.  The bias rides on the first term; the partial sums are added in source order.
+        w0, b0 = _np(state_dict["fuse.0.weight"]), _np(state_dict["fuse.0.bias"])
+        self.fuse0_parts, lo = [], 0
+        for i, wd in enumerate(widths):
+            part = {"p.weight": w0[:, lo:lo + wd], "p.bias": b0 if i == 0 else np.zeros_like(b0)}
+            self.fuse0_parts.append(Conv(part, "p", None, 1, device, pad4=True))
+            lo += wd
         self.fuse2 = Conv(state_dict, "fuse.2", None, 1, device, pad4=True)
         self.classes = int(_np(state_dict["fuse.2.weight"]).shape[0])
 
@@ -342,13 +354,20 @@ class HRNetRefineHip:
                 xs = xs + [grow(xs[-1], act="relu")]
             for m in modules:
                 xs = m(xs)
-        widths = [stem.shape[3]] + [y.shape[3] for y in xs]
-        cat = torch.empty((n, h, w, sum(widths)), dtype=torch.float32, device=x.device)   # torch.cat of the upsampled features
-        off = 0
-        for i, y in enumerate([stem] + xs):
-            upsample_into(y, cat, 1 if i < 2 else 2 ** (i - 1), off, False, None)
-            off += widths[i]
-        y = self.fuse2(self.fuse0(cat, act="relu"))[..., : self.classes]
+        if self.SPLIT_FUSE0:
+            srcs = [stem] + xs
+            base = self.fuse0_parts[1](srcs[1], residual=self.fuse0_parts[0](srcs[0]))          # both at full resolution
+            terms = [(self.fuse0_parts[i](srcs[i]), 2 ** (i - 1)) for i in range(2, len(srcs))]   # 1/2, 1/4, 1/8
+            fused = upsample_sum(base, terms, torch.empty_like(base), "relu")
+        else:
+            widths = [stem.shape[3]] + [y.shape[3] for y in xs]
+            cat = torch.empty((n, h, w, sum(widths)), dtype=torch.float32, device=x.device)   # torch.cat of the upsampled features
+            off = 0
+            for i, y in enumerate([stem] + xs):
+                upsample_into(y, cat, 1 if i < 2 else 2 ** (i - 1), off, False, None)
+                off += widths[i]
+            fused = self.fuse0(cat, act="relu")
+        y = self.fuse2(fused)[..., : self.classes]
         return y.permute(0, 3, 1, 2).contiguous()
 
 
