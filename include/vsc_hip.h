@@ -323,11 +323,13 @@ int vsc_gemm_ln_bf16(const uint16_t *a_dev, const uint16_t *w_dev, const float *
                      const float *gamma_dev, const float *beta_dev, const float *x_in_dev,
                      float *x_out_dev, uint16_t *xb_dev, int64_t m, int32_t n, int32_t k, float eps,
                      void *stream);
-/* The whole MLP of a Swin-V2 block in one kernel, for the narrow stages (c = 128 or 256), in place on the residual stream:
+/* The whole MLP of a Swin-V2 block in one kernel (c = 128, 256 or 512), in place on the residual stream:
  *   x += LayerNorm(GELU(xb W1[4c,c]^T + b1) W2[c,4c]^T + b2) * gamma + beta ;  xb = bf16(x)
- * (Mlp + norm2 + residual of SwinTransformerBlock.forward, torch2scripts.py:190-215, 297-300) -- the hidden activations
- * [m, 4c] never reach memory.  w2p_dev is fc2.weight with its hidden axis in the kernel's contraction order, as made by
- * vsc_swin_mlp_permute_hidden_f32 (host arrays [c, 4c], once per model load) and then converted to bf16. */
+ * (Mlp + norm2 + residual of SwinTransformerBlock.forward, torch2scripts.py:18-35, 190-215, 297-300) -- the hidden activations
+ * [m, 4c] never reach memory.  w2p_dev is fc2.weight in the kernel's contraction order, as made by
+ * vsc_swin_mlp_permute_hidden_f32 (host arrays of c * 4c floats, once per model load) and then converted to bf16: for
+ * c = 128 / 256 the hidden axis of every row reordered inside its 32-blocks, for c = 512 additionally chunk-major
+ * [64 chunks][512][32] (one wave per SIMD with the whole register file: csrc/swin_mlp512.hip; m < 2^21 rows per call). */
 int vsc_swin_mlp_bf16(const uint16_t *w1_dev, const float *b1_dev, const uint16_t *w2p_dev, const float *b2_dev,
                       const float *gamma_dev, const float *beta_dev, float *x_dev, uint16_t *xb_dev, int64_t m, int32_t c,
                       float eps, void *stream);
@@ -336,6 +338,10 @@ int vsc_swin_mlp_permute_hidden_f32(const float *w2_host, float *w2p_host, int32
 int vsc_merge_gather_bf16(const uint16_t *xb_dev, uint16_t *out_dev, int64_t frames, int32_t res,
                           int32_t c, void *stream);
 
+/* Measurement aid for vsc_swin_mlp_bf16 at c = 512: buf_dev (NULL: off) receives, per workgroup and wave, eight uint32 -- shader
+ * cycles spent waiting for the wave's own LDS-DMA pieces, at the chunk barrier, in the chunk's work, before the epilogue, in the
+ * epilogue -- when the timing variant of the kernel runs (vsc_set_option("VSC_SWIN_MLP_ABL", "5")); [ceil(m / 128)][4][8]. */
+int vsc_debug_mlp512_timing(uint32_t *buf_dev);
 /* Measurement aid: one wave spins for `ticks` shader cycles (s_memtime) and stores the elapsed count. */
 int vsc_debug_spin_ticks(uint64_t ticks, uint64_t *out_dev, void *stream);
 

@@ -81,6 +81,15 @@ def test_swin_mlp_hidden_permutation_is_the_documented_bijection(lib):
         S, t, g, i = k >> 5, (k >> 4) & 1, (k >> 2) & 3, k & 3
         assert np.array_equal(dst[:, 32 * S + 8 * g + 4 * t + i], src[:, k])
         assert np.array_equal(np.sort(dst, axis=1), src)
+    # c = 512: chunk-major [64][512][32], the same order inside a 32-block (csrc/swin_mlp512.hip)
+    c = 512
+    src = np.arange(c * 4 * c, dtype=np.float32).reshape(c, 4 * c)
+    dst = np.full(c * 4 * c, -1.0, dtype=np.float32)
+    check(lib.vsc_swin_mlp_permute_hidden_f32(src.ctypes.data, dst.ctypes.data, c))
+    k = np.arange(4 * c)
+    ch, t, g, i = k >> 5, (k >> 4) & 1, (k >> 2) & 3, k & 3
+    assert np.array_equal(dst.reshape(64, c, 32)[ch, :, 8 * g + 4 * t + i].T, src[:, k])
+    assert np.array_equal(np.sort(dst), src.reshape(-1))
     with pytest.raises(VscHipError, match="unsupported"):
         buf = np.zeros((64, 256), dtype=np.float32)
         check(lib.vsc_swin_mlp_permute_hidden_f32(buf.ctypes.data, buf.copy().ctypes.data, 64))
@@ -92,9 +101,15 @@ def test_lds_layouts_are_conflict_free():
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools", "micro"))
     import lds_swizzle_check as L
-    for C in (128, 256):
+    for C in (128, 256, 512):
         assert max(L.cycles(lambda l, j=j, ks=ks: (16 * j + (l & 15)) * 2 * C + (((4 * ks + (l >> 4)) ^ (l & 15)) << 4))
-                   for j in range(4) for ks in range(C // 32)) == 4
+                   for j in range(4 if C < 512 else 2) for ks in range(C // 32)) == 4
+    # swin_mlp512.hip, W2 chunk: 64-byte rows, fragment jo: row 32 (jo >> 1) + 8 (fr >> 2) + 4 (jo & 1) + (fr & 3), piece quad ^ ((row & 1) | ((row >> 3) & 1) << 1)
+    def w2_512(l, jo):
+        fr, quad = l & 15, l >> 4
+        n = 32 * (jo >> 1) + 8 * (fr >> 2) + 4 * (jo & 1) + (fr & 3)
+        return n * 64 + ((quad ^ ((n & 1) | (((n >> 3) & 1) << 1))) << 4)
+    assert max(L.cycles(lambda l, jo=jo: w2_512(l, jo)) for jo in range(32)) == 4
     for tp in range(32, 321, 32):
         s = tp * 2 + 32
         assert max(L.cycles(lambda l, ct=ct, u=u: (ct * 16 + (l & 15)) * s + (32 * u + 8 * (l >> 4)) * 2)

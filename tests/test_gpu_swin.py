@@ -110,7 +110,10 @@ def test_gemm_ln_matches_torch(dev, m, n, k):
     _lib.set_option("VSC_GEMM_LN_V4", None)
 
 
-@pytest.mark.parametrize("m,c", [(5, 128), (1000, 128), (4096, 128), (70001, 128), (3, 256), (777, 256), (40000, 256)])
+@pytest.mark.parametrize("m,c", [(5, 128), (1000, 128), (4096, 128), (70001, 128), (3, 256), (777, 256), (40000, 256),
+                                 # c = 512: the one-wave-per-SIMD kernel (csrc/swin_mlp512.hip): one ragged tile, whole tiles, a ragged last tile of
+                                 # every wave position, more tiles than CUs (stage 2 of Swin-V2-B at 256 frames is 65 536 rows)
+                                 (5, 512), (128, 512), (1000, 512), (33 * 128 + 17, 512), (65536 + 77, 512)])
 def test_swin_mlp_matches_torch(dev, m, c):
     """The fused MLP kernel (both Linears, GELU, LayerNorm, residual, shadow) vs fp32 torch on the same bf16 operands with
     the same rounding point for the hidden activations; ragged last row tiles, more row tiles than CUs."""

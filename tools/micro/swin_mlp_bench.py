@@ -13,11 +13,11 @@ abls = [None] + (sys.argv[1].split(",") if len(sys.argv) > 1 else [])
 for abl in abls:
   _lib.set_option("VSC_SWIN_MLP_ABL", abl)
   print("ablation", abl, "(library built with -DVSC_MLP_ABLATION)" if abl else "")
-  for m, c in ((256 * 4096, 128), (256 * 1024, 256)):
+  for m, c in ((256 * 4096, 128), (256 * 1024, 256), (256 * 256, 512)):
       x = torch.randn(m, c, device=dev)
       xb = x.to(torch.bfloat16)
       w1 = (torch.randn(4 * c, c, device=dev) * c ** -0.5).to(torch.bfloat16)
-      w2 = (torch.randn(c, 4 * c, device=dev) * (4 * c) ** -0.5).to(torch.bfloat16)
+      w2 = (torch.randn(c, 4 * c, device=dev) * (4 * c) ** -0.5).to(torch.bfloat16)   # (timing only: any layout)
       b1, b2 = torch.zeros(4 * c, device=dev), torch.zeros(c, device=dev)
       g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
       ts = []

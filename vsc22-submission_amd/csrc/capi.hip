@@ -126,8 +126,13 @@ extern "C" int vsc_swin_mlp_bf16(const uint16_t *w1, const float *b1, const uint
 
 extern "C" int vsc_swin_mlp_permute_hidden_f32(const float *w2, float *w2p, int32_t c) {
     VSC_REQUIRE(w2 && w2p && w2 != w2p, "swin_mlp_permute_hidden: null / aliased arrays");
-    VSC_REQUIRE(swin_mlp_supported(c), "swin_mlp_permute_hidden: width %d unsupported (128 or 256)", c);
+    VSC_REQUIRE(swin_mlp_supported(c), "swin_mlp_permute_hidden: width %d unsupported (128, 256 or 512)", c);
     swin_mlp_permute_hidden(w2, w2p, c);
+    return VSC_OK;
+}
+
+extern "C" int vsc_debug_mlp512_timing(uint32_t *buf_dev) {
+    swin_mlp512_set_timing_buffer(buf_dev);
     return VSC_OK;
 }
 

@@ -1,0 +1,506 @@
+#!/usr/bin/env python3
+"""Generator of swin_mlp512_loop.inc: the body of the C = 512 fused Swin MLP kernel (swin_mlp512.hip) as ONE inline-asm statement
+with hand-assigned registers.
+
+Why asm: the kernel needs the whole register file of a wave (oacc 256 AGPRs, the rows' xb 128 VGPRs, ~100 more) and the
+compiler's allocator does not survive that.  As HIP source (builtin MFMAs, then asm MFMAs with tied accumulators) it came out
+with 400-560 spilled registers: MFMA accumulators are untied from their C operand, the kernel-wide MFMA form puts GEMM 1's
+accumulators into AGPRs that do not exist any more, the xb operands lived in scratch; with the loop alone in asm and oacc
+handed back as 64 "=a" operands the loop was clean (0 spills) and the LayerNorm epilogue behind it did not finish compiling
+in ten minutes.  So the compiler keeps what it is good at -- operand set-up and the bias rows' copy into LDS -- and this
+script assigns every register of everything else:
+    a[0:255]    oacc[mt][jo] = a[4 (32 mt + jo) ..]          (literal, clobbered)
+    v[0:127]    xf[mt][ks] = v[4 (16 mt + ks) ..] in the loop, the residual rows' quads in the epilogue   (literal, clobbered)
+    v[144:255]  temporaries (map below)                       (literal, clobbered)
+    operands    "+v" w1p[4], w2p (fragment read bases, toggled between the ring slots), b1p (bias pointer);
+                "v"  v1[4], v2 (LDS-DMA lane offsets), vecp (LDS address of b2 | gamma | beta + 32 quad), xboff (row * 1024 + 16 quad),
+                     bp16, bp32 (ds_bpermute addresses of lane ^ 16, lane ^ 32);
+                "s"  w1r, w2r, xr, xbr (buffer descriptors: rows past m lie past the extent -- loads give zeros, stores are dropped),
+                     swave = wave * 1024 (source side), sldsw = LDS base + wave * 1024 (destination side), eps
+    s[40:99] scratch scalars, m0 saved / restored, scc; vcc and exec untouched
+Wait states the compiler would pad and an asm statement must carry itself (cdna_hip_programming.md 5.7):
+    MFMA D (VGPR) -> vector reader: GEMM 1's last MFMA is followed by s_nop 7 + the loop head (>= 12 states);
+    MFMA D (AGPR) -> v_accvgpr_read: s_nop 15 behind the last MFMA;
+    vector write -> MFMA operand: s_nop 1 between the GELU's last v_cvt_pk (hf) and GEMM 2's first MFMA;
+    v_accvgpr_write -> MFMA C: the bias initialisation is hundreds of instructions ahead of the first GEMM 2 MFMA;
+    MFMA chain (D taken whole as the next C): none;  16-byte store -> overwrite of its data: register sets alternate per column group.
+LDS reads return in order: the script tracks the queue and emits counted s_waitcnt lgkmcnt(n).
+
+    python3 gen_mlp512_loop.py > swin_mlp512_loop.inc
+"""
+import struct
+import sys
+
+SLOT = 32768
+LDS_W1, LDS_W2 = 0, 2 * SLOT
+NCH = 64
+PF, STAGGER, TIMING, ABL = 8, 0, False, 0    # defaults; main() builds the variants listed in VARIANTS
+# ABL (diagnostic variants, wrong results): 1 no GELU arithmetic, 2 no LDS-DMA in the loop, 4 no fragment reads, 8 no MFMAs in the loop
+GELU_DEG = 8
+GELU_U = 4.5
+GELU_ZS = 2.0 / (4.5 * 4.5)
+GELU_C = [1.569020897e-01, -7.717858255e-02, 5.482625961e-02, -4.047540203e-02, 2.754251473e-02, -1.697185636e-02, 1.244884357e-02,
+          -9.152771905e-03, 3.170517040e-03]   # gelu_poly.h
+NSTEP = GELU_DEG + 3
+
+
+def f32(x):
+    return "0x%08x" % struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+# ---- register map -------------------------------------------------------------------------------------------------------------
+T = 144
+PFMAX = 10
+def vq(b): return f"v[{b}:{b + 3}]"
+def vp(b): return f"v[{b}:{b + 1}]"
+def HACC(mt, j): return T + 4 * (2 * mt + j)          # 144..159 (the GELU works in place here)
+def WQ(k): return T + 16 + 4 * k                        # 160..199: up to PFMAX fragment quads
+def HF(mt): return T + 56 + 4 * mt                      # 200..207
+def HFN(mt): return T + 64 + 4 * mt                     # 208..215
+def BZ(j): return T + 72 + 4 * j                        # 216..223
+GT, GZ, GQ = T + 80, T + 88, T + 96                     # 224.., 232.., 240..  (four pairs each)
+VU, VC7 = T + 104, T + 106                              # 248 (+U), 250:251 (c7, low half used)
+S_I, S_T, S_T2, S_SLOT, S_M0, S_SO1, S_SO2, S_NU = 40, 41, 42, 43, 44, 45, 46, 47
+S_ZS, S_C8 = 48, 50
+def S_C(k): return 52 + 2 * k                           # k = 0..6 -> s[52:65]
+def sp(b): return f"s[{b}:{b + 1}]"
+
+def ACC(mt, jo): return f"a[{4 * (32 * mt + jo)}:{4 * (32 * mt + jo) + 3}]"
+def ACCR(mt, jo, r): return f"a{4 * (32 * mt + jo) + r}"
+def XF(mt, ks): return vq(4 * (16 * mt + ks))
+def W1P(a): return f"%[w1p{a}]"
+W2P, B1P, V2, W1R, W2R, SW, SLW = "%[w2p]", "%[b1p]", "%[v2]", "%[w1r]", "%[w2r]", "%[swave]", "%[sldsw]"
+VECP, XBOFF, BP16, BP32, XR, XBR, EPS = "%[vecp]", "%[xboff]", "%[bp16]", "%[bp32]", "%[xr]", "%[xbr]", "%[eps]"
+DBGR, DBGOFF = "%[dbgr]", "%[dbgoff]"      # timing variant: per-wave cycle counters go to dbgr at byte offset dbgoff
+S_TS, S_ACC = 70, 80                     # s[70:79] time stamps (pairs), s80.. accumulated differences
+S_MT1X, S_MT1B = 66, 67     # byte offsets of the second 16-row tile in x / xb
+S_SLOT2 = 68                # LDS offset of the W2 slot being refilled (S_SLOT: the W1 slot)
+BID = "%[bid]"
+def V1(a): return f"%[v1{a}]"
+
+
+class Emit:
+    def __init__(self):
+        self.lines = []
+        self.q = []          # outstanding LDS reads (tags), oldest first
+
+    def i(self, s):
+        self.lines.append(s)
+
+    def c(self, s):
+        self.lines.append("; " + s)
+
+    def ds_read(self, tag, dst, addr, off):
+        self.i(f"ds_read_b128 {vq(dst)}, {addr}" + (f" offset:{off}" if off else ""))
+        self.q.append(tag)
+        assert len(self.q) <= 15
+
+    def wait(self, tag):
+        if tag not in self.q:
+            return
+        k = self.q.index(tag)
+        n = len(self.q) - 1 - k
+        self.i(f"s_waitcnt lgkmcnt({n})")
+        self.q = self.q[k + 1:]
+
+    def wait_all(self):
+        if self.q:
+            self.i("s_waitcnt lgkmcnt(0)")
+        self.q = []
+
+
+def frag_addr(g):
+    """(base register, immediate) of the fragment of MFMA group g: 0..31 GEMM 2 (output tile g), 32..63 GEMM 1 (j = e & 1, ks = e >> 1)"""
+    if g < 32:
+        return W2P, 2048 * (g >> 1) + 256 * (g & 1)
+    e = g - 32
+    j, ks = e & 1, e >> 1
+    return W1P(ks & 3), 16384 * j + 256 * (ks >> 2)
+
+
+def group(E, g, end):
+    """the two MFMAs of group g, then the request of the fragment PF groups ahead (none at or beyond `end`)"""
+    E.wait(("f", g))
+    w = vq(WQ(g % PF))
+    if ABL & 8:
+        pass
+    elif g < 32:
+        for mt in range(2):
+            E.i(f"v_mfma_f32_16x16x32_bf16 {ACC(mt, g)}, {w}, {vq(HF(mt))}, {ACC(mt, g)}")
+    else:
+        e = g - 32
+        j, ks = e & 1, e >> 1
+        for mt in range(2):
+            c = "0" if ks == 0 else vq(HACC(mt, j))
+            E.i(f"v_mfma_f32_16x16x32_bf16 {vq(HACC(mt, j))}, {w}, {XF(mt, ks)}, {c}")
+    if g + PF < end and not (ABL & 4):
+        a, off = frag_addr(g + PF)
+        E.ds_read(("f", g + PF), WQ(g % PF), a, off)
+
+
+def dma_items(which):
+    """LDS-DMA of one chunk as 8 items of 4 instructions.  which = 'w1': chunk i + 2 (soffset base S_SO1) -> W1 slot i & 1 (past the last
+    chunk the source lies past the descriptor's extent: zeros arrive, nobody reads them); 'w2': chunk i (S_SO2) -> W2 slot i & 1.
+    m0 = LDS destination of the instruction (wave-uniform), lane l lands at m0 + 16 l."""
+    lds0 = LDS_W1 if which == "w1" else LDS_W2
+    so = S_SO1 if which == "w1" else S_SO2
+    rs = W1R if which == "w1" else W2R
+    items = []
+    for qq in range(8):
+        voff = V1(qq & 3) if which == "w1" else V2
+        items.append([f"s_add_u32 s{S_T}, s{S_SLOT if which == 'w1' else S_SLOT2}, {lds0 + qq * 4096}",
+                      f"s_add_u32 m0, s{S_T}, {SLW}",
+                      f"s_add_u32 s{S_T2}, s{so}, {qq * 4096}",
+                      f"buffer_load_dwordx4 {voff}, {rs}, s{S_T2} offen lds"])
+    return items
+
+
+def dma(E, which):
+    for it in dma_items(which):
+        for l in it:
+            E.i(l)
+
+
+def gelu(E, mt, fill):
+    """bias + GELU + bf16 rounding of the 16-row tile mt: 8 values per lane, in place in HACC(mt, 0..1) -> HF(mt); fill(step) after each step"""
+    x = [HACC(mt, 0), HACC(mt, 0) + 2, HACC(mt, 1), HACC(mt, 1) + 2]    # four pairs
+    bz = [BZ(0), BZ(0) + 2, BZ(1), BZ(1) + 2]
+    t = [GT + 2 * k for k in range(4)]
+    z = [GZ + 2 * k for k in range(4)]
+    q = [GQ + 2 * k for k in range(4)]
+    for k in range(4):
+        E.i(f"v_pk_add_f32 {vp(x[k])}, {vp(x[k])}, {vp(bz[k])}")
+    if ABL & 1:
+        for k in range(4):
+            E.i(f"v_cvt_pk_bf16_f32 v{HF(mt) + k}, v{x[k]}, v{x[k] + 1}")
+        return
+    for k in range(4):
+        for h in range(2):
+            E.i(f"v_med3_f32 v{t[k] + h}, v{x[k] + h}, s{S_NU}, v{VU}")
+    fill(0)
+    for k in range(4):
+        E.i(f"v_pk_mul_f32 {vp(z[k])}, {vp(t[k])}, {vp(t[k])}")
+    for k in range(4):
+        E.i(f"v_pk_fma_f32 {vp(z[k])}, {vp(z[k])}, {sp(S_ZS)}, -1.0 op_sel_hi:[1,0,0]")
+    fill(1)
+    for k in range(4):
+        E.i(f"v_pk_fma_f32 {vp(q[k])}, {vp(z[k])}, {sp(S_C8)}, {vp(VC7)} op_sel_hi:[1,0,0]")
+    fill(2)
+    for c in range(GELU_DEG - 2, -1, -1):
+        for k in range(4):
+            E.i(f"v_pk_fma_f32 {vp(q[k])}, {vp(q[k])}, {vp(z[k])}, {sp(S_C(c))} op_sel_hi:[1,1,0]")
+        fill(GELU_DEG + 1 - c)
+    for k in range(4):
+        E.i(f"v_pk_fma_f32 {vp(q[k])}, {vp(t[k])}, {vp(q[k])}, 0.5 op_sel_hi:[1,1,0]")
+    for k in range(4):
+        E.i(f"v_pk_mul_f32 {vp(x[k])}, {vp(x[k])}, {vp(q[k])}")
+    fill(NSTEP - 1)
+    for k in range(4):
+        E.i(f"v_cvt_pk_bf16_f32 v{HF(mt) + k}, v{x[k]}, v{x[k] + 1}")
+
+
+def stamp(E, k):
+    """timing variant: s[S_TS + 2k : +1] = s_memtime (an SMEM return: the LDS queue must be empty here, and is drained)"""
+    if not TIMING:
+        return
+    assert not E.q
+    E.i(f"s_memtime {sp(S_TS + 2 * k)}")
+    E.i("s_waitcnt lgkmcnt(0)")
+
+
+def lap(E, acc, k1, k0):
+    """timing variant: s[S_ACC + acc] += stamp k1 - stamp k0 (low words)"""
+    if not TIMING:
+        return
+    E.i(f"s_sub_u32 s{S_T}, s{S_TS + 2 * k1}, s{S_TS + 2 * k0}")
+    E.i(f"s_add_u32 s{S_ACC + acc}, s{S_ACC + acc}, s{S_T}")
+
+
+def col_off(jo):
+    """byte offset (fp32 rows) of the lane's four columns of output tile jo, without the 32 quad part: columns 32 (jo >> 1) + 4 (jo & 1) + 8 quad + r"""
+    return 128 * (jo >> 1) + 16 * (jo & 1)
+
+
+def reduce4(E, v, tmp):
+    """v += v of lane ^ 16, then of lane ^ 32: the four lanes (fr, 0..3) that hold one row"""
+    for bp in (BP16, BP32):
+        E.i(f"ds_bpermute_b32 v{tmp}, {bp}, v{v}")
+        E.i("s_waitcnt lgkmcnt(0)")
+        E.i(f"v_add_f32 v{v}, v{v}, v{tmp}")
+
+
+def epilogue(E):
+    """x += LayerNorm(oacc) * gamma + beta (oacc already holds the fc2 bias), shadow = bf16(x), for the wave's two 16-row tiles.
+    Lane (fr, quad) holds, of row 16 mt + fr, the columns 32 pp + 8 quad + 4 t + r in ACC(mt, 2 pp + t)[r]."""
+    XOFF = T                       # v168: row * 2048 + 32 quad
+    MEAN = [T + 2, T + 4]          # pairs (value in the low half)
+    RSTD = [T + 6, T + 8]
+    S, TMP = T + 10, T + 11
+    P0, P1, W = T + 16, T + 18, T + 20           # 184:185, 186:187, 188:191
+    def XIN(jo): return 4 * jo                    # the xf area: 32 quads
+    E.c("---- epilogue")
+    E.i("s_nop 15")
+    E.i(f"v_lshlrev_b32 v{XOFF}, 1, {XBOFF}")
+    E.i(f"s_mov_b32 s{S_MT1X}, {16 * 2048}")
+    E.i(f"s_mov_b32 s{S_MT1B}, {16 * 1024}")
+    E.c("residual rows of tile 0 (they land under the statistics)")
+    for jo in range(32):
+        E.i(f"buffer_load_dwordx4 {vq(XIN(jo))}, v{XOFF}, {XR}, 0 offen offset:{col_off(jo)}")
+    for mt in range(2):
+        E.c(f"statistics of tile {mt}: two passes over the registers")
+        for pas in range(2):
+            E.i(f"v_mov_b32 v{P0}, 0")
+            E.i(f"v_mov_b32 v{P0 + 1}, 0")
+            E.i(f"v_mov_b32 v{P1}, 0")
+            E.i(f"v_mov_b32 v{P1 + 1}, 0")
+            for jo in range(32):
+                w = W + 4 * (jo & 1)          # two work quads, alternating
+                for r in range(4):
+                    E.i(f"v_accvgpr_read_b32 v{w + r}, {ACCR(mt, jo, r)}")
+                if pas == 0:
+                    E.i(f"v_pk_add_f32 {vp(P0)}, {vp(P0)}, {vp(w)}")
+                    E.i(f"v_pk_add_f32 {vp(P1)}, {vp(P1)}, {vp(w + 2)}")
+                else:
+                    E.i(f"v_pk_add_f32 {vp(w)}, {vp(w)}, {vp(MEAN[mt])} op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]")
+                    E.i(f"v_pk_add_f32 {vp(w + 2)}, {vp(w + 2)}, {vp(MEAN[mt])} op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]")
+                    E.i(f"v_pk_fma_f32 {vp(P0)}, {vp(w)}, {vp(w)}, {vp(P0)}")
+                    E.i(f"v_pk_fma_f32 {vp(P1)}, {vp(w + 2)}, {vp(w + 2)}, {vp(P1)}")
+            E.i(f"v_pk_add_f32 {vp(P0)}, {vp(P0)}, {vp(P1)}")
+            E.i(f"v_add_f32 v{S}, v{P0}, v{P0 + 1}")
+            reduce4(E, S, TMP)
+            if pas == 0:
+                E.i(f"v_mul_f32 v{MEAN[mt]}, {f32(1.0 / 512)}, v{S}")
+            else:
+                E.i(f"v_mov_b32 v{TMP}, {EPS}")
+                E.i(f"v_fmac_f32 v{TMP}, {f32(1.0 / 512)}, v{S}")
+                E.i(f"v_rsq_f32 v{RSTD[mt]}, v{TMP}")
+                E.i("s_nop 1")
+    for mt in range(2):
+        E.c(f"tile {mt}: normalise, add the residual rows, store x and the shadow")
+        E.i("s_waitcnt vmcnt(0)")
+        for pp in range(16):
+            base = T + 24 + 28 * (pp & 1)         # register set of this column group: Y0, Y1, K, G0, B0, G1, B1
+            Y = [base, base + 4]
+            K = base + 8
+            G = [base + 12, base + 20]
+            B = [base + 16, base + 24]
+            for t in range(2):
+                jo = 2 * pp + t
+                E.ds_read(("g", jo), G[t], VECP, 2048 + col_off(jo))
+                E.ds_read(("e", jo), B[t], VECP, 4096 + col_off(jo))
+            for t in range(2):
+                jo = 2 * pp + t
+                for r in range(4):
+                    E.i(f"v_accvgpr_read_b32 v{Y[t] + r}, {ACCR(mt, jo, r)}")
+                for h in (0, 2):
+                    E.i(f"v_pk_add_f32 {vp(Y[t] + h)}, {vp(Y[t] + h)}, {vp(MEAN[mt])} op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]")
+                for h in (0, 2):
+                    E.i(f"v_pk_mul_f32 {vp(Y[t] + h)}, {vp(Y[t] + h)}, {vp(RSTD[mt])} op_sel_hi:[1,0]")
+                E.wait(("e", jo))
+                for h in (0, 2):
+                    E.i(f"v_pk_fma_f32 {vp(Y[t] + h)}, {vp(Y[t] + h)}, {vp(G[t] + h)}, {vp(B[t] + h)}")
+                for h in (0, 2):
+                    E.i(f"v_pk_add_f32 {vp(Y[t] + h)}, {vp(Y[t] + h)}, {vp(XIN(jo) + h)}")
+                so = "0" if mt == 0 else f"s{S_MT1X}"
+                E.i(f"buffer_store_dwordx4 {vq(Y[t])}, v{XOFF}, {XR}, {so} offen offset:{col_off(jo)}")
+                if mt == 0:
+                    E.c("the same quad of tile 1's residual rows takes the place of the one just used")
+                    E.i(f"buffer_load_dwordx4 {vq(XIN(jo))}, v{XOFF}, {XR}, s{S_MT1X} offen offset:{col_off(jo)}")
+            for t in range(2):
+                E.i(f"v_cvt_pk_bf16_f32 v{K + 2 * t}, v{Y[t]}, v{Y[t] + 1}")
+                E.i(f"v_cvt_pk_bf16_f32 v{K + 2 * t + 1}, v{Y[t] + 2}, v{Y[t] + 3}")
+            so = "0" if mt == 0 else f"s{S_MT1B}"
+            E.i(f"buffer_store_dwordx4 {vq(K)}, {XBOFF}, {XBR}, {so} offen offset:{64 * pp}")
+        assert not E.q
+
+
+def program():
+    """Schedule of one hidden chunk (iteration i), one workgroup barrier per chunk:
+        [bias values of chunk i requested] barrier [first fragments requested]
+        GELU(i): ONE uninterrupted run of vector instructions -> hf      (the fragments' LDS round trip lands under it)
+        GEMM 2 of chunk i (32 MFMA groups; one LDS-DMA item behind each of the first 16), GEMM 1 of chunk i+1 (32 groups): one run of MFMAs
+    reads W2 slot i & 1 and W1 slot (i+1) & 1; refills W2 slot (i+1) & 1 with chunk i+1 and W1 slot i & 1 with chunk i+2.
+    Why runs and not an interleave: on this part the matrix and the vector pipe do not overlap, and a vector instruction behind an
+    MFMA costs ~16 cycles where it costs 5 behind another vector instruction (tools/micro/single_wave_issue.hip: 64 MFMAs with 32
+    packed FMAs between them take 24.3 cycles per MFMA, alone 16.1) -- the first version, with the polynomial's steps between the
+    MFMA groups, ran 3 500 cycles per chunk against 2 064 of MFMAs + 650 of vector work."""
+    E = Emit()
+    E.c("---- set-up: constants, m0 saved (s_nop 4: a scalar operand may be fresh from a v_readfirstlane)")
+    E.i("s_nop 4")
+    E.i(f"s_mov_b32 s{S_M0}, m0")
+    if TIMING:
+        for a in range(6):
+            E.i(f"s_mov_b32 s{S_ACC + a}, 0")
+        stamp(E, 4)      # kernel start
+    if STAGGER:
+        E.c("start skew: the workgroups of the first round (one per CU) start in four phases, so that the chip-wide bursts of their row")
+        E.c("loads / stores (every CU moves 768 KB at the same moment otherwise) fall under the other phases' MFMAs")
+        E.i(f"s_lshr_b32 s{S_T}, {BID}, 3")
+        E.i(f"s_and_b32 s{S_T}, s{S_T}, 3")
+        E.i(f"s_cmp_lt_u32 {BID}, 256")
+        E.i(f"s_cselect_b32 s{S_T}, s{S_T}, 0")
+        E.i(f"s_mul_i32 s{S_T}, s{S_T}, {STAGGER}")
+        E.i("L_skew%=:")
+        E.i(f"s_cmp_eq_u32 s{S_T}, 0")
+        E.i("s_cbranch_scc1 L_skew_done%=")
+        E.i("s_sleep 32")
+        E.i(f"s_sub_u32 s{S_T}, s{S_T}, 1")
+        E.i("s_branch L_skew%=")
+        E.i("L_skew_done%=:")
+    E.i(f"s_mov_b32 s{S_NU}, {f32(-GELU_U)}")
+    E.i(f"s_mov_b32 s{S_T}, {f32(GELU_U)}")
+    E.i(f"v_mov_b32 v{VU}, s{S_T}")
+    E.i(f"s_mov_b32 s{S_T}, {f32(GELU_C[GELU_DEG - 1])}")
+    E.i(f"v_mov_b32 v{VC7}, s{S_T}")
+    E.i(f"v_mov_b32 v{VC7 + 1}, s{S_T}")
+    for b, val in [(S_ZS, GELU_ZS), (S_C8, GELU_C[GELU_DEG])] + [(S_C(k), GELU_C[k]) for k in range(GELU_DEG - 1)]:
+        E.i(f"s_mov_b32 s{b}, {f32(val)}")
+        E.i(f"s_mov_b32 s{b + 1}, {f32(val)}")
+    E.c("---- W1(0) -> W1 slot 0, W1(1) -> W1 slot 1, W2(0) -> W2 slot 0")
+    for ch in range(2):
+        E.i(f"s_mov_b32 s{S_SLOT}, {ch * SLOT}")
+        E.i(f"s_add_u32 s{S_SO1}, {SW}, {ch * SLOT}")
+        dma(E, "w1")
+    E.i(f"s_mov_b32 s{S_SLOT2}, 0")
+    E.i(f"s_mov_b32 s{S_SO2}, {SW}")
+    dma(E, "w2")
+    E.c("iteration 0 refills W1 slot 0 with chunk 2 and W2 slot 1 with chunk 1")
+    E.i(f"s_mov_b32 s{S_SLOT}, 0")
+    E.i(f"s_mov_b32 s{S_SLOT2}, {SLOT}")
+    E.i(f"s_add_u32 s{S_SO1}, {SW}, {2 * SLOT}")
+    E.i(f"s_add_u32 s{S_SO2}, {SW}, {SLOT}")
+    E.i(f"s_mov_b32 s{S_I}, 0")
+    E.c("---- this wave's rows of xb as B operands of GEMM 1: xf[mt][ks] = xb[row0 + 16 mt + fr][32 ks + 8 quad .. + 7]")
+    E.i(f"s_mov_b32 s{S_MT1B}, {16 * 1024}")
+    for mt in range(2):
+        for ks in range(16):
+            so = "0" if mt == 0 else f"s{S_MT1B}"
+            E.i(f"buffer_load_dwordx4 {XF(mt, ks)}, {XBOFF}, {XBR}, {so} offen offset:{64 * ks}")
+    E.c("the compiler's LDS stores of the bias rows (lgkmcnt) and this wave's DMA pieces and rows (vmcnt), then everybody's")
+    E.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    E.i("s_barrier")
+    E.c("---- oacc = the fc2 bias of its columns (the MFMAs accumulate on top of it)")
+    for jo0 in range(0, 32, 8):
+        for jo in range(jo0, jo0 + 8):
+            E.ds_read(("i", jo), WQ(0) + 4 * (jo - jo0), VECP, col_off(jo))
+        for jo in range(jo0, jo0 + 8):
+            E.wait(("i", jo))
+            for mt in range(2):
+                for r in range(4):
+                    E.i(f"v_accvgpr_write_b32 {ACCR(mt, jo, r)}, v{WQ(0) + 4 * (jo - jo0) + r}")
+    E.c("---- GEMM 1 of chunk 0 (W1 slot 0)")
+    for g in range(32, 32 + PF):
+        a, off = frag_addr(g)
+        E.ds_read(("f", g), WQ(g % PF), a, off)
+    for g in range(32, 64):
+        group(E, g, 64)
+    assert not E.q
+    E.i("s_nop 7")
+    E.c("iteration 0 reads W2 slot 0 and W1 slot 1")
+    for a in range(4):
+        E.i(f"v_xor_b32 {W1P(a)}, 0x8000, {W1P(a)}")
+
+    E.i("L_top%=:")
+    E.c("the chunk's bias values do not wait for the barrier (the table is static)")
+    stamp(E, 0)
+    if not TIMING:
+        E.ds_read(("b", 0), BZ(0), B1P, 0)
+        E.ds_read(("b", 1), BZ(1), B1P, 64)
+    E.i("s_waitcnt vmcnt(0)")
+    stamp(E, 1)
+    E.i("s_barrier")
+    stamp(E, 2)
+    if TIMING:
+        lap(E, 0, 1, 0)      # waiting for this wave's DMA pieces
+        lap(E, 1, 2, 1)      # waiting for the other waves
+        E.ds_read(("b", 0), BZ(0), B1P, 0)
+        E.ds_read(("b", 1), BZ(1), B1P, 64)
+    for g in range(PF):
+        if ABL & 4:
+            break
+        a, off = frag_addr(g)
+        E.ds_read(("f", g), WQ(g % PF), a, off)
+    E.wait(("b", 1))     # (only the two bias reads are waited for: lgkmcnt(PF))
+    for mt in range(2):
+        gelu(E, mt, lambda step: None)
+    E.i(f"v_add_u32 {B1P}, 0x80, {B1P}")
+    E.c("vector write -> MFMA operand: two wait states")
+    E.i("s_nop 1")
+    items = [] if ABL & 2 else dma_items("w2") + dma_items("w1")
+    if ABL & 4:
+        E.wait_all()
+    for g in range(32):
+        group(E, g, 64)
+        if g < len(items):
+            for l in items[g]:
+                E.i(l)
+    E.i(f"s_cmp_eq_u32 s{S_I}, {NCH - 1}")
+    E.i("s_cbranch_scc1 L_done%=")
+    for g in range(32, 64):
+        group(E, g, 64)
+    assert not E.q
+    E.i("s_nop 7")
+    for a in range(4):
+        E.i(f"v_xor_b32 {W1P(a)}, 0x8000, {W1P(a)}")
+    E.i(f"v_xor_b32 {W2P}, 0x8000, {W2P}")
+    E.i(f"s_xor_b32 s{S_SLOT}, s{S_SLOT}, 0x8000")
+    E.i(f"s_xor_b32 s{S_SLOT2}, s{S_SLOT2}, 0x8000")
+    E.i(f"s_add_u32 s{S_SO1}, s{S_SO1}, {SLOT}")
+    E.i(f"s_add_u32 s{S_SO2}, s{S_SO2}, {SLOT}")
+    E.i(f"s_add_u32 s{S_I}, s{S_I}, 1")
+    stamp(E, 3)
+    lap(E, 2, 3, 2)          # the iteration's work behind the barrier
+    E.i("s_branch L_top%=")
+
+    E.i("L_done%=:")
+    E.c("(the last iteration requested the first fragments of a GEMM 1 that does not exist)")
+    E.i("s_waitcnt lgkmcnt(0)")
+    E.q = []
+    stamp(E, 3)
+    epilogue(E)
+    E.i("s_waitcnt vmcnt(0)")
+    if TIMING:
+        stamp(E, 0)
+        lap(E, 3, 3, 4)      # kernel start -> epilogue start
+        lap(E, 4, 0, 3)      # epilogue
+        for a in range(5):
+            E.i(f"v_mov_b32 v{T}, s{S_ACC + a}")
+            E.i(f"buffer_store_dword v{T}, off, {DBGR}, {DBGOFF} offset:{4 * a}")
+        E.i("s_waitcnt vmcnt(0)")
+    E.i(f"s_mov_b32 m0, s{S_M0}")
+    return E.lines
+
+
+# (PF, STAGGER, TIMING): fragments requested PF groups ahead; start skew of the first round's workgroups in units of s_sleep 32 (2 048
+# cycles) per phase (four phases by (blockIdx >> 3) & 3).
+# Variant 0 is what launch_swin_mlp512 runs; the others are reachable through VSC_SWIN_MLP_ABL=<index> (A/B on one box).
+VARIANTS = [(8, 0, False, 0), (8, 4, False, 0), (8, 8, False, 0), (8, 12, False, 0), (8, 16, False, 0), (8, 0, True, 0), (8, 0, False, 8), (8, 0, False, 14), (8, 0, False, 15)]
+
+
+def main():
+    global PF, STAGGER, TIMING, ABL
+    out = ["// GENERATED by gen_mlp512_loop.py -- do not edit.  One asm statement per variant: the body of swin_mlp512_kernel<V>."]
+    for k, (PF, STAGGER, TIMING, ABL) in enumerate(VARIANTS):
+        lines = program()
+        out.append(f"// variant {k}: PF = {PF}, STAGGER = {STAGGER}" + (", cycle counters per wave" if TIMING else "") + (f", ablation {ABL} (wrong results)" if ABL else ""))
+        out.append(f"#define VSC_MLP512_LOOP_ASM_{k} \\")
+        for l in lines:
+            if l.startswith(";"):
+                continue
+            out.append(f'    "{l}\\n" \\')
+        out.append('    ""')
+    out.append(f"#define VSC_MLP512_VARIANTS {len(VARIANTS)}")
+    io = ", ".join([f'[w1p{a}] "+v"(w1p[{a}])' for a in range(4)] + ['[w2p] "+v"(w2p)', '[b1p] "+v"(b1p)'])
+    ins = ", ".join([f'[v1{a}] "v"(v1[{a}])' for a in range(4)] +
+                    ['[v2] "v"(v2)', '[vecp] "v"(vecp)', '[xboff] "v"(xboff)', '[bp16] "v"(bp16)', '[bp32] "v"(bp32)',
+                     '[w1r] "s"(w1r)', '[w2r] "s"(w2r)', '[xr] "s"(xr)', '[xbr] "s"(xbr)', '[swave] "s"(swave)', '[sldsw] "s"(sldsw)', '[eps] "s"(eps)', '[dbgr] "s"(dbgr)', '[dbgoff] "s"(dbgoff)', '[bid] "s"(bid)'])
+    clob = ", ".join([f'"v{r}"' for r in range(0, 128)] + [f'"v{r}"' for r in range(T, 256)] + [f'"a{r}"' for r in range(256)] +
+                     [f'"s{r}"' for r in range(40, 100)] + ['"scc"', '"memory"'])
+    out.append(f"#define VSC_MLP512_LOOP_OUTS {io}")
+    out.append(f"#define VSC_MLP512_LOOP_INS {ins}")
+    out.append(f"#define VSC_MLP512_LOOP_CLOBBERS {clob}")
+    sys.stdout.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()

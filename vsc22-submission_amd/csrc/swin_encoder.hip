@@ -424,6 +424,8 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
 #define PROF(cls) SwinProfScope _ps(e, (cls), st)
     const char *fm = vsc_opt(OPT_SWIN_FUSED_MLP);   // diagnostic / test switch: 0 = fc1 and fc2 as two GEMM launches
     const bool unfused_mlp = fm && fm[0] == '0';
+    const char *f5 = vsc_opt(OPT_SWIN_MLP512);      // diagnostic / test switch: 0 = the 512-wide stage keeps fc1 and fc2 as two GEMM launches
+    const bool unfused_mlp512 = f5 && f5[0] == '0';
     const char *fp = vsc_opt(OPT_SWIN_FUSED_PROJ);   // diagnostic / test switch: 0 = proj + LayerNorm as their own launch
     const bool unfused_proj = fp && fp[0] == '0';
     const char *fg = vsc_opt(OPT_SWIN_FUSED_MERGE);   // diagnostic / test switch: 0 = PatchMerging as a gather kernel + GEMM
@@ -464,7 +466,7 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
                     continue;
                 }
                 { PROF(pc + VSC_SWIN_PROF_PROJ_LN); TRY(gemm_ln(e, w, w.att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, x, x, xb, Ms, C, C, st)); }
-                if (K.fc2_wp && !unfused_mlp) {
+                if (K.fc2_wp && !unfused_mlp && !(C == 512 && unfused_mlp512)) {
                     // both Linears, the GELU between them and the LayerNorm behind them in one kernel (swin_mlp.hip); its time is
                     // booked under fc2_ln, fc1 stays empty
                     PROF(pc + VSC_SWIN_PROF_FC2_LN);

@@ -465,11 +465,13 @@ int launch_c(const MlpArgs &a, hipStream_t stream) {
 
 }  // namespace
 
-bool swin_mlp_supported(int c) { return c == 128 || c == 256; }
+bool swin_mlp_supported(int c) { return c == 128 || c == 256 || c == 512; }
 
 // fc2.weight [c, 4c] with the hidden axis of every 32-block reordered to the kernel's contraction slots:
 //     dst[n][32 S + 8 g + 4 t + i] = src[n][32 S + 16 t + 4 g + i]      (g = 0..3, t = 0, 1, i = 0..3)
+// (c = 512: the chunk-major packing of swin_mlp512.hip -- same element count, same order inside a 32-block)
 void swin_mlp_permute_hidden(const float *src, float *dst, int c) {
+    if (c == 512) return swin_mlp512_pack_w2(src, dst);
     const int h = 4 * c;
     for (int n = 0; n < c; ++n)
         for (int k = 0; k < h; ++k) {
@@ -481,7 +483,8 @@ void swin_mlp_permute_hidden(const float *src, float *dst, int c) {
 int launch_swin_mlp(const uint16_t *w1, const float *b1, const uint16_t *w2p, const float *b2, const float *gamma, const float *beta,
                     float *x, uint16_t *xb, int64_t m, int c, float eps, hipStream_t stream) {
     VSC_REQUIRE(w1 && b1 && w2p && b2 && gamma && beta && x && xb && m > 0, "swin_mlp: null/empty");
-    VSC_REQUIRE(swin_mlp_supported(c), "swin_mlp: width %d unsupported (128 or 256)", c);
+    VSC_REQUIRE(swin_mlp_supported(c), "swin_mlp: width %d unsupported (128, 256 or 512)", c);
+    if (c == 512) return launch_swin_mlp512(w1, b1, w2p, b2, gamma, beta, x, xb, m, eps, stream);
     const MlpArgs a{w1, b1, w2p, b2, gamma, beta, x, xb, m, eps, nullptr, nullptr, nullptr, nullptr, nullptr};
     return c == 128 ? launch_c<128>(a, stream) : launch_c<256>(a, stream);
 }

@@ -244,7 +244,7 @@ def gemm_ln_bf16(a, w, bias, gamma, beta, eps: float, x_in=None):
 
 
 def swin_mlp_bf16(x, w1, b1, w2, b2, gamma, beta, eps: float):
-    """Fused Swin-V2 MLP, widths 128 / 256: -> (x + LayerNorm(gelu(bf16(x) @ w1.T + b1) @ w2.T + b2), its bf16 shadow).
+    """Fused Swin-V2 MLP, widths 128 / 256 / 512: -> (x + LayerNorm(gelu(bf16(x) @ w1.T + b1) @ w2.T + b2), its bf16 shadow).
     w1 [4c, c], w2 [c, 4c] as the module holds them (the hidden-axis reordering the kernel wants is done here)."""
     import numpy as np
     lib = _lib.require_device()
