@@ -192,6 +192,14 @@ int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t n
                    int32_t k, int64_t ref_id_offset, float *out_scores_dev,
                    int64_t *out_ids_dev, void *stream);
 
+/* Merge of per-shard results of vsc_knn_ip_f32 (a bank swept shard by shard, each with its ref_id_offset -- the pipelined form of
+ * the sharded search, where shard s is swept while shard s + 1 is still arriving over xGMI): scores / ids [parts][nq][k], every
+ * list in the search's order (score descending, equal scores by ascending id; unused slots (-FLT_MAX, -1)) -> the k best of the
+ * union in that same order.  parts <= 64.  Equals one vsc_knn_ip_f32 call over the concatenated bank bit for bit
+ * (reference: faiss merges its shards' heaps the same way; infer/vsc/index.py:167-175 searches one flat index). */
+int vsc_knn_merge_parts_f32(const float *scores_dev, const int64_t *ids_dev, int32_t parts, int64_t nq, int32_t k,
+                            float *out_scores_dev, int64_t *out_ids_dev, void *stream);
+
 /* Frees the search scratch (top-k, range search, video-pair maxima) of the current device after waiting for the device;
  * returns the bytes released.  The next search call allocates again. */
 int64_t vsc_search_release_scratch(void);

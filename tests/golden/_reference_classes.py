@@ -13,8 +13,16 @@ are executed, with three helper names supplied:
 * `load_checkpoint`   — mmcv's loader, referenced by `init_weights` only, never by `forward`;
 * `BACKBONES`         — the registry decorator of the training tree: registration only.
 No reference source text is copied: it is read from /root/reference at run time.
+
+The reference tree is UNTRUSTED public content and this loader executes definitions taken from it.  Hence:
+* opt-in only: nothing here runs unless VSC_RUN_REFERENCE_CODE=1 is set (a present /root/reference is not consent);
+* every file is pinned by SHA-256 (_PINNED): a tree that differs from the one these helpers were reviewed against is refused;
+* the import whitelist holds no `os` / `sys` / `subprocess`: the one reference file that imports `os` (video/clip.py, for
+  os.path.join in a checkpoint loader nobody calls) loses that import and the loader function raises NameError if ever called;
+* tests/test_golden_vs_reference.py runs the checks in a child process with a scrubbed environment and a scratch working directory.
 """
 import ast
+import hashlib
 import os
 
 import torch
@@ -26,11 +34,20 @@ CLIP_SRC = "VSC22-Descriptor-Track-1st/train/train_vid_score/video/clip.py"
 SSCD_SRC = "VSC22-Descriptor-Track-1st/train/train_v68/vsc/baseline/model_factory/backbones/sscd.py"
 VSM_SRC = "VSC22-Descriptor-Track-1st/train/train_vid_score/video/model.py"
 
-_ALLOWED_IMPORT_ROOTS = {"torch", "numpy", "typing", "collections", "math", "os", "transformers"}
+_ALLOWED_IMPORT_ROOTS = {"torch", "numpy", "typing", "collections", "math", "transformers"}
+OPT_IN = "VSC_RUN_REFERENCE_CODE"
+# SHA-256 of the reference files whose definitions are executed (the tree this loader was reviewed against)
+_PINNED = {
+    SWIN_SRC: "e66fd2eafa44edc0b3e6aef8f7c397e4de034bc52e9b3d67c13d039afdd97605",
+    CLIP_SRC: "0ed16e443efd547fba54959779a98a6cc0070865d072d0a6aaecd40781a95d03",
+    SSCD_SRC: "daf573dca38b65a3c925b4f6cd85d482312270967c0f758e8a179323a81a9654",
+    VSM_SRC: "c4e627e3df8564372f571683b602247e40c20682fef6da18cce4c3ab2dc7700d",
+}
 
 
 def available() -> bool:
-    return os.path.isdir(REFERENCE)
+    """The reference tree exists AND the caller opted in to executing definitions from it."""
+    return os.path.isdir(REFERENCE) and os.environ.get(OPT_IN) == "1"
 
 
 class DropPath(nn.Module):
@@ -58,8 +75,14 @@ def _unused(*a, **k):
 
 def load_definitions(rel_path: str) -> dict:
     """Namespace with the classes / functions the reference file defines."""
+    if os.environ.get(OPT_IN) != "1":
+        raise RuntimeError(f"executing reference definitions is opt-in: set {OPT_IN}=1")
     path = os.path.join(REFERENCE, rel_path)
-    tree = ast.parse(open(path).read(), filename=path)
+    text = open(path, "rb").read()
+    digest = hashlib.sha256(text).hexdigest()
+    if _PINNED.get(rel_path) != digest:
+        raise RuntimeError(f"{path}: sha256 {digest} is not the pinned one -- the reference tree changed; review before running it")
+    tree = ast.parse(text.decode(), filename=path)
     keep = []
     for node in tree.body:
         if isinstance(node, (ast.ClassDef, ast.FunctionDef)):

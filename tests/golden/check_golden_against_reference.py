@@ -156,7 +156,7 @@ CHECKS = [("swin", check_swin, "tiny_swin"), ("swin", check_swin, "tiny_swin_w8"
 
 def main():
     if not refc.available():
-        print("reference tree absent: nothing checked")
+        print(f"nothing checked: needs /root/reference and {refc.OPT_IN}=1 (this script executes definitions from the reference tree)")
         return 0
     torch.set_num_threads(8)
     for kind, fn, preset in CHECKS:

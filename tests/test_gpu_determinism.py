@@ -102,3 +102,47 @@ def test_persistent_gemm_repeats_and_equals_the_one_tile_kernel(dev, name, m, n,
     assert torch.equal(first, ref), name
     for _ in range(20):
         assert torch.equal(run(), first), name
+
+
+def test_swin_mlp512_repeats_at_stage2_size(dev):
+    """swin_mlp512_kernel (one asm statement with hand-assigned registers and hand-counted waits: csrc/gen_mlp512_loop.py) at Swin-V2-B's
+    stage-2 size, 256 frames = 65 536 rows + a ragged tile: five launches from the same input, bit for bit.  A missing wait state or
+    a too-early barrier shows as a difference between runs long before it shows in a tolerance."""
+    from vsc_hip import ops
+    g = torch.Generator().manual_seed(3)
+    m, c = 65536 + 50, 512
+    x0 = torch.randn(m, c, generator=g)
+    w1, b1 = torch.randn(4 * c, c, generator=g) * c ** -0.5, torch.randn(4 * c, generator=g) * 0.2
+    w2, b2 = torch.randn(c, 4 * c, generator=g) * (4 * c) ** -0.5, torch.randn(c, generator=g) * 0.2
+    gam, bet = 0.3 + 0.05 * torch.randn(c, generator=g), 0.05 * torch.randn(c, generator=g)
+    xd = x0.to(dev)
+    first, first_b = ops.swin_mlp_bf16(xd, w1, b1, w2, b2, gam, bet, 1e-5)
+    assert torch.isfinite(first).all()
+    for _ in range(REPEATS):
+        y, yb = ops.swin_mlp_bf16(xd, w1, b1, w2, b2, gam, bet, 1e-5)
+        assert torch.equal(y, first) and torch.equal(yb, first_b)
+
+
+def test_matching_networks_repeat_at_the_benchmarked_batches(dev):
+    """conv.hip at the sizes bench.py times -- HRNet-W18 refinement net on 16 x 3 x 224 x 224 (3 136 tiles of the split-bf16 direct
+    kernel, the tap-streamed 64-channel kernel, the plane implicit GEMM), MobileNetV3 classifier on 2048 x 3 x 160 x 160 -- five
+    passes each, bit for bit.  These kernels use both mechanisms that corrupted data silently in earlier rounds (LDS-DMA
+    publication through a barrier, 16-byte buffer stores with a scalar offset); their parity tests stop at 16 x 56 x 56."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cnn_synth
+    from vsc_hip import cnn
+    net = cnn.HRNetRefineHip(cnn_synth.hrnet_refine_state(7), dev)
+    x = cnn_synth.similarity_maps(3, 16, 224, 224).to(dev)
+    first = net(x).clone()
+    assert torch.isfinite(first).all()
+    for _ in range(REPEATS):
+        assert torch.equal(net(x), first)
+    del net, x, first
+    cls = cnn.MobileNetV3SmallHip(cnn_synth.mobilenetv3_small_state(1), dev)
+    xc = cnn_synth.similarity_maps(2, 8, 160, 160).to(dev).repeat(256, 1, 1, 1)
+    first = cls(xc).clone()
+    assert torch.isfinite(first).all() and first.shape[0] == 2048
+    for _ in range(REPEATS):
+        assert torch.equal(cls(xc), first)

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity_bounds
 from tools import synth
 from vsc_hip.config import get_config
 
@@ -50,7 +51,24 @@ def test_encoder_matches_golden(dev, preset, golden_dir):
     enc2 = _encoder(preset, int(g["weights_seed"]), max_batch=2, l2_normalize=True)[2]
     d2 = enc2(x).cpu().numpy()
     np.testing.assert_allclose(d2, g["desc_l2"], rtol=0, atol=DESC_L2_ATOL)
+    parity_bounds.check(f"vit/{preset}", d2, g["desc_l2"])      # mean |d| and |mean d|: a bias does not average out
     np.testing.assert_allclose(np.linalg.norm(d2, axis=1), 1.0, atol=1e-5)
+
+
+def test_mean_bound_sees_a_one_percent_scale_error(dev, golden_dir):
+    """The net itself under test: ONE weight tensor of the HIP encoder off by 1 % (5 % for a bias) passes the 1e-3 maximum bound
+    and must FAIL the mean bound of parity_bounds (measured: 1.34e-4 / 1.9e-4 / 1.09e-4 against 1.07e-4)."""
+    g = np.load(os.path.join(golden_dir, "vit_vit_b16_224.npz"))
+    cfg = get_config("vit_b16_224")
+    x = torch.from_numpy(synth.frames(int(g["frames_seed"]), int(g["n_frames"]), cfg)).to(dev)
+    from vsc_hip.encoder import HipEncoder
+    for key, f in (("blocks.5.fc1.weight", 1.01), ("blocks.0.qkv.bias", 1.05), ("blocks.11.proj.weight", 1.01)):
+        w = synth.encoder_weights(int(g["weights_seed"]), cfg)
+        w[key] = (w[key] * f).astype(np.float32)
+        out = HipEncoder(cfg, w, max_batch=2, l2_normalize=True)(x).cpu().numpy()
+        assert np.abs(out - g["desc_l2"]).max() < DESC_L2_ATOL            # invisible to the maximum bound
+        with pytest.raises(AssertionError, match="mean"):
+            parity_bounds.check("vit/vit_b16_224", out, g["desc_l2"])
 
 
 def test_encoder_batching_is_invisible(dev):
@@ -74,6 +92,7 @@ def test_encoder_vs_oracle_fresh_inputs(dev):
         ref = vit_oracle.descriptors({k: torch.from_numpy(v) for k, v in w.items()}, cfg, x).numpy()
     out = enc(x.to(dev)).cpu().numpy()
     np.testing.assert_allclose(out, ref, rtol=0, atol=DESC_L2_ATOL)
+    parity_bounds.check("vit/fresh", out, ref)
     # cosine between HIP and reference descriptors of the same frame
     assert ((out * ref).sum(1) > 0.9999).all()
 
@@ -232,6 +251,7 @@ def test_encoder_in_the_benchmarked_configuration_vs_oracle(dev):
     with torch.no_grad():
         ref = vit_oracle.descriptors({k: torch.from_numpy(v) for k, v in w.items()}, cfg, x[sample]).numpy()
     np.testing.assert_allclose(out_big[sample], ref, rtol=0, atol=DESC_L2_ATOL)
+    parity_bounds.check("vit/benchmarked", out_big[sample], ref)
     assert ((out_big[sample] * ref).sum(1) > 0.9999).all()
     # a second call on the same encoder (workspaces and lanes reused) returns the same bits
     assert np.array_equal(big(xd).cpu().numpy(), out_big)

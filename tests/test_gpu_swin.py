@@ -9,6 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import parity_bounds
 from oracle import swin_oracle
 from tools import synth
 from vsc_hip.swin_config import get_swin_config
@@ -142,8 +143,8 @@ def test_swin_mlp_rejects_other_widths(dev):
 
 
 def test_swin_fused_mlp_equals_two_gemm_path(dev):
-    """Swin-V2-B with the stage-0 / stage-1 MLPs fused (default) and as fc1 + fc2 launches (VSC_SWIN_FUSED_MLP=0): same
-    descriptors to bf16 rounding flips, and the switch is really taken (profile classes)."""
+    """Swin-V2-B with the MLPs of stages 0-2 fused (default) and as fc1 + fc2 launches (VSC_SWIN_FUSED_MLP=0; VSC_SWIN_MLP512=0 for
+    the 512-wide stage alone): same descriptors to bf16 rounding flips, and the switches are really taken (profile classes)."""
     from vsc_hip import _lib
     from vsc_hip.swin_encoder import SwinHipEncoder
     cfg = get_swin_config("swinv2_base_256")
@@ -153,17 +154,30 @@ def test_swin_fused_mlp_equals_two_gemm_path(dev):
     enc.set_profiling(True)
     fused = enc(x).cpu().numpy()
     prof = enc.profile()
-    assert "s0.fc1" not in prof and "s1.fc1" not in prof and prof["s2.fc1"][1] > 0 and prof["s0.fc2_ln"][1] == 2 * cfg.depths[0]
+    # stages 0-2 (widths 128, 256, 512) run one kernel per MLP, booked under fc2_ln; the 1024-wide last stage keeps its two GEMMs
+    assert all(f"s{s}.fc1" not in prof for s in range(3)) and prof["s3.fc1"][1] > 0
+    assert prof["s0.fc2_ln"][1] == 2 * cfg.depths[0] and prof["s2.fc2_ln"][1] == 2 * cfg.depths[2] and prof["s2.proj_ln"][1] == 2 * cfg.depths[2]
     _lib.set_option("VSC_SWIN_FUSED_MLP", "0")
     try:
         enc.set_profiling(True)
         plain = enc(x).cpu().numpy()
         prof = enc.profile()
-        assert prof["s0.fc1"][1] == 2 * cfg.depths[0] and prof["s1.fc1"][1] == 2 * cfg.depths[1]
+        assert all(prof[f"s{s}.fc1"][1] == 2 * cfg.depths[s] for s in range(3))
     finally:
         _lib.set_option("VSC_SWIN_FUSED_MLP", None)
         enc.set_profiling(False)
     assert np.abs(fused - plain).max() < 4e-4
+    # the 512-wide stage alone on the two-GEMM path (VSC_SWIN_MLP512=0): 18 of the 24 blocks change kernels
+    _lib.set_option("VSC_SWIN_MLP512", "0")
+    try:
+        enc.set_profiling(True)
+        plain512 = enc(x).cpu().numpy()
+        prof = enc.profile()
+        assert "s0.fc1" not in prof and prof["s2.fc1"][1] == 2 * cfg.depths[2]
+    finally:
+        _lib.set_option("VSC_SWIN_MLP512", None)
+        enc.set_profiling(False)
+    assert np.abs(fused - plain512).max() < 4e-4 and not np.array_equal(fused, plain512)
 
 
 def test_swin_encoder_is_deterministic_at_full_chunks(dev):
@@ -234,6 +248,7 @@ def test_swin_encoder_matches_golden(dev, preset, golden_dir):
     assert np.abs(desc - g["desc"]).max() < 0.02 * np.abs(g["desc"]).max()
     d2 = SwinHipEncoder(cfg, w, max_batch=3, l2_normalize=True)(x).cpu().numpy()
     np.testing.assert_allclose(d2, g["desc_l2"], rtol=0, atol=1e-3)
+    parity_bounds.check(f"swin/{preset}", d2, g["desc_l2"])     # mean |d| and |mean d| (tests/parity_bounds.py)
     np.testing.assert_allclose(np.linalg.norm(d2, axis=1), 1.0, atol=1e-5)
 
 
@@ -286,6 +301,7 @@ def test_swin_encoder_in_the_benchmarked_configuration_vs_oracle(dev):
     with torch.no_grad():
         ref = swin_oracle.descriptors({k: torch.from_numpy(v) for k, v in w.items()}, cfg, x[sample]).numpy()
     np.testing.assert_allclose(out_big[sample], ref, rtol=0, atol=1e-3)
+    parity_bounds.check("swin/benchmarked", out_big[sample], ref)
     assert np.array_equal(big(xd).cpu().numpy(), out_big)
 
 
@@ -305,8 +321,8 @@ def test_swin_profiling_classes(dev):
     chunks = 3
     assert prof["patchify"][1] == chunks and prof["pool_head"][1] == chunks
     for s in range(cfg.stages):
-        fused_mlp = cfg.dim(s) in (128, 256)     # one kernel for the whole MLP, booked under fc2_ln
-        fused_proj = fused_mlp                   # ... with proj + LayerNorm in front of it as well
+        fused_mlp = cfg.dim(s) in (128, 256, 512)   # one kernel for the whole MLP, booked under fc2_ln
+        fused_proj = cfg.dim(s) in (128, 256)       # ... with proj + LayerNorm in front of it as well
         for kind in ("qkv", "attention", "proj_ln", "fc1", "fc2_ln"):
             ms, n = prof.get(f"s{s}.{kind}", (0.0, 0))
             if (kind == "fc1" and fused_mlp) or (kind == "proj_ln" and fused_proj):

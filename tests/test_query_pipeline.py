@@ -165,6 +165,45 @@ def test_ensemble_on_hip_encoders():
 
 
 @pytest.mark.gpu
+def test_group_batched_postprocessing_equals_the_per_video_steps():
+    """run_query_videos on the GPU batches normalisation / similarity / PCA per group of videos and keeps the features on the device
+    (process_query_group, pinned staging in encode_group): bit for bit the per-video process_query_video on the same features,
+    including a rejected video's placeholder and the rnd_idx sequence, for any grouping."""
+    from vsc_hip.config import get_config
+    from vsc_hip.encoder import HipEncoder
+    from vsc_hip.swin_config import get_swin_config
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    from src.query_postprocess import HipOps
+    dev = torch.device("cuda", 0)
+    vcfg, scfg = get_config("tiny"), get_swin_config("tiny_swin")
+    vit = HipEncoder(vcfg, synth.encoder_weights(3, vcfg), max_batch=8)
+    swin = SwinHipEncoder(scfg, synth.swin_weights(4, scfg), max_batch=8)
+    vids = []
+    for i, n in enumerate([11, 4, 9, 1, 6]):
+        fr = synth.frames(10 + i, n, vcfg)
+        fr[n // 2] = fr[0]                       # a duplicated frame: the filter has something to drop
+        vids.append((f"Q{i:06d}", {vcfg.image_size: torch.from_numpy(fr), scfg.image_size: torch.from_numpy(synth.swin_frames(20 + i, n, scfg))}, np.arange(n)))
+
+    class Fitted:
+        mean_ = synth.normalish(6, (vcfg.out_dim + scfg.out_dim,)) * 0.01
+        components_ = synth.normalish(5, (16, vcfg.out_dim + scfg.out_dim)) / 4.0
+        whiten = False
+
+    pca = HipPCA(Fitted)
+    enc = [(vit, vcfg.image_size), (swin, scfg.image_size)]
+    scores = {"Q000001": 0.0, "Q000003": 0.0005}
+    for group_frames in (1, 14, 1024):
+        finals, per_model = run_query_videos(vids, enc, pca.transform, dict(scores), dev, chunk=8, group_frames=group_frames)
+        rnd = 0
+        for (vid, frames, stamps), got, subs in zip(vids, finals, per_model):
+            raw = [vit(frames[vcfg.image_size].to(dev)).cpu().numpy(), swin(frames[scfg.image_size].to(dev)).cpu().numpy()]
+            want, want_subs, rnd = process_query_video(vid, raw, stamps, scores.get(vid, 1.0), pca.transform, rnd, ops=HipOps)
+            assert np.array_equal(got.feature, want.feature) and np.array_equal(got.timestamps, want.timestamps), (group_frames, vid)
+            assert all(np.array_equal(a.feature, b.feature) for a, b in zip(subs, want_subs))
+    assert len(finals[0].feature) < 11      # the duplicate was dropped
+
+
+@pytest.mark.gpu
 def test_video_scorer_on_hip_path():
     """CLIP tower (tiny_clip preset) -> MS head (a vsm preset matched to its width) -> sigmoid, vs the oracles."""
     from oracle import vit_oracle, vsm_oracle

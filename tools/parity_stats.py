@@ -26,7 +26,7 @@ dev = torch.device("cuda:0")
 
 def stats(name, out, ref):
     d = out.astype(np.float64) - ref.astype(np.float64)
-    print(f"{name:58s} max {np.abs(d).max():.3e}  mean|d| {np.abs(d).mean():.3e}  mean d {d.mean():+.3e}  "
+    print(f"{name:72s} max {np.abs(d).max():.3e}  mean|d| {np.abs(d).mean():.3e}  mean d {d.mean():+.3e}  "
           f"|mean d| per frame max {np.abs(d.mean(1)).max():.3e}", flush=True)
 
 
@@ -52,6 +52,22 @@ def main():
     stats("vit benchmarked configuration vs oracle (8 frames)", big[sample], ref)
     small = HipEncoder(cfg, w, max_batch=8, l2_normalize=True, lanes=1)(x.to(dev)).cpu().numpy()
     stats("vit benchmarked configuration vs small batches (700)", big, small)
+
+    # what a small systematic error looks like in these statistics (the bounds must catch it): ONE weight tensor of the HIP encoder off
+    g = np.load(os.path.join(GOLDEN, "vit_vit_b16_224.npz"))
+    cfg = get_config("vit_b16_224")
+    x = torch.from_numpy(synth.frames(int(g["frames_seed"]), int(g["n_frames"]), cfg)).to(dev)
+    for key, f in (("blocks.5.fc1.weight", 1.01), ("blocks.0.qkv.bias", 1.05), ("blocks.11.proj.weight", 1.01)):
+        w = synth.encoder_weights(int(g["weights_seed"]), cfg)
+        w[key] = (w[key] * f).astype(np.float32)
+        stats(f"vit golden vit_b16_224, {key} x {f}", HipEncoder(cfg, w, max_batch=2, l2_normalize=True)(x).cpu().numpy(), g["desc_l2"])
+    g = np.load(os.path.join(GOLDEN, "swin_swinv2_base_256.npz"))
+    cfg = get_swin_config("swinv2_base_256")
+    x = torch.from_numpy(synth.swin_frames(int(g["frames_seed"]), int(g["n_frames"]), cfg)).to(dev)
+    for key, f in (("layers.2.blocks.5.mlp.fc1.weight", 1.01), ("layers.2.blocks.9.attn.proj.weight", 1.01), ("layers.0.blocks.0.mlp.fc2.bias", 1.05)):
+        w = synth.swin_weights(int(g["weights_seed"]), cfg)
+        w[key] = (w[key] * f).astype(np.float32)
+        stats(f"swin golden swinv2_base_256, {key} x {f}", SwinHipEncoder(cfg, w, max_batch=3, l2_normalize=True)(x).cpu().numpy(), g["desc_l2"])
 
     for preset in ("tiny_swin", "tiny_swin_w8", "swinv2_base_256", "tiny_swin_w24", "swinv2_large_384"):
         g = np.load(os.path.join(GOLDEN, f"swin_{preset}.npz"))

@@ -1617,6 +1617,59 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
     return VSC_OK;
 }
 
+// Merge of per-shard top-k lists (sharded / pipelined search: every shard of the bank was swept on its own, with its id offset):
+// one wave per query, lane p walks part p's list (sorted: score descending, ties by ascending id); k rounds of "best head over the
+// wave" under the search's own order -- greater score first, equal scores by lower id; ids < 0 mark empty slots (faiss: -FLT_MAX, -1).
+__global__ __launch_bounds__(256) void knn_merge_parts_kernel(const float *__restrict__ sc, const int64_t *__restrict__ id, int parts,
+                                                              int64_t nq, int k, float *__restrict__ out_d, int64_t *__restrict__ out_i) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const size_t base = ((size_t)lane * nq + q) * k;
+    int ptr = 0;
+    float hs = -FLT_MAX;
+    long long hi = -1;
+    if (lane < parts) {
+        hs = sc[base];
+        hi = id[base];
+    }
+    for (int i = 0; i < k; ++i) {
+        float bs = hs;
+        long long bi = hi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(bs, o, 64);
+            const unsigned lo = __shfl_xor((unsigned)((unsigned long long)bi & 0xFFFFFFFFu), o, 64);
+            const unsigned up = __shfl_xor((unsigned)((unsigned long long)bi >> 32), o, 64);
+            const long long oi = (long long)(((unsigned long long)up << 32) | lo);
+            const bool take = oi >= 0 && (bi < 0 || os > bs || (os == bs && oi < bi));
+            bs = take ? os : bs;
+            bi = take ? oi : bi;
+        }
+        if (lane == 0) {
+            out_d[q * k + i] = bi < 0 ? -FLT_MAX : bs;
+            out_i[q * k + i] = bi < 0 ? -1 : bi;
+        }
+        if (bi >= 0 && hi == bi) {   // ids are unique across parts: exactly one lane advances
+            ++ptr;
+            hs = ptr < k ? sc[base + ptr] : -FLT_MAX;
+            hi = ptr < k ? id[base + ptr] : -1;
+        }
+    }
+}
+
+extern "C" int vsc_knn_merge_parts_f32(const float *scores_dev, const int64_t *ids_dev, int32_t parts, int64_t nq, int32_t k,
+                                       float *out_scores_dev, int64_t *out_ids_dev, void *stream_) {
+    VSC_REQUIRE(scores_dev && ids_dev && out_scores_dev && out_ids_dev, "knn_merge_parts: null pointer");
+    VSC_REQUIRE(parts >= 1 && parts <= 64, "knn_merge_parts: %d parts (1..64)", parts);
+    VSC_REQUIRE(nq >= 0 && k >= 1 && k <= 1024, "knn_merge_parts: nq / k out of range");
+    if (nq == 0) return VSC_OK;
+    hipLaunchKernelGGL(knn_merge_parts_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, scores_dev, ids_dev, parts, nq, k,
+                       out_scores_dev, out_ids_dev);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
 static int g_knn_last_path = 0;   // 1 exact fp32 sweep, 2 bf16 pre-filter, 3 pre-filter with some query blocks redone on the exact sweep
 extern "C" int vsc_knn_last_path(void) { return g_knn_last_path; }
 

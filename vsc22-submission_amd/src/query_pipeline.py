@@ -11,7 +11,7 @@ from typing import Callable, Dict, Iterable, List, Sequence, Tuple
 import numpy as np
 import torch
 
-from src.query_postprocess import HipOps, SCORE_THRESHOLD, process_query_video
+from src.query_postprocess import HipOps, SCORE_THRESHOLD, process_query_group, process_query_video
 from vsc.index import VideoFeature
 
 
@@ -42,8 +42,11 @@ class VideoScorer:
         """Scores of several videos: the CLIP tower runs over all their (first 256) frames as one stream of
         ``chunk``-frame calls, the MS head once per video."""
         clipped = [f[: self.head.cfg.max_frames] for f in frames_list]
-        feats = encode_group([self.clip], clipped, self.device, self.chunk)[0]
-        return [self.head.score(torch.from_numpy(f).to(self.device)) for f in feats]
+        feats = encode_group([self.clip], clipped, self.device, self.chunk, as_numpy=False)[0]   # stay on the device: the head reads them there
+        if not feats:
+            return []
+        logits = torch.stack([self.head.logit(f) for f in feats])
+        return [float(v) for v in torch.sigmoid(logits).cpu().tolist()]                          # one device -> host copy per group
 
 
 def encode_many(model, frames_list: Sequence[torch.Tensor], device, chunk: int = None) -> List[np.ndarray]:
@@ -60,34 +63,92 @@ def preferred_chunk(models: Sequence, default: int = 256) -> int:
     return min(int(getattr(m, "preferred_batch", default)) for m in models)
 
 
-def encode_group(models: Sequence, frames_list: Sequence[torch.Tensor], device, chunk: int = None) -> List[List[np.ndarray]]:
+class _Stager:
+    """Host -> device staging of frame chunks: two pinned host buffers and two device buffers of one chunk each, and a copy
+    stream.  The host gathers chunk k + 1 from the videos' (pageable) tensors straight into a pinned buffer while chunk k is
+    encoded, and the copy of chunk k + 1 runs on the copy stream under chunk k's kernels -- `torch.cat(buf).to(device)` from
+    pageable memory did both on the critical path (a synchronous copy at pageable speed: as long as the encoders' own time
+    at 0.8 MB of uint8 frames per query frame through the reference's ensemble)."""
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, device, chunk, shape, dtype):
+        key = (str(device), int(chunk), tuple(shape), dtype)
+        st = cls._cache.get(key)
+        if st is None:
+            if len(cls._cache) >= 8:      # a few (input size, dtype) combinations per process; do not grow without bound
+                cls._cache.pop(next(iter(cls._cache)))
+            st = cls._cache[key] = cls(device, chunk, shape, dtype)
+        return st
+
+    def __init__(self, device, chunk, shape, dtype):
+        self.pinned = [torch.empty((chunk,) + tuple(shape), dtype=dtype).pin_memory() for _ in range(2)]
+        self.dev = [torch.empty((chunk,) + tuple(shape), dtype=dtype, device=device) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.copied = [torch.cuda.Event() for _ in range(2)]     # the H2D copy out of pinned[slot] / into dev[slot] is done
+        self.consumed = [torch.cuda.Event() for _ in range(2)]   # every encoder is done reading dev[slot]
+        self.used = [False, False]
+
+    def upload(self, slot, pieces):
+        """pieces: [(tensor, lo, take)] -> device view of the chunk, ordered behind its copy on the caller's stream"""
+        if self.used[slot]:
+            self.copied[slot].synchronize()       # (issued two chunks ago: long done) the pinned buffer may be refilled
+        off = 0
+        for f, lo, take in pieces:
+            self.pinned[slot][off:off + take].copy_(f[lo:lo + take])
+            off += take
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(self.copy_stream):
+            if self.used[slot]:
+                self.copy_stream.wait_event(self.consumed[slot])
+            self.dev[slot][:off].copy_(self.pinned[slot][:off], non_blocking=True)
+            self.copied[slot].record(self.copy_stream)
+        cur.wait_event(self.copied[slot])
+        self.used[slot] = True
+        return self.dev[slot][:off]
+
+    def done(self, slot):
+        self.consumed[slot].record(torch.cuda.current_stream())
+
+
+def encode_group(models: Sequence, frames_list: Sequence[torch.Tensor], device, chunk: int = None, as_numpy: bool = True):
     """Like ``encode_many`` for several backbones that take the SAME frames (the three Swin-V2 models of the ensemble):
-    every chunk is uploaded once and goes through all of them.  -> per model, per video arrays.
-    ``chunk`` = None: ``preferred_chunk(models)``."""
+    every chunk is uploaded once and goes through all of them.  -> per model, per video arrays (``as_numpy=False``: device
+    tensors -- the video-score head takes them where they are).  ``chunk`` = None: ``preferred_chunk(models)``.
+    On a GPU the chunks go through pinned staging buffers and a copy stream (``_Stager``); the per-model outputs of the whole
+    group come back in ONE device -> host copy each."""
     chunk = chunk or preferred_chunk(models)
     lens = [f.shape[0] for f in frames_list]
     total = sum(lens)
     outs = [[] for _ in models]
+    staged = torch.device(device).type == "cuda" and total > 0
+    st = _Stager.get(device, chunk, frames_list[0].shape[1:], frames_list[0].dtype) if staged else None
     # walk the videos chunk by chunk without materialising the concatenation on the host
-    buf, have = [], 0
+    buf, have, k = [], 0, 0
 
     def flush():
-        nonlocal buf, have
+        nonlocal buf, have, k
         if not buf:
             return
-        x = torch.cat(buf).to(device, non_blocking=True) if len(buf) > 1 else buf[0].to(device, non_blocking=True)
+        if staged:
+            x = st.upload(k & 1, buf)
+        else:   # host-logic tests (fake encoders on the CPU); the HIP encoders refuse CPU tensors
+            x = torch.cat([f[lo:lo + take] for f, lo, take in buf]).to(device)
         for i, model in enumerate(models):
             out = model(x)
             if out.dim() == 3:
                 out = out[:, 0]
             outs[i].append(out.detach().float())
-        buf, have = [], 0
+        if staged:
+            st.done(k & 1)
+        buf, have, k = [], 0, k + 1
 
     for f in frames_list:
         lo = 0
         while lo < f.shape[0]:
             take = min(chunk - have, f.shape[0] - lo)
-            buf.append(f[lo:lo + take])
+            buf.append((f, lo, take))
             have += take
             lo += take
             if have == chunk:
@@ -96,9 +157,12 @@ def encode_group(models: Sequence, frames_list: Sequence[torch.Tensor], device, 
     cuts = np.cumsum(lens)[:-1]
     result = []
     for o in outs:
-        full = torch.cat(o).cpu().numpy() if o else np.zeros((0, 0), np.float32)
+        if not o:
+            result.append(np.split(np.zeros((0, 0), np.float32), cuts) if as_numpy else [])
+            continue
+        full = torch.cat(o) if len(o) > 1 else o[0]
         assert full.shape[0] == total
-        result.append(np.split(full, cuts))
+        result.append(np.split(full.cpu().numpy(), cuts) if as_numpy else list(torch.split(full, lens)))
     return result
 
 
@@ -127,17 +191,27 @@ def run_query_videos(videos: Iterable[Tuple[str, Dict[int, torch.Tensor], np.nda
     -> (final descriptors per video, per-model VideoFeatures per video), in input order."""
     finals, per_model = [], []
     rnd_idx = 0
+    # on the GPU with the library's own ops the per-video post-processing is batched per group and the features stay on the device
+    # in between (process_query_group); anything else (the host-logic tests' numpy ops) takes the reference's per-video steps
+    batched = ops is HipOps and torch.device(device).type == "cuda"
     for group in _video_groups(videos, group_frames):
         # backbones that share an input size share the upload of every chunk
         subs_by_model = [None] * len(encoders)
         for size in dict.fromkeys(sz for _, sz in encoders):
             idx = [i for i, (_, sz) in enumerate(encoders) if sz == size]
-            for i, per_video in zip(idx, encode_group([encoders[i][0] for i in idx], [v[1][size] for v in group], device, chunk)):
+            for i, per_video in zip(idx, encode_group([encoders[i][0] for i in idx], [v[1][size] for v in group], device, chunk,
+                                                      as_numpy=not batched)):
                 subs_by_model[i] = per_video
         if scorer is not None:
             clip_frames = [v[1][VideoScorer.KEY] for v in group]
             scores = scorer.batch(clip_frames) if hasattr(scorer, "batch") else [scorer(f) for f in clip_frames]
             video_scores.update({v[0]: sc for v, sc in zip(group, scores)})
+        if batched:
+            f, pm, rnd_idx = process_query_group([v[0] for v in group], subs_by_model, [np.asarray(v[2]) for v in group],
+                                                 [video_scores.get(v[0], 1.0) for v in group], pca_transform, rnd_idx, score_threshold)
+            finals.extend(f)
+            per_model.extend(pm)
+            continue
         for i, (video_id, frames_by_size, timestamps) in enumerate(group):
             subs = [m[i] for m in subs_by_model]
             feat, sub_feats, rnd_idx = process_query_video(video_id, subs, np.asarray(timestamps), video_scores.get(video_id, 1.0),

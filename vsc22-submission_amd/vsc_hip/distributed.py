@@ -59,19 +59,81 @@ def all_gather_rows(local: torch.Tensor, always_collective: bool = False) -> Tup
     return bank, offsets
 
 
+def gather_rows_pipelined(local: torch.Tensor, always_collective: bool = False):
+    """The ranks' row blocks as SEPARATE buffers arriving one after the other: after one size exchange every source rank's shard
+    is broadcast on its own (async), so the caller can work on shard s while shard s + 1 is still on the wire.
+    -> (shards: per source rank a tensor [n_r, dim] -- this rank's own is `local` itself --, works: per source rank the pending
+    broadcast (None for the own shard / a group of one), offsets [world + 1])."""
+    rank, ws = world()
+    if ws == 1 and not (always_collective and dist.is_available() and dist.is_initialized()):
+        return [local], [None], torch.tensor([0, local.shape[0]])
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    all_n = torch.zeros(ws, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(all_n, n)
+    sizes = [int(v) for v in all_n.tolist()]
+    shards, works = [], []
+    # (collectives are issued in the same order -- source rank order -- on every rank; a rank starts sweeping at its own shard,
+    # which needs no transfer, and then walks the sources cyclically)
+    for r in range(ws):
+        if r == rank:
+            buf = local.contiguous()
+        else:
+            buf = torch.empty((sizes[r],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        shards.append(buf)
+        works.append(dist.broadcast(buf, src=r, async_op=True) if sizes[r] > 0 else None)
+    offsets = torch.tensor([0] + sizes).cumsum(0)
+    return shards, works, offsets
+
+
+def merge_parts(scores, ids, k: int, merge: Optional[Callable] = None):
+    """k best of the union of per-shard top-k lists [parts][nq, k] in the search's order (score descending, ties by lower id)."""
+    if len(scores) == 1:
+        return scores[0], ids[0]
+    if merge is None:
+        from . import ops
+        merge = ops.knn_merge_parts
+    return merge(torch.stack(scores), torch.stack(ids))
+
+
 def sharded_knn(queries_local: torch.Tensor, refs_local: torch.Tensor, k: int,
-                knn: Optional[Callable] = None, gather_to: Optional[int] = 0, always_collective: bool = False):
+                knn: Optional[Callable] = None, gather_to: Optional[int] = 0, always_collective: bool = False,
+                pipelined: bool = False, merge: Optional[Callable] = None):
     """Exact top-k of every rank's queries against the union of every rank's references.
 
     refs_local shards are all_gathered into the full bank (ids = position in rank order);
     each rank searches its own queries; results are gathered on rank `gather_to` (None: stay
     local).  `knn(q, r, k) -> (scores, ids)` defaults to the HIP sweep; the CPU/gloo tests
-    pass the oracle here -- a test hook, not a fallback: the default raises without a GPU."""
+    pass the oracle here -- a test hook, not a fallback: the default raises without a GPU.
+
+    pipelined: the bank arrives as one broadcast per source rank (gather_rows_pipelined) and every shard is swept as soon as it
+    has landed -- the own shard first, while all the others are still on the wire -- with its id offset; the per-shard lists are
+    merged (vsc_knn_merge_parts_f32; `merge` is the tests' hook).  Same results as the one-gather form, bit for bit: a shard's
+    top-k holds every member of the global top-k that lives in that shard, and the merge applies the search's own order."""
     if knn is None:
         from . import ops
         knn = ops.knn_ip
-    bank, _ = all_gather_rows(refs_local, always_collective)
-    scores, ids = knn(queries_local, bank, k)
+    if pipelined:
+        rank, ws = world()
+        shards, works, offsets = gather_rows_pipelined(refs_local, always_collective)
+        part_s, part_i = [], []
+        for step in range(len(shards)):
+            r = (rank + step) % len(shards)
+            if works[r] is not None:
+                works[r].wait()          # orders the caller's stream behind that broadcast only
+            if shards[r].shape[0] == 0:
+                continue
+            s, i = knn(queries_local, shards[r], k)      # (a shard with fewer than k rows: the search pads with (-FLT_MAX, -1))
+            off = int(offsets[r])
+            i = torch.where(i >= 0, i + off, i)
+            part_s.append(s)
+            part_i.append(i)
+        if part_s:
+            scores, ids = merge_parts(part_s, part_i, k, merge)
+        else:
+            scores, ids = knn(queries_local, refs_local, k)     # an empty bank everywhere: the search's own empty result
+    else:
+        bank, _ = all_gather_rows(refs_local, always_collective)
+        scores, ids = knn(queries_local, bank, k)
     if gather_to is None or (world()[1] == 1 and not always_collective):
         return scores, ids
     all_scores, _ = all_gather_rows(scores, always_collective)
@@ -79,3 +141,25 @@ def sharded_knn(queries_local: torch.Tensor, refs_local: torch.Tensor, k: int,
     if world()[0] == gather_to:
         return all_scores, all_ids
     return None, None
+
+
+def score_norm_bias(queries: torch.Tensor, noise: torch.Tensor, beta: float = 1.0, nk: int = 1, knn: Optional[Callable] = None) -> torch.Tensor:
+    """CSLS bias of every query row against the (replicated) noise bank: -beta * mean of its nk largest <q, noise>
+    (infer/vsc/baseline/score_normalization.py:95-105, 141-150) -> [nq, 1]."""
+    if knn is None:
+        from . import ops
+        knn = ops.knn_ip
+    sims, _ = knn(queries, noise, nk)
+    return -beta * sims[:, :nk].mean(dim=1, keepdim=True)
+
+
+def sharded_knn_score_normalized(queries_local: torch.Tensor, refs_local: torch.Tensor, noise: torch.Tensor, k: int, beta: float = 1.0,
+                                 nk: int = 1, knn: Optional[Callable] = None, **kw):
+    """BASELINE.json configs[3]: "global top-k + score-norm" on the sharded path.  Score normalisation is one extra dimension
+    (query' = [q, bias(q)], ref' = [r, 1]: score_normalization.py:34-105): every rank computes the bias of ITS query shard against
+    the noise bank -- small, replicated on every rank, no collective -- appends the constant column to ITS reference shard, and the
+    sharded search runs on the widened descriptors.  -> sharded_knn's result; scores are <q, r> + bias(q)."""
+    bias = score_norm_bias(queries_local, noise, beta, nk, knn)
+    q2 = torch.cat([queries_local, bias.to(queries_local.dtype)], dim=1).contiguous()
+    r2 = torch.cat([refs_local, torch.ones_like(refs_local[:, :1])], dim=1).contiguous()
+    return sharded_knn(q2, r2, k, knn=knn, **kw)

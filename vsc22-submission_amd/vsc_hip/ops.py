@@ -96,6 +96,19 @@ def knn_ip(q, r, k: int, ref_id_offset: int = 0):
     return scores, ids
 
 
+def knn_merge_parts(scores, ids):
+    """scores / ids [parts, nq, k]: per-shard results of knn_ip (each with its ref_id_offset) -> the k best of the union, in the
+    search's order (score descending, equal scores by ascending id)."""
+    lib = _lib.require_device()
+    scores, ids = _dev(scores, torch.float32), _dev(ids, torch.int64)
+    parts, nq, k = scores.shape
+    assert ids.shape == scores.shape and 1 <= parts <= 64
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
+    check(lib.vsc_knn_merge_parts_f32(ptr(scores), ptr(ids), parts, nq, k, ptr(out_s), ptr(out_i), current_stream()))
+    return out_s, out_i
+
+
 def range_search_ip(q, r, radius: float, ref_id_offset: int = 0, capacity: int = 1 << 20):
     """All pairs with <q, r> > radius.  -> (lims [nq+1] int64, scores, ids), hits of query i in
     lims[i]:lims[i+1], ascending reference id (faiss range_search layout)."""
