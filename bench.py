@@ -43,6 +43,7 @@ import torch
 
 BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md), quoted at the 2.4 GHz peak clock
 F32_MFMA_PEAK_TFLOPS = 157.3
+HBM_PEAK_TBS = 8.0          # HBM3E (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 achievable by a copy)
 PEAK_SCLK_MHZ = 2400.0
 
 
@@ -115,6 +116,8 @@ def parse():
     ap.add_argument("--search-steps", type=int, default=1)
     ap.add_argument("--no-swin", action="store_true")
     ap.add_argument("--no-matching", action="store_true")
+    ap.add_argument("--no-ensemble", action="store_true")
+    ap.add_argument("--ensemble-videos", type=int, default=52, help="query videos (40 frames each) of the end-to-end ensemble secondary")
     ap.add_argument("--force-sharded-search", action="store_true",
                     help="run the N > 1 search leg (RCCL all_gather + sweep) even with one rank; needs torchrun's env")
     ap.add_argument("--swin-batch", type=int, default=256)
@@ -346,35 +349,43 @@ def bench_search(dev, args):
 
 
 def bench_search_sharded(dev, args, dist, rank, world):
-    """N > 1: the path of BASELINE.json configs[3] at bench size -- every rank holds nr / N reference descriptors and
-    its own nq queries; one RCCL all_gather assembles the bank, then each rank sweeps its queries against all of it
-    (vsc_hip.distributed.sharded_knn).  Weak scaling: per-GPU sweep work is fixed.  Collective: runs on every rank."""
+    """N > 1: the path of BASELINE.json configs[3] at bench size -- "global top-k + score-norm": every rank holds nr / N reference
+    descriptors and its own nq queries; every rank normalises ITS queries against the (replicated, 100k-row) noise bank, the bank is
+    assembled source shard by source shard over RCCL and every shard is swept as it lands (vsc_hip.distributed.
+    sharded_knn_score_normalized(pipelined=True)); the one-gather form is timed beside it.  Weak scaling: per-GPU sweep work is fixed.
+    Collective: runs on every rank."""
     from vsc_hip import ops
-    from vsc_hip.distributed import sharded_knn
+    from vsc_hip.distributed import sharded_knn_score_normalized
     d, k = 512, args.search_k
     nq, nr_local = args.search_nq, args.search_nr // world
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     r = torch.randn(nr_local, d, generator=g, device=dev)
     q = torch.randn(nq, d, generator=g, device=dev)
-    ops.l2_normalize_(r)
-    ops.l2_normalize_(q)
-    sharded_knn(q[:256], r, k, gather_to=None)   # warm: RCCL communicator, scratch
-    times = []
-    for _ in range(max(args.search_steps, 1)):
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        D, I = sharded_knn(q, r, k, gather_to=None)
-        torch.cuda.synchronize()
-        dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        times.append(float(dt.item()))
-    t = sum(times) / len(times)
+    gn = torch.Generator(device=dev).manual_seed(99)          # the same noise bank on every rank
+    noise = torch.randn(min(100_000, max(args.search_nr // 10, 1024)), d, generator=gn, device=dev)
+    for t in (r, q, noise):
+        ops.l2_normalize_(t)
+    res = {}
+    for name, pipelined in (("pipelined", True), ("one_gather", False)):
+        sharded_knn_score_normalized(q[:256], r, noise, k, gather_to=None, pipelined=pipelined)   # warm: RCCL communicator, scratch
+        times = []
+        for _ in range(max(args.search_steps, 1)):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            D, I = sharded_knn_score_normalized(q, r, noise, k, gather_to=None, pipelined=pipelined)
+            torch.cuda.synchronize()
+            dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            times.append(float(dt.item()))
+        res[name] = sum(times) / len(times)
+    t = min(res.values())
     pairs = float(world) * nq * (nr_local * world)
-    return {"metric": "Mpairs/s (512-d exact top-k, bank all_gathered over RCCL, every rank sweeps its own queries)",
+    return {"metric": "Mpairs/s (512-d exact top-k with score normalisation, bank all_gathered over RCCL shard by shard, every rank sweeps its own queries)",
             "value": round(pairs / t / 1e6, 1), "unit": "Mpairs/s", "n_gpus": world, "nq_per_gpu": nq,
             "nr_total": nr_local * world, "k": k, "dtype": "bf16 sweep / f32 re-score", "ms_per_sweep_incl_all_gather": round(t * 1e3, 3),
-            "scaling": "weak", "all_gather_bytes_per_rank": nr_local * d * 4 * (world - 1)}
+            "ms_pipelined": round(res["pipelined"] * 1e3, 3), "ms_one_gather": round(res["one_gather"] * 1e3, 3), "score_norm_noise_rows": int(noise.shape[0]),
+            "scaling": "weak", "all_gather_bytes_per_rank": nr_local * (d + 1) * 4 * (world - 1)}
 
 
 def swin_traffic():
@@ -421,6 +432,7 @@ def bench_swin(dev, args):
     enc.set_profiling(False)
     enc.close()
     kernels, gemm_ms, gemm_flop, all_ms = {}, 0.0, 0.0, 0.0
+    gemm_bytes, gemm_launches = 0.0, 0
     frames_prof = b * psteps
     for name, (ms, cnt) in prof.items():
         flop, is_gemm = 0.0, False
@@ -441,8 +453,23 @@ def bench_swin(dev, args):
                     if f"s{st}.proj_ln" not in prof:                # ... and the projection in front of them (PROJ form)
                         flop += 2.0 * T * C * C * cfg.depths[st]
             is_gemm = kind != "attention"
+            # algorithmic bytes of ONE launch of this class (args.swin_batch frames): operands in + results out, weights once.
+            # x fp32 4 B, shadow / qkv / attention output / hidden bf16 2 B per element.
+            M, fused_mlp, fused_proj = float(args.swin_batch * T), f"s{st}.fc1" not in prof, f"s{st}.proj_ln" not in prof
+            per_launch = {"qkv": M * C * 2 + M * 3 * C * 2 + 3 * C * C * 2,
+                          "proj_ln": M * C * 2 + M * C * (4 + 4 + 2) + C * C * 2,
+                          "fc1": M * C * 2 + M * 4 * C * 2 + 4 * C * C * 2,
+                          "fc2_ln": (M * C * 2 + M * C * (4 + 4 + 2) + 8 * C * C * 2 + (M * C * 2 + C * C * 2 if fused_proj else 0)) if fused_mlp
+                                    else M * 4 * C * 2 + M * C * (4 + 4 + 2) + 4 * C * C * 2,
+                          "merge": M * C * 2 + (M / 4) * 2 * C * (4 + 2) + 8 * C * C * 2}.get(kind)
+            if per_launch and is_gemm:
+                kernels.setdefault(name, {})["algorithmic_bytes_per_launch"] = round(per_launch)
+                gemm_bytes += per_launch * cnt
+                gemm_launches += cnt
         tf = flop * frames_prof / (ms * 1e-3) / 1e12 if flop and ms else None
-        kernels[name] = {"ms_per_step": round(ms / psteps, 4), "launches_per_step": cnt // psteps, "avg_launch_us": round(ms / cnt * 1e3, 2)}
+        kernels.setdefault(name, {}).update({"ms_per_step": round(ms / psteps, 4), "launches_per_step": cnt // psteps, "avg_launch_us": round(ms / cnt * 1e3, 2)})
+        if "algorithmic_bytes_per_launch" in kernels[name]:
+            kernels[name]["tb_per_s"] = round(kernels[name]["algorithmic_bytes_per_launch"] / (ms / cnt * 1e-3) / 1e12, 2)
         if tf:
             kernels[name]["tflops"] = round(tf, 1)
             kernels[name]["frac"] = round(tf / BF16_PEAK_TFLOPS, 4)
@@ -458,10 +485,12 @@ def bench_swin(dev, args):
             "ms_per_step": round(dt * 1e3, 3),
             "dtype": "bf16", "gflop_per_frame": round(cfg.flops_per_frame() / 1e9, 2),
             "model_tflops": round(cfg.flops_per_frame() * b / dt / 1e12, 1),
-            "roofline": {"bound": "mfma", "kernel": "all GEMM launches of the Swin-V2-B step (gemm_ln_kernel: proj / fc2 / merge / patch embedding with their "
-                                                    "LayerNorms; gemm_bf16_v4 / v3 / v2: qkv, fc1)",
+            "roofline": {"bound": "mfma", "kernel": "all GEMM-class launches of the Swin-V2-B step (swin_mlp_kernel / swin_mlp512_kernel: the whole MLP of a block of stages "
+                                                    "0-2; gemm_ln_kernel / gemm_bf16_v4<LN_RES>: proj / merge / patch embedding with their LayerNorms; gemm_bf16_v4 / v3 / v2: qkv, stage-3 fc1)",
                          "achieved": round(gemm_tf, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tf / BF16_PEAK_TFLOPS, 4), "traffic": None if traffic is None else round(traffic[0]),
+                         "algorithmic_bytes_per_launch": round(gemm_bytes / gemm_launches) if gemm_launches else None,
+                         "traffic_over_algorithmic": None if traffic is None or not gemm_launches else round(traffic[0] / (gemm_bytes / gemm_launches), 2),
                          "traffic_unit": None if traffic is None else f"memory-side bytes per GEMM-class launch, mean over {traffic[1]} launches "
                                                                         f"({traffic[2]}: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)",
                          "window_attention_mfma_busy": wbusy,
@@ -481,9 +510,9 @@ def bench_matching(dev, args):
     from vsc_hip import cnn
 
     def run(model, x, iters):
-        cnn.FLOPS = [0.0]
+        cnn.FLOPS = [0.0, 0.0]
         model(x)
-        flop = cnn.FLOPS[0]
+        flop = (cnn.FLOPS[0], cnn.FLOPS[1])    # (all convolution calls, the share on the bf16 pipe with split operands)
         cnn.FLOPS = None
         model(x)
         torch.cuda.synchronize()
@@ -497,10 +526,14 @@ def bench_matching(dev, args):
 
     cls = cnn.MobileNetV3SmallHip(cnn_synth.mobilenetv3_small_state(1), dev)
     xc = cnn_synth.similarity_maps(2, 8, 160, 160).to(dev).repeat(256, 1, 1, 1)
-    dtc, fc = run(cls, xc, 5)
+    dtc, (fc, _) = run(cls, xc, 5)
     ref = cnn.HRNetRefineHip(cnn_synth.hrnet_refine_state(3), dev)
     xr = cnn_synth.similarity_maps(4, 16, 224, 224).to(dev)
-    dtr, fr = run(ref, xr, 5)
+    dtr, (fr, fr_x3) = run(ref, xr, 5)
+    # time floor of the pass if every layer ran at the roof of the pipe that executes it: fp32 matrix pipe 157.3 TF/s; split-bf16 layers
+    # issue six bf16 MFMA products per logical product: 2500 / 6 = 417 logical TF/s
+    x3_roof = BF16_PEAK_TFLOPS / 6.0
+    floor_s = (fr - fr_x3) / (F32_MFMA_PEAK_TFLOPS * 1e12) + fr_x3 / (x3_roof * 1e12)
     return {"dtype": "f32 (HRNet's thin 3 x 3 layers: bf16 pipe on split operands x = x1 + x2 + x3, six products, fp32 accumulation -- fp32-level error)",
             "peak_tflops": F32_MFMA_PEAK_TFLOPS,
             "classifier": {"model": "mobilenetv3_small_100, 2 classes", "batch": list(xc.shape), "ms": round(dtc * 1e3, 2),
@@ -508,7 +541,12 @@ def bench_matching(dev, args):
                            "tflops": round(fc / dtc / 1e12, 2), "frac_of_f32_mfma_peak": round(fc / dtc / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},
             "refiner": {"model": "hrnet_w18 features + fuse head", "batch": list(xr.shape), "ms_per_pass": round(dtr * 1e3, 2),
                         "maps_per_s": round(xr.shape[0] / dtr, 1), "gflop_per_map": round(fr / xr.shape[0] / 1e9, 3),
-                        "tflops": round(fr / dtr / 1e12, 2), "frac_of_f32_mfma_peak": round(fr / dtr / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)},
+                        "tflops": round(fr / dtr / 1e12, 2), "frac_of_f32_mfma_peak": round(fr / dtr / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                        "flop_share_on_split_bf16_pipe": round(fr_x3 / fr, 4), "split_bf16_logical_roof_tflops": round(x3_roof, 1),
+                        "frac_of_per_pipe_roof": round(floor_s / dtr, 4),
+                        "per_pipe_note": "frac_of_per_pipe_roof = (fp32-pipe FLOPs / 157.3 TF/s + split-bf16 logical FLOPs / 417 TF/s) / measured time: "
+                                         "every layer priced against the pipe that runs it (vsc_conv_last_pipe); frac_of_f32_mfma_peak prices all of "
+                                         "them against the fp32 pipe and is not a roofline fraction for the split layers"},
             "note": "whole-network wall time per batch, inputs resident in HBM; FLOPs = 2 x MACs of every convolution call "
                     "(depthwise included), each counted once whatever pipe ran it: frac_of_f32_mfma_peak prices the network against the fp32 matrix pipe; "
                     "parity of these networks is unpinned (DESIGN.md section 3)"}
@@ -624,8 +662,14 @@ def main():
             # committed PMC pass (profiles/r04_pmc_mfma_busy.json, else the round-2 file)
             att_flop = cfg.layers * 4.0 * cfg.tokens * cfg.tokens * cfg.width
             tf = att_flop * args.batch * psteps / (prof["attention"][0] * 1e-3) / 1e12
+            # its bytes: q, k, v in (3 D bf16 per token) and the context out (D bf16 per token) -- the kernel is bound by them, not by the pipe
+            att_bytes = 8.0 * cfg.tokens * cfg.width * min(args.max_batch, args.batch)
+            att_us = 1e3 * prof["attention"][0] / max(prof["attention"][1], 1)
+            tbs = att_bytes / (att_us * 1e-6) / 1e12
             per_class["attention"].update({"tflops": round(tf, 1), "frac": round(tf / BF16_PEAK_TFLOPS, 4),
-                                           "mfma_busy": attention_mfma_busy("attention_kernel")})
+                                           "mfma_busy": attention_mfma_busy("attention_kernel"),
+                                           "bound": "hbm", "algorithmic_bytes_per_launch": round(att_bytes), "tb_per_s": round(tbs, 2),
+                                           "frac_hbm": round(tbs / HBM_PEAK_TBS, 4), "hbm_peak_tb_per_s": HBM_PEAK_TBS})
         traffic, algo_bytes, traffic_src = gemm_traffic(cfg, min(args.max_batch, args.batch))
         line = {
             "metric": "frames/s (ViT-B/16 224x224 encode -> L2-normalised 512-d descriptors)",
@@ -681,6 +725,13 @@ def main():
             torch.cuda.empty_cache()
         if not args.no_matching and secondary:
             line["matching"] = bench_matching(dev, args)
+            torch.cuda.empty_cache()
+        if not args.no_ensemble and secondary:
+            try:
+                from tools import ensemble_bench
+                line["ensemble"] = ensemble_bench.measure(dev, args.ensemble_videos, 40)
+            except Exception as exc:  # noqa: BLE001 -- a secondary: the primary line must still be printed
+                line["ensemble"] = {"error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.empty_cache()
         if not args.no_search and secondary:
             line["search"] = bench_search(dev, args)

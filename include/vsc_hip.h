@@ -405,10 +405,19 @@ int vsc_upsample_sum_f32(const float *base_dev, int32_t ldb, const float *src0_d
                          int32_t factor1, const float *src2_dev, int32_t factor2, int64_t n, int32_t h, int32_t w, int32_t c,
                          int32_t act, float *out_dev, int32_t ldo, void *stream);
 
+/* Diagnostic (bench.py: FLOPs per pipe): which pipe the last vsc_conv2d_f32 call of this process ran on -- 0 the fp32 matrix / vector
+ * pipe, 1 the bf16 matrix pipe on split operands (3 x 3 / stride 1 layers with 20, 36, 64, 72, 144 input channels and the 256 -> <= 32
+ * transition, unless VSC_CONV_X3=0 / VSC_CONV_DIRECT=0: six bf16 products per multiply, fp32-level error). */
+int vsc_conv_last_pipe(void);
+
 /* fp32 multi-head self-attention for short sequences: out[t, h*dh:(h+1)*dh] = softmax(q k^T / sqrt(dh)) v per head, qkv
  * [tokens, 3 * heads * head_dim] float32 as q | k | v column blocks.  Used by the video-score head (BERT encoder over <= 258
  * tokens, infer/extract_query_feats.py:165-173), whose sigmoid gate is compared with 1e-3 and therefore runs in fp32. */
 int vsc_attention_f32(const float *qkv_dev, float *out_dev, int32_t tokens, int32_t heads, int32_t head_dim, void *stream);
+/* The same for `seqs` sequences of the same length stored back to back (qkv [seqs * tokens, 3 * heads * head_dim]): the video-score
+ * heads of a group of query videos in one launch per layer (their Linears and LayerNorms are row-wise and take all rows at once). */
+int vsc_attention_f32_batch(const float *qkv_dev, float *out_dev, int32_t tokens, int32_t heads, int32_t head_dim, int32_t seqs,
+                            void *stream);
 
 #ifdef __cplusplus
 }

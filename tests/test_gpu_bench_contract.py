@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_json_contract():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64", "--max-batch", "64",
-           "--search-nq", "1024", "--search-nr", "50000", "--search-steps", "1", "--swin-batch", "8", "--no-cpu-baseline"]
+           "--search-nq", "1024", "--search-nr", "50000", "--search-steps", "1", "--swin-batch", "8", "--no-cpu-baseline", "--ensemble-videos", "2"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip()]
@@ -32,9 +32,17 @@ def test_bench_json_contract():
     sw = d["swin"]
     assert sw["roofline"]["bound"] == "mfma" and sw["roofline"]["achieved"] > 0 and "s3.fc1" in sw["kernels"] and "s2.fc1" not in sw["kernels"] and "s2.proj_ln" in sw["kernels"] and "s0.proj_ln" not in sw["kernels"]   # (stages 0-2: one kernel per MLP, booked under fc2_ln; stages 0, 1: proj inside it as well)
     assert sw["kernels"]["s2.qkv"]["launches_per_step"] == 36 and sw["kernels"]["s2.qkv"]["tflops"] > 0
-    # matching-track networks
+    assert sw["roofline"]["algorithmic_bytes_per_launch"] > 0 and sw["kernels"]["s2.fc2_ln"]["algorithmic_bytes_per_launch"] > 0
+    # ViT attention: priced against the HBM roof (its bytes), next to the MFMA numbers
+    att = d["kernels"]["attention"]
+    assert att["bound"] == "hbm" and 0 < att["frac_hbm"] < 1 and att["tb_per_s"] > 0 and att["tflops"] > 0
+    # matching-track networks: every layer priced against the pipe that runs it
     mt = d["matching"]
     assert mt["classifier"]["maps_per_s"] > 0 and mt["refiner"]["maps_per_s"] > 0 and 0 < mt["refiner"]["frac_of_f32_mfma_peak"] < 1
+    assert 0.3 < mt["refiner"]["flop_share_on_split_bf16_pipe"] < 1 and 0 < mt["refiner"]["frac_of_per_pipe_roof"] < 1
+    # the reference's real workload end to end (3 x Swin-V2-B + vit_v68 + CLIP gate from uint8 host frames)
+    en = d["ensemble"]
+    assert en["value"] > 0 and en["encoder_bound_frames_per_s"] > en["value"] and set(en["models_frames_per_s"]) == {"swinv2_base_256", "vit_v68", "clip_vit_l14_224"}
 
 
 def test_bench_stdout_is_one_line_with_a_process_group():
@@ -43,7 +51,7 @@ def test_bench_stdout_is_one_line_with_a_process_group():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded-search", "--steps", "2", "--warmup", "1",
            "--batch", "64", "--max-batch", "64", "--search-nq", "1024", "--search-nr", "50000", "--search-steps", "1",
-           "--no-swin", "--no-matching", "--no-cpu-baseline"]
+           "--no-swin", "--no-matching", "--no-cpu-baseline", "--no-ensemble"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip()]
@@ -53,3 +61,5 @@ def test_bench_stdout_is_one_line_with_a_process_group():
     # the N > 1 search leg ran on a real RCCL communicator: bank all_gather (all_gather_into_tensor) + local sweep
     assert d["search"]["n_gpus"] == 1 and d["search"]["scaling"] == "weak" and d["search"]["all_gather_bytes_per_rank"] == 0
     assert "all_gather" in d["search"]["metric"] and d["search"]["nr_total"] == 50000
+    # configs[3]: score normalisation is in the sharded leg, and the pipelined (shard-by-shard) gather is timed beside the one-gather form
+    assert "score normalisation" in d["search"]["metric"] and d["search"]["ms_pipelined"] > 0 and d["search"]["ms_one_gather"] > 0

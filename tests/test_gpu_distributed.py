@@ -61,3 +61,61 @@ def test_sharded_search_full_bank_one_rank_rccl():
     out = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + SCRIPT], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "sharded 8M-row bank ok" in out.stdout
+
+
+def test_knn_merge_parts_equals_one_search_over_the_whole_bank():
+    """vsc_knn_merge_parts_f32: a 300k-row bank swept as five ragged shards (one smaller than k, duplicated rows across shards so that
+    tied scores meet in the merge) with their id offsets and merged == one vsc_knn_ip_f32 call over the whole bank, bit for bit."""
+    import torch
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "vsc22-submission_amd")]
+    from vsc_hip import _lib, ops
+    _lib.require_device()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(11)
+    nr, nq, d, k = 300_000, 777, 128, 40
+    refs = torch.randn(nr, d, generator=g, device=dev)
+    q = torch.randn(nq, d, generator=g, device=dev)
+    refs[150_000] = refs[7]
+    refs[299_999] = refs[7]
+    q[0] = refs[7]
+    D, I = ops.knn_ip(q, refs, k)
+    cuts = [0, 100_000, 100_020, 180_000, 299_990, nr]          # shards of 100 000, 20 (< k), 79 980, 119 990, 10 rows
+    parts = [ops.knn_ip(q, refs[a:b].contiguous(), k, ref_id_offset=a) for a, b in zip(cuts[:-1], cuts[1:])]
+    Dm, Im = ops.knn_merge_parts(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(Im, I) and torch.equal(Dm.view(torch.int32), D.view(torch.int32))
+    assert I[0, :3].tolist() == [7, 150_000, 299_999]
+
+
+PIPE_SCRIPT = r"""
+import os, sys
+import torch, torch.distributed as dist
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vsc22-submission_amd")]
+from vsc_hip import _lib, ops, distributed as vdist
+_lib.require_device()
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+g = torch.Generator(device=dev).manual_seed(5)
+refs = torch.randn(500_000, 512, generator=g, device=dev); ops.l2_normalize_(refs)
+q = torch.randn(4096, 512, generator=g, device=dev); ops.l2_normalize_(q)
+noise = torch.randn(20_000, 512, generator=g, device=dev); ops.l2_normalize_(noise)
+a = vdist.sharded_knn(q, refs, 100, always_collective=True, gather_to=None)
+b = vdist.sharded_knn(q, refs, 100, always_collective=True, gather_to=None, pipelined=True)      # RCCL broadcast (async) + wait + sweep
+assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+Dn, In = vdist.sharded_knn_score_normalized(q, refs, noise, 100, beta=1.2, nk=3, always_collective=True, gather_to=None, pipelined=True)
+bias = vdist.score_norm_bias(q, noise, 1.2, 3)
+D1, I1 = ops.knn_ip(torch.cat([q, bias], 1).contiguous(), torch.cat([refs, torch.ones_like(refs[:, :1])], 1).contiguous(), 100)
+assert torch.equal(In, I1) and torch.equal(Dn, D1)
+# the bias is a per-query constant: the ranking of a query's references is the un-normalised one, the scores are shifted by it
+assert torch.equal(In, a[1]) or (In != a[1]).float().mean() < 1e-3
+assert torch.allclose(Dn, a[0] + bias, atol=2e-6)
+dist.destroy_process_group()
+print("pipelined + score-normalised sharded search ok")
+"""
+
+
+def test_pipelined_and_score_normalised_sharded_search_one_rank_rccl():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29542", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + PIPE_SCRIPT], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "score-normalised sharded search ok" in out.stdout

@@ -84,3 +84,21 @@ def test_head_rejects_bad_input():
         head.logit(torch.zeros(4, cfg.feat_dim + 1, device="cuda"))
     with pytest.raises(HipPathUnavailable):
         head.logit(torch.zeros(4, cfg.feat_dim))
+
+
+def test_batched_head_equals_one_video_at_a_time():
+    """VideoScoreHead.logits: videos of equal length share every launch of the head (row-wise Linears / LayerNorms, back-to-back
+    sequences in vsc_attention_f32_batch) -- bit for bit the logits of the one-at-a-time path, for mixed lengths (grouped by
+    length), a video that fills all max_frames slots, and one longer than that."""
+    from tools import synth
+    from vsc_hip.video_score import VideoScoreHead
+    from vsc_hip.vsm_config import get_vsm_config
+    cfg = get_vsm_config("tiny_vsm")
+    w = synth.vsm_weights(3, cfg)
+    head = VideoScoreHead(cfg, w)
+    lens = [5, 9, 5, cfg.max_frames, 1, 9, cfg.max_frames + 3, 5]
+    vids = [torch.from_numpy(synth.normalish(40 + i, (n, cfg.feat_dim))).cuda() for i, n in enumerate(lens)]
+    together = head.logits(vids)
+    alone = torch.stack([head.logits([v])[0] for v in vids])
+    assert together.shape == (len(lens),) and torch.equal(together, alone)
+    assert torch.equal(head.logit(vids[1]), together[1])

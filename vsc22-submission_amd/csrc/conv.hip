@@ -1587,6 +1587,8 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restr
     __shared__ float red[8];
     const int q = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int width = heads * dh, ld = 3 * width;
+    qkv += (int64_t)blockIdx.z * tokens * ld;      // blockIdx.z: one of several sequences of the same length, back to back
+    out += (int64_t)blockIdx.z * tokens * width;
     for (int d = tid; d < dh; d += 256) qs[d] = qkv[(int64_t)q * ld + hd * dh + d];
     __syncthreads();
     const float scale = rsqrtf((float)dh);
@@ -1653,11 +1655,15 @@ extern "C" int vsc_conv_pack_weight_f32(const float *w_dev, float *packed_dev, i
     return VSC_OK;
 }
 
+static int g_conv_last_pipe = 0;   // 0: fp32 matrix / vector pipe, 1: bf16 matrix pipe on split operands (six products per multiply)
+extern "C" int vsc_conv_last_pipe(void) { return g_conv_last_pipe; }
+
 extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t w, int32_t cin, int32_t ldx,
                               const float *w_packed_dev, const float *bias_dev, int32_t cout, int32_t kh, int32_t kw,
                               int32_t stride, int32_t pad, const float *res_dev, int32_t ldr, int32_t act, float *out_dev,
                               int32_t ldo, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    g_conv_last_pipe = 0;
     VSC_REQUIRE(x_dev && w_packed_dev && out_dev, "conv2d: null operand");
     VSC_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && kh > 0 && kw > 0 && stride > 0 && pad >= 0, "conv2d: bad shape");
     VSC_REQUIRE(ldx >= cin && ldo >= cout && (!res_dev || ldr >= cout), "conv2d: leading dimensions smaller than the channel counts");
@@ -1710,6 +1716,7 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
             X3GemmArgs a{xpl, wpl, bias_dev, res_dev, out_dev, n * (int64_t)h * w, (int)n, h, w, cin, cout, ldo, ldr, act, nks, kp, cin / 8, wr_total,
                          (unsigned)xplane, (unsigned)wplane};
             const dim3 grid((unsigned)((a.rows + 127) / 128), groups);
+            g_conv_last_pipe = 1;
             hipLaunchKernelGGL((conv_x3_gemm_kernel<5>), grid, dim3(512), 0, stream, a);
             VSC_CHECK_LAUNCH();
             return VSC_OK;
@@ -1721,6 +1728,7 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
             static int cus_tap[16] = {};
             if (!cus_tap[dev]) VSC_CHECK_HIP(hipDeviceGetAttribute(&cus_tap[dev], hipDeviceAttributeMultiprocessorCount, dev));
             const unsigned grid = (unsigned)(a.ntiles < cus_tap[dev] ? a.ntiles : cus_tap[dev]);
+            g_conv_last_pipe = 1;
             if (cin == 256) hipLaunchKernelGGL((conv3x3_tap_x3_kernel<8, 2, 4>), dim3(grid), dim3(512), 0, stream, a);
             else hipLaunchKernelGGL((conv3x3_tap_x3_kernel<8, 4, 1>), dim3(grid), dim3(512), 0, stream, a);
             VSC_CHECK_LAUNCH();
@@ -1744,11 +1752,15 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
                 b.tiles_y = (h + 3) / 4;
                 b.ntiles = (int64_t)b.tiles_x * b.tiles_y * n;
                 const unsigned g36 = (unsigned)(b.ntiles < cus_direct[dev] ? b.ntiles : cus_direct[dev]);
+                g_conv_last_pipe = 1;
                 hipLaunchKernelGGL((conv3x3_direct_x3_kernel<5, 36, 3, 1>), dim3(g36), dim3(512), 0, stream, b);
                 VSC_CHECK_LAUNCH();
                 return VSC_OK;
             }
-            if (!(x3 && x3[0] == '0') && cin == 20 && cout <= 20 && n * (int64_t)h * w * (ldo > ldr ? ldo : ldr) * 4 < (1ll << 31)) hipLaunchKernelGGL((conv3x3_direct_x3_kernel<3, 20, 2, 2>), dim3(grid), dim3(512), 0, stream, a);
+            if (!(x3 && x3[0] == '0') && cin == 20 && cout <= 20 && n * (int64_t)h * w * (ldo > ldr ? ldo : ldr) * 4 < (1ll << 31)) {
+                g_conv_last_pipe = 1;
+                hipLaunchKernelGGL((conv3x3_direct_x3_kernel<3, 20, 2, 2>), dim3(grid), dim3(512), 0, stream, a);
+            }
             else if (cin == 20 && cout <= 32) hipLaunchKernelGGL((conv3x3_direct_kernel<5, 1, 32>), dim3(grid), dim3(512), 0, stream, a);
             else if (cin == 20) hipLaunchKernelGGL((conv3x3_direct_kernel<5, 2, 40>), dim3(grid), dim3(512), 0, stream, a);
             else if (cout <= 32) hipLaunchKernelGGL((conv3x3_direct_kernel<9, 1, 32>), dim3(grid), dim3(512), 0, stream, a);
@@ -2018,13 +2030,18 @@ extern "C" int vsc_upsample_add_f32(const float *src_dev, int64_t n, int32_t h, 
     return VSC_OK;
 }
 
-extern "C" int vsc_attention_f32(const float *qkv_dev, float *out_dev, int32_t tokens, int32_t heads, int32_t head_dim, void *stream_) {
+extern "C" int vsc_attention_f32_batch(const float *qkv_dev, float *out_dev, int32_t tokens, int32_t heads, int32_t head_dim, int32_t seqs,
+                                       void *stream_) {
     VSC_REQUIRE(qkv_dev && out_dev && tokens > 0 && heads > 0 && head_dim > 0, "attention_f32: bad arguments");
-    VSC_REQUIRE(tokens <= 8192 && heads < 65536, "attention_f32: %d tokens / %d heads unsupported", tokens, heads);
+    VSC_REQUIRE(tokens <= 8192 && heads < 65536 && seqs >= 1 && seqs < 65536, "attention_f32: %d tokens / %d heads / %d sequences unsupported", tokens, heads, seqs);
     const size_t smem = (size_t)(tokens + 5 * head_dim) * 4;
     VSC_REQUIRE(smem <= 48 * 1024, "attention_f32: %d tokens x head_dim %d exceeds the kernel's LDS budget", tokens, head_dim);
-    hipLaunchKernelGGL(attention_f32_kernel, dim3(tokens, heads), dim3(256), smem, (hipStream_t)stream_, qkv_dev, out_dev, tokens, heads,
+    hipLaunchKernelGGL(attention_f32_kernel, dim3(tokens, heads, seqs), dim3(256), smem, (hipStream_t)stream_, qkv_dev, out_dev, tokens, heads,
                        head_dim);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
+}
+
+extern "C" int vsc_attention_f32(const float *qkv_dev, float *out_dev, int32_t tokens, int32_t heads, int32_t head_dim, void *stream_) {
+    return vsc_attention_f32_batch(qkv_dev, out_dev, tokens, heads, head_dim, 1, stream_);
 }

@@ -45,7 +45,7 @@ class VideoScorer:
         feats = encode_group([self.clip], clipped, self.device, self.chunk, as_numpy=False)[0]   # stay on the device: the head reads them there
         if not feats:
             return []
-        logits = torch.stack([self.head.logit(f) for f in feats])
+        logits = self.head.logits(feats)     # videos of equal length share the head's launches
         return [float(v) for v in torch.sigmoid(logits).cpu().tolist()]                          # one device -> host copy per group
 
 

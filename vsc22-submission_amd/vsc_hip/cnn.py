@@ -16,7 +16,8 @@ import torch
 from . import _lib
 from ._lib import check, current_stream, ptr
 
-FLOPS = None   # measurement hook (bench.py): a one-element list here accumulates 2 * MACs of every convolution call
+FLOPS = None   # measurement hook (bench.py): a list here accumulates [0] 2 * MACs of every convolution call, [1] (if present) the share of
+               # them that vsc_conv2d_f32 ran on the bf16 matrix pipe with split operands (vsc_conv_last_pipe)
 
 ACT = {None: 0, "none": 0, "relu": 1, "hard_swish": 2, "hard_sigmoid": 3, "gelu": 4}
 BN_EPS = 1e-5
@@ -91,11 +92,14 @@ class Conv:
         ldo = out.shape[3]
         if residual is not None:
             assert residual.shape == (n, ho, wo, self.cout) and residual.is_contiguous()
-        if FLOPS is not None:
-            FLOPS[0] += 2.0 * n * ho * wo * self.cout * self.cin * self.kh * self.kw
         view = out.view(-1)[coff:] if coff else out
         check(lib.vsc_conv2d_f32(ptr(x), n, h, w, c, c, ptr(self.w), ptr(self.b), self.cout, self.kh, self.kw, self.stride,
                                  self.pad, ptr(residual), self.cout, ACT[act], ptr(view), ldo, current_stream()))
+        if FLOPS is not None:
+            f = 2.0 * n * ho * wo * self.cout * self.cin * self.kh * self.kw
+            FLOPS[0] += f
+            if len(FLOPS) > 1 and lib.vsc_conv_last_pipe() == 1:     # the share that ran on the bf16 pipe with split operands
+                FLOPS[1] += f
         return out
 
 

@@ -77,41 +77,64 @@ class VideoScoreHead:
             })
         self.out_w, self.out_b = f32("output_proj.weight"), f32("output_proj.bias")
 
-    def _attention(self, qkv: torch.Tensor, tokens: int) -> torch.Tensor:
+    def _attention(self, qkv: torch.Tensor, tokens: int, seqs: int = 1) -> torch.Tensor:
         lib = _lib.require_device()
-        out = torch.empty((tokens, self.cfg.hidden), dtype=torch.float32, device=qkv.device)
-        _lib.check(lib.vsc_attention_f32(_lib.ptr(qkv), _lib.ptr(out), tokens, self.cfg.heads, self.cfg.hidden // self.cfg.heads,
-                                         _lib.current_stream()))
+        out = torch.empty((seqs * tokens, self.cfg.hidden), dtype=torch.float32, device=qkv.device)
+        _lib.check(lib.vsc_attention_f32_batch(_lib.ptr(qkv), _lib.ptr(out), tokens, self.cfg.heads, self.cfg.hidden // self.cfg.heads, seqs,
+                                               _lib.current_stream()))
         return out
 
     def logit(self, clip_cls: torch.Tensor) -> torch.Tensor:
         """clip_cls [n, feat_dim] (device): the CLIP [CLS] feature of each frame of ONE video -> 0-d logit tensor."""
-        cfg = self.cfg
-        if clip_cls.dim() != 2 or clip_cls.shape[1] != cfg.feat_dim or clip_cls.shape[0] == 0:
-            raise ValueError(f"expected [n >= 1, {cfg.feat_dim}] features, got {tuple(clip_cls.shape)}")
-        if not clip_cls.is_cuda:
-            raise _lib.HipPathUnavailable("video-score features must be on the GPU (no CPU fallback)")
-        rows, with_sep = compact_tokens(clip_cls.shape[0], cfg.max_frames)
-        f = clip_cls[: cfg.max_frames].float()
-        if rows > f.shape[0]:
-            f = torch.cat([f, torch.zeros(rows - f.shape[0], cfg.feat_dim, device=f.device)])
+        return self.logits([clip_cls])[0]
 
-        def lin(layer, x, act=None, residual=None):   # [T, in] -> [T, out] through the NHWC convolution entry point
+    def logits(self, videos) -> torch.Tensor:
+        """One [n_v, feat_dim] device tensor per video -> [len(videos)] logits.  Videos with the same number of frames go through the
+        head TOGETHER: every Linear / LayerNorm is row-wise and takes all their tokens in one launch, the attention takes them as
+        back-to-back sequences (vsc_attention_f32_batch) -- the head of one 40-frame video is ~150 launches of a few microseconds of
+        work each, and a group of 26 query videos spent a quarter of its time issuing them one video after the other.  The rows of a
+        video see the same fp32 fma chains whatever else is in the launch: the logits equal the one-at-a-time ones bit for bit."""
+        cfg = self.cfg
+        out = [None] * len(videos)
+        by_len = {}
+        for i, f in enumerate(videos):
+            if f.dim() != 2 or f.shape[1] != cfg.feat_dim or f.shape[0] == 0:
+                raise ValueError(f"expected [n >= 1, {cfg.feat_dim}] features, got {tuple(f.shape)}")
+            if not f.is_cuda:
+                raise _lib.HipPathUnavailable("video-score features must be on the GPU (no CPU fallback)")
+            by_len.setdefault(min(int(f.shape[0]), cfg.max_frames), []).append(i)
+        for n, idx in by_len.items():
+            vals = self._logits_same_length([videos[i][: cfg.max_frames].float() for i in idx], n)
+            for j, i in enumerate(idx):
+                out[i] = vals[j]
+        return torch.stack(out)
+
+    def _logits_same_length(self, feats, n: int) -> torch.Tensor:
+        cfg = self.cfg
+        V = len(feats)
+        rows, with_sep = compact_tokens(n, cfg.max_frames)
+        f = torch.stack(feats)                                   # [V, n, feat]
+        if rows > n:
+            f = torch.cat([f, torch.zeros(V, rows - n, cfg.feat_dim, device=f.device)], dim=1)
+        f = f.reshape(V * rows, cfg.feat_dim)
+
+        def lin(layer, x, act=None, residual=None):   # [R, in] -> [R, out] through the NHWC convolution entry point
             r = None if residual is None else residual.reshape(1, x.shape[0], 1, -1)
             return layer(x.contiguous().reshape(1, x.shape[0], 1, x.shape[1]), act=act, residual=r).reshape(x.shape[0], -1)
 
-        vision = ops.layernorm(lin(self.proj, f), self.proj_g, self.proj_beta, cfg.proj_ln_eps, out_f32=True)
-        toks = [self.cls_emb[None], vision] + ([self.sep_emb[None]] if with_sep else [])
-        emb = torch.cat(toks) + self.pos_type[: rows + 1 + int(with_sep)]
-        T = emb.shape[0]
+        vision = ops.layernorm(lin(self.proj, f), self.proj_g, self.proj_beta, cfg.proj_ln_eps, out_f32=True).reshape(V, rows, -1)
+        T = rows + 1 + int(with_sep)
+        toks = [self.cls_emb[None, None].expand(V, 1, -1), vision] + ([self.sep_emb[None, None].expand(V, 1, -1)] if with_sep else [])
+        emb = (torch.cat(toks, dim=1) + self.pos_type[:T]).reshape(V * T, -1).contiguous()
         x, _ = ops.ln_residual(emb, self.emb_g, self.emb_b, cfg.ln_eps)
         for L in self.layers:
-            att = self._attention(lin(L["qkv"], x), T)
+            att = self._attention(lin(L["qkv"], x), T, V)
             x, _ = ops.ln_residual(lin(L["o"], att, residual=x), L["ln1_g"], L["ln1_b"], cfg.ln_eps)
             h = lin(L["fc1"], x, act="gelu")
             x, _ = ops.ln_residual(lin(L["fc2"], h, residual=x), L["ln2_g"], L["ln2_b"], cfg.ln_eps)
-        pooled = torch.cat([x[0], x.sum(dim=0) / (T + 1e-5)])
-        return (self.out_w[0] * pooled).sum() + self.out_b[0]
+        x = x.reshape(V, T, -1)
+        pooled = torch.cat([x[:, 0], x.sum(dim=1) / (T + 1e-5)], dim=1)
+        return (self.out_w[0] * pooled).sum(dim=1) + self.out_b[0]
 
     def score(self, clip_cls: torch.Tensor) -> float:
         return float(torch.sigmoid(self.logit(clip_cls)))
