@@ -372,10 +372,14 @@ int vsc_conv_pack_weight_f32(const float *w_dev, float *packed_dev, int32_t cout
  * Layers that materialise their patch matrix share ONE grow-only scratch buffer per device: issue the convolutions of a
  * device from one stream at a time (calls from several host threads are serialised on an internal mutex, their kernels
  * are not ordered against each other).
- * Arithmetic: fp32 products with fp32 accumulation on the fp32 matrix pipe; 3 x 3 / stride 1 / pad 1 layers with 20, 36, 64, 72 or
- * 144 input channels instead multiply bf16 triples (x = x1 + x2 + x3, six products per multiply, fp32 accumulation) -- the same
- * error against float64 as the fp32 pipe; VSC_CONV_X3=0 (vsc_set_option) switches that off.  The 72- / 144-channel form keeps its
- * split operands in a second per-device scratch buffer: the one-stream-at-a-time rule above covers it too. */
+ * Arithmetic: fp32 products with fp32 accumulation on the fp32 matrix pipe.  These 3 x 3 / stride 1 / pad 1 layers instead multiply
+ * bf16 triples (x = x1 + x2 + x3, six products per multiply, fp32 accumulation: the same error against float64 as the fp32 pipe):
+ *     cin == 20 with cout <= 20, cin == 36 with cout <= 36           (cin as passed: HRNet's 18 channels come padded to 20)
+ *     cin == 64 with cout <= 64, cin == 256 with cout <= 32          dense rows (ldx == cin), >= 65 536 output pixels
+ *     cin == 72 or 144 with 48 <= cout <= 160                        dense rows, 8 192 <= pixels, <= 16 M input elements
+ * each only with 16-byte aligned x / weights / out / res / bias (anything else takes the fp32 tile kernels); VSC_CONV_X3=0 or
+ * VSC_CONV_DIRECT=0 (vsc_set_option) switch all of them off; vsc_conv_last_pipe() tells which pipe a call took.  The 72- / 144-
+ * channel form keeps its split operands in a second per-device scratch buffer: the one-stream-at-a-time rule above covers it too. */
 int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t w, int32_t cin, int32_t ldx, const float *w_packed_dev,
                    const float *bias_dev, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
                    const float *res_dev, int32_t ldr, int32_t act, float *out_dev, int32_t ldo, void *stream);

@@ -38,6 +38,17 @@ def test_every_declared_symbol_is_exported(lib):
 def test_library_reports_version_and_no_device_without_gpu(lib):
     import torch
     assert b"gfx950" in lib.vsc_version()
+    # the loaded library was built from THIS tree: vsc_version() carries the hash of csrc/* + include/vsc_hip.h (csrc/Makefile: HASHED).
+    # .so files are git-ignored and travel to the GPU box as untracked artefacts -- a stale one must fail here, not be tested silently.
+    import glob
+    import hashlib
+    csrc = os.path.join(ROOT, "vsc22-submission_amd", "csrc")
+    names = sorted([os.path.basename(p) for ext in ("*.hip", "*.h", "*.inc") for p in glob.glob(os.path.join(csrc, ext))] + ["Makefile"])
+    h = hashlib.sha256()
+    for n in names:
+        h.update(open(os.path.join(csrc, n), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "vsc_hip.h"), "rb").read())
+    assert ("src " + h.hexdigest()[:16]).encode() in lib.vsc_version(), (lib.vsc_version(), h.hexdigest()[:16], "rebuild: make -C vsc22-submission_amd/csrc")
     if not torch.cuda.is_available():
         assert lib.vsc_device_count() <= 0
 

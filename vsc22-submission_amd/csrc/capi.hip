@@ -14,7 +14,11 @@ void vsc_set_error(const char *fmt, ...) {
 
 extern "C" const char *vsc_last_error(void) { return g_err; }
 
-extern "C" const char *vsc_version(void) { return "vsc_hip 0.1 (gfx950)"; }
+#ifndef VSC_SRC_HASH
+#define VSC_SRC_HASH "unhashed"
+#endif
+// "... src <hash>": first 16 hex digits of the SHA-256 over the sources the Makefile lists (HASHED) -- tests/test_capi_symbols.py recomputes it
+extern "C" const char *vsc_version(void) { return "vsc_hip 0.1 (gfx950) src " VSC_SRC_HASH; }
 
 extern "C" int vsc_device_count(void) {
     int n = 0;

@@ -145,7 +145,11 @@ struct GemmExtra {
     int *xflags = nullptr;           // LN_RES, N = 512: [256 workgroups][2] tiles published, counting up across launches from `epoch`
     int epoch = 0;
 };
-// bytes of the pair-exchange workspace of launch_gemm_ln_bf16 (one per stream that may run it)
+// bytes of the pair-exchange workspace of launch_gemm_ln_bf16 (one per stream that may run it).
+// Contract: the workspace's flag words count up from launch to launch; the count ("epoch") is kept by the launcher in a host map keyed
+// by the workspace pointer and passed to the kernel as an argument.  Hence (1) one workspace serves ONE stream at a time; (2) whoever
+// frees a workspace calls gemm_ln_workspace_forget(ws) first -- a later allocation at the same address would otherwise inherit a stale
+// epoch over whatever the new memory holds; (3) launches that use it cannot be captured into a HIP graph (the launcher refuses).
 constexpr size_t VSC_GEMM_LN_WS_BYTES = 2 * 256 * 256 * 2 * 4 + 256 * 2 * 4;
 void gemm_ln_workspace_forget(const void *ws);   // call before freeing a workspace that was passed to launch_gemm_ln_bf16
 int launch_gemm_bf16_ex(const uint16_t *a, const uint16_t *w, const float *bias, const float *aux, void *out, int64_t m,

@@ -1680,12 +1680,15 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
         const char *de = vsc_opt(OPT_CONV_DIRECT);   // diagnostic / test switch: 0 = the implicit-GEMM path
         const int64_t xbytes = n * (int64_t)h * w * ldx * 4;
         const char *x3e = vsc_opt(OPT_CONV_X3);
-        const bool tap_x3 = !(de && de[0] == '0') && !(x3e && x3e[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && ((cin == 64 && cout <= 64) || (cin == 256 && cout <= 32)) && ldx == cin &&
+        // the epilogues of the direct / tap / plane kernels move out, res and bias 16 bytes at a time whenever ldo and ldr are multiples
+        // of 4: an output window at an offset (Conv.__call__(out=..., coff=...)) or a caller's unaligned buffer takes the tile kernels
+        const bool io16 = (((uintptr_t)out_dev | (uintptr_t)(res_dev ? res_dev : out_dev) | (uintptr_t)(bias_dev ? bias_dev : out_dev)) & 15) == 0;
+        const bool tap_x3 = io16 && !(de && de[0] == '0') && !(x3e && x3e[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && ((cin == 64 && cout <= 64) || (cin == 256 && cout <= 32)) && ldx == cin &&
                             (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 && xbytes < (1ll << 31) && (!res_dev || ldr >= cout) &&
                             n * (int64_t)h * w * (ldo > ldr ? ldo : ldr) * 4 < (1ll << 31) && n * (int64_t)h * w >= 65536;
         // wide 3 x 3 layers on small maps: both operands split into planes once, implicit GEMM on the bf16 pipe (conv_x3_gemm_kernel)
         const int64_t in_elems = n * (int64_t)h * w * cin;
-        const bool x3gemm = !(de && de[0] == '0') && !(x3e && x3e[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (cin == 72 || cin == 144) &&
+        const bool x3gemm = io16 && !(de && de[0] == '0') && !(x3e && x3e[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (cin == 72 || cin == 144) &&
                             ldx == cin && cout >= 48 && cout <= 160 && (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 && in_elems * 6 < (1ll << 31) &&
                             in_elems <= (16ll << 20) && (!res_dev || ldr >= cout) && n * (int64_t)h * w >= 8192 && n * (int64_t)h * w < (1ll << 31);
         if (x3gemm) {
@@ -1734,7 +1737,7 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
             VSC_CHECK_LAUNCH();
             return VSC_OK;
         }
-        const bool direct = !(de && de[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cout <= 40 && (cin == 20 || cin == 36) &&
+        const bool direct = io16 && !(de && de[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && cout <= 40 && (cin == 20 || cin == 36) &&
                             (ldx & 3) == 0 && (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 && xbytes < (1ll << 31) &&
                             (!res_dev || ldr >= cout);
         if (direct) {
@@ -1827,7 +1830,7 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
     // 1 x 1, stride 1, dense rows of a multiple of 32 channels: the input IS the patch matrix
     const bool in_place = kh == 1 && kw == 1 && stride == 1 && pad == 0 && ldx == cin && (cin % KS) == 0 && (((uintptr_t)x_dev) & 15) == 0;
     const char *nm = vsc_opt(OPT_CONV_NARROW_MAX);
-    const bool narrow = cout <= (nm ? atoi(nm) : 160);   // <= 3 channel tiles of 32: the thin layers (see conv_gemm_narrow_kernel)
+    const bool narrow = cout <= (nm ? atoi(nm) : 160);   // <= 5 channel tiles of 32 (VSC_CONV_NARROW_MAX): the thin and the 144-wide layers (see conv_gemm_narrow_kernel)
     // patches gathered inside the GEMM's staging (narrow kernel): 4-channel chunks, table-sized K, 16-bit image coordinates
     const char *imp_env = vsc_opt(OPT_CONV_IMPLICIT);   // diagnostic / test switch, read per call
     const bool no_implicit = imp_env && imp_env[0] == '0';

@@ -1006,14 +1006,16 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8]
         // Forward progress: the partner (blockIdx ^ 8) runs the row's other tile in the SAME round of a grid with one workgroup
         // per CU on every CU (launch_v4 checks grid == CUs and whole tile pairs; launch_gemm_ln_bf16 checks the CU count), so it
         // is resident and reaches its own publish without waiting for anybody.  Should that assumption ever break (a CU mask,
-        // a partitioned device) the wait is BOUNDED: ~2^21 polls of >= 128 cycles (>= 0.1 s against a tile time of 80 us), then
-        // a trap -- the launch fails with a HIP error at the next synchronisation instead of hanging the queue.
+        // a partitioned device) the wait is BOUNDED: ~2^25 polls of >= 128 cycles (seconds against a tile time of 80 us -- long enough
+        // for a preempted or profiler-serialised partner, which a 0.1-s bound was not), then a trap: the launch fails with a HIP error
+        // at the next synchronisation instead of hanging the queue.  (A trap ends the whole HIP context; it is the last resort behind
+        // the launcher's residency checks, not a flow-control path.)
         const int *flag = p.ex.xflags + (blockIdx.x ^ 8) * 2 + wm;
         int polls = 0;   // (the flag is read as a wave-uniform value, so the loop and its counter stay on the scalar side: no VGPR)
         // (flags count up across launches -- p.ex.epoch is this launch's base -- so nothing has to be zeroed between launches)
         while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - (p.ex.epoch + iter + 1) < 0) {
             __builtin_amdgcn_s_sleep(2);
-            if (++polls > (1 << 21)) __builtin_trap();
+            if (++polls > (1 << 25)) __builtin_trap();
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1875,6 +1877,11 @@ int launch_gemm_ln_bf16(const uint16_t *a, const uint16_t *w, const float *bias,
                 if (g >= 16 && g <= cus && g % 16 == 0 && tiles_m * tiles_n >= g) grid = g;
             }
             if (tiles_n == 2) {
+                // The epoch lives on the host and is baked into the kernel arguments: a captured launch replayed from a HIP graph would
+                // wait for flag values of the capture, not of the replay -- refuse stream capture (common.h: the workspace contract).
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                VSC_CHECK_HIP(hipStreamIsCapturing(stream, &cap));
+                VSC_REQUIRE(cap == hipStreamCaptureStatusNone, "gemm_ln (N = 512 pair exchange): not capturable into a HIP graph (per-launch epoch)");
                 // the flags of a workspace count up from launch to launch (zeroed once, when the workspace is first seen): no memset
                 // node between the GEMMs of a block.  One launch advances them by its tiles per workgroup.
                 std::lock_guard<std::mutex> lock(g_ln_ws_mutex);

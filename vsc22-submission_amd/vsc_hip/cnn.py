@@ -330,7 +330,9 @@ class HRNetRefineHip:
         for wd in widths:
             real += list(range(off, off + wd))
             off += wd + (-wd % 4)
-        self.fuse0 = Conv(state_dict, "fuse.0", None, 1, device, pad4=True, cin_map=(real, off))
+        # the 336-wide form of fuse.0 (over the concatenation) is only built when SPLIT_FUSE0 is off (diagnostic / test switch)
+        self._fuse0_args = (state_dict, (real, off), device)
+        self._fuse0 = None
         # fuse.0 is a 1 x 1 convolution over torch.cat of nearest-upsampled features, and a 1 x 1 convolution commutes with nearest
         # upsampling: conv(cat_s up(x_s)) = sum_s up(conv_s(x_s)) with conv_s = the weight columns of source s.  Per source at its OWN
         # resolution (the 72- / 144-wide branches at 1/16 and 1/64 of the pixels), no 336-channel tensor (1.08 GB written and read):
@@ -370,7 +372,10 @@ class HRNetRefineHip:
             for i, y in enumerate([stem] + xs):
                 upsample_into(y, cat, 1 if i < 2 else 2 ** (i - 1), off, False, None)
                 off += widths[i]
-            fused = self.fuse0(cat, act="relu")
+            if self._fuse0 is None:
+                sd0, cmap, dev0 = self._fuse0_args
+                self._fuse0 = Conv(sd0, "fuse.0", None, 1, dev0, pad4=True, cin_map=cmap)
+            fused = self._fuse0(cat, act="relu")
         y = self.fuse2(fused)[..., : self.classes]
         return y.permute(0, 3, 1, 2).contiguous()
 
