@@ -342,6 +342,14 @@ int vsc_swin_mlp_bf16(const uint16_t *w1_dev, const float *b1_dev, const uint16_
                       const float *gamma_dev, const float *beta_dev, float *x_dev, uint16_t *xb_dev, int64_t m, int32_t c,
                       float eps, void *stream);
 int vsc_swin_mlp_permute_hidden_f32(const float *w2_host, float *w2p_host, int32_t c);
+/* The whole second half of a Swin-V2 block in one kernel (c = 128, 256 or 512), in place on the residual stream
+ * (SwinTransformerBlock.forward after the window attention, torch2scripts.py:284-300):
+ *   x1 = x + LayerNorm(att Wp[c,c]^T + bp) * gamma1 + beta1 ;  x = x1 + LayerNorm(GELU(bf16(x1) W1^T + b1) W2^T + b2) * gamma2 + beta2 ;  xb = bf16(x)
+ * att_dev [m, c] bf16 is the attention output; xb_dev is written only (the MLP's input is formed in registers).  w2p_dev as for
+ * vsc_swin_mlp_bf16.  At c = 512 x1 passes through x_dev once as fp32 between the two halves; m < 2^21. */
+int vsc_swin_proj_mlp_bf16(const uint16_t *att_dev, const uint16_t *wp_dev, const float *bp_dev, const float *gamma1_dev, const float *beta1_dev,
+                           const uint16_t *w1_dev, const float *b1_dev, const uint16_t *w2p_dev, const float *b2_dev, const float *gamma2_dev,
+                           const float *beta2_dev, float *x_dev, uint16_t *xb_dev, int64_t m, int32_t c, float eps, void *stream);
 /* PatchMerging gather on bf16 tokens [frames, res, res, c] -> [frames*(res/2)^2, 4c] */
 int vsc_merge_gather_bf16(const uint16_t *xb_dev, uint16_t *out_dev, int64_t frames, int32_t res,
                           int32_t c, void *stream);

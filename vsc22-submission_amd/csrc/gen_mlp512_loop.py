@@ -34,7 +34,7 @@ import sys
 SLOT = 32768
 LDS_W1, LDS_W2 = 0, 2 * SLOT
 NCH = 64
-PF, STAGGER, TIMING, ABL = 8, 0, False, 0    # defaults; main() builds the variants listed in VARIANTS
+PF, STAGGER, TIMING, ABL, PROJ = 8, 0, False, 0, False    # defaults; main() builds the variants listed in VARIANTS
 # ABL (diagnostic variants, wrong results): 1 no GELU arithmetic, 2 no LDS-DMA in the loop, 4 no fragment reads, 8 no MFMAs in the loop
 GELU_DEG = 8
 GELU_U = 4.5
@@ -71,10 +71,12 @@ def XF(mt, ks): return vq(4 * (16 * mt + ks))
 def W1P(a): return f"%[w1p{a}]"
 W2P, B1P, V2, W1R, W2R, SW, SLW = "%[w2p]", "%[b1p]", "%[v2]", "%[w1r]", "%[w2r]", "%[swave]", "%[sldsw]"
 VECP, XBOFF, BP16, BP32, XR, XBR, EPS = "%[vecp]", "%[xboff]", "%[bp16]", "%[bp32]", "%[xr]", "%[xbr]", "%[eps]"
+ATTR, WPR = "%[attr]", "%[wpr]"      # PROJ: descriptors of the attention output rows and of attn.proj.weight
 DBGR, DBGOFF = "%[dbgr]", "%[dbgoff]"      # timing variant: per-wave cycle counters go to dbgr at byte offset dbgoff
 S_TS, S_ACC = 70, 80                     # s[70:79] time stamps (pairs), s80.. accumulated differences
 S_MT1X, S_MT1B = 66, 67     # byte offsets of the second 16-row tile in x / xb
 S_SLOT2 = 68                # LDS offset of the W2 slot being refilled (S_SLOT: the W1 slot)
+S_LB1, S_LB2 = 69, 86       # m0 bases of the two refills (slot base + LDS base + this wave's 1 KiB)
 BID = "%[bid]"
 def V1(a): return f"%[v1{a}]"
 
@@ -83,6 +85,7 @@ class Emit:
     def __init__(self):
         self.lines = []
         self.q = []          # outstanding LDS reads (tags), oldest first
+        self.vq = []         # outstanding vector-memory operations tracked for counted waits (proj_ln)
 
     def i(self, s):
         self.lines.append(s)
@@ -108,6 +111,23 @@ class Emit:
             self.i("s_waitcnt lgkmcnt(0)")
         self.q = []
 
+    # vector-memory operations (loads and stores retire in issue order on this part: the compiler's own counted vmcnt waits rely on it)
+    def vm(self, tag, text):
+        self.i(text)
+        self.vq.append(tag)
+        assert len(self.vq) <= 63
+
+    def vm_wait(self, tag):
+        if tag not in self.vq:
+            return
+        k = self.vq.index(tag)
+        self.i(f"s_waitcnt vmcnt({len(self.vq) - 1 - k})")
+        self.vq = self.vq[k + 1:]
+
+    def vm_wait_all(self):
+        self.i("s_waitcnt vmcnt(0)")
+        self.vq = []
+
 
 def frag_addr(g):
     """(base register, immediate) of the fragment of MFMA group g: 0..31 GEMM 2 (output tile g), 32..63 GEMM 1 (j = e & 1, ks = e >> 1)"""
@@ -118,58 +138,74 @@ def frag_addr(g):
     return W1P(ks & 3), 16384 * j + 256 * (ks >> 2)
 
 
-def group(E, g, end):
-    """the two MFMAs of group g, then the request of the fragment PF groups ahead (none at or beyond `end`)"""
+def group(E, g, end, between=(), after=()):
+    """the two MFMAs of group g, then the request of the fragment PF groups ahead (none at or beyond `end`).  `between`: up to three
+    scalar / memory instructions issued in the shadow of the first MFMA (an MFMA occupies the matrix pipe for 16 cycles and one issue
+    slot of 4: three more instructions of other kinds fit behind it for free -- put behind the SECOND MFMA they delay the next
+    group's first one); `after`: instructions behind the fragment request."""
     E.wait(("f", g))
     w = vq(WQ(g % PF))
+    first, second = [], []
     if ABL & 8:
         pass
     elif g < 32:
-        for mt in range(2):
-            E.i(f"v_mfma_f32_16x16x32_bf16 {ACC(mt, g)}, {w}, {vq(HF(mt))}, {ACC(mt, g)}")
+        first.append(f"v_mfma_f32_16x16x32_bf16 {ACC(0, g)}, {w}, {vq(HF(0))}, {ACC(0, g)}")
+        second.append(f"v_mfma_f32_16x16x32_bf16 {ACC(1, g)}, {w}, {vq(HF(1))}, {ACC(1, g)}")
     else:
         e = g - 32
         j, ks = e & 1, e >> 1
-        for mt in range(2):
-            c = "0" if ks == 0 else vq(HACC(mt, j))
-            E.i(f"v_mfma_f32_16x16x32_bf16 {vq(HACC(mt, j))}, {w}, {XF(mt, ks)}, {c}")
+        for mt, lst in ((0, first), (1, second)):
+            c = vq(BZ(j)) if ks == 0 else vq(HACC(mt, j))     # a chain starts from the fc1 bias of its four hidden units
+            lst.append(f"v_mfma_f32_16x16x32_bf16 {vq(HACC(mt, j))}, {w}, {XF(mt, ks)}, {c}")
+    for l in first:
+        E.i(l)
+    for l in between:
+        E.i(l)
+    for l in second:
+        E.i(l)
     if g + PF < end and not (ABL & 4):
         a, off = frag_addr(g + PF)
         E.ds_read(("f", g + PF), WQ(g % PF), a, off)
+    for l in after:
+        E.i(l)
 
 
 def dma_items(which):
-    """LDS-DMA of one chunk as 8 items of 4 instructions.  which = 'w1': chunk i + 2 (soffset base S_SO1) -> W1 slot i & 1 (past the last
-    chunk the source lies past the descriptor's extent: zeros arrive, nobody reads them); 'w2': chunk i (S_SO2) -> W2 slot i & 1.
-    m0 = LDS destination of the instruction (wave-uniform), lane l lands at m0 + 16 l."""
-    lds0 = LDS_W1 if which == "w1" else LDS_W2
+    """LDS-DMA of one chunk as 8 items ([scalar set-up], [the load]).  which = 'w1': chunk i + 2 (soffset base S_SO1) -> W1 slot i & 1
+    (past the last chunk the source lies past the descriptor's extent: zeros arrive, nobody reads them); 'w2': chunk i + 1 (S_SO2) -> W2
+    slot (i + 1) & 1.  m0 = LDS destination of the instruction (wave-uniform: S_LB1 / S_LB2 = slot base + this wave's 1 KiB), lane l
+    lands at m0 + 16 l."""
     so = S_SO1 if which == "w1" else S_SO2
+    lb = S_LB1 if which == "w1" else S_LB2
     rs = W1R if which == "w1" else W2R
     items = []
     for qq in range(8):
         voff = V1(qq & 3) if which == "w1" else V2
-        items.append([f"s_add_u32 s{S_T}, s{S_SLOT if which == 'w1' else S_SLOT2}, {lds0 + qq * 4096}",
-                      f"s_add_u32 m0, s{S_T}, {SLW}",
-                      f"s_add_u32 s{S_T2}, s{so}, {qq * 4096}",
-                      f"buffer_load_dwordx4 {voff}, {rs}, s{S_T2} offen lds"])
+        items.append(([f"s_add_u32 m0, s{lb}, {qq * 4096}", f"s_add_u32 s{S_T2}, s{so}, {qq * 4096}"],
+                      [f"buffer_load_dwordx4 {voff}, {rs}, s{S_T2} offen lds"]))
     return items
 
 
+def dma_bases(E):
+    """LDS destination bases of this iteration's refills: W1 slot S_SLOT, W2 slot S_SLOT2, + LDS base + wave * 1024"""
+    E.i(f"s_add_u32 s{S_LB1}, s{S_SLOT}, {SLW}")
+    E.i(f"s_add_u32 s{S_LB2}, s{S_SLOT2}, {SLW}")
+    E.i(f"s_add_u32 s{S_LB2}, s{S_LB2}, {LDS_W2}")
+
+
 def dma(E, which):
-    for it in dma_items(which):
-        for l in it:
+    for pre, load in dma_items(which):
+        for l in pre + load:
             E.i(l)
 
 
 def gelu(E, mt, fill):
-    """bias + GELU + bf16 rounding of the 16-row tile mt: 8 values per lane, in place in HACC(mt, 0..1) -> HF(mt); fill(step) after each step"""
+    """GELU + bf16 rounding of the 16-row tile mt (the fc1 bias is already in: GEMM 1's chains start from it): 8 values per lane, in place in
+    HACC(mt, 0..1) -> HF(mt); fill(step) after each step"""
     x = [HACC(mt, 0), HACC(mt, 0) + 2, HACC(mt, 1), HACC(mt, 1) + 2]    # four pairs
-    bz = [BZ(0), BZ(0) + 2, BZ(1), BZ(1) + 2]
     t = [GT + 2 * k for k in range(4)]
     z = [GZ + 2 * k for k in range(4)]
     q = [GQ + 2 * k for k in range(4)]
-    for k in range(4):
-        E.i(f"v_pk_add_f32 {vp(x[k])}, {vp(x[k])}, {vp(bz[k])}")
     if ABL & 1:
         for k in range(4):
             E.i(f"v_cvt_pk_bf16_f32 v{HF(mt) + k}, v{x[k]}, v{x[k] + 1}")
@@ -216,6 +252,12 @@ def lap(E, acc, k1, k0):
     E.i(f"s_add_u32 s{S_ACC + acc}, s{S_ACC + acc}, s{S_T}")
 
 
+def SC1():
+    """PROJ: the residual rows the epilogue reads were stored by this same wave earlier in the launch (x1): read them at agent scope
+    (past the CU's vector cache, which holds the lines of x the projection phase loaded)"""
+    return " sc1" if PROJ else ""
+
+
 def col_off(jo):
     """byte offset (fp32 rows) of the lane's four columns of output tile jo, without the 32 quad part: columns 32 (jo >> 1) + 4 (jo & 1) + 8 quad + r"""
     return 128 * (jo >> 1) + 16 * (jo & 1)
@@ -229,23 +271,8 @@ def reduce4(E, v, tmp):
         E.i(f"v_add_f32 v{v}, v{v}, v{tmp}")
 
 
-def epilogue(E):
-    """x += LayerNorm(oacc) * gamma + beta (oacc already holds the fc2 bias), shadow = bf16(x), for the wave's two 16-row tiles.
-    Lane (fr, quad) holds, of row 16 mt + fr, the columns 32 pp + 8 quad + 4 t + r in ACC(mt, 2 pp + t)[r]."""
-    XOFF = T                       # v168: row * 2048 + 32 quad
-    MEAN = [T + 2, T + 4]          # pairs (value in the low half)
-    RSTD = [T + 6, T + 8]
-    S, TMP = T + 10, T + 11
-    P0, P1, W = T + 16, T + 18, T + 20           # 184:185, 186:187, 188:191
-    def XIN(jo): return 4 * jo                    # the xf area: 32 quads
-    E.c("---- epilogue")
-    E.i("s_nop 15")
-    E.i(f"v_lshlrev_b32 v{XOFF}, 1, {XBOFF}")
-    E.i(f"s_mov_b32 s{S_MT1X}, {16 * 2048}")
-    E.i(f"s_mov_b32 s{S_MT1B}, {16 * 1024}")
-    E.c("residual rows of tile 0 (they land under the statistics)")
-    for jo in range(32):
-        E.i(f"buffer_load_dwordx4 {vq(XIN(jo))}, v{XOFF}, {XR}, 0 offen offset:{col_off(jo)}")
+def ln_stats(E, MEAN, RSTD, S, TMP, P0, P1, W):
+    """row statistics of the wave's two 16-row tiles over the accumulator registers: two passes, a row sits in four lanes"""
     for mt in range(2):
         E.c(f"statistics of tile {mt}: two passes over the registers")
         for pas in range(2):
@@ -275,6 +302,160 @@ def epilogue(E):
                 E.i(f"v_fmac_f32 v{TMP}, {f32(1.0 / 512)}, v{S}")
                 E.i(f"v_rsq_f32 v{RSTD[mt]}, v{TMP}")
                 E.i("s_nop 1")
+
+
+def proj_gemm(E):
+    """PROJ: oacc = att Wp^T + bp for the wave's 32 rows, as sixteen 32-column chunks on GEMM 1's machinery (the attention output rows
+    are the B operands in the xf registers, a chunk of Wp goes through the W1 ring, a chain starts from the bias of its columns).  The
+    chunk's LDS row 16 j + 4 q + r holds Wp row 32 c + 8 q + 4 j + r (the permutation is applied to the DMA source offset), so that the
+    accumulator of hidden-style tile j is exactly oacc[mt][2 c + j]: lane (fr, quad) holds the columns 32 c + 8 quad + 4 j + r.
+    The last two chunks' refills already bring the MLP's W1(0) / W1(1)."""
+    def wp_items(chunk):          # Wp chunk `chunk` -> W1 slot chunk & 1
+        items = []
+        for qq in range(8):
+            src = chunk * SLOT + (8 * (qq & 3) + 4 * (qq >> 2)) * 1024
+            items.append(([f"s_add_u32 m0, s{S_LB1}, {qq * 4096}", f"s_add_u32 s{S_T2}, {SW}, {src}"],
+                          [f"buffer_load_dwordx4 {V1(qq & 3)}, {WPR}, s{S_T2} offen lds"]))
+        return items
+
+    def w1_items(chunk):          # the MLP's W1 chunk (natural row order) -> W1 slot chunk & 1
+        items = []
+        for qq in range(8):
+            items.append(([f"s_add_u32 m0, s{S_LB1}, {qq * 4096}", f"s_add_u32 s{S_T2}, {SW}, {chunk * SLOT + qq * 4096}"],
+                          [f"buffer_load_dwordx4 {V1(qq & 3)}, {W1R}, s{S_T2} offen lds"]))
+        return items
+
+    E.c("---- PROJ: Wp(0), Wp(1) -> the W1 slots, W2(0) -> W2 slot 0, the attention output rows -> operand registers")
+    for ch in range(2):
+        E.i(f"s_add_u32 s{S_LB1}, {SLW}, {ch * SLOT}")
+        for pre, load in wp_items(ch):
+            for l in pre + load:
+                E.i(l)
+    E.i(f"s_mov_b32 s{S_SLOT2}, 0")
+    E.i(f"s_mov_b32 s{S_SO2}, {SW}")
+    E.i(f"s_mov_b32 s{S_SLOT}, 0")
+    dma_bases(E)
+    dma(E, "w2")
+    E.i(f"s_mov_b32 s{S_MT1B}, {16 * 1024}")
+    for mt in range(2):
+        for ks in range(16):
+            so = "0" if mt == 0 else f"s{S_MT1B}"
+            E.i(f"buffer_load_dwordx4 {XF(mt, ks)}, {XBOFF}, {ATTR}, {so} offen offset:{64 * ks}")
+    E.i("s_waitcnt lgkmcnt(0)")
+    for c in range(16):
+        E.c(f"projection chunk {c}: columns {32 * c} .. {32 * c + 31}")
+        E.i("s_waitcnt vmcnt(0)")
+        E.i("s_barrier")
+        for j in range(2):
+            E.ds_read(("b", j), BZ(j), VECP, 6144 + 128 * c + 16 * j)
+        for g in range(32, 32 + PF):
+            a, off = frag_addr(g)
+            E.ds_read(("f", g), WQ(g % PF), a, off)
+        # refill of the slot read by the PREVIOUS chunk (free behind the barrier above): Wp(c + 1) for c >= 1 ... here: chunk c reads slot
+        # c & 1; slot (c + 1) & 1 was read by chunk c - 1 and takes chunk c + 1 -- which the prologue already brought for c = 0
+        items = []
+        if c >= 1:
+            nxt = c + 1
+            E.i(f"s_add_u32 s{S_LB1}, {SLW}, {(nxt & 1) * SLOT}")
+            items = wp_items(nxt) if nxt < 16 else w1_items(0)
+        for g in range(32, 64):
+            k = g - 32
+            pre, load = items[k // 2] if k % 2 == 0 and k // 2 < len(items) else ((), ())
+            group(E, g, 64, between=pre, after=load)
+        assert not E.q
+        E.c("MFMA D -> vector reader")
+        E.i("s_nop 7")
+        E.i("s_nop 3")
+        for mt in range(2):
+            for j in range(2):
+                for r in range(4):
+                    E.i(f"v_accvgpr_write_b32 {ACCR(mt, 2 * c + j, r)}, v{HACC(mt, j) + r}")
+        for a in range(4):
+            E.i(f"v_xor_b32 {W1P(a)}, 0x8000, {W1P(a)}")
+    E.c("every wave is done with the W1 ring: slot 1 takes the MLP's W1(1) (slot 0 got W1(0) under chunk 15)")
+    E.i("s_barrier")
+    E.i(f"s_add_u32 s{S_LB1}, {SLW}, {SLOT}")
+    for pre, load in w1_items(1):
+        for l in pre + load:
+            E.i(l)
+
+
+def proj_ln(E):
+    """PROJ: x1 = x + LayerNorm(oacc) * gamma1 + beta1 for the wave's rows; x1 goes back to memory as fp32 (the residual of the MLP's
+    own LayerNorm reads it there) and, rounded to bf16, into the xf registers: the 8 consecutive columns a lane holds per column group
+    ARE GEMM 1's B operand of that k-step.  The residual rows stream through a ring of eight quads requested eight quads ahead."""
+    XOFF = T
+    MEAN = [T + 2, T + 4]
+    RSTD = [T + 6, T + 8]
+    S, TMP = T + 10, T + 11
+    P0, P1, W = T + 16, T + 18, T + 20
+    RING = 8
+    def XW(n): return 224 + 4 * (n % RING)        # v224..v255 (the GELU's registers: its constants are set up behind this phase)
+    E.c("---- PROJ: LayerNorm + residual of the projection")
+    E.i(f"v_lshlrev_b32 v{XOFF}, 1, {XBOFF}")
+    E.i(f"s_mov_b32 s{S_MT1X}, {16 * 2048}")
+    def load(n):
+        mt, jo = n // 32, n % 32
+        so = "0" if mt == 0 else f"s{S_MT1X}"
+        E.vm(("x", n), f"buffer_load_dwordx4 {vq(XW(n))}, v{XOFF}, {XR}, {so} offen offset:{col_off(jo)}")
+    E.vq = []
+    for n in range(RING):
+        load(n)
+    ln_stats(E, MEAN, RSTD, S, TMP, P0, P1, W)
+    for mt in range(2):
+        for pp in range(16):
+            base = T + 24 + 24 * (pp & 1)         # register set of this column group: Y0, Y1, G0, B0, G1, B1
+            Y = [base, base + 4]
+            G = [base + 8, base + 16]
+            B = [base + 12, base + 20]
+            for t in range(2):
+                jo = 2 * pp + t
+                E.ds_read(("g", jo), G[t], VECP, 8192 + col_off(jo))
+                E.ds_read(("e", jo), B[t], VECP, 10240 + col_off(jo))
+            for t in range(2):
+                jo = 2 * pp + t
+                n = 32 * mt + jo
+                for r in range(4):
+                    E.i(f"v_accvgpr_read_b32 v{Y[t] + r}, {ACCR(mt, jo, r)}")
+                for h in (0, 2):
+                    E.i(f"v_pk_add_f32 {vp(Y[t] + h)}, {vp(Y[t] + h)}, {vp(MEAN[mt])} op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]")
+                for h in (0, 2):
+                    E.i(f"v_pk_mul_f32 {vp(Y[t] + h)}, {vp(Y[t] + h)}, {vp(RSTD[mt])} op_sel_hi:[1,0]")
+                E.wait(("e", jo))
+                for h in (0, 2):
+                    E.i(f"v_pk_fma_f32 {vp(Y[t] + h)}, {vp(Y[t] + h)}, {vp(G[t] + h)}, {vp(B[t] + h)}")
+                E.vm_wait(("x", n))
+                for h in (0, 2):
+                    E.i(f"v_pk_add_f32 {vp(Y[t] + h)}, {vp(Y[t] + h)}, {vp(XW(n) + h)}")
+                so = "0" if mt == 0 else f"s{S_MT1X}"
+                E.vm(("s", n), f"buffer_store_dwordx4 {vq(Y[t])}, v{XOFF}, {XR}, {so} offen offset:{col_off(jo)}")
+                if n + RING < 64:
+                    load(n + RING)
+            xf = 4 * (16 * mt + pp)               # XF(mt, pp)
+            for t in range(2):
+                E.i(f"v_cvt_pk_bf16_f32 v{xf + 2 * t}, v{Y[t]}, v{Y[t] + 1}")
+                E.i(f"v_cvt_pk_bf16_f32 v{xf + 2 * t + 1}, v{Y[t] + 2}, v{Y[t] + 3}")
+    assert not E.q
+
+
+def epilogue(E):
+    """x += LayerNorm(oacc) * gamma + beta (oacc already holds the fc2 bias), shadow = bf16(x), for the wave's two 16-row tiles.
+    Lane (fr, quad) holds, of row 16 mt + fr, the columns 32 pp + 8 quad + 4 t + r in ACC(mt, 2 pp + t)[r]."""
+    XOFF = T                       # v168: row * 2048 + 32 quad
+    MEAN = [T + 2, T + 4]          # pairs (value in the low half)
+    RSTD = [T + 6, T + 8]
+    S, TMP = T + 10, T + 11
+    P0, P1, W = T + 16, T + 18, T + 20           # 184:185, 186:187, 188:191
+    def XIN(jo): return 4 * jo                    # the xf area: 32 quads
+    E.c("---- epilogue")
+    E.i("s_nop 15")
+    E.i(f"v_lshlrev_b32 v{XOFF}, 1, {XBOFF}")
+    E.i(f"s_mov_b32 s{S_MT1X}, {16 * 2048}")
+    E.i(f"s_mov_b32 s{S_MT1B}, {16 * 1024}")
+    E.c("residual rows of tile 0 (they land under the statistics)")
+    for jo in range(32):
+        E.i(f"buffer_load_dwordx4 {vq(XIN(jo))}, v{XOFF}, {XR}, 0 offen offset:{col_off(jo)}" + SC1())
+    ln_stats(E, MEAN, RSTD, S, TMP, P0, P1, W)
     for mt in range(2):
         E.c(f"tile {mt}: normalise, add the residual rows, store x and the shadow")
         E.i("s_waitcnt vmcnt(0)")
@@ -305,7 +486,7 @@ def epilogue(E):
                 E.i(f"buffer_store_dwordx4 {vq(Y[t])}, v{XOFF}, {XR}, {so} offen offset:{col_off(jo)}")
                 if mt == 0:
                     E.c("the same quad of tile 1's residual rows takes the place of the one just used")
-                    E.i(f"buffer_load_dwordx4 {vq(XIN(jo))}, v{XOFF}, {XR}, s{S_MT1X} offen offset:{col_off(jo)}")
+                    E.i(f"buffer_load_dwordx4 {vq(XIN(jo))}, v{XOFF}, {XR}, s{S_MT1X} offen offset:{col_off(jo)}" + SC1())
             for t in range(2):
                 E.i(f"v_cvt_pk_bf16_f32 v{K + 2 * t}, v{Y[t]}, v{Y[t] + 1}")
                 E.i(f"v_cvt_pk_bf16_f32 v{K + 2 * t + 1}, v{Y[t] + 2}, v{Y[t] + 3}")
@@ -356,26 +537,38 @@ def program():
     for b, val in [(S_ZS, GELU_ZS), (S_C8, GELU_C[GELU_DEG])] + [(S_C(k), GELU_C[k]) for k in range(GELU_DEG - 1)]:
         E.i(f"s_mov_b32 s{b}, {f32(val)}")
         E.i(f"s_mov_b32 s{b + 1}, {f32(val)}")
-    E.c("---- W1(0) -> W1 slot 0, W1(1) -> W1 slot 1, W2(0) -> W2 slot 0")
-    for ch in range(2):
-        E.i(f"s_mov_b32 s{S_SLOT}, {ch * SLOT}")
-        E.i(f"s_add_u32 s{S_SO1}, {SW}, {ch * SLOT}")
-        dma(E, "w1")
-    E.i(f"s_mov_b32 s{S_SLOT2}, 0")
-    E.i(f"s_mov_b32 s{S_SO2}, {SW}")
-    dma(E, "w2")
+    if PROJ:
+        proj_gemm(E)
+        proj_ln(E)
+        E.c("the GELU's vector constants (their registers served as the residual ring above)")
+        E.i(f"s_mov_b32 s{S_T}, {f32(GELU_U)}")
+        E.i(f"v_mov_b32 v{VU}, s{S_T}")
+        E.i(f"s_mov_b32 s{S_T}, {f32(GELU_C[GELU_DEG - 1])}")
+        E.i(f"v_mov_b32 v{VC7}, s{S_T}")
+        E.i(f"v_mov_b32 v{VC7 + 1}, s{S_T}")
+    else:
+        E.c("---- W1(0) -> W1 slot 0, W1(1) -> W1 slot 1, W2(0) -> W2 slot 0")
+        E.i(f"s_mov_b32 s{S_SLOT2}, 0")
+        E.i(f"s_mov_b32 s{S_SO2}, {SW}")
+        for ch in range(2):
+            E.i(f"s_mov_b32 s{S_SLOT}, {ch * SLOT}")
+            E.i(f"s_add_u32 s{S_SO1}, {SW}, {ch * SLOT}")
+            dma_bases(E)
+            dma(E, "w1")
+        dma(E, "w2")
     E.c("iteration 0 refills W1 slot 0 with chunk 2 and W2 slot 1 with chunk 1")
     E.i(f"s_mov_b32 s{S_SLOT}, 0")
     E.i(f"s_mov_b32 s{S_SLOT2}, {SLOT}")
     E.i(f"s_add_u32 s{S_SO1}, {SW}, {2 * SLOT}")
     E.i(f"s_add_u32 s{S_SO2}, {SW}, {SLOT}")
     E.i(f"s_mov_b32 s{S_I}, 0")
-    E.c("---- this wave's rows of xb as B operands of GEMM 1: xf[mt][ks] = xb[row0 + 16 mt + fr][32 ks + 8 quad .. + 7]")
-    E.i(f"s_mov_b32 s{S_MT1B}, {16 * 1024}")
-    for mt in range(2):
-        for ks in range(16):
-            so = "0" if mt == 0 else f"s{S_MT1B}"
-            E.i(f"buffer_load_dwordx4 {XF(mt, ks)}, {XBOFF}, {XBR}, {so} offen offset:{64 * ks}")
+    if not PROJ:
+        E.c("---- this wave's rows of xb as B operands of GEMM 1: xf[mt][ks] = xb[row0 + 16 mt + fr][32 ks + 8 quad .. + 7]")
+        E.i(f"s_mov_b32 s{S_MT1B}, {16 * 1024}")
+        for mt in range(2):
+            for ks in range(16):
+                so = "0" if mt == 0 else f"s{S_MT1B}"
+                E.i(f"buffer_load_dwordx4 {XF(mt, ks)}, {XBOFF}, {XBR}, {so} offen offset:{64 * ks}")
     E.c("the compiler's LDS stores of the bias rows (lgkmcnt) and this wave's DMA pieces and rows (vmcnt), then everybody's")
     E.i("s_waitcnt vmcnt(0) lgkmcnt(0)")
     E.i("s_barrier")
@@ -388,7 +581,10 @@ def program():
             for mt in range(2):
                 for r in range(4):
                     E.i(f"v_accvgpr_write_b32 {ACCR(mt, jo, r)}, v{WQ(0) + 4 * (jo - jo0) + r}")
-    E.c("---- GEMM 1 of chunk 0 (W1 slot 0)")
+    E.c("---- GEMM 1 of chunk 0 (W1 slot 0); its chains start from the fc1 bias of the chunk's hidden units")
+    E.ds_read(("b", 0), BZ(0), B1P, 0)
+    E.ds_read(("b", 1), BZ(1), B1P, 64)
+    E.i(f"v_add_u32 {B1P}, 0x80, {B1P}")
     for g in range(32, 32 + PF):
         a, off = frag_addr(g)
         E.ds_read(("f", g), WQ(g % PF), a, off)
@@ -401,11 +597,7 @@ def program():
         E.i(f"v_xor_b32 {W1P(a)}, 0x8000, {W1P(a)}")
 
     E.i("L_top%=:")
-    E.c("the chunk's bias values do not wait for the barrier (the table is static)")
     stamp(E, 0)
-    if not TIMING:
-        E.ds_read(("b", 0), BZ(0), B1P, 0)
-        E.ds_read(("b", 1), BZ(1), B1P, 64)
     E.i("s_waitcnt vmcnt(0)")
     stamp(E, 1)
     E.i("s_barrier")
@@ -413,27 +605,25 @@ def program():
     if TIMING:
         lap(E, 0, 1, 0)      # waiting for this wave's DMA pieces
         lap(E, 1, 2, 1)      # waiting for the other waves
-        E.ds_read(("b", 0), BZ(0), B1P, 0)
-        E.ds_read(("b", 1), BZ(1), B1P, 64)
     for g in range(PF):
         if ABL & 4:
             break
         a, off = frag_addr(g)
         E.ds_read(("f", g), WQ(g % PF), a, off)
-    E.wait(("b", 1))     # (only the two bias reads are waited for: lgkmcnt(PF))
+    dma_bases(E)
     for mt in range(2):
         gelu(E, mt, lambda step: None)
+    E.c("the fc1 bias of chunk i + 1: GEMM 1's chains of this iteration start from it (GELU(i) above was the last reader of chunk i's)")
+    E.ds_read(("b", 0), BZ(0), B1P, 0)
+    E.ds_read(("b", 1), BZ(1), B1P, 64)
     E.i(f"v_add_u32 {B1P}, 0x80, {B1P}")
-    E.c("vector write -> MFMA operand: two wait states")
-    E.i("s_nop 1")
+    E.c("(vector write -> MFMA operand: the two LDS requests and the add above are the wait states)")
     items = [] if ABL & 2 else dma_items("w2") + dma_items("w1")
     if ABL & 4:
         E.wait_all()
     for g in range(32):
-        group(E, g, 64)
-        if g < len(items):
-            for l in items[g]:
-                E.i(l)
+        pre, load = items[g // 2] if g % 2 == 0 and g // 2 < len(items) else ((), ())
+        group(E, g, 64, between=pre, after=load)
     E.i(f"s_cmp_eq_u32 s{S_I}, {NCH - 1}")
     E.i("s_cbranch_scc1 L_done%=")
     for g in range(32, 64):
@@ -471,18 +661,19 @@ def program():
     return E.lines
 
 
-# (PF, STAGGER, TIMING): fragments requested PF groups ahead; start skew of the first round's workgroups in units of s_sleep 32 (2 048
+# (PF, STAGGER, TIMING, ABL, PROJ): fragments requested PF groups ahead; start skew of the first round's workgroups in units of s_sleep 32 (2 048
 # cycles) per phase (four phases by (blockIdx >> 3) & 3).
-# Variant 0 is what launch_swin_mlp512 runs; the others are reachable through VSC_SWIN_MLP_ABL=<index> (A/B on one box).
-VARIANTS = [(8, 0, False, 0), (8, 4, False, 0), (8, 8, False, 0), (8, 12, False, 0), (8, 16, False, 0), (8, 0, True, 0), (8, 0, False, 8), (8, 0, False, 14), (8, 0, False, 15)]
+# Variant 0 is what launch_swin_mlp512 runs, variant 1 launch_swin_proj_mlp512; the others are reachable through VSC_SWIN_MLP_ABL=<index>.
+VARIANTS = [(8, 0, False, 0, False), (8, 0, False, 0, True), (8, 0, False, 1, False), (8, 0, False, 2, False), (8, 0, False, 4, False), (8, 0, True, 0, False),
+            (8, 0, False, 8, False), (8, 0, False, 14, False), (8, 0, False, 15, False)]
 
 
 def main():
-    global PF, STAGGER, TIMING, ABL
+    global PF, STAGGER, TIMING, ABL, PROJ
     out = ["// GENERATED by gen_mlp512_loop.py -- do not edit.  One asm statement per variant: the body of swin_mlp512_kernel<V>."]
-    for k, (PF, STAGGER, TIMING, ABL) in enumerate(VARIANTS):
+    for k, (PF, STAGGER, TIMING, ABL, PROJ) in enumerate(VARIANTS):
         lines = program()
-        out.append(f"// variant {k}: PF = {PF}, STAGGER = {STAGGER}" + (", cycle counters per wave" if TIMING else "") + (f", ablation {ABL} (wrong results)" if ABL else ""))
+        out.append(f"// variant {k}: PF = {PF}, STAGGER = {STAGGER}" + (", cycle counters per wave" if TIMING else "") + (f", ablation {ABL} (wrong results)" if ABL else "") + (", PROJ: attention projection + LayerNorm + residual in front" if PROJ else ""))
         out.append(f"#define VSC_MLP512_LOOP_ASM_{k} \\")
         for l in lines:
             if l.startswith(";"):
@@ -493,7 +684,7 @@ def main():
     io = ", ".join([f'[w1p{a}] "+v"(w1p[{a}])' for a in range(4)] + ['[w2p] "+v"(w2p)', '[b1p] "+v"(b1p)'])
     ins = ", ".join([f'[v1{a}] "v"(v1[{a}])' for a in range(4)] +
                     ['[v2] "v"(v2)', '[vecp] "v"(vecp)', '[xboff] "v"(xboff)', '[bp16] "v"(bp16)', '[bp32] "v"(bp32)',
-                     '[w1r] "s"(w1r)', '[w2r] "s"(w2r)', '[xr] "s"(xr)', '[xbr] "s"(xbr)', '[swave] "s"(swave)', '[sldsw] "s"(sldsw)', '[eps] "s"(eps)', '[dbgr] "s"(dbgr)', '[dbgoff] "s"(dbgoff)', '[bid] "s"(bid)'])
+                     '[w1r] "s"(w1r)', '[w2r] "s"(w2r)', '[xr] "s"(xr)', '[xbr] "s"(xbr)', '[swave] "s"(swave)', '[sldsw] "s"(sldsw)', '[eps] "s"(eps)', '[dbgr] "s"(dbgr)', '[dbgoff] "s"(dbgoff)', '[bid] "s"(bid)', '[attr] "s"(attr)', '[wpr] "s"(wpr)'])
     clob = ", ".join([f'"v{r}"' for r in range(0, 128)] + [f'"v{r}"' for r in range(T, 256)] + [f'"a{r}"' for r in range(256)] +
                      [f'"s{r}"' for r in range(40, 100)] + ['"scc"', '"memory"'])
     out.append(f"#define VSC_MLP512_LOOP_OUTS {io}")

@@ -426,6 +426,8 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
     const bool unfused_mlp = fm && fm[0] == '0';
     const char *f5 = vsc_opt(OPT_SWIN_MLP512);      // diagnostic / test switch: 0 = the 512-wide stage keeps fc1 and fc2 as two GEMM launches
     const bool unfused_mlp512 = f5 && f5[0] == '0';
+    const char *f6 = vsc_opt(OPT_SWIN_PROJ512);     // diagnostic / test switch: 0 = the 512-wide stage keeps proj + LayerNorm as their own launch
+    const bool unfused_proj512 = f6 && f6[0] == '0';
     const char *fp = vsc_opt(OPT_SWIN_FUSED_PROJ);   // diagnostic / test switch: 0 = proj + LayerNorm as their own launch
     const bool unfused_proj = fp && fp[0] == '0';
     const char *fg = vsc_opt(OPT_SWIN_FUSED_MERGE);   // diagnostic / test switch: 0 = PatchMerging as a gather kernel + GEMM
@@ -457,7 +459,7 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
                 const SwinBlockW &K = e->stages[s].blocks[b];
                 { PROF(pc + VSC_SWIN_PROF_QKV); TRY(launch_gemm_bf16(xb, K.qkv_w, K.qkv_b, nullptr, w.qkv, Ms, 3 * C, C, VSC_EPI_BF16, 0, st)); }
                 { PROF(pc + VSC_SWIN_PROF_ATTENTION); TRY(launch_window_attention(w.qkv, w.att, K.bias, K.scale, (int)Bs, R, W, e->shift(s, b), H, st)); }
-                if (K.fc2_wp && !unfused_mlp && !unfused_proj && swin_proj_mlp_supported(C)) {
+                if (K.fc2_wp && !unfused_mlp && !unfused_proj && swin_proj_mlp_supported(C) && !(C == 512 && (unfused_mlp512 || unfused_proj512))) {
                     // the whole second half of the block -- proj, LayerNorm, residual, MLP, LayerNorm, residual -- in one kernel; its time
                     // is booked under fc2_ln, proj_ln and fc1 stay empty
                     PROF(pc + VSC_SWIN_PROF_FC2_LN);

@@ -489,14 +489,15 @@ int launch_swin_mlp(const uint16_t *w1, const float *b1, const uint16_t *w2p, co
     return c == 128 ? launch_c<128>(a, stream) : launch_c<256>(a, stream);
 }
 
-bool swin_proj_mlp_supported(int c) { return c == 128 || c == 256; }
+bool swin_proj_mlp_supported(int c) { return c == 128 || c == 256 || c == 512; }
 
 // proj + LayerNorm + residual + the MLP block of one Swin-V2 block in one launch (swin_mlp_kernel<..., PROJ>): x, xb updated in place
 int launch_swin_proj_mlp(const uint16_t *att, const uint16_t *wp, const float *bp, const float *gamma1, const float *beta1, const uint16_t *w1,
                          const float *b1, const uint16_t *w2p, const float *b2, const float *gamma2, const float *beta2, float *x, uint16_t *xb,
                          int64_t m, int c, float eps, hipStream_t stream) {
     VSC_REQUIRE(att && wp && bp && gamma1 && beta1 && w1 && b1 && w2p && b2 && gamma2 && beta2 && x && xb && m > 0, "swin_proj_mlp: null/empty");
-    VSC_REQUIRE(swin_proj_mlp_supported(c), "swin_proj_mlp: width %d unsupported (128, 256)", c);
+    VSC_REQUIRE(swin_proj_mlp_supported(c), "swin_proj_mlp: width %d unsupported (128, 256, 512)", c);
+    if (c == 512) return launch_swin_proj_mlp512(att, wp, bp, gamma1, beta1, w1, b1, w2p, b2, gamma2, beta2, x, xb, m, eps, stream);
     const MlpArgs a{w1, b1, w2p, b2, gamma2, beta2, x, xb, m, eps, att, wp, bp, gamma1, beta1};
     return c == 128 ? launch_proj_c<128>(a, stream) : launch_proj_c<256>(a, stream);
 }

@@ -46,11 +46,16 @@ struct Mlp512Args {
     int64_t m;
     float eps;
     uint32_t *dbg;         // timing variant: [workgroups][4 waves][8] cycle counters (nullptr otherwise)
+    // PROJ (variant 1): the attention projection and its LayerNorm in front, in the same kernel --
+    //     x1 = x + LayerNorm(att Wp^T + bp) * gamma1 + beta1;  then the MLP block on x1
+    const uint16_t *att;   // [m, 512] attention output
+    const uint16_t *wp;    // [512, 512] attn.proj.weight
+    const float *bp, *gamma1, *beta1;   // [512]
 };
 
 constexpr int C = 512, H = 4 * C, NW = 4, MT = 2, RW = 16 * MT, R = NW * RW, HC = 32;
 constexpr int SLOT = HC * C * 2;   // one chunk of either matrix: 32 KiB
-constexpr int LDS_W1 = 0, LDS_W2 = 2 * SLOT, LDS_B1 = 4 * SLOT, LDS_VEC = LDS_B1 + H * 4, LDS_BYTES = LDS_VEC + 3 * C * 4;
+constexpr int LDS_W1 = 0, LDS_W2 = 2 * SLOT, LDS_B1 = 4 * SLOT, LDS_VEC = LDS_B1 + H * 4, LDS_BYTES = LDS_VEC + 6 * C * 4;   // vectors: b2 | gamma | beta | bp | gamma1 | beta1
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // V: variant of the generated body (gen_mlp512_loop.py VARIANTS); 0 is the one in use, the others serve same-box A/B runs
@@ -103,7 +108,15 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
         b2s[i] = p.b2[i];
         gs[i] = p.gamma[i];
         bs[i] = p.beta[i];
+        if (V == 1) {
+            bs[C + i] = p.bp[i];
+            bs[2 * C + i] = p.gamma1[i];
+            bs[3 * C + i] = p.beta1[i];
+        }
     }
+    // PROJ: rows of the attention output / attn.proj.weight (other variants: empty descriptors, never used)
+    const __amdgpu_buffer_rsrc_t attr = __builtin_amdgcn_make_buffer_rsrc((void *)p.att, 0, p.att ? (int)(uint32_t)(p.m * C * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wpr = __builtin_amdgcn_make_buffer_rsrc((void *)p.wp, 0, p.wp ? C * C * 2 : 0, 0x00020000);
     // ---- everything else: rows in, the hidden-axis loop, LayerNorm + residual + shadow out
 #define VSC_MLP512_BODY(K) asm volatile(VSC_MLP512_LOOP_ASM_##K : VSC_MLP512_LOOP_OUTS : VSC_MLP512_LOOP_INS : VSC_MLP512_LOOP_CLOBBERS)
     static_assert(VSC_MLP512_VARIANTS == 9, "variant dispatch below");
@@ -156,10 +169,9 @@ int launch_swin_mlp512(const uint16_t *w1, const float *b1, const uint16_t *w2c,
                        float *x, uint16_t *xb, int64_t m, float eps, hipStream_t stream) {
     VSC_REQUIRE(w1 && b1 && w2c && b2 && gamma && beta && x && xb && m > 0, "swin_mlp512: null/empty");
     VSC_REQUIRE(m < (1ll << 21), "swin_mlp512: %lld rows (x is addressed through one 4-GiB buffer descriptor: < 2^21 rows per call)", (long long)m);
-    const Mlp512Args a{w1, b1, w2c, b2, gamma, beta, x, xb, m, eps, g_mlp512_dbg};
+    const Mlp512Args a{w1, b1, w2c, b2, gamma, beta, x, xb, m, eps, g_mlp512_dbg, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (const char *e = vsc_opt(OPT_SWIN_MLP_ABL)) {   // diagnostic: another variant of the generated body
         switch (atoi(e)) {
-            case 1: return launch_k<1>(a, stream);
             case 2: return launch_k<2>(a, stream);
             case 3: return launch_k<3>(a, stream);
             case 4: return launch_k<4>(a, stream);
@@ -171,4 +183,16 @@ int launch_swin_mlp512(const uint16_t *w1, const float *b1, const uint16_t *w2c,
         }
     }
     return launch_k<0>(a, stream);
+}
+
+// proj + LayerNorm + residual + the MLP block of one Swin-V2 block at C = 512 in one launch (variant 1 of the generated body):
+//     x1 = x + LayerNorm(att Wp^T + bp) gamma1 + beta1;   x = x1 + LayerNorm(GELU(bf16(x1) W1^T + b1) W2^T + b2) gamma2 + beta2;   xb = bf16(x)
+// x1 passes through memory once as fp32 (the second LayerNorm's residual); its bf16 shadow never leaves the registers.
+int launch_swin_proj_mlp512(const uint16_t *att, const uint16_t *wp, const float *bp, const float *gamma1, const float *beta1, const uint16_t *w1,
+                            const float *b1, const uint16_t *w2c, const float *b2, const float *gamma2, const float *beta2, float *x, uint16_t *xb,
+                            int64_t m, float eps, hipStream_t stream) {
+    VSC_REQUIRE(att && wp && bp && gamma1 && beta1 && w1 && b1 && w2c && b2 && gamma2 && beta2 && x && xb && m > 0, "swin_proj_mlp512: null/empty");
+    VSC_REQUIRE(m < (1ll << 21), "swin_proj_mlp512: %lld rows (x is addressed through one 4-GiB buffer descriptor: < 2^21 rows per call)", (long long)m);
+    const Mlp512Args a{w1, b1, w2c, b2, gamma2, beta2, x, xb, m, eps, nullptr, att, wp, bp, gamma1, beta1};
+    return launch_k<1>(a, stream);
 }

@@ -277,6 +277,28 @@ def swin_mlp_bf16(x, w1, b1, w2, b2, gamma, beta, eps: float):
     return x, xb
 
 
+def swin_proj_mlp_bf16(x, att, wp, bp, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, eps: float):
+    """The second half of a Swin-V2 block in one launch, widths 128 / 256 / 512:
+    x1 = x + LN(att @ wp.T + bp) * gamma1 + beta1;  -> (x1 + LN(gelu(bf16(x1) @ w1.T + b1) @ w2.T + b2) * gamma2 + beta2, its bf16 shadow).
+    att [m, c] (rounded to bf16 here); weights as the module holds them."""
+    import numpy as np
+    lib = _lib.require_device()
+    x = _dev(x, torch.float32).clone()
+    m, c = x.shape
+    dev = x.device
+    xb = torch.empty((m, c), dtype=torch.bfloat16, device=dev)
+    attd = _dev(att.to(dev), torch.bfloat16)
+    w2h = np.ascontiguousarray(w2.detach().float().cpu().numpy())
+    w2p = np.empty_like(w2h)
+    check(lib.vsc_swin_mlp_permute_hidden_f32(w2h.ctypes.data, w2p.ctypes.data, c))
+    wpd, w1d = _dev(wp.to(dev), torch.bfloat16), _dev(w1.to(dev), torch.bfloat16)
+    w2d = torch.from_numpy(w2p).to(dev).to(torch.bfloat16)
+    f = [_dev(t.to(dev), torch.float32) for t in (bp, gamma1, beta1, b1, b2, gamma2, beta2)]
+    check(lib.vsc_swin_proj_mlp_bf16(ptr(attd), ptr(wpd), ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(w1d), ptr(f[3]), ptr(w2d), ptr(f[4]), ptr(f[5]),
+                                     ptr(f[6]), ptr(x), ptr(xb), m, c, eps, current_stream()))
+    return x, xb
+
+
 def merge_gather_bf16(xb, frames: int, res: int):
     lib = _lib.require_device()
     xb = _dev(xb, torch.bfloat16)
