@@ -179,6 +179,33 @@ def test_knn_in_the_benchmarked_regime_single_split_many_items_per_workgroup(dev
     assert (srt[:, 1:] != srt[:, :-1]).all()
 
 
+def test_knn_tail_balancing_is_invisible(dev):
+    """The query blocks of a call's last partial round are swept as a second, finer-grained sweep (vsc_knn_ip_f32: tail balancing;
+    140 000 queries = 547 blocks = two whole rounds of 256 + 35 blocks, which take 7 reference splits each): the same bits as the
+    one-sweep form (VSC_KNN_TAIL=0), and the profile adds the two sweeps up."""
+    import ctypes
+    from vsc_hip import _lib, ops
+    lib = _lib.require_device()
+    g = torch.Generator(device=dev).manual_seed(12)
+    r = torch.randn(300_000, 512, generator=g, device=dev)
+    q = torch.randn(140_000, 512, generator=g, device=dev)
+    ops.l2_normalize_(r)
+    ops.l2_normalize_(q)
+    q[139_999] = r[77]                                   # a planted neighbour in the tail part
+    lib.vsc_knn_set_profiling(1)
+    D, I = ops.knn_ip(q, r, 50)
+    ms = (ctypes.c_float * 4)()
+    _lib.check(lib.vsc_knn_last_profile(ms))
+    lib.vsc_knn_set_profiling(0)
+    assert lib.vsc_knn_last_path() == 2 and int(I[139_999, 0]) == 77 and ms[1] > 0
+    _lib.set_option("VSC_KNN_TAIL", "0")
+    try:
+        D0, I0 = ops.knn_ip(q, r, 50)
+    finally:
+        _lib.set_option("VSC_KNN_TAIL", None)
+    assert torch.equal(I, I0) and torch.equal(D.view(torch.int32), D0.view(torch.int32))
+
+
 def test_knn_bank_beyond_one_buffer_descriptor(dev):
     """A split is addressed through one buffer descriptor (32-bit extent): 8191 tiles = 2 096 896 rows of 512-d bf16.  With
     nq >= 65 281 (256 query blocks -> one split wanted) and 2.2 M references the cap forces two splits (knn.hip,

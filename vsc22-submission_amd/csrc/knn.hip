@@ -1352,23 +1352,32 @@ extern "C" int64_t vsc_search_release_scratch(void) { return scratch_release(); 
 
 // ---- per-phase HIP events of the last top-k call (bench.py: duration of the dominant kernel, on the caller's stream)
 static bool g_knn_profiling = false;
-static hipEvent_t g_knn_ev[5];
-static bool g_knn_ev_made = false, g_knn_ev_valid = false;
+static hipEvent_t g_knn_ev[2][5];   // two sets: a call whose last round of query blocks is swept as a second, finer-grained sweep (tail
+static int g_knn_set = 0, g_knn_sets_valid = 0;   // balancing in vsc_knn_ip_f32) records both; vsc_knn_last_profile adds them up
+static bool g_knn_ev_made = false;
 static void knn_mark(int i, hipStream_t stream) {
     if (!g_knn_profiling) return;
     if (!g_knn_ev_made) {
-        for (auto &e : g_knn_ev) (void)hipEventCreate(&e);
+        for (auto &set : g_knn_ev)
+            for (auto &e : set) (void)hipEventCreate(&e);
         g_knn_ev_made = true;
     }
-    (void)hipEventRecord(g_knn_ev[i], stream);
-    if (i == 4) g_knn_ev_valid = true;
+    (void)hipEventRecord(g_knn_ev[g_knn_set][i], stream);
+    if (i == 4) g_knn_sets_valid = g_knn_set + 1;
 }
-extern "C" void vsc_knn_set_profiling(int on) { g_knn_profiling = on != 0; g_knn_ev_valid = false; }
+extern "C" void vsc_knn_set_profiling(int on) { g_knn_profiling = on != 0; g_knn_sets_valid = 0; g_knn_set = 0; }
 extern "C" int vsc_knn_last_profile(float ms_out[4]) {
     VSC_REQUIRE(ms_out, "knn_last_profile: null pointer");
-    VSC_REQUIRE(g_knn_ev_valid, "knn_last_profile: no profiled vsc_knn_ip_f32 call (vsc_knn_set_profiling(1) first)");
-    VSC_CHECK_HIP(hipEventSynchronize(g_knn_ev[4]));
-    for (int i = 0; i < 4; ++i) VSC_CHECK_HIP(hipEventElapsedTime(&ms_out[i], g_knn_ev[i], g_knn_ev[i + 1]));
+    VSC_REQUIRE(g_knn_sets_valid > 0, "knn_last_profile: no profiled vsc_knn_ip_f32 call (vsc_knn_set_profiling(1) first)");
+    for (int i = 0; i < 4; ++i) ms_out[i] = 0.f;
+    for (int s = 0; s < g_knn_sets_valid; ++s) {
+        VSC_CHECK_HIP(hipEventSynchronize(g_knn_ev[s][4]));
+        for (int i = 0; i < 4; ++i) {
+            float ms = 0.f;
+            VSC_CHECK_HIP(hipEventElapsedTime(&ms, g_knn_ev[s][i], g_knn_ev[s][i + 1]));
+            ms_out[i] += ms;
+        }
+    }
     return VSC_OK;
 }
 
@@ -1464,7 +1473,16 @@ static int sweep_plan(int64_t nq, int64_t nr, int dp, SweepPlan *out) {
         want = 4 * nsg;
         if (want > pl.total_tiles / 4) xmap = false;   // splits of a few tiles: not worth it, plain order
     }
-    if (!xmap) want = (256 + pl.nqb - 1) / pl.nqb;
+    if (!xmap) {
+        want = (256 + pl.nqb - 1) / pl.nqb;
+        // fewer query blocks than workgroups: items = nqb * want are dealt in rounds of 256; one split less can end in whole rounds where
+        // one more spills a handful of items into an extra round (67 blocks: 4 splits = 268 items = two quarter-size rounds, 3 splits =
+        // 201 items = one third-size round)
+        if (pl.nqb < 256 && want > 1) {
+            auto rounds = [&](int64_t w) { return (double)((pl.nqb * w + 255) / 256) / (double)w; };
+            if (rounds(want - 1) < rounds(want)) --want;
+        }
+    }
     if (want > 256) want = 256;
     if (want > pl.total_tiles) want = pl.total_tiles;
     if (want < 1) want = 1;
@@ -1691,6 +1709,24 @@ extern "C" int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev
         if (e[0] == 'b') prefilter = k <= 512;
     }
     if (prefilter) {
+        // Tail balancing.  Query blocks (256 queries) are dealt to 256 persistent workgroups in rounds; with one split per block a call
+        // of 3 907 blocks (1M queries) runs 15.26 rounds and its sixteenth keeps 67 of 256 CUs busy.  The blocks of that last partial
+        // round are swept as a call of their own, which cuts the bank into as many splits as fill the chip once (sweep_plan): a
+        // third-size round instead of a whole one.  Queries are independent: the results are the same bits.  VSC_KNN_TAIL=0: one sweep.
+        const int64_t nqb = (nq + SQ - 1) / SQ, rem = nqb % 256;
+        const char *tb = vsc_opt(OPT_KNN_TAIL);
+        g_knn_set = 0;
+        if (!(tb && tb[0] == '0') && nqb >= 512 && rem != 0 && rem <= 160) {
+            const int64_t head = (nqb - rem) * SQ;
+            int fb0 = 0, fb1 = 0;
+            int rc = knn_prefilter(q_dev, head, r_dev, nr, d, k, ref_id_offset, out_scores_dev, out_ids_dev, stream, &fb0);
+            if (rc) return rc;
+            g_knn_set = 1;
+            rc = knn_prefilter(q_dev + head * d, nq - head, r_dev, nr, d, k, ref_id_offset, out_scores_dev + head * k, out_ids_dev + head * k, stream, &fb1);
+            g_knn_set = 0;
+            g_knn_last_path = (fb0 || fb1) ? 3 : 2;
+            return rc;
+        }
         int fb = 0;
         const int rc = knn_prefilter(q_dev, nq, r_dev, nr, d, k, ref_id_offset, out_scores_dev, out_ids_dev, stream, &fb);
         g_knn_last_path = fb ? 3 : 2;
