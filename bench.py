@@ -153,7 +153,7 @@ def gemm_traffic(cfg, chunk):
             "4": chunk * (t - 1) * cfg.patch_dim * 2 + cfg.patch_dim * d * 2 + chunk * (t - 1) * d * 4}
     n = sum(launches.values())
     algorithmic = sum(launches[k] * algo[k] for k in launches) / n
-    for name, prefix in (("r04_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")), ("r03_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")), ("r02_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")),
+    for name, prefix in (("r05_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")), ("r04_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")), ("r03_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")), ("r02_pmc_per_launch.json", ("gemm_bf16_v4_kernel<", "gemm_bf16_v3_kernel<")),
                          ("r01_pmc_per_launch_v2.json", ("gemm_bf16_v2_kernel<",))):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))["per_launch"]
@@ -202,7 +202,7 @@ def cpu_baseline(cfg, weights, frames_np, budget_s=15.0):
 def attention_mfma_busy(kernel_prefix, path_hint=""):
     """MFMA-busy fraction of a kernel's launches from the committed PMC pass (tools/pmc_mfma_busy.py: SQ_VALU_MFMA_BUSY_CYCLES /
     (GPU cycles x 1024 SIMDs); PMC needs rocprofv3, so it is not collected live) -> {"value", "source"} or None."""
-    for name in (f"r04_pmc_mfma_busy{path_hint}.json", "r02_pmc_mfma_busy.json"):
+    for name in (f"r05_pmc_mfma_busy{path_hint}.json", f"r04_pmc_mfma_busy{path_hint}.json", "r02_pmc_mfma_busy.json"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", name)))
             rows = [r for r in prof["kernels"] if r["kernel"].startswith(kernel_prefix) and r.get("mfma_busy") is not None]
@@ -257,7 +257,7 @@ def search_traffic():
     separate passes over tools/knn_bench.py; reads = 2 x FETCH_SIZE on gfx950, see gemm_traffic).  -> (bytes, nq, nr) of
     the profiled launch, or None."""
     try:
-        name = next(n for n in ("r04_pmc_knn.json", "r03_pmc_knn.json", "r02_pmc_knn.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        name = next(n for n in ("r05_pmc_knn.json", "r04_pmc_knn.json", "r03_pmc_knn.json", "r02_pmc_knn.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         prof = json.load(open(os.path.join(ROOT, "profiles", name)))
         key = prof.get("sweep_kernel_key") or next(k for k in prof["per_launch"] if k.startswith("knn_sweep_bf16_kernel"))
         v = prof["per_launch"][key]
@@ -390,16 +390,16 @@ def bench_search_sharded(dev, args, dist, rank, world):
 
 def swin_traffic():
     """Mean memory-side bytes per GEMM-class launch of the Swin step (gemm_ln_kernel, gemm_bf16_v*, swin_mlp_kernel) from the
-    committed PMC passes over `tools/swin_bench.py 256 3 256` (profiles/r04_pmc_swin.json; 2 x FETCH_SIZE + WRITE_SIZE as in
+    committed PMC passes over `tools/swin_bench.py 256 3 256` (profiles/r05_pmc_swin.json; 2 x FETCH_SIZE + WRITE_SIZE as in
     gemm_traffic) -> (bytes, launches, source) or None."""
     try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_swin.json")))["per_launch"]
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_swin.json")))["per_launch"]
         tot, n = 0.0, 0
         for key, v in prof.items():
-            if key.startswith(("gemm_ln_kernel", "gemm_bf16_v", "swin_mlp_kernel")) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            if key.startswith(("gemm_ln_kernel", "gemm_bf16_v", "swin_mlp_kernel", "swin_mlp512_kernel")) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 tot += v["launches"] * (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
                 n += v["launches"]
-        return (tot / n, n, "profiles/r04_pmc_swin.json") if n else None
+        return (tot / n, n, "profiles/r05_pmc_swin.json") if n else None
     except (OSError, KeyError, ValueError):
         return None
 
@@ -659,7 +659,7 @@ def main():
             per_class[k]["frac"] = round(per_class[k]["tflops"] / BF16_PEAK_TFLOPS, 4)
         if prof.get("attention", (0, 0))[0] > 0:
             # the two attention GEMMs (Q K^T and P V): 4 T^2 head_dim per head and frame; MFMA-busy share of the launch from the
-            # committed PMC pass (profiles/r04_pmc_mfma_busy.json, else the round-2 file)
+            # committed PMC pass (profiles/r05_pmc_mfma_busy.json, else the round-2 file)
             att_flop = cfg.layers * 4.0 * cfg.tokens * cfg.tokens * cfg.width
             tf = att_flop * args.batch * psteps / (prof["attention"][0] * 1e-3) / 1e12
             # its bytes: q, k, v in (3 D bf16 per token) and the context out (D bf16 per token) -- the kernel is bound by them, not by the pipe

@@ -3,7 +3,7 @@
 # summary of the same command at 3 steps, and separate --pmc passes (FETCH_SIZE / WRITE_SIZE) for the encoder GEMMs and the
 # similarity sweep.  Outputs under gpurun_out/<tag>/; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -16,6 +16,9 @@ tail -c 600 "$OUT/bench_default.json"
 (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o enc -- python $OLDPWD/bench.py $SHORT > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err")
 (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats_knn" -o knn -- python $OLDPWD/tools/knn_bench.py 65536 1000000 100 2 > "$OUT/knn_under_rocprof.txt" 2> "$OUT/stats_knn.err")
 (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats_swin" -o swin -- python $OLDPWD/tools/swin_bench.py 256 3 256 > "$OUT/swin_under_rocprof.txt" 2> "$OUT/stats_swin.err")
+(cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats_cnn" -o cnn -- python $OLDPWD/tools/cnn_bench.py > "$OUT/cnn_under_rocprof.txt" 2> "$OUT/stats_cnn.err")
+# the reference's real workload end to end, with the synchronising breakdown (where the host-side time goes)
+python tools/ensemble_bench.py 52 40 --breakdown > "$OUT/ensemble.json" 2> "$OUT/ensemble.err"
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && rocprofv3 --pmc $c -d "$OUT/pmc_$c" -o enc --output-format csv -- python $OLDPWD/bench.py $SHORT > /dev/null 2> "$OUT/pmc_$c.err")
   (cd /tmp && timeout 600 rocprofv3 --pmc $c -d "$OUT/pmcknn_$c" -o knn --output-format csv -- python $OLDPWD/tools/knn_bench.py 8192 1000000 100 1 > /dev/null 2> "$OUT/pmcknn_$c.err")

@@ -72,7 +72,10 @@ __device__ __forceinline__ int w2_swz(int row) { return ((row >> 1) & 1) | (((ro
 // is shared, and its bf16 shadow (8 consecutive columns per lane and column pair) IS the B operand of GEMM 1: x1 and its shadow
 // never go to memory (1.6 of the 3.2 GB the two launches moved at 256 frames of stage 0), the residual of the second LayerNorm is
 // taken from the registers.
-template <int C, int NW, int ABL = 0, bool PROJ = false>
+// SEQ: the chunk's vector work as ONE run between two runs of MFMAs (GEMM 1 | GELU of all four tiles | GEMM 2) instead of the polynomial's
+// steps between MFMA groups: a vector instruction behind an MFMA costs ~16 cycles where it costs 5 behind another vector instruction
+// (tools/micro/single_wave_issue.hip)
+template <int C, int NW, int ABL = 0, bool PROJ = false, bool SEQ = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpArgs p) {
 #define MFMA(a, b, c) ((ABL & 2) ? (c) + (f32x4_t){(float)(a)[0], (float)(b)[0], 0.f, 0.f} : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0))
     constexpr int RW = C == 128 ? 32 : 16, MT = RW / 16, R = NW * RW;
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
             f32x2_t v[NP];
             bias_of(0, v);
             constexpr int NE = 2 * KS1;
-            gelu_with(v, [&](int step) {
+            auto fill_b = [&](int step) {
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
                     if (e * NSTEP / NE != step) continue;
@@ -355,14 +358,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
                     for (int mt = 0; mt < MT; ++mt)
                         hacc[mt][j] = MFMA(wq[e & 1], xf[mt][ks], (ks == 0 ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : hacc[mt][j]));
                 }
-            });
+            };
+            if (SEQ) {
+#pragma unroll
+                for (int st = 0; st < NSTEP; ++st) fill_b(st);
+                __builtin_amdgcn_sched_barrier(0);
+                gelu_with(v, [&](int) {});
+            } else gelu_with(v, fill_b);
             pack_to(0, v);
         }
         // ---- C: GELU(tiles 2, 3) || GEMM 2, k-step 0: JO MFMA groups
         {
             f32x2_t v[NP];
             bias_of(1, v);
-            gelu_with(v, [&](int step) {
+            auto fill_c = [&](int step) {
 #pragma unroll
                 for (int e = 0; e < JO; ++e) {
                     if (e * NSTEP / JO != step) continue;
@@ -370,7 +379,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) oacc[mt][e] = MFMA(wq[e & 1], hf[mt][0].v, oacc[mt][e]);
                 }
-            });
+            };
+            if (SEQ) {
+                gelu_with(v, [&](int) {});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int st = 0; st < NSTEP; ++st) fill_c(st);
+            } else gelu_with(v, fill_c);
             pack_to(1, v);
         }
         // ---- D: GEMM 2, k-step 1
@@ -433,7 +448,16 @@ int launch_proj_c(const MlpArgs &a, hipStream_t stream) {
     }
     const int64_t grid = (a.m + R - 1) / R;
     VSC_REQUIRE(grid < (1ll << 31), "swin_mlp: grid too large");
-    hipLaunchKernelGGL((swin_mlp_kernel<C, NW, 0, true>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, a);
+    const char *sq = vsc_opt(OPT_SWIN_MLP_SEQ);   // diagnostic: 1 = the vector work of a chunk as one run (SEQ)
+    if (sq && sq[0] == '1') {
+        static bool seq_attr[16] = {};
+        if (dev >= 16 || !seq_attr[dev]) {
+            VSC_CHECK_HIP(hipFuncSetAttribute((const void *)swin_mlp_kernel<C, NW, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            if (dev < 16) seq_attr[dev] = true;
+        }
+        hipLaunchKernelGGL((swin_mlp_kernel<C, NW, 0, true, true>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, a);
+    } else
+        hipLaunchKernelGGL((swin_mlp_kernel<C, NW, 0, true>), dim3((unsigned)grid), dim3(NW * 64), smem, stream, a);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }
