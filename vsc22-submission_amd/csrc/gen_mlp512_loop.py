@@ -325,43 +325,51 @@ def proj_gemm(E):
                           [f"buffer_load_dwordx4 {V1(qq & 3)}, {W1R}, s{S_T2} offen lds"]))
         return items
 
-    E.c("---- PROJ: Wp(0), Wp(1) -> the W1 slots, W2(0) -> W2 slot 0, the attention output rows -> operand registers")
-    for ch in range(2):
-        E.i(f"s_add_u32 s{S_LB1}, {SLW}, {ch * SLOT}")
-        for pre, load in wp_items(ch):
-            for l in pre + load:
-                E.i(l)
-    E.i(f"s_mov_b32 s{S_SLOT2}, 0")
-    E.i(f"s_mov_b32 s{S_SO2}, {SW}")
-    E.i(f"s_mov_b32 s{S_SLOT}, 0")
-    dma_bases(E)
-    dma(E, "w2")
+    E.c("---- PROJ: the attention output rows -> operand registers; Wp(0 .. 2) -> ring slots 0 .. 2 (during the projection all FOUR 32-KiB")
+    E.c("slots of the two rings hold Wp chunks: chunk c in slot c & 3, requested three chunks ahead, counted waits)")
+    E.vq = []
     E.i(f"s_mov_b32 s{S_MT1B}, {16 * 1024}")
     for mt in range(2):
         for ks in range(16):
             so = "0" if mt == 0 else f"s{S_MT1B}"
-            E.i(f"buffer_load_dwordx4 {XF(mt, ks)}, {XBOFF}, {ATTR}, {so} offen offset:{64 * ks}")
+            E.vm(("att", mt, ks), f"buffer_load_dwordx4 {XF(mt, ks)}, {XBOFF}, {ATTR}, {so} offen offset:{64 * ks}")
+
+    def issue(chunk):             # ring refill `chunk` (16, 17: the MLP's W1(0), W1(1); >= 18: nothing) -> slot chunk & 3
+        if chunk >= 18:
+            return []
+        items = wp_items(chunk) if chunk < 16 else w1_items(chunk - 16)
+        out = []
+        for qq, (pre, load) in enumerate(items):
+            pre = [pre[0].replace(f"s{S_LB1}, {qq * 4096}", f"{SLW}, {(chunk & 3) * SLOT + qq * 4096}"), pre[1]]
+            out.append((pre, load, ("w", chunk, qq)))
+        return out
+
+    for chunk in range(3):
+        for pre, load, tag in issue(chunk):
+            for l in pre:
+                E.i(l)
+            E.vm(tag, load[0])
     E.i("s_waitcnt lgkmcnt(0)")
+    cur = 0                       # slot the fragment bases point at
     for c in range(16):
         E.c(f"projection chunk {c}: columns {32 * c} .. {32 * c + 31}")
-        E.i("s_waitcnt vmcnt(0)")
+        E.vm_wait(("w", c, 7))    # this wave's pieces of chunk c (and everything older: the attention rows); younger requests stay in flight
         E.i("s_barrier")
         for j in range(2):
             E.ds_read(("b", j), BZ(j), VECP, 6144 + 128 * c + 16 * j)
         for g in range(32, 32 + PF):
             a, off = frag_addr(g)
             E.ds_read(("f", g), WQ(g % PF), a, off)
-        # refill of the slot read by the PREVIOUS chunk (free behind the barrier above): Wp(c + 1) for c >= 1 ... here: chunk c reads slot
-        # c & 1; slot (c + 1) & 1 was read by chunk c - 1 and takes chunk c + 1 -- which the prologue already brought for c = 0
-        items = []
-        if c >= 1:
-            nxt = c + 1
-            E.i(f"s_add_u32 s{S_LB1}, {SLW}, {(nxt & 1) * SLOT}")
-            items = wp_items(nxt) if nxt < 16 else w1_items(0)
+        # slot (c + 3) & 3 = (c - 1) & 3 was read by chunk c - 1: free behind the barrier above
+        items = issue(c + 3)
         for g in range(32, 64):
             k = g - 32
-            pre, load = items[k // 2] if k % 2 == 0 and k // 2 < len(items) else ((), ())
-            group(E, g, 64, between=pre, after=load)
+            if k % 2 == 0 and k // 2 < len(items):
+                pre, load, tag = items[k // 2]
+                group(E, g, 64, between=pre)
+                E.vm(tag, load[0])
+            else:
+                group(E, g, 64)
         assert not E.q
         E.c("MFMA D -> vector reader")
         E.i("s_nop 7")
@@ -370,14 +378,19 @@ def proj_gemm(E):
             for j in range(2):
                 for r in range(4):
                     E.i(f"v_accvgpr_write_b32 {ACCR(mt, 2 * c + j, r)}, v{HACC(mt, j) + r}")
+        nxt = (c + 1) & 3
         for a in range(4):
-            E.i(f"v_xor_b32 {W1P(a)}, 0x8000, {W1P(a)}")
-    E.c("every wave is done with the W1 ring: slot 1 takes the MLP's W1(1) (slot 0 got W1(0) under chunk 15)")
+            E.i(f"v_xor_b32 {W1P(a)}, {hex((cur ^ nxt) * SLOT)}, {W1P(a)}")
+        cur = nxt
+    assert cur == 0
+    E.c("every wave is done with the ring: W2(0) -> W2 slot 0 (the MLP's W1(0), W1(1) arrived as chunks 16, 17)")
     E.i("s_barrier")
-    E.i(f"s_add_u32 s{S_LB1}, {SLW}, {SLOT}")
-    for pre, load in w1_items(1):
-        for l in pre + load:
-            E.i(l)
+    E.i(f"s_mov_b32 s{S_SLOT2}, 0")
+    E.i(f"s_mov_b32 s{S_SO2}, {SW}")
+    E.i(f"s_mov_b32 s{S_SLOT}, 0")
+    dma_bases(E)
+    dma(E, "w2")
+    E.vq = []
 
 
 def proj_ln(E):
