@@ -1,5 +1,6 @@
 """swin_mlp512_kernel<V>: the variants of the generated body (csrc/gen_mlp512_loop.py VARIANTS) on one box -- time at Swin-V2-B's stage-2
-shape (256 frames: 65 536 rows) and bit equality with variant 0 (they differ in schedule only).  (run on the GPU box)
+shape (256 frames: 65 536 rows) and bit equality with variant 0 (they differ in schedule only).  Variants >= 2 exist in a diagnostic
+build only:   make -C vsc22-submission_amd/csrc clean && make -C vsc22-submission_amd/csrc -j8 EXTRA=-DVSC_MLP_ABLATION   (run on the GPU box)
     python tools/micro/mlp512_variants.py [variants, default 0,1,2,3,4,5]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

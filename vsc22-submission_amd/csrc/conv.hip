@@ -1682,7 +1682,9 @@ extern "C" int vsc_conv2d_f32(const float *x_dev, int64_t n, int32_t h, int32_t 
         const char *x3e = vsc_opt(OPT_CONV_X3);
         // the epilogues of the direct / tap / plane kernels move out, res and bias 16 bytes at a time whenever ldo and ldr are multiples
         // of 4: an output window at an offset (Conv.__call__(out=..., coff=...)) or a caller's unaligned buffer takes the tile kernels
-        const bool io16 = (((uintptr_t)out_dev | (uintptr_t)(res_dev ? res_dev : out_dev) | (uintptr_t)(bias_dev ? bias_dev : out_dev)) & 15) == 0;
+        // (with ldo or ldr not a multiple of 4 those epilogues use scalar accesses anyway: any alignment is fine then)
+        const bool vec_io = ((ldo | (res_dev ? ldr : 0)) & 3) == 0;
+        const bool io16 = !vec_io || (((uintptr_t)out_dev | (uintptr_t)(res_dev ? res_dev : out_dev) | (uintptr_t)(bias_dev ? bias_dev : out_dev)) & 15) == 0;
         const bool tap_x3 = io16 && !(de && de[0] == '0') && !(x3e && x3e[0] == '0') && kh == 3 && kw == 3 && stride == 1 && pad == 1 && ((cin == 64 && cout <= 64) || (cin == 256 && cout <= 32)) && ldx == cin &&
                             (((uintptr_t)x_dev | (uintptr_t)w_packed_dev) & 15) == 0 && xbytes < (1ll << 31) && (!res_dev || ldr >= cout) &&
                             n * (int64_t)h * w * (ldo > ldr ? ldo : ldr) * 4 < (1ll << 31) && n * (int64_t)h * w >= 65536;

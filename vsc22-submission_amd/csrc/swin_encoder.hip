@@ -459,7 +459,9 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
                 const SwinBlockW &K = e->stages[s].blocks[b];
                 { PROF(pc + VSC_SWIN_PROF_QKV); TRY(launch_gemm_bf16(xb, K.qkv_w, K.qkv_b, nullptr, w.qkv, Ms, 3 * C, C, VSC_EPI_BF16, 0, st)); }
                 { PROF(pc + VSC_SWIN_PROF_ATTENTION); TRY(launch_window_attention(w.qkv, w.att, K.bias, K.scale, (int)Bs, R, W, e->shift(s, b), H, st)); }
-                if (K.fc2_wp && !unfused_mlp && !unfused_proj && swin_proj_mlp_supported(C) && !(C == 512 && (unfused_mlp512 || unfused_proj512))) {
+                // (the 512-wide kernel addresses x through one 4-GiB buffer descriptor: chunks of >= 2^21 rows keep the GEMM launches)
+                const bool mlp512_ok = C != 512 || (!unfused_mlp512 && Ms < (1ll << 21));
+                if (K.fc2_wp && !unfused_mlp && !unfused_proj && swin_proj_mlp_supported(C) && mlp512_ok && !(C == 512 && unfused_proj512)) {
                     // the whole second half of the block -- proj, LayerNorm, residual, MLP, LayerNorm, residual -- in one kernel; its time
                     // is booked under fc2_ln, proj_ln and fc1 stay empty
                     PROF(pc + VSC_SWIN_PROF_FC2_LN);
@@ -468,7 +470,7 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
                     continue;
                 }
                 { PROF(pc + VSC_SWIN_PROF_PROJ_LN); TRY(gemm_ln(e, w, w.att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, x, x, xb, Ms, C, C, st)); }
-                if (K.fc2_wp && !unfused_mlp && !(C == 512 && unfused_mlp512)) {
+                if (K.fc2_wp && !unfused_mlp && mlp512_ok) {
                     // both Linears, the GELU between them and the LayerNorm behind them in one kernel (swin_mlp.hip); its time is
                     // booked under fc2_ln, fc1 stays empty
                     PROF(pc + VSC_SWIN_PROF_FC2_LN);

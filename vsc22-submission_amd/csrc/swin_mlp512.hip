@@ -58,7 +58,8 @@ constexpr int SLOT = HC * C * 2;   // one chunk of either matrix: 32 KiB
 constexpr int LDS_W1 = 0, LDS_W2 = 2 * SLOT, LDS_B1 = 4 * SLOT, LDS_VEC = LDS_B1 + H * 4, LDS_BYTES = LDS_VEC + 6 * C * 4;   // vectors: b2 | gamma | beta | bp | gamma1 | beta1
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
-// V: variant of the generated body (gen_mlp512_loop.py VARIANTS); 0 is the one in use, the others serve same-box A/B runs
+// V: variant of the generated body (gen_mlp512_loop.py VARIANTS): 0 the MLP, 1 proj + LayerNorm + MLP; 2 .. 8 (ablations, cycle counters)
+// exist in -DVSC_MLP_ABLATION builds only (make EXTRA=-DVSC_MLP_ABLATION; tools/micro/mlp512_variants.py)
 template <int V>
 __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     static_assert(VSC_MLP512_VARIANTS == 9, "variant dispatch below");
     if (V == 0) VSC_MLP512_BODY(0);
     else if (V == 1) VSC_MLP512_BODY(1);
+#ifdef VSC_MLP_ABLATION   // the ablation variants compute WRONG results and the timing variant writes counters: diagnostic builds only
     else if (V == 2) VSC_MLP512_BODY(2);
     else if (V == 3) VSC_MLP512_BODY(3);
     else if (V == 4) VSC_MLP512_BODY(4);
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     else if (V == 6) VSC_MLP512_BODY(6);
     else if (V == 7) VSC_MLP512_BODY(7);
     else VSC_MLP512_BODY(8);
+#endif
 #undef VSC_MLP512_BODY
 }
 
@@ -170,7 +173,8 @@ int launch_swin_mlp512(const uint16_t *w1, const float *b1, const uint16_t *w2c,
     VSC_REQUIRE(w1 && b1 && w2c && b2 && gamma && beta && x && xb && m > 0, "swin_mlp512: null/empty");
     VSC_REQUIRE(m < (1ll << 21), "swin_mlp512: %lld rows (x is addressed through one 4-GiB buffer descriptor: < 2^21 rows per call)", (long long)m);
     const Mlp512Args a{w1, b1, w2c, b2, gamma, beta, x, xb, m, eps, g_mlp512_dbg, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (const char *e = vsc_opt(OPT_SWIN_MLP_ABL)) {   // diagnostic: another variant of the generated body
+#ifdef VSC_MLP_ABLATION
+    if (const char *e = vsc_opt(OPT_SWIN_MLP_ABL)) {   // diagnostic build: another variant of the generated body (ablations give wrong results)
         switch (atoi(e)) {
             case 2: return launch_k<2>(a, stream);
             case 3: return launch_k<3>(a, stream);
@@ -182,6 +186,7 @@ int launch_swin_mlp512(const uint16_t *w1, const float *b1, const uint16_t *w2c,
             default: break;
         }
     }
+#endif
     return launch_k<0>(a, stream);
 }
 
