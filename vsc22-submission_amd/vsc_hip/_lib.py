@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvsc_hip.so")
+# VSC_HIP_LIB: another build of the library (same-box A/B runs of an experimental kernel build, tools/micro/*); default: the in-tree one
+LIB_PATH = os.environ.get("VSC_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libvsc_hip.so")
 
 EPI_BF16, EPI_GELU_BF16, EPI_QGELU_BF16, EPI_RESADD_F32, EPI_PATCH_F32, EPI_F32 = range(6)
 PROF_CLASSES = ("patchify", "gemm_patch", "layernorm", "gemm_qkv", "attention", "gemm_proj",
