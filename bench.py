@@ -444,14 +444,20 @@ def bench_swin(dev, args):
             T, N = R * R, min(cfg.window_size, R) ** 2
             per_block = {"qkv": 2.0 * T * 3 * C * C, "proj_ln": 2.0 * T * C * C, "fc1": 2.0 * T * 4 * C * C, "fc2_ln": 2.0 * T * 4 * C * C,
                          "attention": 4.0 * T * N * C}.get(kind)
+            # blocks whose qkv Linear ran inside the previous block's fused kernel (stage 2: csrc/swin_mlp512.hip, variant 9), as a
+            # share of the stage's blocks: the qkv class has that many launches fewer than the fc2_ln class
+            qkv_inside = 1.0 - prof[f"s{st}.qkv"][1] / prof[f"s{st}.fc2_ln"][1]
             if kind == "merge":
                 flop = 2.0 * (T // 4) * (2 * C) * (4 * C)
             else:
                 flop = per_block * cfg.depths[st]
+                if kind == "qkv":
+                    flop *= 1.0 - qkv_inside
                 if kind == "fc2_ln" and f"s{st}.fc1" not in prof:   # fused MLP kernel (swin_mlp.hip): both Linears in this class
                     flop *= 2
                     if f"s{st}.proj_ln" not in prof:                # ... and the projection in front of them (PROJ form)
                         flop += 2.0 * T * C * C * cfg.depths[st]
+                    flop += 2.0 * T * 3 * C * C * cfg.depths[st] * qkv_inside   # ... and the next block's qkv Linear behind them
             is_gemm = kind != "attention"
             # algorithmic bytes of ONE launch of this class (args.swin_batch frames): operands in + results out, weights once.
             # x fp32 4 B, shadow / qkv / attention output / hidden bf16 2 B per element.
@@ -459,7 +465,9 @@ def bench_swin(dev, args):
             per_launch = {"qkv": M * C * 2 + M * 3 * C * 2 + 3 * C * C * 2,
                           "proj_ln": M * C * 2 + M * C * (4 + 4 + 2) + C * C * 2,
                           "fc1": M * C * 2 + M * 4 * C * 2 + 4 * C * C * 2,
-                          "fc2_ln": (M * C * 2 + M * C * (4 + 4 + 2) + 8 * C * C * 2 + (M * C * 2 + C * C * 2 if fused_proj else 0)) if fused_mlp
+                          # (fused, PROJ form: att in, x in and out, shadow out, W1 W2 Wp; with the next qkv inside: qkv out instead of the shadow, + Wqkv)
+                          "fc2_ln": (M * C * 2 + M * C * (4 + 4 + 2) + 8 * C * C * 2 + (M * C * 2 + C * C * 2 if fused_proj else 0)
+                                     + qkv_inside * (M * 3 * C * 2 - M * C * 2 + 3 * C * C * 2)) if fused_mlp
                                     else M * 4 * C * 2 + M * C * (4 + 4 + 2) + 4 * C * C * 2,
                           "merge": M * C * 2 + (M / 4) * 2 * C * (4 + 2) + 8 * C * C * 2}.get(kind)
             if per_launch and is_gemm:

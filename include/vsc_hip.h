@@ -350,6 +350,14 @@ int vsc_swin_mlp_permute_hidden_f32(const float *w2_host, float *w2p_host, int32
 int vsc_swin_proj_mlp_bf16(const uint16_t *att_dev, const uint16_t *wp_dev, const float *bp_dev, const float *gamma1_dev, const float *beta1_dev,
                            const uint16_t *w1_dev, const float *b1_dev, const uint16_t *w2p_dev, const float *b2_dev, const float *gamma2_dev,
                            const float *beta2_dev, float *x_dev, uint16_t *xb_dev, int64_t m, int32_t c, float eps, void *stream);
+/* ... and the NEXT block's qkv Linear behind it (c = 512 only -- the stage with 18 blocks, torch2scripts.py:284-300 followed by the
+ * next block's WindowAttention.forward first line, :120-125):   qkv_next = bf16(x) Wq[3c,c]^T + bq   with x the block's output.
+ * The bf16 shadow never leaves the registers (no xb_dev), the next block's qkv launch and its read of the shadow are gone.
+ * bq_dev [3c] = (q_bias | 0 | v_bias).  Same bits as vsc_swin_proj_mlp_bf16 followed by vsc_gemm_bf16 on its shadow. */
+int vsc_swin_proj_mlp_qkv_bf16(const uint16_t *att_dev, const uint16_t *wp_dev, const float *bp_dev, const float *gamma1_dev, const float *beta1_dev,
+                               const uint16_t *w1_dev, const float *b1_dev, const uint16_t *w2p_dev, const float *b2_dev, const float *gamma2_dev,
+                               const float *beta2_dev, const uint16_t *wq_dev, const float *bq_dev, float *x_dev, uint16_t *qkv_next_dev,
+                               int64_t m, int32_t c, float eps, void *stream);
 /* PatchMerging gather on bf16 tokens [frames, res, res, c] -> [frames*(res/2)^2, 4c] */
 int vsc_merge_gather_bf16(const uint16_t *xb_dev, uint16_t *out_dev, int64_t frames, int32_t res,
                           int32_t c, void *stream);

@@ -154,6 +154,32 @@ def test_swin_proj_mlp_matches_torch(dev, m, c):
     assert torch.equal(xb.cpu(), x.cpu().to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("m", [5, 128, 1000, 33 * 128 + 17, 65536 + 77])
+def test_swin_proj_mlp_qkv_equals_proj_mlp_then_gemm(dev, m):
+    """The next block's qkv Linear in the fused kernel's epilogue (vsc_swin_proj_mlp_qkv_bf16, variant 9 of the generated body) vs
+    the two launches it replaces: x bit for bit the proj+MLP kernel's; qkv = vsc_gemm_bf16 on that kernel's shadow up to bf16
+    rounding flips (same bf16 operands, fp32 accumulation from zero, bias added last) -- and against fp32 torch."""
+    from vsc_hip import ops
+    c = 512
+    x0, att = _rand(31, (m, c)), _rand(32, (m, c)).to(torch.bfloat16)
+    wp, bp = _rand(33, (c, c), c ** -0.5), _rand(34, (c,), 0.2)
+    g1, be1 = 0.3 + _rand(35, (c,), 0.05), _rand(36, (c,), 0.05)
+    w1, b1 = _rand(22, (4 * c, c), c ** -0.5), _rand(23, (4 * c,), 0.2)
+    w2, b2 = _rand(24, (c, 4 * c), (4 * c) ** -0.5), _rand(25, (c,), 0.2)
+    g2, be2 = 0.3 + _rand(26, (c,), 0.05), _rand(27, (c,), 0.05)
+    wq, bq = _rand(37, (3 * c, c), c ** -0.5), _rand(38, (3 * c,), 0.2)
+    x_ref, xb_ref = ops.swin_proj_mlp_bf16(x0.to(dev), att, wp, bp, g1, be1, w1, b1, w2, b2, g2, be2, 1e-5)
+    x, qkv = ops.swin_proj_mlp_qkv_bf16(x0.to(dev), att, wp, bp, g1, be1, w1, b1, w2, b2, g2, be2, wq, bq, 1e-5)
+    assert torch.equal(x, x_ref)
+    t = xb_ref.float().cpu() @ wq.to(torch.bfloat16).float().T + bq
+    torch.testing.assert_close(qkv.float().cpu(), t, rtol=2 ** -7, atol=2e-3)
+    # the stand-alone GEMM sums K in another tile order: same values up to rounding flips of the bf16 result
+    g = ops.gemm_bf16(xb_ref, wq.to(dev).to(torch.bfloat16), bq.to(dev))
+    assert float((qkv != g).float().mean()) < 0.02
+    torch.testing.assert_close(qkv.float(), g.float(), rtol=2 ** -7, atol=1e-5)
+    assert abs(float((qkv.float() - g.float()).mean())) < 1e-5
+
+
 def test_swin_mlp_rejects_other_widths(dev):
     from vsc_hip import ops
     from vsc_hip._lib import VscHipError
@@ -199,6 +225,21 @@ def test_swin_fused_mlp_equals_two_gemm_path(dev):
         _lib.set_option("VSC_SWIN_MLP512", None)
         enc.set_profiling(False)
     assert np.abs(fused - plain512).max() < 4e-4 and not np.array_equal(fused, plain512)
+    # the 512-wide stage with every block launching its own qkv GEMM (VSC_SWIN_QKV512=0; default: blocks 1..17 get their qkv
+    # from the previous block's kernel, only the first one launches the GEMM -- per chunk)
+    assert prof["s2.qkv"][1] == 2 * cfg.depths[2]
+    enc.set_profiling(True)
+    enc(x)
+    assert enc.profile()["s2.qkv"][1] == 2 and enc.profile()["s1.qkv"][1] == 2 * cfg.depths[1]
+    _lib.set_option("VSC_SWIN_QKV512", "0")
+    try:
+        enc.set_profiling(True)
+        own_qkv = enc(x).cpu().numpy()
+        assert enc.profile()["s2.qkv"][1] == 2 * cfg.depths[2]
+    finally:
+        _lib.set_option("VSC_SWIN_QKV512", None)
+        enc.set_profiling(False)
+    assert np.abs(fused - own_qkv).max() < 4e-4
 
 
 def test_swin_encoder_is_deterministic_at_full_chunks(dev):
@@ -348,6 +389,8 @@ def test_swin_profiling_classes(dev):
             ms, n = prof.get(f"s{s}.{kind}", (0.0, 0))
             if (kind == "fc1" and fused_mlp) or (kind == "proj_ln" and fused_proj):
                 assert n == 0
+            elif kind == "qkv" and cfg.dim(s) == 512:
+                assert n == chunks and ms > 0     # the first block's only: the others' qkv comes out of the previous block's kernel
             else:
                 assert n == chunks * cfg.depths[s] and ms > 0
         if s + 1 < cfg.stages:

@@ -134,6 +134,13 @@ extern "C" int vsc_swin_proj_mlp_bf16(const uint16_t *att, const uint16_t *wp, c
     return launch_swin_proj_mlp(att, wp, bp, g1, be1, w1, b1, w2p, b2, g2, be2, x, xb, m, c, eps, (hipStream_t)stream);
 }
 
+extern "C" int vsc_swin_proj_mlp_qkv_bf16(const uint16_t *att, const uint16_t *wp, const float *bp, const float *g1, const float *be1, const uint16_t *w1,
+                                          const float *b1, const uint16_t *w2p, const float *b2, const float *g2, const float *be2, const uint16_t *wq,
+                                          const float *bq, float *x, uint16_t *qkv_next, int64_t m, int32_t c, float eps, void *stream) {
+    VSC_REQUIRE(c == 512, "swin_proj_mlp_qkv: width %d unsupported (512)", c);
+    return launch_swin_proj_mlp_qkv512(att, wp, bp, g1, be1, w1, b1, w2p, b2, g2, be2, wq, bq, x, qkv_next, m, eps, (hipStream_t)stream);
+}
+
 extern "C" int vsc_swin_mlp_permute_hidden_f32(const float *w2, float *w2p, int32_t c) {
     VSC_REQUIRE(w2 && w2p && w2 != w2p, "swin_mlp_permute_hidden: null / aliased arrays");
     VSC_REQUIRE(swin_mlp_supported(c), "swin_mlp_permute_hidden: width %d unsupported (128, 256 or 512)", c);

@@ -44,7 +44,7 @@ void vsc_set_error(const char *fmt, ...);
     X(ATTN_SKEW) X(ATTN_ABL) X(ATTN_NI) X(ATTN_DMA) X(CONV_IMPLICIT) X(CONV_DIRECT) X(CONV_REMAP) X(CONV_PERSIST) X(CONV_STAGES) X(CONV_WAVES) X(CONV_NARROW_MAX) X(CONV_NARROW_NT) X(CONV_EXPAND) X(DWCONV_SMALL) X(CONV_STEM) X(CONV_STREAM_MIN_COUT) X(CONV_X3)      \
     X(GEMM_GROUP_N) X(GEMM_V4_SKEW) X(GEMM_TIMING_PRINT) X(GEMM_V4) X(GEMM_V4_GRID) X(GEMM_SKEW_NS_PER_K) X(GEMM_CFG)    \
     X(GEMM_V3) X(GEMM_ABL) X(GEMM_V1) X(KNN_TRIG) X(KNN_ABL) X(KNN_PATH) X(KNN_XCD_MAP) X(KNN_DELTA) X(KNN_TAIL) X(RANGE_PATH) X(PAIRMAX_PATH) X(WATTN_ABL)      \
-    X(SWIN_SPLIT_LN) X(SWIN_SPLIT_K) X(GEMM_LN_V4) X(SWIN_FUSED_MLP) X(SWIN_MLP512) X(SWIN_PROJ512) X(SWIN_FUSED_PROJ) X(SWIN_MLP_ABL) X(SWIN_MLP_SEQ) X(SWIN_FUSED_MERGE) X(SWIN_ROW_MAX) X(LN_LIGHT) X(WATTN_STREAM)
+    X(SWIN_SPLIT_LN) X(SWIN_SPLIT_K) X(GEMM_LN_V4) X(SWIN_FUSED_MLP) X(SWIN_MLP512) X(SWIN_PROJ512) X(SWIN_QKV512) X(SWIN_FUSED_PROJ) X(SWIN_MLP_ABL) X(SWIN_MLP_SEQ) X(SWIN_FUSED_MERGE) X(SWIN_ROW_MAX) X(LN_LIGHT) X(WATTN_STREAM)
 enum VscOpt {
 #define X(n) OPT_##n,
     VSC_OPT_LIST(X)
@@ -188,6 +188,9 @@ void swin_mlp512_pack_w2(const float *src, float *dst);
 int launch_swin_proj_mlp512(const uint16_t *att, const uint16_t *wp, const float *bp, const float *gamma1, const float *beta1, const uint16_t *w1,
                             const float *b1, const uint16_t *w2c, const float *b2, const float *gamma2, const float *beta2, float *x, uint16_t *xb,
                             int64_t m, float eps, hipStream_t stream);
+int launch_swin_proj_mlp_qkv512(const uint16_t *att, const uint16_t *wp, const float *bp, const float *gamma1, const float *beta1, const uint16_t *w1,
+                                const float *b1, const uint16_t *w2c, const float *b2, const float *gamma2, const float *beta2, const uint16_t *wq,
+                                const float *bq, float *x, uint16_t *qkv_next, int64_t m, float eps, hipStream_t stream);
 void swin_mlp512_set_timing_buffer(uint32_t *buf);   // diagnostic: [workgroups][4][8] cycle counters of the timing variant (VSC_SWIN_MLP_ABL=5)
 int launch_swin_mlp512(const uint16_t *w1, const float *b1, const uint16_t *w2c, const float *b2, const float *gamma, const float *beta,
                        float *x, uint16_t *xb, int64_t m, float eps, hipStream_t stream);

@@ -34,7 +34,7 @@ import sys
 SLOT = 32768
 LDS_W1, LDS_W2 = 0, 2 * SLOT
 NCH = 64
-PF, STAGGER, TIMING, ABL, PROJ = 8, 0, False, 0, False    # defaults; main() builds the variants listed in VARIANTS
+PF, STAGGER, TIMING, ABL, PROJ, QKV = 8, 0, False, 0, False, False    # defaults; main() builds the variants listed in VARIANTS
 # ABL (diagnostic variants, wrong results): 1 no GELU arithmetic, 2 no LDS-DMA in the loop, 4 no fragment reads, 8 no MFMAs in the loop
 GELU_DEG = 8
 GELU_U = 4.5
@@ -72,6 +72,7 @@ def W1P(a): return f"%[w1p{a}]"
 W2P, B1P, V2, W1R, W2R, SW, SLW = "%[w2p]", "%[b1p]", "%[v2]", "%[w1r]", "%[w2r]", "%[swave]", "%[sldsw]"
 VECP, XBOFF, BP16, BP32, XR, XBR, EPS = "%[vecp]", "%[xboff]", "%[bp16]", "%[bp32]", "%[xr]", "%[xbr]", "%[eps]"
 ATTR, WPR = "%[attr]", "%[wpr]"      # PROJ: descriptors of the attention output rows and of attn.proj.weight
+WQR, QR, QOFF = "%[dbgr]", "%[xbr]", "v200"   # QKV (no operands left: 16 VGPRs outside the clobbers, SGPRs likewise): the kernel passes the next block's qkv weight in the timing buffer's place and the qkv rows in the shadow's; row * 3072 + 16 quad is derived from xboff
 DBGR, DBGOFF = "%[dbgr]", "%[dbgoff]"      # timing variant: per-wave cycle counters go to dbgr at byte offset dbgoff
 S_TS, S_ACC = 70, 80                     # s[70:79] time stamps (pairs), s80.. accumulated differences
 S_MT1X, S_MT1B = 66, 67     # byte offsets of the second 16-row tile in x / xb
@@ -138,7 +139,7 @@ def frag_addr(g):
     return W1P(ks & 3), 16384 * j + 256 * (ks >> 2)
 
 
-def group(E, g, end, between=(), after=()):
+def group(E, g, end, between=(), after=(), zero_start=False):
     """the two MFMAs of group g, then the request of the fragment PF groups ahead (none at or beyond `end`).  `between`: up to three
     scalar / memory instructions issued in the shadow of the first MFMA (an MFMA occupies the matrix pipe for 16 cycles and one issue
     slot of 4: three more instructions of other kinds fit behind it for free -- put behind the SECOND MFMA they delay the next
@@ -155,7 +156,7 @@ def group(E, g, end, between=(), after=()):
         e = g - 32
         j, ks = e & 1, e >> 1
         for mt, lst in ((0, first), (1, second)):
-            c = vq(BZ(j)) if ks == 0 else vq(HACC(mt, j))     # a chain starts from the fc1 bias of its four hidden units
+            c = ("0" if zero_start else vq(BZ(j))) if ks == 0 else vq(HACC(mt, j))     # a chain starts from the bias of its four hidden units (or from zero)
             lst.append(f"v_mfma_f32_16x16x32_bf16 {vq(HACC(mt, j))}, {w}, {XF(mt, ks)}, {c}")
     for l in first:
         E.i(l)
@@ -393,10 +394,13 @@ def proj_gemm(E):
     E.vq = []
 
 
-def proj_ln(E):
-    """PROJ: x1 = x + LayerNorm(oacc) * gamma1 + beta1 for the wave's rows; x1 goes back to memory as fp32 (the residual of the MLP's
-    own LayerNorm reads it there) and, rounded to bf16, into the xf registers: the 8 consecutive columns a lane holds per column group
-    ARE GEMM 1's B operand of that k-step.  The residual rows stream through a ring of eight quads requested eight quads ahead."""
+def proj_ln(E, gam=8192, bet=10240, agent_scope=False, head=None):
+    """x_new = x + LayerNorm(oacc) * gamma + beta for the wave's rows; x_new goes back to memory as fp32 and, rounded to bf16, into the xf
+    registers: the 8 consecutive columns a lane holds per column group ARE the B operand of that k-step of a GEMM-1-type product.
+    The residual rows stream through a ring of eight quads requested eight quads ahead.
+    PROJ (defaults): oacc = att Wp^T + bp, gamma1 / beta1, the residual is x; x1 is what the MLP's own LayerNorm reads back later.
+    QKV epilogue (gam / bet of norm2, agent_scope: the residual is the x1 this wave stored earlier in the launch): the registers then
+    hold the shadow of the block's OUTPUT -- the operand of the next block's qkv Linear."""
     XOFF = T
     MEAN = [T + 2, T + 4]
     RSTD = [T + 6, T + 8]
@@ -404,14 +408,17 @@ def proj_ln(E):
     P0, P1, W = T + 16, T + 18, T + 20
     RING = 8
     def XW(n): return 224 + 4 * (n % RING)        # v224..v255 (the GELU's registers: its constants are set up behind this phase)
-    E.c("---- PROJ: LayerNorm + residual of the projection")
+    E.c("---- LayerNorm + residual, results to memory (fp32) and to the operand registers (bf16)")
     E.i(f"v_lshlrev_b32 v{XOFF}, 1, {XBOFF}")
     E.i(f"s_mov_b32 s{S_MT1X}, {16 * 2048}")
     def load(n):
         mt, jo = n // 32, n % 32
         so = "0" if mt == 0 else f"s{S_MT1X}"
-        E.vm(("x", n), f"buffer_load_dwordx4 {vq(XW(n))}, v{XOFF}, {XR}, {so} offen offset:{col_off(jo)}")
-    E.vq = []
+        E.vm(("x", n), f"buffer_load_dwordx4 {vq(XW(n))}, v{XOFF}, {XR}, {so} offen offset:{col_off(jo)}" + (" sc1" if agent_scope else ""))
+    if head is None:
+        E.vq = []
+    else:
+        head()
     for n in range(RING):
         load(n)
     ln_stats(E, MEAN, RSTD, S, TMP, P0, P1, W)
@@ -423,8 +430,8 @@ def proj_ln(E):
             B = [base + 12, base + 20]
             for t in range(2):
                 jo = 2 * pp + t
-                E.ds_read(("g", jo), G[t], VECP, 8192 + col_off(jo))
-                E.ds_read(("e", jo), B[t], VECP, 10240 + col_off(jo))
+                E.ds_read(("g", jo), G[t], VECP, gam + col_off(jo))
+                E.ds_read(("e", jo), B[t], VECP, bet + col_off(jo))
             for t in range(2):
                 jo = 2 * pp + t
                 n = 32 * mt + jo
@@ -449,6 +456,84 @@ def proj_ln(E):
                 E.i(f"v_cvt_pk_bf16_f32 v{xf + 2 * t}, v{Y[t]}, v{Y[t] + 1}")
                 E.i(f"v_cvt_pk_bf16_f32 v{xf + 2 * t + 1}, v{Y[t] + 2}, v{Y[t] + 3}")
     assert not E.q
+
+
+def qkv_phase(E):
+    """QKV: the NEXT block's qkv Linear on this block's output rows, which never leave the registers as bf16:
+        qkv[rows, 0:1536] = bf16(x_out) Wqkv^T + (q_bias | 0 | v_bias)
+    as 48 chunks of 32 columns on GEMM 1's machinery (proj_gemm's ring scheme: chunk c in slot c & 3, requested three chunks ahead,
+    counted waits; Wqkv's rows permuted at the DMA source so that a lane ends with 8 consecutive columns: one 16-byte store per row
+    tile and chunk).  The accumulation starts from zero and the bias is added at the end -- the order of the stand-alone qkv GEMM, so
+    the result is the same bits.  Replaces a launch that read the 67-MB shadow back (which is then not written at all)."""
+    NQC = 48
+    QOFF_SO = 87          # s87: byte offset of the second 16-row tile in the qkv rows
+
+    def wq_items(chunk):
+        items = []
+        for qq in range(8):
+            src = chunk * SLOT + (8 * (qq & 3) + 4 * (qq >> 2)) * 1024
+            items.append(([f"s_add_u32 m0, {SLW}, {(chunk & 3) * SLOT + qq * 4096}", f"s_add_u32 s{S_T2}, {SW}, {src}"],
+                          f"buffer_load_dwordx4 {V1(qq & 3)}, {WQR}, s{S_T2} offen lds", ("q", chunk, qq)))
+        return items
+
+    def head():
+        E.c("every wave is past the last GEMM 2: the ring takes the first chunks of the next block's Wqkv")
+        E.vq = []
+        E.i("s_barrier")
+        for chunk in range(3):
+            for pre, load, tag in wq_items(chunk):
+                for l in pre:
+                    E.i(l)
+                E.vm(tag, load)
+
+    E.c("---- epilogue of the QKV variant: MFMA D -> v_accvgpr_read")
+    E.i("s_nop 15")
+    proj_ln(E, gam=2048, bet=4096, agent_scope=PROJ, head=head)
+    E.i(f"s_mov_b32 s{QOFF_SO}, {16 * 3072}")
+    E.c("row * 3072 + 16 quad = 3 xboff - 2 (16 quad), xboff = row * 1024 + 16 quad")
+    E.i(f"v_and_b32 v201, 0x3ff, {XBOFF}")
+    E.i(f"v_lshl_add_u32 {QOFF}, {XBOFF}, 1, {XBOFF}")
+    E.i(f"v_lshlrev_b32 v201, 1, v201")
+    E.i(f"v_sub_u32 {QOFF}, {QOFF}, v201")
+    cur = 0
+    for c in range(NQC):
+        E.c(f"qkv chunk {c}: columns {32 * c} .. {32 * c + 31}")
+        E.vm_wait(("q", c, 7))
+        E.i("s_barrier")
+        for j in range(2):
+            E.ds_read(("b", j), BZ(j), VECP, 12288 + 128 * c + 16 * j)
+        for g in range(32, 32 + PF):
+            a, off = frag_addr(g)
+            E.ds_read(("f", g), WQ(g % PF), a, off)
+        items = wq_items(c + 3) if c + 3 < NQC else []
+        for g in range(32, 64):
+            k = g - 32
+            if k % 2 == 0 and k // 2 < len(items):
+                pre, load, tag = items[k // 2]
+                group(E, g, 64, between=pre, zero_start=True)
+                E.vm(tag, load)
+            else:
+                group(E, g, 64, zero_start=True)
+        assert not E.q or all(t[0] == "b" for t in E.q)
+        E.wait_all()
+        E.c("MFMA D -> vector reader; + bias, round, store (register sets alternate: the previous chunk's stores may still be reading theirs)")
+        E.i("s_nop 7")
+        E.i("s_nop 3")
+        K = [224 + 16 * (c & 1), 228 + 16 * (c & 1)]   # v224..v255: the GELU's registers (the fragment ring and the accumulators are live here)
+        for mt in range(2):
+            for j in range(2):
+                for h in (0, 2):
+                    E.i(f"v_pk_add_f32 {vp(HACC(mt, j) + h)}, {vp(HACC(mt, j) + h)}, {vp(BZ(j) + h)}")
+            for j in range(2):
+                E.i(f"v_cvt_pk_bf16_f32 v{K[mt] + 2 * j}, v{HACC(mt, j)}, v{HACC(mt, j) + 1}")
+                E.i(f"v_cvt_pk_bf16_f32 v{K[mt] + 2 * j + 1}, v{HACC(mt, j) + 2}, v{HACC(mt, j) + 3}")
+            so = "0" if mt == 0 else f"s{QOFF_SO}"
+            E.vm(("o", c, mt), f"buffer_store_dwordx4 {vq(K[mt])}, {QOFF}, {QR}, {so} offen offset:{64 * c}")
+        nxt = (c + 1) & 3
+        for a in range(4):
+            E.i(f"v_xor_b32 {W1P(a)}, {hex((cur ^ nxt) * SLOT)}, {W1P(a)}")
+        cur = nxt
+    E.vq = []
 
 
 def epilogue(E):
@@ -660,7 +745,10 @@ def program():
     E.i("s_waitcnt lgkmcnt(0)")
     E.q = []
     stamp(E, 3)
-    epilogue(E)
+    if QKV:
+        qkv_phase(E)
+    else:
+        epilogue(E)
     E.i("s_waitcnt vmcnt(0)")
     if TIMING:
         stamp(E, 0)
@@ -677,16 +765,16 @@ def program():
 # (PF, STAGGER, TIMING, ABL, PROJ): fragments requested PF groups ahead; start skew of the first round's workgroups in units of s_sleep 32 (2 048
 # cycles) per phase (four phases by (blockIdx >> 3) & 3).
 # Variant 0 is what launch_swin_mlp512 runs, variant 1 launch_swin_proj_mlp512; the others are reachable through VSC_SWIN_MLP_ABL=<index>.
-VARIANTS = [(8, 0, False, 0, False), (8, 0, False, 0, True), (8, 0, False, 1, False), (8, 0, False, 2, False), (8, 0, False, 4, False), (8, 0, True, 0, False),
-            (8, 0, False, 8, False), (8, 0, False, 14, False), (8, 0, False, 15, False)]
+VARIANTS = [(8, 0, False, 0, False, False), (8, 0, False, 0, True, False), (8, 0, False, 1, False, False), (8, 0, False, 2, False, False), (8, 0, False, 4, False, False),
+            (8, 0, True, 0, False, False), (8, 0, False, 8, False, False), (8, 0, False, 14, False, False), (8, 0, False, 15, False, False), (8, 0, False, 0, True, True)]
 
 
 def main():
-    global PF, STAGGER, TIMING, ABL, PROJ
+    global PF, STAGGER, TIMING, ABL, PROJ, QKV
     out = ["// GENERATED by gen_mlp512_loop.py -- do not edit.  One asm statement per variant: the body of swin_mlp512_kernel<V>."]
-    for k, (PF, STAGGER, TIMING, ABL, PROJ) in enumerate(VARIANTS):
+    for k, (PF, STAGGER, TIMING, ABL, PROJ, QKV) in enumerate(VARIANTS):
         lines = program()
-        out.append(f"// variant {k}: PF = {PF}, STAGGER = {STAGGER}" + (", cycle counters per wave" if TIMING else "") + (f", ablation {ABL} (wrong results)" if ABL else "") + (", PROJ: attention projection + LayerNorm + residual in front" if PROJ else ""))
+        out.append(f"// variant {k}: PF = {PF}, STAGGER = {STAGGER}" + (", cycle counters per wave" if TIMING else "") + (f", ablation {ABL} (wrong results)" if ABL else "") + (", PROJ: attention projection + LayerNorm + residual in front" if PROJ else "") + (", QKV: the next block's qkv Linear behind" if QKV else ""))
         out.append(f"#define VSC_MLP512_LOOP_ASM_{k} \\")
         for l in lines:
             if l.startswith(";"):

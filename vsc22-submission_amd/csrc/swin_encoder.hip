@@ -428,6 +428,8 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
     const bool unfused_mlp512 = f5 && f5[0] == '0';
     const char *f6 = vsc_opt(OPT_SWIN_PROJ512);     // diagnostic / test switch: 0 = the 512-wide stage keeps proj + LayerNorm as their own launch
     const bool unfused_proj512 = f6 && f6[0] == '0';
+    const char *f7 = vsc_opt(OPT_SWIN_QKV512);      // diagnostic / test switch: 0 = every block of the 512-wide stage launches its own qkv GEMM
+    const bool unfused_qkv512 = f7 && f7[0] == '0';
     const char *fp = vsc_opt(OPT_SWIN_FUSED_PROJ);   // diagnostic / test switch: 0 = proj + LayerNorm as their own launch
     const bool unfused_proj = fp && fp[0] == '0';
     const char *fg = vsc_opt(OPT_SWIN_FUSED_MERGE);   // diagnostic / test switch: 0 = PatchMerging as a gather kernel + GEMM
@@ -455,9 +457,11 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
             const int64_t Bs = B, Ms = M;
             float *x = w.x;
             uint16_t *xb = w.xb;
+            bool qkv_ready = false;   // the previous block's kernel already left this block's qkv in w.qkv
             for (int b = 0; b < c.depths[s]; ++b) {
                 const SwinBlockW &K = e->stages[s].blocks[b];
-                { PROF(pc + VSC_SWIN_PROF_QKV); TRY(launch_gemm_bf16(xb, K.qkv_w, K.qkv_b, nullptr, w.qkv, Ms, 3 * C, C, VSC_EPI_BF16, 0, st)); }
+                if (!qkv_ready) { PROF(pc + VSC_SWIN_PROF_QKV); TRY(launch_gemm_bf16(xb, K.qkv_w, K.qkv_b, nullptr, w.qkv, Ms, 3 * C, C, VSC_EPI_BF16, 0, st)); }
+                qkv_ready = false;
                 { PROF(pc + VSC_SWIN_PROF_ATTENTION); TRY(launch_window_attention(w.qkv, w.att, K.bias, K.scale, (int)Bs, R, W, e->shift(s, b), H, st)); }
                 // (the 512-wide kernel addresses x through one 4-GiB buffer descriptor: chunks of >= 2^21 rows keep the GEMM launches)
                 const bool mlp512_ok = C != 512 || (!unfused_mlp512 && Ms < (1ll << 21));
@@ -465,6 +469,15 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
                     // the whole second half of the block -- proj, LayerNorm, residual, MLP, LayerNorm, residual -- in one kernel; its time
                     // is booked under fc2_ln, proj_ln and fc1 stay empty
                     PROF(pc + VSC_SWIN_PROF_FC2_LN);
+                    if (C == 512 && b + 1 < c.depths[s] && !unfused_qkv512 && Ms * 3072 < (1ll << 32)) {
+                        // ... and the NEXT block's qkv Linear behind it, from the registers that hold the new shadow: the shadow is not
+                        // written (the stage's last block writes it for the PatchMerging), the next qkv launch does not happen
+                        const SwinBlockW &N = e->stages[s].blocks[b + 1];
+                        TRY(launch_swin_proj_mlp_qkv512(w.att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, K.fc1_w, K.fc1_b, K.fc2_wp, K.fc2_b, K.n2_g, K.n2_b,
+                                                        N.qkv_w, N.qkv_b, x, w.qkv, Ms, e->cfg.ln_eps, st));
+                        qkv_ready = true;
+                        continue;
+                    }
                     TRY(launch_swin_proj_mlp(w.att, K.proj_w, K.proj_b, K.n1_g, K.n1_b, K.fc1_w, K.fc1_b, K.fc2_wp, K.fc2_b, K.n2_g, K.n2_b, x, xb,
                                              Ms, C, e->cfg.ln_eps, st));
                     continue;

@@ -51,11 +51,15 @@ struct Mlp512Args {
     const uint16_t *att;   // [m, 512] attention output
     const uint16_t *wp;    // [512, 512] attn.proj.weight
     const float *bp, *gamma1, *beta1;   // [512]
+    // QKV (variant 9, with PROJ): the NEXT block's qkv Linear behind the block -- qkv = bf16(x) Wq^T + bq; the shadow xb is then not written
+    const uint16_t *wq;    // [1536, 512] the next block's attn.qkv.weight
+    const float *bq;       // [1536] (q_bias | 0 | v_bias)
+    uint16_t *qkv;         // [m, 1536]
 };
 
 constexpr int C = 512, H = 4 * C, NW = 4, MT = 2, RW = 16 * MT, R = NW * RW, HC = 32;
 constexpr int SLOT = HC * C * 2;   // one chunk of either matrix: 32 KiB
-constexpr int LDS_W1 = 0, LDS_W2 = 2 * SLOT, LDS_B1 = 4 * SLOT, LDS_VEC = LDS_B1 + H * 4, LDS_BYTES = LDS_VEC + 6 * C * 4;   // vectors: b2 | gamma | beta | bp | gamma1 | beta1
+constexpr int LDS_W1 = 0, LDS_W2 = 2 * SLOT, LDS_B1 = 4 * SLOT, LDS_VEC = LDS_B1 + H * 4, LDS_BYTES = LDS_VEC + 9 * C * 4;   // vectors: b2 | gamma | beta | bp | gamma1 | beta1 | bq [1536]
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // V: variant of the generated body (gen_mlp512_loop.py VARIANTS): 0 the MLP, 1 proj + LayerNorm + MLP; 2 .. 8 (ablations, cycle counters)
@@ -76,7 +80,9 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc((void *)p.w2c, 0, H * C * 2, 0x00020000);
     // x / xb rows through descriptors over the m rows that exist: rows past m return zeros and their stores are dropped
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)(uint32_t)(p.m * C * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t xbr = __builtin_amdgcn_make_buffer_rsrc((void *)p.xb, 0, (int)(uint32_t)(p.m * C * 2), 0x00020000);
+    // (QKV: the qkv rows [m, 1536] stand in the shadow's descriptor, which that variant never writes)
+    const __amdgpu_buffer_rsrc_t xbr = V == 9 ? __builtin_amdgcn_make_buffer_rsrc((void *)p.qkv, 0, (int)(uint32_t)(p.m * 3 * C * 2), 0x00020000)
+                                              : __builtin_amdgcn_make_buffer_rsrc((void *)p.xb, 0, (int)(uint32_t)(p.m * C * 2), 0x00020000);
     uint32_t v1[4];   // W1: LDS row q = chunk row q, LDS piece `lane` <- source piece lane ^ (q & 15), q & 15 = 4 (qq & 3) + wave
 #pragma unroll
     for (int a = 0; a < 4; ++a) v1[a] = (uint32_t)((lane ^ (4 * a + wave)) << 4);
@@ -100,7 +106,9 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     const uint32_t xboff = (uint32_t)(row0 + fr) * (uint32_t)(C * 2) + 16u * (uint32_t)quad;   // byte offset of row (0, fr), columns 8 quad .., in xb
     const uint32_t bp16 = (uint32_t)((lane ^ 16) << 2), bp32 = (uint32_t)((lane ^ 32) << 2);
     const uint32_t eps = __builtin_amdgcn_readfirstlane(__float_as_uint(p.eps));
-    const __amdgpu_buffer_rsrc_t dbgr = __builtin_amdgcn_make_buffer_rsrc((void *)p.dbg, 0, p.dbg ? (int)(gridDim.x * NW * 32) : 0, 0x00020000);
+    // (QKV: the next block's qkv weight [1536, 512] stands in the timing buffer's descriptor -- the asm has no operand to spare)
+    const __amdgpu_buffer_rsrc_t dbgr = V == 9 ? __builtin_amdgcn_make_buffer_rsrc((void *)p.wq, 0, 3 * C * C * 2, 0x00020000)
+                                               : __builtin_amdgcn_make_buffer_rsrc((void *)p.dbg, 0, p.dbg ? (int)(gridDim.x * NW * 32) : 0, 0x00020000);
     const uint32_t dbgoff = (blockIdx.x * NW + (uint32_t)wave) * 32u;
     const uint32_t bid = blockIdx.x;
 
@@ -109,10 +117,15 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
         b2s[i] = p.b2[i];
         gs[i] = p.gamma[i];
         bs[i] = p.beta[i];
-        if (V == 1) {
+        if (V == 1 || V == 9) {
             bs[C + i] = p.bp[i];
             bs[2 * C + i] = p.gamma1[i];
             bs[3 * C + i] = p.beta1[i];
+        }
+        if (V == 9) {
+            bs[4 * C + i] = p.bq[i];
+            bs[5 * C + i] = p.bq[C + i];
+            bs[6 * C + i] = p.bq[2 * C + i];
         }
     }
     // PROJ: rows of the attention output / attn.proj.weight (other variants: empty descriptors, never used)
@@ -120,9 +133,10 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     const __amdgpu_buffer_rsrc_t wpr = __builtin_amdgcn_make_buffer_rsrc((void *)p.wp, 0, p.wp ? C * C * 2 : 0, 0x00020000);
     // ---- everything else: rows in, the hidden-axis loop, LayerNorm + residual + shadow out
 #define VSC_MLP512_BODY(K) asm volatile(VSC_MLP512_LOOP_ASM_##K : VSC_MLP512_LOOP_OUTS : VSC_MLP512_LOOP_INS : VSC_MLP512_LOOP_CLOBBERS)
-    static_assert(VSC_MLP512_VARIANTS == 9, "variant dispatch below");
+    static_assert(VSC_MLP512_VARIANTS == 10, "variant dispatch below");
     if (V == 0) VSC_MLP512_BODY(0);
     else if (V == 1) VSC_MLP512_BODY(1);
+    else if (V == 9) VSC_MLP512_BODY(9);
 #ifdef VSC_MLP_ABLATION   // the ablation variants compute WRONG results and the timing variant writes counters: diagnostic builds only
     else if (V == 2) VSC_MLP512_BODY(2);
     else if (V == 3) VSC_MLP512_BODY(3);
@@ -172,7 +186,7 @@ int launch_swin_mlp512(const uint16_t *w1, const float *b1, const uint16_t *w2c,
                        float *x, uint16_t *xb, int64_t m, float eps, hipStream_t stream) {
     VSC_REQUIRE(w1 && b1 && w2c && b2 && gamma && beta && x && xb && m > 0, "swin_mlp512: null/empty");
     VSC_REQUIRE(m < (1ll << 21), "swin_mlp512: %lld rows (x is addressed through one 4-GiB buffer descriptor: < 2^21 rows per call)", (long long)m);
-    const Mlp512Args a{w1, b1, w2c, b2, gamma, beta, x, xb, m, eps, g_mlp512_dbg, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const Mlp512Args a{w1, b1, w2c, b2, gamma, beta, x, xb, m, eps, g_mlp512_dbg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 #ifdef VSC_MLP_ABLATION
     if (const char *e = vsc_opt(OPT_SWIN_MLP_ABL)) {   // diagnostic build: another variant of the generated body (ablations give wrong results)
         switch (atoi(e)) {
@@ -198,6 +212,18 @@ int launch_swin_proj_mlp512(const uint16_t *att, const uint16_t *wp, const float
                             int64_t m, float eps, hipStream_t stream) {
     VSC_REQUIRE(att && wp && bp && gamma1 && beta1 && w1 && b1 && w2c && b2 && gamma2 && beta2 && x && xb && m > 0, "swin_proj_mlp512: null/empty");
     VSC_REQUIRE(m < (1ll << 21), "swin_proj_mlp512: %lld rows (x is addressed through one 4-GiB buffer descriptor: < 2^21 rows per call)", (long long)m);
-    const Mlp512Args a{w1, b1, w2c, b2, gamma2, beta2, x, xb, m, eps, nullptr, att, wp, bp, gamma1, beta1};
+    const Mlp512Args a{w1, b1, w2c, b2, gamma2, beta2, x, xb, m, eps, nullptr, att, wp, bp, gamma1, beta1, nullptr, nullptr, nullptr};
     return launch_k<1>(a, stream);
+}
+
+// ... and the NEXT block's qkv Linear behind it (variant 9): qkv_next = bf16(x) Wq^T + bq straight from the registers that hold the new
+// shadow, which is then not written to memory at all (xb is untouched).  m * 3072 must fit 32 bits.
+int launch_swin_proj_mlp_qkv512(const uint16_t *att, const uint16_t *wp, const float *bp, const float *gamma1, const float *beta1, const uint16_t *w1,
+                                const float *b1, const uint16_t *w2c, const float *b2, const float *gamma2, const float *beta2, const uint16_t *wq,
+                                const float *bq, float *x, uint16_t *qkv_next, int64_t m, float eps, hipStream_t stream) {
+    VSC_REQUIRE(att && wp && bp && gamma1 && beta1 && w1 && b1 && w2c && b2 && gamma2 && beta2 && wq && bq && x && qkv_next && m > 0,
+                "swin_proj_mlp_qkv512: null/empty");
+    VSC_REQUIRE(m * 3072 < (1ll << 32), "swin_proj_mlp_qkv512: %lld rows (the qkv rows are addressed through one 4-GiB buffer descriptor)", (long long)m);
+    const Mlp512Args a{w1, b1, w2c, b2, gamma2, beta2, x, nullptr, m, eps, nullptr, att, wp, bp, gamma1, beta1, wq, bq, qkv_next};
+    return launch_k<9>(a, stream);
 }

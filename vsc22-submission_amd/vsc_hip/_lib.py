@@ -86,6 +86,7 @@ SIGNATURES = {
     "vsc_swin_mlp_permute_hidden_f32": (c_int32, [c_void_p, c_void_p, c_int32]),
     "vsc_debug_mlp512_timing": (c_int32, [c_void_p]),
     "vsc_swin_proj_mlp_bf16": (c_int32, [c_void_p] * 13 + [c_int64, c_int32, ctypes.c_float, c_void_p]),
+    "vsc_swin_proj_mlp_qkv_bf16": (c_int32, [c_void_p] * 15 + [c_int64, c_int32, ctypes.c_float, c_void_p]),
     "vsc_merge_gather_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "vsc_pair_similarity_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p,
                                           c_void_p, c_int64, c_void_p]),

@@ -299,6 +299,26 @@ def swin_proj_mlp_bf16(x, att, wp, bp, gamma1, beta1, w1, b1, w2, b2, gamma2, be
     return x, xb
 
 
+def swin_proj_mlp_qkv_bf16(x, att, wp, bp, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, wq, bq, eps: float):
+    """swin_proj_mlp_bf16 with the next block's qkv Linear behind it (width 512): -> (x_out fp32, qkv_next = bf16(x_out) @ wq.T + bq as bf16)."""
+    import numpy as np
+    lib = _lib.require_device()
+    x = _dev(x, torch.float32).clone()
+    m, c = x.shape
+    dev = x.device
+    qkv = torch.empty((m, 3 * c), dtype=torch.bfloat16, device=dev)
+    attd = _dev(att.to(dev), torch.bfloat16)
+    w2h = np.ascontiguousarray(w2.detach().float().cpu().numpy())
+    w2p = np.empty_like(w2h)
+    check(lib.vsc_swin_mlp_permute_hidden_f32(w2h.ctypes.data, w2p.ctypes.data, c))
+    wpd, w1d, wqd = (_dev(t.to(dev), torch.bfloat16) for t in (wp, w1, wq))
+    w2d = torch.from_numpy(w2p).to(dev).to(torch.bfloat16)
+    f = [_dev(t.to(dev), torch.float32) for t in (bp, gamma1, beta1, b1, b2, gamma2, beta2, bq)]
+    check(lib.vsc_swin_proj_mlp_qkv_bf16(ptr(attd), ptr(wpd), ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(w1d), ptr(f[3]), ptr(w2d), ptr(f[4]), ptr(f[5]),
+                                         ptr(f[6]), ptr(wqd), ptr(f[7]), ptr(x), ptr(qkv), m, c, eps, current_stream()))
+    return x, qkv
+
+
 def merge_gather_bf16(xb, frames: int, res: int):
     lib = _lib.require_device()
     xb = _dev(xb, torch.bfloat16)
