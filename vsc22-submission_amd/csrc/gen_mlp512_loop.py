@@ -35,7 +35,8 @@ SLOT = 32768
 LDS_W1, LDS_W2 = 0, 2 * SLOT
 NCH = 64
 PF, STAGGER, TIMING, ABL, PROJ, QKV = 8, 0, False, 0, False, False    # defaults; main() builds the variants listed in VARIANTS
-# ABL (diagnostic variants, wrong results): 1 no GELU arithmetic, 2 no LDS-DMA in the loop, 4 no fragment reads, 8 no MFMAs in the loop
+# ABL (diagnostic variants, wrong results): 1 no GELU arithmetic, 2 no LDS-DMA in the loop, 4 no fragment reads, 8 no MFMAs in the loop;
+# in the QKV phase: 16 no LDS-DMA, 32 no chunk barrier, 64 no bias + rounding + store, 128 no fragment reads
 GELU_DEG = 8
 GELU_U = 4.5
 GELU_ZS = 2.0 / (4.5 * 4.5)
@@ -72,7 +73,7 @@ def W1P(a): return f"%[w1p{a}]"
 W2P, B1P, V2, W1R, W2R, SW, SLW = "%[w2p]", "%[b1p]", "%[v2]", "%[w1r]", "%[w2r]", "%[swave]", "%[sldsw]"
 VECP, XBOFF, BP16, BP32, XR, XBR, EPS = "%[vecp]", "%[xboff]", "%[bp16]", "%[bp32]", "%[xr]", "%[xbr]", "%[eps]"
 ATTR, WPR = "%[attr]", "%[wpr]"      # PROJ: descriptors of the attention output rows and of attn.proj.weight
-WQR, QR, QOFF = "%[dbgr]", "%[xbr]", "v200"   # QKV (no operands left: 16 VGPRs outside the clobbers, SGPRs likewise): the kernel passes the next block's qkv weight in the timing buffer's place and the qkv rows in the shadow's; row * 3072 + 16 quad is derived from xboff
+WQR, QR = "%[dbgr]", "%[xbr]"   # QKV (no operands left: 16 VGPRs outside the clobbers, SGPRs likewise): the kernel passes the next block's qkv weight in the timing buffer's place and the qkv rows in the shadow's; row * 3072 + 16 quad is derived from xboff
 DBGR, DBGOFF = "%[dbgr]", "%[dbgoff]"      # timing variant: per-wave cycle counters go to dbgr at byte offset dbgoff
 S_TS, S_ACC = 70, 80                     # s[70:79] time stamps (pairs), s80.. accumulated differences
 S_MT1X, S_MT1B = 66, 67     # byte offsets of the second 16-row tile in x / xb
@@ -164,7 +165,7 @@ def group(E, g, end, between=(), after=(), zero_start=False):
         E.i(l)
     for l in second:
         E.i(l)
-    if g + PF < end and not (ABL & 4):
+    if g + PF < end and not (ABL & 4) and not (ABL & 128 and zero_start):
         a, off = frag_addr(g + PF)
         E.ds_read(("f", g + PF), WQ(g % PF), a, off)
     for l in after:
@@ -461,78 +462,184 @@ def proj_ln(E, gam=8192, bet=10240, agent_scope=False, head=None):
 def qkv_phase(E):
     """QKV: the NEXT block's qkv Linear on this block's output rows, which never leave the registers as bf16:
         qkv[rows, 0:1536] = bf16(x_out) Wqkv^T + (q_bias | 0 | v_bias)
-    as 48 chunks of 32 columns on GEMM 1's machinery (proj_gemm's ring scheme: chunk c in slot c & 3, requested three chunks ahead,
-    counted waits; Wqkv's rows permuted at the DMA source so that a lane ends with 8 consecutive columns: one 16-byte store per row
-    tile and chunk).  The accumulation starts from zero and the bias is added at the end -- the order of the stand-alone qkv GEMM, so
-    the result is the same bits.  Replaces a launch that read the 67-MB shadow back (which is then not written at all)."""
-    NQC = 48
-    QOFF_SO = 87          # s87: byte offset of the second 16-row tile in the qkv rows
+    on GEMM 1's machinery, 64 columns (two 32-row chunks A, B of Wqkv = two ring slots) per barrier: 24 double chunks, double chunk s
+    in slots 2 (s & 1) and + 1, the next one requested while this one is multiplied (Wqkv's rows permuted at the DMA source so that a
+    lane ends with 8 consecutive columns per chunk: one 16-byte store per row tile and chunk).  The 64 MFMA groups of a double chunk
+    are ONE stream -- the fragment ring runs across the A / B boundary, B accumulates in a second register set and A's bias + rounding
+    + stores sit behind B's first two groups, so the matrix pipe never drains for them.  The accumulation starts from zero and the
+    bias is added at the end -- the order of the stand-alone qkv GEMM.  Replaces a launch that read the 67-MB shadow back (which is
+    then not written at all).
+    A LOOP of 12 passes x 2 double chunks (the ring's period): everything that depends on the pass sits in three scalar registers
+    and one vector register that advance once per pass.
+    Measured on the way here (tools/micro/qkv512_phase.py, profiles/r05_qkv512_phase.txt): one barrier per 32-column chunk cost
+    2 270 cycles per chunk against 1 024 of MFMA issue -- 1 850 of them in the 32 groups themselves, the same groups that take
+    1 300 inside the MLP loop's 64-group iterations: what a barrier costs is the four waves' drift plus a cold fragment ring."""
+    NS = 24
+    STAMP = bool(ABL & 1024)
+    S_QO1, S_QI, S_QB, S_QO0 = 87, 88, 89, 90    # byte offset of the second / first 16-row tile in the qkv rows (+ 256 per pass); passes left; DMA source base
+    VB, QOFF = "v249", "v248"                    # bias base (+ 512 per pass); row * 3072 + 16 quad
+    def HACC1(mt, j): return 200 + 4 * (2 * mt + j)      # B's accumulators (the GELU's fragment registers)
+    def BZ1(j): return 232 + 4 * j                       # B's bias
+    KSET = [[224, 228], [240, 244]]                      # rounded results of A / B (v224..v231, v240..v247)
 
-    def wq_items(chunk):
+    def perm(chunk, qq):
+        return chunk * SLOT + (8 * (qq & 3) + 4 * (qq >> 2)) * 1024
+
+    def wq_items(chunk, rolled=False):
+        """LDS-DMA of chunk `chunk` into slot chunk & 3; rolled: requested by the pass before its own (chunk = 4 pass + r, r = 2 .. 5
+        relative to the requesting pass): source = S_QB (this wave's rows + 4 pass SLOT) + the rest.  The last pass requests chunks
+        48, 49, past Wqkv's end: zeros arrive, nobody reads them -- the scalar offset is part of the descriptor's range check on
+        this part: tools/micro/buffer_soffset_range.hip"""
         items = []
         for qq in range(8):
-            src = chunk * SLOT + (8 * (qq & 3) + 4 * (qq >> 2)) * 1024
-            items.append(([f"s_add_u32 m0, {SLW}, {(chunk & 3) * SLOT + qq * 4096}", f"s_add_u32 s{S_T2}, {SW}, {src}"],
+            if rolled:
+                src, base = perm(chunk - 4 * ((chunk - 2) >> 2), qq), f"s{S_QB}"
+            else:
+                src, base = perm(chunk, qq), SW
+            items.append(([f"s_add_u32 m0, {SLW}, {(chunk & 3) * SLOT + qq * 4096}", f"s_add_u32 s{S_T2}, {base}, {src}"],
                           f"buffer_load_dwordx4 {V1(qq & 3)}, {WQR}, s{S_T2} offen lds", ("q", chunk, qq)))
         return items
 
     def head():
-        E.c("every wave is past the last GEMM 2: the ring takes the first chunks of the next block's Wqkv")
+        E.c("every wave is past the last GEMM 2: the ring takes the first double chunk of the next block's Wqkv")
         E.vq = []
         E.i("s_barrier")
-        for chunk in range(3):
+        for chunk in range(2):
             for pre, load, tag in wq_items(chunk):
                 for l in pre:
                     E.i(l)
                 E.vm(tag, load)
 
-    E.c("---- epilogue of the QKV variant: MFMA D -> v_accvgpr_read")
-    E.i("s_nop 15")
-    proj_ln(E, gam=2048, bet=4096, agent_scope=PROJ, head=head)
-    E.i(f"s_mov_b32 s{QOFF_SO}, {16 * 3072}")
-    E.c("row * 3072 + 16 quad = 3 xboff - 2 (16 quad), xboff = row * 1024 + 16 quad")
-    E.i(f"v_and_b32 v201, 0x3ff, {XBOFF}")
-    E.i(f"v_lshl_add_u32 {QOFF}, {XBOFF}, 1, {XBOFF}")
-    E.i(f"v_lshlrev_b32 v201, 1, v201")
-    E.i(f"v_sub_u32 {QOFF}, {QOFF}, v201")
-    cur = 0
-    for c in range(NQC):
-        E.c(f"qkv chunk {c}: columns {32 * c} .. {32 * c + 31}")
-        E.vm_wait(("q", c, 7))
-        E.i("s_barrier")
-        for j in range(2):
-            E.ds_read(("b", j), BZ(j), VECP, 12288 + 128 * c + 16 * j)
-        for g in range(32, 32 + PF):
-            a, off = frag_addr(g)
-            E.ds_read(("f", g), WQ(g % PF), a, off)
-        items = wq_items(c + 3) if c + 3 < NQC else []
-        for g in range(32, 64):
-            k = g - 32
-            if k % 2 == 0 and k // 2 < len(items):
-                pre, load, tag = items[k // 2]
-                group(E, g, 64, between=pre, zero_start=True)
-                E.vm(tag, load)
-            else:
-                group(E, g, 64, zero_start=True)
-        assert not E.q or all(t[0] == "b" for t in E.q)
-        E.wait_all()
-        E.c("MFMA D -> vector reader; + bias, round, store (register sets alternate: the previous chunk's stores may still be reading theirs)")
-        E.i("s_nop 7")
-        E.i("s_nop 3")
-        K = [224 + 16 * (c & 1), 228 + 16 * (c & 1)]   # v224..v255: the GELU's registers (the fragment ring and the accumulators are live here)
+    def qstamp(k):
+        """diagnostic: s[70 + 2k : +1] = s_memtime (an SMEM return: only where the LDS queue is empty)"""
+        if STAMP:
+            assert not E.q
+            E.i(f"s_memtime s[{70 + 2 * k}:{71 + 2 * k}]")
+            E.i("s_waitcnt lgkmcnt(0)")
+
+    def finish(c, half):
+        """+ bias, round, store the 32 columns of chunk c (r = its position in the pass)"""
+        if ABL & 64:
+            return
+        r = c & 3
+        H, B, K = (HACC, BZ, KSET[0]) if half == 0 else (HACC1, BZ1, KSET[1])
         for mt in range(2):
             for j in range(2):
                 for h in (0, 2):
-                    E.i(f"v_pk_add_f32 {vp(HACC(mt, j) + h)}, {vp(HACC(mt, j) + h)}, {vp(BZ(j) + h)}")
+                    E.i(f"v_pk_add_f32 {vp(H(mt, j) + h)}, {vp(H(mt, j) + h)}, {vp(B(j) + h)}")
             for j in range(2):
-                E.i(f"v_cvt_pk_bf16_f32 v{K[mt] + 2 * j}, v{HACC(mt, j)}, v{HACC(mt, j) + 1}")
-                E.i(f"v_cvt_pk_bf16_f32 v{K[mt] + 2 * j + 1}, v{HACC(mt, j) + 2}, v{HACC(mt, j) + 3}")
-            so = "0" if mt == 0 else f"s{QOFF_SO}"
-            E.vm(("o", c, mt), f"buffer_store_dwordx4 {vq(K[mt])}, {QOFF}, {QR}, {so} offen offset:{64 * c}")
-        nxt = (c + 1) & 3
+                E.i(f"v_cvt_pk_bf16_f32 v{K[mt] + 2 * j}, v{H(mt, j)}, v{H(mt, j) + 1}")
+                E.i(f"v_cvt_pk_bf16_f32 v{K[mt] + 2 * j + 1}, v{H(mt, j) + 2}, v{H(mt, j) + 3}")
+            if not (ABL & 4096):    # (diagnostic: the arithmetic without the stores)
+                E.vm(("o", c, mt), f"buffer_store_dwordx4 {vq(K[mt])}, {QOFF}, {QR}, s{S_QO0 if mt == 0 else S_QO1} offen offset:{64 * r}")
+
+    def frag(G):
+        a, off = frag_addr(32 + (G & 31))
+        return a, off + SLOT * (G >> 5)
+
+    def double_chunk(s_):
+        """double chunk s_ = chunks 2 s_ (A) and 2 s_ + 1 (B), ring slots 2 (s_ & 1) and + 1 (the fragment bases point at A's)"""
+        cA, cB = 2 * s_, 2 * s_ + 1
+        E.c(f"qkv double chunk {s_}: columns {64 * s_} .. {64 * s_ + 63}")
+        qstamp(0)
+        E.vm_wait(("q", cB, 7))
+        if ABL & 16 and s_ >= 1:
+            E.vm_wait(("o", cB - 2, 1))
+        if not (ABL & 32):
+            E.i("s_barrier")
+        qstamp(1)
+        for half, B in ((0, BZ), (1, BZ1)):
+            for j in range(2):
+                E.ds_read(("b", half, j), B(j), VB, 12288 + 128 * ((cA + half) & 3) + 16 * j)
+        if not (ABL & 128):
+            for G in range(PF):
+                a, off = frag(G)
+                E.ds_read(("f", G), WQ(G % PF), a, off)
+        items = [] if ABL & 16 else wq_items(cA + 2, True) + wq_items(cB + 2, True)
+        for G in range(64):
+            half, e = G >> 5, G & 31
+            j, ks = e & 1, e >> 1
+            H = HACC if half == 0 else HACC1
+            E.wait(("f", G))
+            w = vq(WQ(G % PF))
+            pre, load, tag = items[G] if G < len(items) else ((), None, None)      # all sixteen requests early: they have the rest of this double chunk to land
+            for mt in range(2):
+                if not (ABL & 8):
+                    E.i(f"v_mfma_f32_16x16x32_bf16 {vq(H(mt, j))}, {w}, {XF(mt, ks)}, {'0' if ks == 0 else vq(H(mt, j))}")
+                if mt == 0:
+                    for l in pre:
+                        E.i(l)
+            if G + PF < 64 and not (ABL & 128):
+                a, off = frag(G + PF)
+                E.ds_read(("f", G + PF), WQ(G % PF), a, off)
+            if load:
+                E.vm(tag, load)
+            if G == 33:
+                E.c("A's results (its last MFMA was issued 4 MFMAs = 64 cycles ago): + bias, round, store")
+                finish(cA, 0)
+        assert not E.q or all(t[0] == "b" for t in E.q)
+        E.wait_all()
+        E.c("MFMA D -> vector reader; B's results")
+        E.i("s_nop 7")
+        E.i("s_nop 3")
+        qstamp(2)
+        finish(cB, 1)
         for a in range(4):
-            E.i(f"v_xor_b32 {W1P(a)}, {hex((cur ^ nxt) * SLOT)}, {W1P(a)}")
-        cur = nxt
+            E.i(f"v_xor_b32 {W1P(a)}, {hex(2 * SLOT)}, {W1P(a)}")
+        qstamp(3)
+        for k in range(3):
+            if STAMP:
+                E.i(f"s_sub_u32 s{S_T}, s{70 + 2 * (k + 1)}, s{70 + 2 * k}")
+                E.i(f"s_add_u32 s{80 + k}, s{80 + k}, s{S_T}")
+
+    E.c("---- epilogue of the QKV variant: MFMA D -> v_accvgpr_read")
+    E.i("s_nop 15")
+    proj_ln(E, gam=2048, bet=4096, agent_scope=PROJ, head=head)
+    E.i(f"s_mov_b32 s{S_QO0}, 0")
+    E.i(f"s_mov_b32 s{S_QO1}, {16 * 3072}")
+    E.i(f"s_mov_b32 s{S_QB}, {SW}")
+    E.c("row * 3072 + 16 quad = 3 xboff - 2 (16 quad), xboff = row * 1024 + 16 quad")
+    E.i(f"v_and_b32 {VB}, 0x3ff, {XBOFF}")
+    E.i(f"v_lshl_add_u32 {QOFF}, {XBOFF}, 1, {XBOFF}")
+    E.i(f"v_lshlrev_b32 {VB}, 1, {VB}")
+    E.i(f"v_sub_u32 {QOFF}, {QOFF}, {VB}")
+    E.i(f"v_mov_b32 {VB}, {VECP}")
+    if STAMP:
+        E.i("s_memtime s[92:93]")
+        for k in range(4):
+            E.i(f"s_mov_b32 s{80 + k}, 0")
+    # the pass's text in the steady state: generate pass 0 (thrown away), pass 1 (kept), pass 2 (must be the same text).  The counted
+    # vmcnt waits of the steady state are right for pass 0 as well: there the operations younger than a wait's target are the
+    # steady state's plus the LayerNorm's loads and stores, all of them issued after the target -- the wait only asks for more.
+    texts = []
+    for it in range(3):
+        mark = len(E.lines)
+        for h in range(2):
+            double_chunk(2 * it + h)
+        texts.append(E.lines[mark:])
+        del E.lines[mark:]
+    strip = lambda t: [l for l in t if not l.startswith(";")]
+    assert strip(texts[1]) == strip(texts[2])
+    E.i(f"s_mov_b32 s{S_QI}, {NS // 2}")
+    E.i("L_qkv%=:")
+    E.lines.extend(texts[1])
+    E.c("next pass: 4 chunks = 4 ring slots of Wqkv rows, 128 columns of bias and of the qkv rows")
+    E.i(f"s_add_u32 s{S_QB}, s{S_QB}, {4 * SLOT}")
+    E.i(f"s_add_u32 s{S_QO0}, s{S_QO0}, 256")
+    E.i(f"s_add_u32 s{S_QO1}, s{S_QO1}, 256")
+    E.i(f"v_add_u32 {VB}, 512, {VB}")
+    E.i(f"s_sub_u32 s{S_QI}, s{S_QI}, 1")
+    E.i(f"s_cmp_lg_u32 s{S_QI}, 0")
+    E.i("s_cbranch_scc1 L_qkv%=")
+    if STAMP:
+        E.c("diagnostic: (the whole phase | waiting for the LDS-DMA and at the barrier | fragments + MFMAs + A's results | B's results), shader cycles summed over the double chunks, into the first 16 bytes of the lane's qkv row")
+        E.i("s_memtime s[94:95]")
+        E.i("s_waitcnt lgkmcnt(0)")
+        E.i("s_sub_u32 s92, s94, s92")
+        E.i("v_mov_b32 v208, s92")
+        for k in range(3):
+            E.i(f"v_mov_b32 v{209 + k}, s{80 + k}")
+        E.i(f"buffer_store_dwordx4 v[208:211], {QOFF}, {QR}, 0 offen")
     E.vq = []
 
 
@@ -771,6 +878,9 @@ VARIANTS = [(8, 0, False, 0, False, False), (8, 0, False, 0, True, False), (8, 0
 
 def main():
     global PF, STAGGER, TIMING, ABL, PROJ, QKV
+    import os
+    if os.environ.get("VSC_GEN_QKV_ABL"):   # diagnostic builds (make EXTRA=-DVSC_MLP_ABLATION): the QKV phase's ablations as variants 10 .. 13
+        VARIANTS.extend((8, 0, False, a, True, True) for a in (16, 32, 64, 128, 1024, 4096))
     out = ["// GENERATED by gen_mlp512_loop.py -- do not edit.  One asm statement per variant: the body of swin_mlp512_kernel<V>."]
     for k, (PF, STAGGER, TIMING, ABL, PROJ, QKV) in enumerate(VARIANTS):
         lines = program()

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     // x / xb rows through descriptors over the m rows that exist: rows past m return zeros and their stores are dropped
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void *)p.x, 0, (int)(uint32_t)(p.m * C * 4), 0x00020000);
     // (QKV: the qkv rows [m, 1536] stand in the shadow's descriptor, which that variant never writes)
-    const __amdgpu_buffer_rsrc_t xbr = V == 9 ? __builtin_amdgcn_make_buffer_rsrc((void *)p.qkv, 0, (int)(uint32_t)(p.m * 3 * C * 2), 0x00020000)
+    const __amdgpu_buffer_rsrc_t xbr = V >= 9 ? __builtin_amdgcn_make_buffer_rsrc((void *)p.qkv, 0, (int)(uint32_t)(p.m * 3 * C * 2), 0x00020000)
                                               : __builtin_amdgcn_make_buffer_rsrc((void *)p.xb, 0, (int)(uint32_t)(p.m * C * 2), 0x00020000);
     uint32_t v1[4];   // W1: LDS row q = chunk row q, LDS piece `lane` <- source piece lane ^ (q & 15), q & 15 = 4 (qq & 3) + wave
 #pragma unroll
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     const uint32_t bp16 = (uint32_t)((lane ^ 16) << 2), bp32 = (uint32_t)((lane ^ 32) << 2);
     const uint32_t eps = __builtin_amdgcn_readfirstlane(__float_as_uint(p.eps));
     // (QKV: the next block's qkv weight [1536, 512] stands in the timing buffer's descriptor -- the asm has no operand to spare)
-    const __amdgpu_buffer_rsrc_t dbgr = V == 9 ? __builtin_amdgcn_make_buffer_rsrc((void *)p.wq, 0, 3 * C * C * 2, 0x00020000)
+    const __amdgpu_buffer_rsrc_t dbgr = V >= 9 ? __builtin_amdgcn_make_buffer_rsrc((void *)p.wq, 0, 3 * C * C * 2, 0x00020000)
                                                : __builtin_amdgcn_make_buffer_rsrc((void *)p.dbg, 0, p.dbg ? (int)(gridDim.x * NW * 32) : 0, 0x00020000);
     const uint32_t dbgoff = (blockIdx.x * NW + (uint32_t)wave) * 32u;
     const uint32_t bid = blockIdx.x;
@@ -117,12 +117,12 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
         b2s[i] = p.b2[i];
         gs[i] = p.gamma[i];
         bs[i] = p.beta[i];
-        if (V == 1 || V == 9) {
+        if (V == 1 || V >= 9) {
             bs[C + i] = p.bp[i];
             bs[2 * C + i] = p.gamma1[i];
             bs[3 * C + i] = p.beta1[i];
         }
-        if (V == 9) {
+        if (V >= 9) {
             bs[4 * C + i] = p.bq[i];
             bs[5 * C + i] = p.bq[C + i];
             bs[6 * C + i] = p.bq[2 * C + i];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     const __amdgpu_buffer_rsrc_t wpr = __builtin_amdgcn_make_buffer_rsrc((void *)p.wp, 0, p.wp ? C * C * 2 : 0, 0x00020000);
     // ---- everything else: rows in, the hidden-axis loop, LayerNorm + residual + shadow out
 #define VSC_MLP512_BODY(K) asm volatile(VSC_MLP512_LOOP_ASM_##K : VSC_MLP512_LOOP_OUTS : VSC_MLP512_LOOP_INS : VSC_MLP512_LOOP_CLOBBERS)
-    static_assert(VSC_MLP512_VARIANTS == 10, "variant dispatch below");
+    static_assert(VSC_MLP512_VARIANTS == 10 || VSC_MLP512_VARIANTS == 16, "variant dispatch below (16: VSC_GEN_QKV_ABL=1 python gen_mlp512_loop.py)");
     if (V == 0) VSC_MLP512_BODY(0);
     else if (V == 1) VSC_MLP512_BODY(1);
     else if (V == 9) VSC_MLP512_BODY(9);
@@ -144,7 +144,15 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     else if (V == 5) VSC_MLP512_BODY(5);
     else if (V == 6) VSC_MLP512_BODY(6);
     else if (V == 7) VSC_MLP512_BODY(7);
-    else VSC_MLP512_BODY(8);
+    else if (V == 8) VSC_MLP512_BODY(8);
+#if VSC_MLP512_VARIANTS == 16
+    else if (V == 10) VSC_MLP512_BODY(10);
+    else if (V == 11) VSC_MLP512_BODY(11);
+    else if (V == 12) VSC_MLP512_BODY(12);
+    else if (V == 13) VSC_MLP512_BODY(13);
+    else if (V == 14) VSC_MLP512_BODY(14);
+    else if (V == 15) VSC_MLP512_BODY(15);
+#endif
 #endif
 #undef VSC_MLP512_BODY
 }
@@ -225,5 +233,18 @@ int launch_swin_proj_mlp_qkv512(const uint16_t *att, const uint16_t *wp, const f
                 "swin_proj_mlp_qkv512: null/empty");
     VSC_REQUIRE(m * 3072 < (1ll << 32), "swin_proj_mlp_qkv512: %lld rows (the qkv rows are addressed through one 4-GiB buffer descriptor)", (long long)m);
     const Mlp512Args a{w1, b1, w2c, b2, gamma2, beta2, x, nullptr, m, eps, nullptr, att, wp, bp, gamma1, beta1, wq, bq, qkv_next};
+#if defined(VSC_MLP_ABLATION) && VSC_MLP512_VARIANTS == 16
+    if (const char *e = vsc_opt(OPT_SWIN_MLP_ABL)) {   // diagnostic build: the QKV phase's ablations (wrong results)
+        switch (atoi(e)) {
+            case 10: return launch_k<10>(a, stream);
+            case 11: return launch_k<11>(a, stream);
+            case 12: return launch_k<12>(a, stream);
+            case 13: return launch_k<13>(a, stream);
+            case 14: return launch_k<14>(a, stream);
+            case 15: return launch_k<15>(a, stream);
+            default: break;
+        }
+    }
+#endif
     return launch_k<9>(a, stream);
 }
