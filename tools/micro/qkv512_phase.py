@@ -41,9 +41,10 @@ def med(v):
 
 
 names = {1: "proj + MLP without the phase", 0: "the stand-alone qkv GEMM", 9: "the phase as shipped", 10: "no LDS-DMA in the chunk loop", 11: "no barrier",
-         12: "no bias + rounding + store", 13: "no fragment reads", 14: "stamped", 15: "bias + rounding, no stores"}
-RIGHT = (9,)      # variants whose results must equal variant 9's
-variants = [1, 0] + [int(a) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else "9,10,11,12,13,14,15".split(","))]
+         12: "no bias + rounding + store", 13: "no fragment reads", 14: "stamped", 15: "bias + rounding, no stores",
+         16: "fragment ring of 10", 17: "ring refills every other group", 18: "ring of 10 + refills every other group"}
+RIGHT = (9, 16, 17, 18)      # variants whose results must equal variant 9's
+variants = [1, 0] + [int(a) for a in (sys.argv[1].split(",") if len(sys.argv) > 1 else "9,10,11,12,13,14,15,16,17,18".split(","))]
 
 
 def launch(v):

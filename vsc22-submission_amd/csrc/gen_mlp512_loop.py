@@ -476,6 +476,8 @@ def qkv_phase(E):
     1 300 inside the MLP loop's 64-group iterations: what a barrier costs is the four waves' drift plus a cold fragment ring."""
     NS = 24
     STAMP = bool(ABL & 1024)
+    PF = 10 if ABL & 8192 else 8                 # (experiment: a deeper fragment ring -- v160..v199)
+    SPARSE = bool(ABL & 16384)                   # (experiment: a ring refill every other group of the first 32 instead of every group of the first 16)
     S_QO1, S_QI, S_QB, S_QO0 = 87, 88, 89, 90    # byte offset of the second / first 16-row tile in the qkv rows (+ 256 per pass); passes left; DMA source base
     VB, QOFF = "v249", "v248"                    # bias base (+ 512 per pass); row * 3072 + 16 quad
     def HACC1(mt, j): return 200 + 4 * (2 * mt + j)      # B's accumulators (the GELU's fragment registers)
@@ -562,7 +564,8 @@ def qkv_phase(E):
             H = HACC if half == 0 else HACC1
             E.wait(("f", G))
             w = vq(WQ(G % PF))
-            pre, load, tag = items[G] if G < len(items) else ((), None, None)      # all sixteen requests early: they have the rest of this double chunk to land
+            k = G // 2 if SPARSE and G % 2 == 0 else (G if not SPARSE else 99)
+            pre, load, tag = items[k] if k < len(items) else ((), None, None)      # all sixteen requests early: they have the rest of this double chunk to land
             for mt in range(2):
                 if not (ABL & 8):
                     E.i(f"v_mfma_f32_16x16x32_bf16 {vq(H(mt, j))}, {w}, {XF(mt, ks)}, {'0' if ks == 0 else vq(H(mt, j))}")
@@ -880,7 +883,7 @@ def main():
     global PF, STAGGER, TIMING, ABL, PROJ, QKV
     import os
     if os.environ.get("VSC_GEN_QKV_ABL"):   # diagnostic builds (make EXTRA=-DVSC_MLP_ABLATION): the QKV phase's ablations as variants 10 .. 13
-        VARIANTS.extend((8, 0, False, a, True, True) for a in (16, 32, 64, 128, 1024, 4096))
+        VARIANTS.extend((8, 0, False, a, True, True) for a in (16, 32, 64, 128, 1024, 4096, 8192, 16384, 8192 + 16384))
     out = ["// GENERATED by gen_mlp512_loop.py -- do not edit.  One asm statement per variant: the body of swin_mlp512_kernel<V>."]
     for k, (PF, STAGGER, TIMING, ABL, PROJ, QKV) in enumerate(VARIANTS):
         lines = program()

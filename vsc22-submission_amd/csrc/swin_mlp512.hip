@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     const __amdgpu_buffer_rsrc_t wpr = __builtin_amdgcn_make_buffer_rsrc((void *)p.wp, 0, p.wp ? C * C * 2 : 0, 0x00020000);
     // ---- everything else: rows in, the hidden-axis loop, LayerNorm + residual + shadow out
 #define VSC_MLP512_BODY(K) asm volatile(VSC_MLP512_LOOP_ASM_##K : VSC_MLP512_LOOP_OUTS : VSC_MLP512_LOOP_INS : VSC_MLP512_LOOP_CLOBBERS)
-    static_assert(VSC_MLP512_VARIANTS == 10 || VSC_MLP512_VARIANTS == 16, "variant dispatch below (16: VSC_GEN_QKV_ABL=1 python gen_mlp512_loop.py)");
+    static_assert(VSC_MLP512_VARIANTS == 10 || VSC_MLP512_VARIANTS == 19, "variant dispatch below (19: VSC_GEN_QKV_ABL=1 python gen_mlp512_loop.py)");
     if (V == 0) VSC_MLP512_BODY(0);
     else if (V == 1) VSC_MLP512_BODY(1);
     else if (V == 9) VSC_MLP512_BODY(9);
@@ -145,13 +145,16 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     else if (V == 6) VSC_MLP512_BODY(6);
     else if (V == 7) VSC_MLP512_BODY(7);
     else if (V == 8) VSC_MLP512_BODY(8);
-#if VSC_MLP512_VARIANTS == 16
+#if VSC_MLP512_VARIANTS == 19
     else if (V == 10) VSC_MLP512_BODY(10);
     else if (V == 11) VSC_MLP512_BODY(11);
     else if (V == 12) VSC_MLP512_BODY(12);
     else if (V == 13) VSC_MLP512_BODY(13);
     else if (V == 14) VSC_MLP512_BODY(14);
     else if (V == 15) VSC_MLP512_BODY(15);
+    else if (V == 16) VSC_MLP512_BODY(16);
+    else if (V == 17) VSC_MLP512_BODY(17);
+    else if (V == 18) VSC_MLP512_BODY(18);
 #endif
 #endif
 #undef VSC_MLP512_BODY
@@ -233,7 +236,7 @@ int launch_swin_proj_mlp_qkv512(const uint16_t *att, const uint16_t *wp, const f
                 "swin_proj_mlp_qkv512: null/empty");
     VSC_REQUIRE(m * 3072 < (1ll << 32), "swin_proj_mlp_qkv512: %lld rows (the qkv rows are addressed through one 4-GiB buffer descriptor)", (long long)m);
     const Mlp512Args a{w1, b1, w2c, b2, gamma2, beta2, x, nullptr, m, eps, nullptr, att, wp, bp, gamma1, beta1, wq, bq, qkv_next};
-#if defined(VSC_MLP_ABLATION) && VSC_MLP512_VARIANTS == 16
+#if defined(VSC_MLP_ABLATION) && VSC_MLP512_VARIANTS == 19
     if (const char *e = vsc_opt(OPT_SWIN_MLP_ABL)) {   // diagnostic build: the QKV phase's ablations (wrong results)
         switch (atoi(e)) {
             case 10: return launch_k<10>(a, stream);
@@ -242,6 +245,9 @@ int launch_swin_proj_mlp_qkv512(const uint16_t *att, const uint16_t *wp, const f
             case 13: return launch_k<13>(a, stream);
             case 14: return launch_k<14>(a, stream);
             case 15: return launch_k<15>(a, stream);
+            case 16: return launch_k<16>(a, stream);
+            case 17: return launch_k<17>(a, stream);
+            case 18: return launch_k<18>(a, stream);
             default: break;
         }
     }
