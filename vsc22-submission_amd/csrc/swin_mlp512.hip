@@ -71,7 +71,6 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, quad = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * R + wave * RW;
 
     // ---- operands of the kernel body (swin_mlp512_loop.inc, generated by gen_mlp512_loop.py: the register map is there)
     // LDS-DMA of one chunk (32 KiB, contiguous in memory): instruction q = 4 qq + wave covers the chunk's LDS bytes [1024 q, 1024 q + 1024);
@@ -97,20 +96,12 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     //   W1 fragment (j, ks): row 16 j + fr, piece (4 ks + quad) ^ fr = 16 (ks >> 2) + ((4 (ks & 3) + quad) ^ fr)  -> w1p[ks & 3] + 16384 j + 256 (ks >> 2)
     //   W2 fragment jo:      row n = 32 (jo >> 1) + 4 (jo & 1) + 8 (fr >> 2) + (fr & 3), piece quad ^ swz(n), swz(n) = (fr & 1) | ((fr >> 2) & 1) << 1
     //                                                                                                            -> w2p + 2048 (jo >> 1) + 256 (jo & 1)
-    uint32_t w1p[4], w2p, b1p;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) w1p[a] = ldsbase + (uint32_t)(LDS_W1 + fr * 1024 + (((4 * a + quad) ^ fr) << 4));
-    w2p = ldsbase + (uint32_t)(LDS_W2 + (8 * (fr >> 2) + (fr & 3)) * 64 + ((quad ^ ((fr & 1) | (((fr >> 2) & 1) << 1))) << 4));
-    b1p = ldsbase + (uint32_t)(LDS_B1 + 16 * quad);    // this lane's four bias values of hidden tile 0 of the chunk at hand
     const uint32_t vecp = ldsbase + (uint32_t)(LDS_VEC + 32 * quad);   // b2 | gamma | beta (2 KiB apart), this lane's column offset
-    const uint32_t xboff = (uint32_t)(row0 + fr) * (uint32_t)(C * 2) + 16u * (uint32_t)quad;   // byte offset of row (0, fr), columns 8 quad .., in xb
     const uint32_t bp16 = (uint32_t)((lane ^ 16) << 2), bp32 = (uint32_t)((lane ^ 32) << 2);
     const uint32_t eps = __builtin_amdgcn_readfirstlane(__float_as_uint(p.eps));
     // (QKV: the next block's qkv weight [1536, 512] stands in the timing buffer's descriptor -- the asm has no operand to spare)
     const __amdgpu_buffer_rsrc_t dbgr = V >= 9 ? __builtin_amdgcn_make_buffer_rsrc((void *)p.wq, 0, 3 * C * C * 2, 0x00020000)
-                                               : __builtin_amdgcn_make_buffer_rsrc((void *)p.dbg, 0, p.dbg ? (int)(gridDim.x * NW * 32) : 0, 0x00020000);
-    const uint32_t dbgoff = (blockIdx.x * NW + (uint32_t)wave) * 32u;
-    const uint32_t bid = blockIdx.x;
+                                               : __builtin_amdgcn_make_buffer_rsrc((void *)p.dbg, 0, p.dbg ? (int)(((p.m + R - 1) / R) * NW * 32) : 0, 0x00020000);
 
     for (int i = tid; i < H; i += NW * 64) b1s[i] = p.b1[i];
     for (int i = tid; i < C; i += NW * 64) {
@@ -131,7 +122,21 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
     // PROJ: rows of the attention output / attn.proj.weight (other variants: empty descriptors, never used)
     const __amdgpu_buffer_rsrc_t attr = __builtin_amdgcn_make_buffer_rsrc((void *)p.att, 0, p.att ? (int)(uint32_t)(p.m * C * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t wpr = __builtin_amdgcn_make_buffer_rsrc((void *)p.wp, 0, p.wp ? C * C * 2 : 0, 0x00020000);
-    // ---- everything else: rows in, the hidden-axis loop, LayerNorm + residual + shadow out
+    // ---- everything else: rows in, the hidden-axis loop, LayerNorm + residual + shadow out -- per 128-row tile; a workgroup walks the
+    // tiles blockIdx, blockIdx + gridDim, ... (grid = tiles: one each; a smaller grid (VSC_SWIN_MLP512_GRID) makes the workgroups
+    // persistent).  What the body toggles or advances (the fragment bases, the bias pointer) is set up again per tile.
+    const int ntiles = (int)((p.m + R - 1) / R);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = (int64_t)tile * R + wave * RW;
+    uint32_t w1p[4], w2p, b1p;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) w1p[a] = ldsbase + (uint32_t)(LDS_W1 + fr * 1024 + (((4 * a + quad) ^ fr) << 4));
+    w2p = ldsbase + (uint32_t)(LDS_W2 + (8 * (fr >> 2) + (fr & 3)) * 64 + ((quad ^ ((fr & 1) | (((fr >> 2) & 1) << 1))) << 4));
+    b1p = ldsbase + (uint32_t)(LDS_B1 + 16 * quad);    // this lane's four bias values of hidden tile 0 of the chunk at hand
+    const uint32_t xboff = (uint32_t)(row0 + fr) * (uint32_t)(C * 2) + 16u * (uint32_t)quad;   // byte offset of row (0, fr), columns 8 quad .., in xb
+    const uint32_t dbgoff = ((uint32_t)tile * NW + (uint32_t)wave) * 32u;
+    const uint32_t bid = (uint32_t)tile;
+    if (tile != (int)blockIdx.x) __syncthreads();   // every wave is done with the previous tile's last ring slots (and the body ends on s_waitcnt vmcnt(0))
 #define VSC_MLP512_BODY(K) asm volatile(VSC_MLP512_LOOP_ASM_##K : VSC_MLP512_LOOP_OUTS : VSC_MLP512_LOOP_INS : VSC_MLP512_LOOP_CLOBBERS)
     static_assert(VSC_MLP512_VARIANTS == 10 || VSC_MLP512_VARIANTS == 19, "variant dispatch below (19: VSC_GEN_QKV_ABL=1 python gen_mlp512_loop.py)");
     if (V == 0) VSC_MLP512_BODY(0);
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
 #endif
 #endif
 #undef VSC_MLP512_BODY
+    }
 }
 
 uint32_t *g_mlp512_dbg = nullptr;   // vsc_debug_mlp512_timing
@@ -171,8 +177,12 @@ int launch_k(const Mlp512Args &a, hipStream_t stream) {
         VSC_CHECK_HIP(hipFuncSetAttribute((const void *)swin_mlp512_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         if (dev < 16) attr_set[dev] = true;
     }
-    const int64_t grid = (a.m + R - 1) / R;
+    int64_t grid = (a.m + R - 1) / R;
     VSC_REQUIRE(grid < (1ll << 31), "swin_mlp512: grid too large");
+    if (const char *g = vsc_opt(OPT_SWIN_MLP512_GRID)) {   // experiment: persistent workgroups (e.g. 128: half the chip per launch, the other lane's kernel beside it)
+        const int64_t want = atoll(g);
+        if (want > 0 && want < grid) grid = want;
+    }
     hipLaunchKernelGGL((swin_mlp512_kernel<V>), dim3((unsigned)grid), dim3(NW * 64), LDS_BYTES, stream, a);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
