@@ -1488,7 +1488,13 @@ static int sweep_plan(int64_t nq, int64_t nr, int dp, SweepPlan *out) {
     if (want < 1) want = 1;
     pl.tiles_per_split = (pl.total_tiles + want - 1) / want;
     const int64_t max_tiles = ((1ll << 31) - 1) / ((int64_t)SR * dp * 2);   // a split is one buffer descriptor (32-bit extent)
-    if (pl.tiles_per_split > max_tiles) pl.tiles_per_split = max_tiles;
+    if (pl.tiles_per_split > max_tiles) {
+        // equal splits, not max_tiles + a remainder: at 2 Mi rows x 512 that was 8191 tiles + 1, the items alternate between the two
+        // splits, a workgroup's items keep their parity (grid 256), and every other workgroup swept nothing but one-tile items
+        // (755 TFLOP/s where 1 Mi rows run 1 208: tools/micro/knn_bank_size.py)
+        const int64_t ns = (pl.total_tiles + max_tiles - 1) / max_tiles;
+        pl.tiles_per_split = (pl.total_tiles + ns - 1) / ns;
+    }
     pl.splits = (int)((pl.total_tiles + pl.tiles_per_split - 1) / pl.tiles_per_split);
     const int64_t work = (int64_t)pl.nqb * pl.splits;
     pl.xcd_map = xmap ? 1 : 0;
