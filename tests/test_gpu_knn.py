@@ -206,6 +206,39 @@ def test_knn_tail_balancing_is_invisible(dev):
     assert torch.equal(I, I0) and torch.equal(D.view(torch.int32), D0.view(torch.int32))
 
 
+@pytest.mark.parametrize("nq", [12_000, 40_000, 70_000])
+def test_knn_split_plans_chosen_by_the_cost_model(dev, nq):
+    """sweep_plan picks the number of reference splits by a cost model (rounds of 256 work items x the per-list warm-up): 12 000 queries
+    = 47 blocks (XCD-aware order with 4 splits or the plain order with 5, no longer 16), 40 000 = 157 blocks x 3 splits (two
+    third-size rounds, no longer 1.23 rounds of halves), 70 000 = 274 blocks = one whole round + an 18-block tail swept as a call of its
+    own in 14 splits (no longer two rounds).  Rows from every part of every plan against the oracle, bit for bit, and the tail
+    switch gives the same bits."""
+    from oracle import knn_oracle
+    from vsc_hip import _lib, ops
+    nr, k = 300_000, 100
+    rt = _device_bank(dev, 21, nr)
+    qt = _device_bank(dev, 22, nq)
+    qt[nq - 1] = rt[nr - 1]
+    qt[0] = rt[123]
+    D, I = ops.knn_ip(qt, rt, k)
+    assert _last_path() == 2
+    rows = np.unique(np.r_[0:6, 255:258, 2047:2050, nq // 2:nq // 2 + 3, 65535:65538, nq - 6:nq])
+    rows = rows[rows < nq]
+    Dr, Ir = knn_oracle.knn_ip(qt[torch.from_numpy(rows).to(dev)].cpu().numpy(), rt.cpu().numpy(), k)
+    Dh, Ih = D.cpu().numpy(), I.cpu().numpy()
+    assert np.array_equal(Ih[rows], Ir) and np.array_equal(Dh[rows].view(np.uint32), Dr.view(np.uint32))
+    assert Ih[0, 0] == 123 and Ih[nq - 1, 0] == nr - 1
+    assert (Dh[:, :-1] >= Dh[:, 1:]).all() and Ih.min() >= 0 and Ih.max() < nr
+    _lib.set_option("VSC_KNN_TAIL", "0")
+    _lib.set_option("VSC_KNN_XCD_MAP", "0")
+    try:
+        D0, I0 = ops.knn_ip(qt, rt, k)
+    finally:
+        _lib.set_option("VSC_KNN_TAIL", None)
+        _lib.set_option("VSC_KNN_XCD_MAP", None)
+    assert torch.equal(I, I0) and torch.equal(D.view(torch.int32), D0.view(torch.int32))
+
+
 def test_knn_bank_beyond_one_buffer_descriptor(dev):
     """A split is addressed through one buffer descriptor (32-bit extent): 8191 tiles = 2 096 896 rows of 512-d bf16.  With
     nq >= 65 281 (256 query blocks -> one split wanted) and 2.2 M references the cap forces two splits (knn.hip,

@@ -1437,12 +1437,13 @@ static int knn_exact(const float *q_dev, int64_t nq, const float *r_dev, int64_t
 struct SweepPlan {
     int nqb, splits, grid, xcd_map;
     int64_t total_tiles, tiles_per_split;
+    double cost;   // the model's estimate, in units of "one workgroup sweeps the whole bank"
 };
 static int sweep_plan(int64_t nq, int64_t nr, int dp, SweepPlan *out) {
     SweepPlan pl{};
     pl.nqb = (int)((nq + SQ - 1) / SQ);
     pl.total_tiles = (nr + SR - 1) / SR;
-    int64_t want = (256 + pl.nqb - 1) / pl.nqb;   // enough (query block, ref split) items for one workgroup per CU
+    int64_t want = 1;
     int dev = 0, cus = 0;
     VSC_CHECK_HIP(hipGetDevice(&dev));
     static int cus_of[MAX_DEVICES] = {};
@@ -1451,38 +1452,37 @@ static int sweep_plan(int64_t nq, int64_t nr, int dp, SweepPlan *out) {
         VSC_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         if (dev >= 0 && dev < MAX_DEVICES) cus_of[dev] = cus;
     }
-    // XCD-aware order (see the kernel): super-items of 8 query blocks x 4 splits, one per XCD at a time.  The number of
-    // split groups makes the super-items a multiple of the 8 XCDs when there are few of them.
+    // The number of reference splits by a cost model, in units of "one workgroup sweeps the whole bank":
+    //   plain order     nqb * w items dealt in rounds of 256, an item = 1 / w of the bank:   ceil(nqb w / 256) / w
+    //   XCD-aware order super-items of 8 query blocks x 4 splits, one per XCD at a time (see the kernel), w = 4 c:
+    //                   ceil(ceil(nqb / 8) c / 8) / (4 c), times 0.95 (what the L2 residency of the query blocks buys)
+    // times 1 + 0.09 (w - 1): every (query, split) list pays its own warm-up appends before its threshold filters anything and
+    // is re-scored on its own (measured: 65 536 x 1M with 4 splits instead of 1: 65.6 -> 83.4 ms).  Before round 5 the rule was
+    // "enough items for one round" (plain) / "least idle XCD slots" (XCD-aware), which ignored both the quantisation of later
+    // rounds and the per-list cost: 12 000 x 1M took 28.8 ms (16 splits) where 16 384 x 1M takes 19.3, 40 000 x 1M 59 ms (157
+    // blocks x 2 splits = 1.23 rounds of half size) -- tools/micro/knn_nq_scan.sh, profiles/r05_knn_nq_scan.txt.
+    const double alpha = 0.09;
+    double best = 1e30;
+    const int64_t wmax = pl.total_tiles < 256 ? pl.total_tiles : 256;
+    for (int64_t w = 1; w <= wmax; ++w) {
+        const double c = (double)((pl.nqb * w + 255) / 256) / (double)w * (1.0 + alpha * (double)(w - 1));
+        if (c < best - 1e-9) { best = c; want = w; }
+    }
     const char *xe = vsc_opt(OPT_KNN_XCD_MAP);
-    // Only where the plain order would cut the bank into >= 4 splits anyway (nqb <= 64): every (query, split) list pays its
-    // own warm-up (k (1 + ln(tiles / k)) appends before its threshold is worth anything), so forcing 4 splits on a call
-    // that needs one costs 3.4 x the appends (65 536 x 1M: 65.6 -> 83.4 ms) against the 5.5 % the L2 residency buys.
-    // VSC_KNN_XCD_MAP=1 forces it on for larger calls (the per-query union of the bands keeps the re-scoring cost).
-    bool xmap = cus == 256 && pl.nqb >= 8 && pl.total_tiles >= 32 && !(xe && xe[0] == '0') && (pl.nqb <= 64 || (xe && xe[0] == '1'));
-    if (xmap) {
+    // XCD-aware order: only for calls of 8 .. 64 query blocks (VSC_KNN_XCD_MAP=1: any size from 8 blocks; =0: never)
+    const bool forced = xe && xe[0] == '1';
+    bool xmap = false;
+    if (cus == 256 && pl.nqb >= 8 && pl.total_tiles >= 32 && !(xe && xe[0] == '0') && (pl.nqb <= 64 || forced)) {
         const int nqg = (pl.nqb + 7) / 8;
-        int nsg = 1;
-        if (nqg < 64) {
-            double best = 1e30;
-            for (int c = (8 + nqg - 1) / nqg, e = c + 8; c < e; ++c) {
-                const int items = nqg * c;
-                const double waste = (double)((items + 7) / 8 * 8) / items;
-                if (waste < best - 1e-9) { best = waste; nsg = c; }
-            }
+        double xbest = 1e30;
+        int64_t xwant = 0;
+        for (int64_t c = 1; c <= 64 && 4 * c <= pl.total_tiles / 4; ++c) {
+            const double cost = (double)((nqg * c + 7) / 8) / (double)(4 * c) * (1.0 + alpha * (double)(4 * c - 1)) * 0.95;
+            if (cost < xbest - 1e-9) { xbest = cost; xwant = 4 * c; }
         }
-        want = 4 * nsg;
-        if (want > pl.total_tiles / 4) xmap = false;   // splits of a few tiles: not worth it, plain order
+        if (xwant && (forced || xbest < best)) { xmap = true; want = xwant; best = xbest; }
     }
-    if (!xmap) {
-        want = (256 + pl.nqb - 1) / pl.nqb;
-        // fewer query blocks than workgroups: items = nqb * want are dealt in rounds of 256; one split less can end in whole rounds where
-        // one more spills a handful of items into an extra round (67 blocks: 4 splits = 268 items = two quarter-size rounds, 3 splits =
-        // 201 items = one third-size round)
-        if (pl.nqb < 256 && want > 1) {
-            auto rounds = [&](int64_t w) { return (double)((pl.nqb * w + 255) / 256) / (double)w; };
-            if (rounds(want - 1) < rounds(want)) --want;
-        }
-    }
+    pl.cost = best;
     if (want > 256) want = 256;
     if (want > pl.total_tiles) want = pl.total_tiles;
     if (want < 1) want = 1;
@@ -1719,10 +1719,23 @@ extern "C" int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev
         // of 3 907 blocks (1M queries) runs 15.26 rounds and its sixteenth keeps 67 of 256 CUs busy.  The blocks of that last partial
         // round are swept as a call of their own, which cuts the bank into as many splits as fill the chip once (sweep_plan): a
         // third-size round instead of a whole one.  Queries are independent: the results are the same bits.  VSC_KNN_TAIL=0: one sweep.
+        // (Round 5, second step: from 257 blocks on -- 70 000 x 1M ran two rounds, 107 ms, for 1.07 rounds of work -- and decided by the
+        // plan's cost model instead of a fixed window of remainders.)
         const int64_t nqb = (nq + SQ - 1) / SQ, rem = nqb % 256;
         const char *tb = vsc_opt(OPT_KNN_TAIL);
         g_knn_set = 0;
-        if (!(tb && tb[0] == '0') && nqb >= 512 && rem != 0 && rem <= 160) {
+        bool split_tail = false;
+        if (!(tb && tb[0] == '0') && nqb > 256 && rem != 0) {
+            // by the plan's own cost model: whole rounds at one split + the tail's best plan + a second pack of the bank and the
+            // launches (~0.05 of a round), against the best plan for the call as a whole
+            const int dp = (d + 63) / 64 * 64;
+            SweepPlan whole, head_pl, tail_pl;
+            int rc;
+            if ((rc = sweep_plan(nq, nr, dp, &whole)) || (rc = sweep_plan((nqb - rem) * SQ, nr, dp, &head_pl)) ||
+                (rc = sweep_plan(nq - (nqb - rem) * SQ, nr, dp, &tail_pl))) return rc;
+            split_tail = head_pl.cost + tail_pl.cost + 0.05 < whole.cost;
+        }
+        if (split_tail) {
             const int64_t head = (nqb - rem) * SQ;
             int fb0 = 0, fb1 = 0;
             int rc = knn_prefilter(q_dev, head, r_dev, nr, d, k, ref_id_offset, out_scores_dev, out_ids_dev, stream, &fb0);
