@@ -192,6 +192,16 @@ int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t n
                    int32_t k, int64_t ref_id_offset, float *out_scores_dev,
                    int64_t *out_ids_dev, void *stream);
 
+/* vsc_knn_ip_f32 with a per-query floor: the k best of {r : <q, r> >= floor_dev[q]}, unused slots (-FLT_MAX, -1).  For a bank swept
+ * shard by shard (the pipelined form of the sharded search, infer/vsc/baseline/score_normalization.py:107-150 at configs[3]'s
+ * size): floor = the k-th best score of the shards merged so far -- nothing below it can enter the final list, ties at the floor
+ * still can (lower id first) -- so a later shard's lists start with a threshold instead of paying their warm-up appends again
+ * (a 1M x 125k sweep runs at 870 TFLOP/s, the same rows as one of eight shards behind a floor at the whole bank's rate).
+ * floor_dev NULL: vsc_knn_ip_f32.  -FLT_MAX / -inf entries: no floor for that query. */
+int vsc_knn_ip_floor_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d, int32_t k,
+                         int64_t ref_id_offset, const float *floor_dev, float *out_scores_dev, int64_t *out_ids_dev,
+                         void *stream);
+
 /* Merge of per-shard results of vsc_knn_ip_f32 (a bank swept shard by shard, each with its ref_id_offset -- the pipelined form of
  * the sharded search, where shard s is swept while shard s + 1 is still arriving over xGMI): scores / ids [parts][nq][k], every
  * list in the search's order (score descending, equal scores by ascending id; unused slots (-FLT_MAX, -1)) -> the k best of the

@@ -21,9 +21,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _oracle_knn(q, r, k):
+def _oracle_knn(q, r, k, floor=None):
+    """the oracle's top-k; floor [nq]: only references with score >= floor[q] (vsc_knn_ip_floor_f32's statement), empty slots (-FLT_MAX, -1)"""
     from oracle import knn_oracle
     D, I = knn_oracle.knn_ip(q.numpy(), r.numpy(), k)
+    if floor is not None:
+        cut = (D < floor.numpy()[:, None]) & (I >= 0)
+        D, I = D.copy(), I.copy()
+        D[cut], I[cut] = np.finfo(np.float32).min, -1
     return torch.from_numpy(D), torch.from_numpy(I)
 
 
@@ -62,6 +67,8 @@ def _worker_pipelined(rank, world_size, port, out_dir):
         q_mine = qs[qlo:qhi]
         a = vdist.sharded_knn(q_mine, mine, k, knn=_oracle_knn, gather_to=None)
         b = vdist.sharded_knn(q_mine, mine, k, knn=_oracle_knn, gather_to=None, pipelined=True, merge=_oracle_merge)
+        b0 = vdist.sharded_knn(q_mine, mine, k, knn=_oracle_knn, gather_to=None, pipelined=True, merge=_oracle_merge, carry=False)   # plain per-shard sweeps
+        assert torch.equal(b[0], b0[0]) and torch.equal(b[1], b0[1])
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         an = vdist.sharded_knn_score_normalized(q_mine, mine, noise, k, beta=1.2, nk=3, knn=_oracle_knn, gather_to=None)
         bn = vdist.sharded_knn_score_normalized(q_mine, mine, noise, k, beta=1.2, nk=3, knn=_oracle_knn, gather_to=None, pipelined=True, merge=_oracle_merge)

@@ -239,6 +239,57 @@ def test_knn_split_plans_chosen_by_the_cost_model(dev, nq):
     assert torch.equal(I, I0) and torch.equal(D.view(torch.int32), D0.view(torch.int32))
 
 
+@pytest.mark.parametrize("path", ["bf16", "exact"])
+def test_knn_with_a_floor_bit_exact(dev, path):
+    """vsc_knn_ip_floor_f32: the k best of {r : <q, r> >= floor[q]} -- on the pre-filter sweep the floor is where a list's threshold
+    starts, on the exact sweep it only cuts the tail off -- against the oracle's list cut at the floor, bit for bit; floors at an
+    exact score (ties stay in), above every score (empty list), at -FLT_MAX / -inf (no floor)."""
+    from oracle import knn_oracle
+    from vsc_hip import _lib, ops
+    nq, nr, k = 700, 70_000, 50
+    rt = _device_bank(dev, 31, nr)
+    qt = _device_bank(dev, 32, nq)
+    rt[60_000] = rt[5]                                        # a duplicate row: equal scores, two ids
+    Dr, Ir = knn_oracle.knn_ip(qt.cpu().numpy(), rt.cpu().numpy(), k)
+    floor = Dr[:, k // 2].copy()                              # exactly the 26th score: 26 entries stay (ties included)
+    floor[0:8] = Dr[0:8, 0] + 1.0                             # nothing reaches it
+    floor[8:16] = np.finfo(np.float32).min
+    floor[16:24] = -np.inf
+    floor[24:32] = Dr[24:32, k - 1] - 0.25                    # below the whole list
+    _lib.set_option("VSC_KNN_PATH", path)
+    try:
+        D, I = ops.knn_ip(qt, rt, k, floor=torch.from_numpy(floor).to(dev))
+        assert _last_path() == (2 if path == "bf16" else 1)
+    finally:
+        _lib.set_option("VSC_KNN_PATH", None)
+    cut = Dr < floor[:, None]
+    De, Ie = Dr.copy(), Ir.copy()
+    De[cut], Ie[cut] = np.finfo(np.float32).min, -1
+    assert np.array_equal(I.cpu().numpy(), Ie) and np.array_equal(D.cpu().numpy().view(np.uint32), De.view(np.uint32))
+    assert (Ie[0:8] == -1).all() and (Ie[8:32] >= 0).all() and (Ie[40, : k // 2 + 1] >= 0).all()
+
+
+def test_knn_shard_by_shard_with_carried_floor_equals_one_sweep(dev):
+    """vsc_hip.distributed.sweep_shards (the pipelined sharded search's loop) over eight unequal local shards -- one of them shorter
+    than k, one empty, duplicates of one row in three shards -- with the running k-th score carried as the next shard's floor, and
+    without: both equal one sweep over the concatenated bank, bit for bit."""
+    from vsc_hip import ops
+    from vsc_hip.distributed import sweep_shards
+    nq, k = 3000, 100
+    bank = _device_bank(dev, 41, 400_000)
+    qt = _device_bank(dev, 42, nq)
+    bank[250_007] = bank[11]
+    bank[399_999] = bank[11]
+    qt[5] = bank[11]
+    cuts = [0, 90_000, 90_040, 90_040, 180_000, 250_000, 250_008, 330_000, 400_000]
+    D, I = ops.knn_ip(qt, bank, k)
+    for carry in (True, False):
+        shards = ((bank[cuts[j]:cuts[j + 1]], cuts[j]) for j in range(8))
+        Ds, Is = sweep_shards(qt, shards, k, ops.knn_ip, None, carry)
+        assert torch.equal(Is, I) and torch.equal(Ds.view(torch.int32), D.view(torch.int32)), carry
+    assert I[5, :3].tolist() == [11, 250_007, 399_999]
+
+
 def test_knn_bank_beyond_one_buffer_descriptor(dev):
     """A split is addressed through one buffer descriptor (32-bit extent): 8191 tiles = 2 096 896 rows of 512-d bf16.  With
     nq >= 65 281 (256 query blocks -> one split wanted) and 2.2 M references the cap forces two splits (knn.hip,

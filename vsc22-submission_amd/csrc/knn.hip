@@ -627,6 +627,7 @@ struct SweepArgs {
     int xcd_map = 0;             // 1: work items are dealt to the XCDs as 8 query blocks x 4 reference splits (see the kernel)
     int thr_mode = 0;            // 1: fixed-threshold sweep (video pair maxima): a pair survives when s~ >= thr0 - eps_q; lists never compact
     float thr0 = 0.f;
+    const float *floor = nullptr;   // top-k with a per-query floor (vsc_knn_ip_floor_f32): a list's threshold STARTS at floor[q] - eps_q instead of -inf
 };
 
 // stats (queries): [n][4] = (|x|, |bf16 x|, |x - bf16 x|, 0); max_bits (refs): [0] max |x|, [1] max |x - bf16 x| as float bits
@@ -795,7 +796,8 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
             }
             eps_s[tid] = e2;
             // fixed threshold: exact s <= s~ + eps, so s~ + eps <= thr0 rules a pair out; everything else is re-scored exactly
-            thr_s[tid] = p.thr_mode ? p.thr0 - 0.5f * e2 : -INFINITY;
+            // (top-k with a floor: exact s < floor[q] cannot enter the caller's running top-k, and s~ < floor[q] - eps implies it)
+            thr_s[tid] = p.thr_mode ? p.thr0 - 0.5f * e2 : (p.floor && q0 + tid < p.nq ? p.floor[q0 + tid] - 0.5f * e2 : -INFINITY);
             // first compaction as soon as a tile's worth of scores is in (everything is appended until a threshold exists)
             trig_s[tid] = p.thr_mode ? TRIG : (p.k + 64 < SR ? SR : (p.k + 64 < TRIG ? p.k + 64 : TRIG));
         }
@@ -858,7 +860,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
                             const int kept = compact_band<EPL, 20>(l, n < CAP ? n : CAP, p.k, eps_s[ql], l, CAP, &thr, lane);
                             if (lane == 0) {
                                 cnt_s[ql] = kept;
-                                thr_s[ql] = thr;
+                                thr_s[ql] = fmaxf(thr, thr_s[ql]);   // (never below where a floor started it)
                                 // next compaction DELTA appends from here: with a stale threshold a list takes ~k (t / t0)
                                 // appends between tiles t0 and t, so rounds are geometrically spaced with ratio 1 + DELTA / k
                                 // and a sweep costs ~DELTA ln(tiles) / ln(1 + DELTA / k) appends per query (DELTA = k: 1.4 x
@@ -1529,7 +1531,7 @@ static int launch_sweep(const SweepArgs &a, int grid, hipStream_t stream) {
 // bound is not finite, are redone on the exact sweep; *fell_back = number of such blocks.
 static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d, int32_t k,
                          int64_t ref_id_offset, float *out_scores_dev, int64_t *out_ids_dev, hipStream_t stream,
-                         int *fell_back) {
+                         int *fell_back, const float *floor_dev = nullptr) {
     const int dp = (d + 63) / 64 * 64;
     const int epl = k <= 256 ? 16 : 32;          // CAP = 1024 / 2048 keys per list, KEEP = CAP / 2 survivors
     const int cap = 64 * epl, keep = cap / 2;
@@ -1568,6 +1570,7 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
                 splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
                 (int *)ncand, fb_dev, 0, nullptr, cap - 2 * SR};
     a.xcd_map = pl.xcd_map;
+    a.floor = floor_dev;
     if (const char *e = vsc_opt(OPT_KNN_TRIG)) { const int t = atoi(e); if (t >= k && t <= cap - 2 * SR) a.trig = t; }
     a.delta = cap;   // measured (tools/micro/knn_trig.py, 65536 x 1M, k = 100): 64 / 100 / 150 / 200 / 400 appends between compactions -> 79.6 / 73.4 / 71.0 / 68.7 / 66.8 ms: the
                      // appends are already within 25 % of their floor (the 2 eps band doubles the effective k), rounds stall the workgroup
@@ -1697,10 +1700,41 @@ extern "C" int vsc_knn_merge_parts_f32(const float *scores_dev, const int64_t *i
 static int g_knn_last_path = 0;   // 1 exact fp32 sweep, 2 bf16 pre-filter, 3 pre-filter with some query blocks redone on the exact sweep
 extern "C" int vsc_knn_last_path(void) { return g_knn_last_path; }
 
+// out[q][j >= first j with score < floor[q]] = (-FLT_MAX, -1): the lists are sorted, so a floor cuts a tail off.  Applied whatever
+// sweep produced the list, so that the result is "the k best of {r : <q, r> >= floor[q]}" exactly (the pre-filter lets a few pairs
+// with s~ >= floor - eps but s < floor through, the exact sweep knows no floor at all).
+__global__ __launch_bounds__(256) void knn_floor_kernel(const float *__restrict__ floor, int64_t nq, int k, float *__restrict__ out_d,
+                                                        int64_t *__restrict__ out_i) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq * k) return;
+    if (out_i[i] >= 0 && out_d[i] < floor[i / k]) {
+        out_d[i] = -FLT_MAX;
+        out_i[i] = -1;
+    }
+}
+
+static int knn_ip_impl(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d, int32_t k, int64_t ref_id_offset,
+                       const float *floor_dev, float *out_scores_dev, int64_t *out_ids_dev, hipStream_t stream);
+
 extern "C" int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr,
                               int32_t d, int32_t k, int64_t ref_id_offset, float *out_scores_dev,
                               int64_t *out_ids_dev, void *stream_) {
+    return knn_ip_impl(q_dev, nq, r_dev, nr, d, k, ref_id_offset, nullptr, out_scores_dev, out_ids_dev, (hipStream_t)stream_);
+}
+
+extern "C" int vsc_knn_ip_floor_f32(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d, int32_t k,
+                                    int64_t ref_id_offset, const float *floor_dev, float *out_scores_dev, int64_t *out_ids_dev,
+                                    void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    const int rc = knn_ip_impl(q_dev, nq, r_dev, nr, d, k, ref_id_offset, floor_dev, out_scores_dev, out_ids_dev, stream);
+    if (rc || !floor_dev || nq <= 0) return rc;
+    hipLaunchKernelGGL(knn_floor_kernel, dim3(blocks_for(nq * k)), dim3(256), 0, stream, floor_dev, nq, k, out_scores_dev, out_ids_dev);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+static int knn_ip_impl(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d, int32_t k, int64_t ref_id_offset,
+                       const float *floor_dev, float *out_scores_dev, int64_t *out_ids_dev, hipStream_t stream) {
     VSC_REQUIRE(q_dev && r_dev && out_scores_dev && out_ids_dev, "knn: null pointer");
     VSC_REQUIRE(nq > 0 && nr > 0, "knn: empty query or reference set (nq=%lld nr=%lld)", (long long)nq,
                 (long long)nr);
@@ -1738,16 +1772,17 @@ extern "C" int vsc_knn_ip_f32(const float *q_dev, int64_t nq, const float *r_dev
         if (split_tail) {
             const int64_t head = (nqb - rem) * SQ;
             int fb0 = 0, fb1 = 0;
-            int rc = knn_prefilter(q_dev, head, r_dev, nr, d, k, ref_id_offset, out_scores_dev, out_ids_dev, stream, &fb0);
+            int rc = knn_prefilter(q_dev, head, r_dev, nr, d, k, ref_id_offset, out_scores_dev, out_ids_dev, stream, &fb0, floor_dev);
             if (rc) return rc;
             g_knn_set = 1;
-            rc = knn_prefilter(q_dev + head * d, nq - head, r_dev, nr, d, k, ref_id_offset, out_scores_dev + head * k, out_ids_dev + head * k, stream, &fb1);
+            rc = knn_prefilter(q_dev + head * d, nq - head, r_dev, nr, d, k, ref_id_offset, out_scores_dev + head * k, out_ids_dev + head * k, stream, &fb1,
+                               floor_dev ? floor_dev + head : nullptr);
             g_knn_set = 0;
             g_knn_last_path = (fb0 || fb1) ? 3 : 2;
             return rc;
         }
         int fb = 0;
-        const int rc = knn_prefilter(q_dev, nq, r_dev, nr, d, k, ref_id_offset, out_scores_dev, out_ids_dev, stream, &fb);
+        const int rc = knn_prefilter(q_dev, nq, r_dev, nr, d, k, ref_id_offset, out_scores_dev, out_ids_dev, stream, &fb, floor_dev);
         g_knn_last_path = fb ? 3 : 2;
         return rc;
     }

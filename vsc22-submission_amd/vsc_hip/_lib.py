@@ -98,6 +98,7 @@ SIGNATURES = {
     "vsc_debug_spin_ticks": (c_int32, [ctypes.c_uint64, c_void_p, c_void_p]),
     "vsc_knn_ip_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int64,
                                  c_void_p, c_void_p, c_void_p]),
+    "vsc_knn_ip_floor_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "vsc_knn_merge_parts_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "vsc_conv_packed_k": (c_int32, [c_int32, c_int32, c_int32]),
     "vsc_conv_pack_weight_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),

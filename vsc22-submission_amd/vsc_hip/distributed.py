@@ -95,9 +95,32 @@ def merge_parts(scores, ids, k: int, merge: Optional[Callable] = None):
     return merge(torch.stack(scores), torch.stack(ids))
 
 
+def sweep_shards(queries: torch.Tensor, shards, k: int, knn: Callable, merge: Optional[Callable] = None, carry: bool = True):
+    """The bank as a sequence of shards: `shards` yields (rows [n_s, dim], id offset) -- each when it has landed --, every shard is
+    swept on its own and merged into the running top-k.  -> (scores, ids), or (None, None) for an empty sequence.
+    carry: from the second shard on the sweep gets the running list's k-th score as a per-query FLOOR (vsc_knn_ip_floor_f32):
+    nothing below it can enter the result, so a shard's candidate lists start with a threshold instead of paying their warm-up
+    appends again (eight 125k-row shards otherwise sweep at 0.72 of the whole bank's rate).  Same bits either way: the floor only
+    removes entries the merge would drop (ties at the floor are kept, the search's order decides them)."""
+    scores = ids = None
+    for rows, off in shards:
+        if rows.shape[0] == 0:
+            continue
+        if carry and scores is not None:
+            s, i = knn(queries, rows, k, floor=scores[:, k - 1].contiguous())     # (fewer than k so far: the slot holds -FLT_MAX, no floor)
+        else:
+            s, i = knn(queries, rows, k)      # (a shard with fewer than k rows: the search pads with (-FLT_MAX, -1))
+        i = torch.where(i >= 0, i + off, i)
+        if scores is None:
+            scores, ids = s, i
+        else:
+            scores, ids = merge_parts([scores, s], [ids, i], k, merge)
+    return scores, ids
+
+
 def sharded_knn(queries_local: torch.Tensor, refs_local: torch.Tensor, k: int,
                 knn: Optional[Callable] = None, gather_to: Optional[int] = 0, always_collective: bool = False,
-                pipelined: bool = False, merge: Optional[Callable] = None):
+                pipelined: bool = False, merge: Optional[Callable] = None, carry: bool = True):
     """Exact top-k of every rank's queries against the union of every rank's references.
 
     refs_local shards are all_gathered into the full bank (ids = position in rank order);
@@ -106,8 +129,9 @@ def sharded_knn(queries_local: torch.Tensor, refs_local: torch.Tensor, k: int,
     pass the oracle here -- a test hook, not a fallback: the default raises without a GPU.
 
     pipelined: the bank arrives as one broadcast per source rank (gather_rows_pipelined) and every shard is swept as soon as it
-    has landed -- the own shard first, while all the others are still on the wire -- with its id offset; the per-shard lists are
-    merged (vsc_knn_merge_parts_f32; `merge` is the tests' hook).  Same results as the one-gather form, bit for bit: a shard's
+    has landed -- the own shard first, while all the others are still on the wire -- with its id offset and, from the second one
+    on, the running k-th score as a floor (sweep_shards; carry=False: plain per-shard sweeps); the per-shard lists are merged
+    into the running list (vsc_knn_merge_parts_f32; `merge` is the tests' hook).  Same results as the one-gather form, bit for bit: a shard's
     top-k holds every member of the global top-k that lives in that shard, and the merge applies the search's own order."""
     if knn is None:
         from . import ops
@@ -115,21 +139,15 @@ def sharded_knn(queries_local: torch.Tensor, refs_local: torch.Tensor, k: int,
     if pipelined:
         rank, ws = world()
         shards, works, offsets = gather_rows_pipelined(refs_local, always_collective)
-        part_s, part_i = [], []
-        for step in range(len(shards)):
-            r = (rank + step) % len(shards)
-            if works[r] is not None:
-                works[r].wait()          # orders the caller's stream behind that broadcast only
-            if shards[r].shape[0] == 0:
-                continue
-            s, i = knn(queries_local, shards[r], k)      # (a shard with fewer than k rows: the search pads with (-FLT_MAX, -1))
-            off = int(offsets[r])
-            i = torch.where(i >= 0, i + off, i)
-            part_s.append(s)
-            part_i.append(i)
-        if part_s:
-            scores, ids = merge_parts(part_s, part_i, k, merge)
-        else:
+        def landed():
+            for step in range(len(shards)):
+                r = (rank + step) % len(shards)
+                if works[r] is not None:
+                    works[r].wait()          # orders the caller's stream behind that broadcast only
+                yield shards[r], int(offsets[r])
+
+        scores, ids = sweep_shards(queries_local, landed(), k, knn, merge, carry)
+        if scores is None:
             scores, ids = knn(queries_local, refs_local, k)     # an empty bank everywhere: the search's own empty result
     else:
         bank, _ = all_gather_rows(refs_local, always_collective)

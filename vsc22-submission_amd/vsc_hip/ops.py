@@ -74,10 +74,11 @@ def l2_normalize_(x):
     return x
 
 
-def knn_ip(q, r, k: int, ref_id_offset: int = 0):
+def knn_ip(q, r, k: int, ref_id_offset: int = 0, floor=None):
     """Exact inner-product top-k.  q [nq,d], r [nr,d] float32 on the GPU ->
     (scores [nq,k] float32 descending, ids [nq,k] int64).  Empty inputs follow
-    faiss: nq == 0 -> empty outputs; nr == 0 -> all (-FLT_MAX, -1)."""
+    faiss: nq == 0 -> empty outputs; nr == 0 -> all (-FLT_MAX, -1).
+    floor [nq] float32: only references with <q, r> >= floor[q] (vsc_knn_ip_floor_f32; unused slots (-FLT_MAX, -1))."""
     lib = _lib.require_device()
     q, r = _dev(q, torch.float32), _dev(r, torch.float32)
     nq, d = q.shape
@@ -90,6 +91,11 @@ def knn_ip(q, r, k: int, ref_id_offset: int = 0):
     if nr == 0:
         scores.fill_(torch.finfo(torch.float32).min)
         ids.fill_(-1)
+        return scores, ids
+    if floor is not None:
+        floor = _dev(floor, torch.float32)
+        assert floor.shape == (nq,)
+        check(lib.vsc_knn_ip_floor_f32(ptr(q), nq, ptr(r), nr, d, k, ref_id_offset, ptr(floor), ptr(scores), ptr(ids), current_stream()))
         return scores, ids
     check(lib.vsc_knn_ip_f32(ptr(q), nq, ptr(r), nr, d, k, ref_id_offset, ptr(scores), ptr(ids),
                              current_stream()))
