@@ -64,6 +64,9 @@ def _last_path():
 @pytest.mark.parametrize("nq,nr,d,k", [
     (3, 5, 3, 2), (64, 1000, 512, 10), (130, 1001, 511, 7), (1, 70000, 512, 1), (257, 20000, 512, 100),
     (5, 40, 16, 64), (300, 3000, 64, 500), (700, 9000, 100, 257), (513, 4097, 512, 33),
+    # widths whose packed rows are an even, non-power-of-two number of K-tiles (513 -> 640: the score-normalised search; 384; 577 -> 640)
+    # with the re-scoring's tail columns behind its 32-float chunks, and k on the large list form (129 .. 384)
+    (300, 20000, 513, 10), (257, 30000, 384, 20), (130, 20000, 577, 5), (200, 40000, 512, 256), (64, 9000, 200, 130),
 ])
 def test_knn_prefilter_path_bit_exact(dev, force_prefilter, nq, nr, d, k):
     """The bf16 pre-filter sweep + exact re-scoring (VSC_KNN_PATH=bf16 forces it at every size) returns the same bits

@@ -807,7 +807,7 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
         const int q_rows = (int)(p.nq - q0 < SQ ? p.nq - q0 : SQ);
         // One LDS-DMA stream over all reference tiles of this split: the K-tile sequence (ref tile, k) is walked
         // without a prologue per tile -- while a tile is filtered the first units of the next one are already landing.
-        // Needs a power-of-two number (>= 2) of K-tiles per row (dp = 128, 256, 512, ...); otherwise tile by tile.
+        // Needs an even number of K-tiles per row (the ring's slots alternate with the K-tile's parity); dp = 64: tile by tile.
         const int nkt = p.dp / 64;
         constexpr bool stream = STREAM;   // chosen by the launcher (launch_sweep)
         const int64_t split_rows = (t_end * SR < p.nr ? t_end * SR : p.nr) - t_begin * SR;
@@ -816,8 +816,13 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
         const int ntl = (int)(t_end - t_begin);
         if (stream) {
             ml64::init(c, p.qb + q0 * p.dp, p.dp, q_rows, p.rb + t_begin * SR * p.dp, p.dp, (int)split_rows, lds, wave, lane);
-            c.kt_shift = __builtin_ctz(nkt);
-            c.kt_mask = nkt - 1;
+            if ((nkt & (nkt - 1)) == 0) {
+                c.kt_shift = __builtin_ctz(nkt);
+                c.kt_mask = nkt - 1;
+            } else {   // an even count that is not a power of two (dp = 384, 640, 768, ...: prefilter_dp makes odd counts even)
+                c.kt_n = (uint32_t)nkt;
+                c.kt_inv = (uint32_t)(((1ull << 32) + (uint32_t)nkt - 1) / (uint32_t)nkt);
+            }
             c.w_tile_stride = (uint32_t)(SR * p.dp * 2);
             ml64::prologue(c, ntl * nkt);
         }
@@ -1157,8 +1162,11 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
         acc[i] = 0.f;
     }
     const int live = (n + 63) >> 6;   // register rows that hold at least one candidate (wave-uniform)
-    if ((d & 31) == 0) {
-        // Coalesced gather.  A lane per candidate walking its own row touches 64 different lines per load instruction
+    typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // rows of a width that is no multiple of 4 start on any dword
+    if (d >= 32) {
+        // Coalesced gather (whole 32-float chunks; a tail d % 32 -- the score-normalised search's 513th column -- goes lane by lane
+        // behind them, in the chain's order; until round 5 every width that is no multiple of 32 took the lane-per-row loop below:
+        // 107 ms for 65 536 x 1M at d = 513 where d = 512 takes 4).  A lane per candidate walking its own row touches 64 different lines per load instruction
         // and re-fetches every line eight times (PMC: 7 x the algorithmic bytes).  Instead the wave fetches, for 64
         // candidates at a time, one whole 128-byte line per candidate and 32-float chunk (8 lanes x 16 B per line, 8
         // instructions), transposes through LDS (rows of 36 floats: conflict-free for both the 16-byte row-major
@@ -1174,7 +1182,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
             for (int j = 0; j < 8; ++j) src[j] = r + (int64_t)__shfl(ids[i], j * 8 + sub, 64) * d + col;
             f32x4_t v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4_t *)(src[j]);
+            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4_u *)(src[j]);
             float a = 0.f;
             const int nch = d >> 5;
             for (int ch = 0; ch < nch; ++ch) {
@@ -1183,7 +1191,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
                 for (int j = 0; j < 8; ++j) *(f32x4_t *)(b + (j * 8 + sub) * 36 + col) = v[j];
                 const int nx = (ch + 1 < nch ? ch + 1 : ch) * 32;   // the last chunk is fetched twice rather than branching
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = *(const f32x4_t *)(src[j] + nx);
+                for (int j = 0; j < 8; ++j) v[j] = *(const f32x4_u *)(src[j] + nx);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const float *qc = qrow + ch * 32;
@@ -1198,6 +1206,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float *__restric
                 // the buffer written two chunks from now is this one: its reads above are complete before the
                 // writes of chunk ch + 2 are issued (in-order LDS queue of the same wave)
             }
+            for (int kk = nch * 32; kk < d; ++kk) a = fmaf(qrow[kk], rrow[i][kk], a);
             acc[i] = a;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1435,6 +1444,15 @@ static int knn_exact(const float *q_dev, int64_t nq, const float *r_dev, int64_t
     return VSC_OK;
 }
 
+// Row length of the packed bf16 operands of a pre-filter sweep: d rounded up to whole K-tiles of 64 -- and to an EVEN number of them
+// from three on, so that the split is walked as one LDS-DMA stream (the tile-by-tile form costs 2.7 x: 65 536 x 1M at d = 513, the
+// score-normalised search's width, 173.5 ms against 63.7 at d = 512; one more zero K-tile costs 11 %).
+static inline int prefilter_dp(int d) {
+    int dp = (d + 63) / 64 * 64;
+    if (dp >= 192 && ((dp / 64) & 1)) dp += 64;
+    return dp;
+}
+
 // How a pre-filter sweep is cut into work items (query block, reference split) and dealt to the workgroups.
 struct SweepPlan {
     int nqb, splits, grid, xcd_map;
@@ -1523,7 +1541,7 @@ static int launch_sweep_t(const SweepArgs &a, int grid, hipStream_t stream) {
 template <int EPL>
 static int launch_sweep(const SweepArgs &a, int grid, hipStream_t stream) {
     const int nkt = a.dp / 64;
-    const bool streamed = nkt >= 2 && (nkt & (nkt - 1)) == 0;   // one LDS-DMA stream over the split (see the kernel)
+    const bool streamed = nkt >= 2 && (nkt & 1) == 0;   // one LDS-DMA stream over the split (see the kernel)
     return streamed ? launch_sweep_t<EPL, true>(a, grid, stream) : launch_sweep_t<EPL, false>(a, grid, stream);
 }
 
@@ -1532,8 +1550,11 @@ static int launch_sweep(const SweepArgs &a, int grid, hipStream_t stream) {
 static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int64_t nr, int32_t d, int32_t k,
                          int64_t ref_id_offset, float *out_scores_dev, int64_t *out_ids_dev, hipStream_t stream,
                          int *fell_back, const float *floor_dev = nullptr) {
-    const int dp = (d + 63) / 64 * 64;
-    const int epl = k <= 256 ? 16 : 32;          // CAP = 1024 / 2048 keys per list, KEEP = CAP / 2 survivors
+    const int dp = prefilter_dp(d);
+    // CAP = 1024 / 2048 keys per list, KEEP = CAP / 2 survivors.  A list must hold k + its 2 eps band (about as many again) + a tile's
+    // appends: the small form up to k = 128, the large one up to k = 384 (k = 256 on the small form overflowed its bands and redid every
+    // block on the exact sweep: 1 490 ms for 65 536 x 1M against 105 now; tools/micro/knn_kd_scan.py)
+    const int epl = k <= 128 ? 16 : 32;
     const int cap = 64 * epl, keep = cap / 2;
     SweepPlan pl;
     int rc;
@@ -1743,7 +1764,9 @@ static int knn_ip_impl(const float *q_dev, int64_t nq, const float *r_dev, int64
     VSC_REQUIRE(nr < (1ll << 32) - 1, "knn: more than 2^32-2 references in one call");
     // Path: the pre-filter pays once the sweep dominates (its fixed costs: two pack passes, the re-scoring launch and
     // one host synchronisation for the fallback flag).  VSC_KNN_PATH=exact|bf16 forces one (tests run both).
-    bool prefilter = k <= 512 && nr >= 4096 && nq * nr >= (1ll << 24);
+    // (beyond k = 384 the bands outgrow the lists, and so they do beyond d = 1024, where the error bound d 2^-22 |q||r| widens them:
+    // the exact sweep at once instead of a pre-filter sweep whose every block is redone -- 65 536 x 1M at d = 2048: 2 560 ms)
+    bool prefilter = k <= 384 && d <= 1024 && nr >= 4096 && nq * nr >= (1ll << 24);
     if (const char *e = vsc_opt(OPT_KNN_PATH)) {
         if (e[0] == 'e') prefilter = false;
         if (e[0] == 'b') prefilter = k <= 512;
@@ -1762,7 +1785,7 @@ static int knn_ip_impl(const float *q_dev, int64_t nq, const float *r_dev, int64
         if (!(tb && tb[0] == '0') && nqb > 256 && rem != 0) {
             // by the plan's own cost model: whole rounds at one split + the tail's best plan + a second pack of the bank and the
             // launches (~0.05 of a round), against the best plan for the call as a whole
-            const int dp = (d + 63) / 64 * 64;
+            const int dp = prefilter_dp(d);
             SweepPlan whole, head_pl, tail_pl;
             int rc;
             if ((rc = sweep_plan(nq, nr, dp, &whole)) || (rc = sweep_plan((nqb - rem) * SQ, nr, dp, &head_pl)) ||
@@ -1813,7 +1836,7 @@ static int range_prefilter(const float *q_dev, int64_t nq, const float *r_dev, i
                            int64_t ref_id_offset, int64_t *lims_dev, float *out_scores_dev, int64_t *out_ids_dev,
                            int64_t capacity, int64_t *total_out, hipStream_t stream, int *overflow) {
     constexpr int EPL = 32;
-    const int dp = (d + 63) / 64 * 64;
+    const int dp = prefilter_dp(d);
     const int cap = 64 * EPL, keep = cap / 2;
     SweepPlan pl;
     int rc;
@@ -2030,7 +2053,7 @@ static int pair_max_prefilter(const float *q_dev, int64_t nq, const int32_t *qvi
                               const int32_t *rvid, int32_t n_r_videos, int32_t d, float threshold, unsigned *table,
                               hipStream_t stream, int *fell_back) {
     constexpr int EPL = 32;
-    const int dp = (d + 63) / 64 * 64;
+    const int dp = prefilter_dp(d);
     const int cap = 64 * EPL, keep = cap / 2;
     SweepPlan pl;
     int rc;

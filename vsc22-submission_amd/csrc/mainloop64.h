@@ -73,6 +73,9 @@ struct Ctx {
     int kt_shift = 31;
     uint32_t kt_mask = 0x7fffffffu;
     uint32_t w_tile_stride = 0;
+    // ... or, for a K-tile count per row that is not a power of two (kt_inv != 0): W tile index = t / kt_n = (t * kt_inv) >> 32 with
+    // kt_inv = ceil(2^32 / kt_n) (exact for t < 2^32 / kt_n), k-tile = t - that * kt_n.  Scalar arithmetic (t is wave-uniform).
+    uint32_t kt_inv = 0, kt_n = 1;
 };
 
 // a_rows / w_rows: rows of the tile that exist (>= 1).  Rows past the edge are outside the buffer descriptor's
@@ -117,7 +120,13 @@ __device__ __forceinline__ void stage_unit(const Ctx &c, int slot, int ktile) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const uint32_t off = KIND == 0 ? c.a_off[HALF][jj] : c.w_off[HALF][jj];
-        const uint32_t soff = ((uint32_t)ktile & c.kt_mask) * 128u + (KIND == 0 ? 0u : ((uint32_t)ktile >> c.kt_shift) * c.w_tile_stride);
+        uint32_t soff;
+        if (c.kt_inv) {
+            const uint32_t wt = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)(uint32_t)ktile * c.kt_inv) >> 32));
+            soff = ((uint32_t)ktile - wt * c.kt_n) * 128u + (KIND == 0 ? 0u : wt * c.w_tile_stride);
+        } else {
+            soff = ((uint32_t)ktile & c.kt_mask) * 128u + (KIND == 0 ? 0u : ((uint32_t)ktile >> c.kt_shift) * c.w_tile_stride);
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(KIND == 0 ? c.a_rsrc : c.w_rsrc,
                                                  (lptr_t)(c.lds + slot * UNIT_BYTES + (c.wave + 8 * jj) * 1024), 16, off,
                                                  soff, 0, 0);
