@@ -610,7 +610,7 @@ constexpr int SQ = 256, SR = 256;   // sweep tile: queries x refs
 
 struct SweepArgs {
     const uint16_t *qb, *rb;     // bf16 [nq, dp], [nr, dp]
-    const float *qstats;         // [nq][4] = (|q|, |bf16 q|, |q - bf16 q|, 0)
+    const float *qstats;         // [nq][4] = (|q|, |bf16 q|, |q - bf16 q|, floor: -inf, or the query's floor of vsc_knn_ip_floor_f32)
     const unsigned *rmax_bits;   // [0] max |r|, [1] max |r - bf16 r| as float bits
     int64_t nq, nr;
     int dp, k, nqb, splits;
@@ -627,7 +627,6 @@ struct SweepArgs {
     int xcd_map = 0;             // 1: work items are dealt to the XCDs as 8 query blocks x 4 reference splits (see the kernel)
     int thr_mode = 0;            // 1: fixed-threshold sweep (video pair maxima): a pair survives when s~ >= thr0 - eps_q; lists never compact
     float thr0 = 0.f;
-    const float *floor = nullptr;   // top-k with a per-query floor (vsc_knn_ip_floor_f32): a list's threshold STARTS at floor[q] - eps_q instead of -inf
 };
 
 // stats (queries): [n][4] = (|x|, |bf16 x|, |x - bf16 x|, 0); max_bits (refs): [0] max |x|, [1] max |x - bf16 x| as float bits
@@ -652,7 +651,7 @@ __global__ __launch_bounds__(256) void knn_pack_bf16_kernel(const float *__restr
         sh = wave_sum(sh);
         sd = wave_sum(sd);
         if (lane == 0) {
-            if (stats) *(float4 *)(stats + row * 4) = make_float4(sqrtf(ss), sqrtf(sh), sqrtf(sd), 0.f);
+            if (stats) *(float4 *)(stats + row * 4) = make_float4(sqrtf(ss), sqrtf(sh), sqrtf(sd), -INFINITY);   // .w: the query's floor (none)
             if (max_bits) {   // norms are >= 0, so their float bits order like unsigned ints (NaN sorts above everything)
                 // a million same-address atomics serialise (23 ms per 1M rows): look first, update only when this row raises
                 // the maximum -- a stale read can only cause a redundant atomic, never a missed one
@@ -730,7 +729,10 @@ __device__ __forceinline__ unsigned shift_in_ge(unsigned m, float a, float thr) 
     return m;
 }
 
-template <int EPL, bool STREAM, bool DIAG = false>   // DIAG: the VSC_KNN_ABL switches / counters are compiled in (timing diagnostics)
+// STREAM: 0 tile by tile, 1 one LDS-DMA stream per split with a power-of-two number of K-tiles per row, 2 the same with any even number
+// (a kernel of its own: the stream index's division must not sit in the power-of-two form's K loop -- as a run-time branch there it cost
+// the 1M x 1M sweep 8 %)
+template <int EPL, int STREAM, bool DIAG = false>   // DIAG: the VSC_KNN_ABL switches / counters are compiled in (timing diagnostics)
 __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
     const int abl = DIAG ? p.abl : 0;
     constexpr int CAP = 64 * EPL, KEEP = CAP / 2;
@@ -788,16 +790,19 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
         t_end = t_end > p.total_tiles ? p.total_tiles : t_end;
         if (tid < SQ) {
             cnt_s[tid] = 0;
-            float e2 = 0.f;
+            float e2 = 0.f, floor = -INFINITY;
             if (q0 + tid < p.nq) {
                 const float4 st = *(const float4 *)(p.qstats + (q0 + tid) * 4);
+                floor = st.w;
                 e2 = 2.0f * (1.02f * (st.z * rmax + st.y * drmax) + p.cd * st.x * rmax);
                 if (!(e2 < INFINITY)) p.fallback[0] = p.fallback[1 + qb] = 1;   // NaN / Inf operands: no bound, the exact sweep decides
             }
             eps_s[tid] = e2;
             // fixed threshold: exact s <= s~ + eps, so s~ + eps <= thr0 rules a pair out; everything else is re-scored exactly
             // (top-k with a floor: exact s < floor[q] cannot enter the caller's running top-k, and s~ < floor[q] - eps implies it)
-            thr_s[tid] = p.thr_mode ? p.thr0 - 0.5f * e2 : (p.floor && q0 + tid < p.nq ? p.floor[q0 + tid] - 0.5f * e2 : -INFINITY);
+            // (the floor rides in the fourth float of the query's statistics: a pointer of its own in the kernel's arguments cost 19 more
+            // spilled scalar registers in the K loop's surroundings and 1 % of the 1M x 1M sweep)
+            thr_s[tid] = p.thr_mode ? p.thr0 - 0.5f * e2 : floor - 0.5f * e2;
             // first compaction as soon as a tile's worth of scores is in (everything is appended until a threshold exists)
             trig_s[tid] = p.thr_mode ? TRIG : (p.k + 64 < SR ? SR : (p.k + 64 < TRIG ? p.k + 64 : TRIG));
         }
@@ -809,14 +814,15 @@ __global__ __launch_bounds__(512, 2) void knn_sweep_bf16_kernel(SweepArgs p) {
         // without a prologue per tile -- while a tile is filtered the first units of the next one are already landing.
         // Needs an even number of K-tiles per row (the ring's slots alternate with the K-tile's parity); dp = 64: tile by tile.
         const int nkt = p.dp / 64;
-        constexpr bool stream = STREAM;   // chosen by the launcher (launch_sweep)
+        constexpr bool stream = STREAM != 0;   // chosen by the launcher (launch_sweep)
         const int64_t split_rows = (t_end * SR < p.nr ? t_end * SR : p.nr) - t_begin * SR;
         ml64::Ctx c;
         ml64::Frags fr;
         const int ntl = (int)(t_end - t_begin);
         if (stream) {
             ml64::init(c, p.qb + q0 * p.dp, p.dp, q_rows, p.rb + t_begin * SR * p.dp, p.dp, (int)split_rows, lds, wave, lane);
-            if ((nkt & (nkt - 1)) == 0) {
+            c.kt_general = STREAM == 2;
+            if (STREAM != 2) {
                 c.kt_shift = __builtin_ctz(nkt);
                 c.kt_mask = nkt - 1;
             } else {   // an even count that is not a power of two (dp = 384, 640, 768, ...: prefilter_dp makes odd counts even)
@@ -1453,6 +1459,11 @@ static inline int prefilter_dp(int d) {
     return dp;
 }
 
+__global__ __launch_bounds__(256) void knn_set_floor_kernel(const float *__restrict__ floor, float *__restrict__ qstats, int64_t nq) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q < nq) qstats[q * 4 + 3] = floor[q] == floor[q] ? floor[q] : -INFINITY;   // (a NaN floor is no floor)
+}
+
 // How a pre-filter sweep is cut into work items (query block, reference split) and dealt to the workgroups.
 struct SweepPlan {
     int nqb, splits, grid, xcd_map;
@@ -1523,7 +1534,7 @@ static int sweep_plan(int64_t nq, int64_t nr, int dp, SweepPlan *out) {
     return VSC_OK;
 }
 
-template <int EPL, bool STREAM>
+template <int EPL, int STREAM>
 static int launch_sweep_t(const SweepArgs &a, int grid, hipStream_t stream) {
     constexpr int smem = ml64::RING_BYTES + 5120 + 8 * 4 * 64 * 12;
     if (a.abl) {   // diagnostics requested (VSC_KNN_ABL): the instrumented build of the kernel
@@ -1542,7 +1553,8 @@ template <int EPL>
 static int launch_sweep(const SweepArgs &a, int grid, hipStream_t stream) {
     const int nkt = a.dp / 64;
     const bool streamed = nkt >= 2 && (nkt & 1) == 0;   // one LDS-DMA stream over the split (see the kernel)
-    return streamed ? launch_sweep_t<EPL, true>(a, grid, stream) : launch_sweep_t<EPL, false>(a, grid, stream);
+    if (!streamed) return launch_sweep_t<EPL, 0>(a, grid, stream);
+    return (nkt & (nkt - 1)) == 0 ? launch_sweep_t<EPL, 1>(a, grid, stream) : launch_sweep_t<EPL, 2>(a, grid, stream);
 }
 
 // bf16 pre-filter sweep + exact re-scoring.  Query blocks (256 queries) whose candidate bands did not fit, or whose
@@ -1591,7 +1603,10 @@ static int knn_prefilter(const float *q_dev, int64_t nq, const float *r_dev, int
                 splits, total_tiles, tiles_per_split, cd, (unsigned long long *)lists, (unsigned long long *)cand,
                 (int *)ncand, fb_dev, 0, nullptr, cap - 2 * SR};
     a.xcd_map = pl.xcd_map;
-    a.floor = floor_dev;
+    if (floor_dev) {
+        hipLaunchKernelGGL(knn_set_floor_kernel, dim3(blocks_for(nq)), dim3(256), 0, stream, floor_dev, (float *)qstats, nq);
+        VSC_CHECK_LAUNCH();
+    }
     if (const char *e = vsc_opt(OPT_KNN_TRIG)) { const int t = atoi(e); if (t >= k && t <= cap - 2 * SR) a.trig = t; }
     a.delta = cap;   // measured (tools/micro/knn_trig.py, 65536 x 1M, k = 100): 64 / 100 / 150 / 200 / 400 appends between compactions -> 79.6 / 73.4 / 71.0 / 68.7 / 66.8 ms: the
                      // appends are already within 25 % of their floor (the 2 eps band doubles the effective k), rounds stall the workgroup

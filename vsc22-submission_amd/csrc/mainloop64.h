@@ -76,6 +76,7 @@ struct Ctx {
     // ... or, for a K-tile count per row that is not a power of two (kt_inv != 0): W tile index = t / kt_n = (t * kt_inv) >> 32 with
     // kt_inv = ceil(2^32 / kt_n) (exact for t < 2^32 / kt_n), k-tile = t - that * kt_n.  Scalar arithmetic (t is wave-uniform).
     uint32_t kt_inv = 0, kt_n = 1;
+    bool kt_general = false;   // set from a template parameter by the caller: the pow2 form must not carry the other form's scalar work in its K loop
 };
 
 // a_rows / w_rows: rows of the tile that exist (>= 1).  Rows past the edge are outside the buffer descriptor's
@@ -121,7 +122,7 @@ __device__ __forceinline__ void stage_unit(const Ctx &c, int slot, int ktile) {
     for (int jj = 0; jj < 2; ++jj) {
         const uint32_t off = KIND == 0 ? c.a_off[HALF][jj] : c.w_off[HALF][jj];
         uint32_t soff;
-        if (c.kt_inv) {
+        if (c.kt_general) {
             const uint32_t wt = __builtin_amdgcn_readfirstlane((uint32_t)(((uint64_t)(uint32_t)ktile * c.kt_inv) >> 32));
             soff = ((uint32_t)ktile - wt * c.kt_n) * 128u + (KIND == 0 ? 0u : wt * c.w_tile_stride);
         } else {
