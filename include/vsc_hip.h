@@ -448,6 +448,12 @@ int vsc_attention_f32(const float *qkv_dev, float *out_dev, int32_t tokens, int3
  * heads of a group of query videos in one launch per layer (their Linears and LayerNorms are row-wise and take all rows at once). */
 int vsc_attention_f32_batch(const float *qkv_dev, float *out_dev, int32_t tokens, int32_t heads, int32_t head_dim, int32_t seqs,
                             void *stream);
+/* ... and for sequences of different lengths (the video-score heads of a group of query videos of any lengths in one launch per
+ * layer; train_vid_score/video/model.py: one video per forward): sequence z = rows row_offsets_dev[z] .. row_offsets_dev[z + 1] of
+ * qkv_dev / out_dev (int32 [seqs + 1] on the device), max_tokens = the longest sequence.  A row's result is the same bits as in
+ * vsc_attention_f32 on its sequence alone. */
+int vsc_attention_f32_varlen(const float *qkv_dev, float *out_dev, const int32_t *row_offsets_dev, int32_t seqs, int32_t max_tokens,
+                             int32_t heads, int32_t head_dim, void *stream);
 
 #ifdef __cplusplus
 }

@@ -87,9 +87,9 @@ def test_head_rejects_bad_input():
 
 
 def test_batched_head_equals_one_video_at_a_time():
-    """VideoScoreHead.logits: videos of equal length share every launch of the head (row-wise Linears / LayerNorms, back-to-back
-    sequences in vsc_attention_f32_batch) -- bit for bit the logits of the one-at-a-time path, for mixed lengths (grouped by
-    length), a video that fills all max_frames slots, and one longer than that."""
+    """VideoScoreHead.logits: the videos of a group share every launch of the head whatever their lengths (row-wise Linears /
+    LayerNorms, back-to-back sequences of their own lengths in vsc_attention_f32_varlen) -- bit for bit the logits of the
+    one-at-a-time path, for mixed lengths, a video that fills all max_frames slots, and one longer than that."""
     from tools import synth
     from vsc_hip.video_score import VideoScoreHead
     from vsc_hip.vsm_config import get_vsm_config

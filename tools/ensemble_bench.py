@@ -2,7 +2,7 @@
 3 x Swin-V2-B/256 + vit_v68 (ViT-B/32-384 + SSCD head) + the video-score gate (CLIP ViT-L/14 -> MS head), L2-normalise,
 concatenate (2048-d), near-duplicate filter, PCA 2048 -> 512 -- src/query_pipeline.run_query_videos, i.e. what
 infer/extract_query_feats.py:143-254 does per query video with the models infer/infer_ref.sh:7 lists.
-      python tools/ensemble_bench.py [videos] [frames_per_video] [--f32] [--breakdown]
+      python tools/ensemble_bench.py [videos] [frames_per_video] [--f32] [--breakdown] [--ragged]
 `measure()` is what bench.py reports as its `ensemble` secondary: the end-to-end rate from uint8 HOST frames, every model's own
 rate on device-resident frames, and the encoder-bound rate those imply (1 / sum of the models' per-frame times)."""
 import os
@@ -42,7 +42,8 @@ def build(dev):
     return {"swins": swins, "vit": vit, "clip": clip, "scorer": scorer, "cfgs": (scfg, vcfg, ccfg)}
 
 
-def videos(models, n_videos, n_frames, u8=True):
+def videos(models, n_videos, n_frames, u8=True, ragged=False):
+    """ragged: video v has 10 + 37 v mod (2 n_frames - 19) frames instead of n_frames each (the same total on average)"""
     scfg, vcfg, ccfg = models["cfgs"]
     if u8:
         base = {k: torch.from_numpy(synth.uniform(s, (8, size, size, 3), 0.0, 256.0).astype(np.uint8))
@@ -50,8 +51,9 @@ def videos(models, n_videos, n_frames, u8=True):
     else:
         base = {256: torch.from_numpy(synth.swin_frames(1, 8, scfg)), 384: torch.from_numpy(synth.frames(2, 8, vcfg)),
                 "clip": torch.from_numpy(synth.frames(3, 8, ccfg))}
-    reps = (n_frames + 7) // 8
-    return [(f"Q{v:06d}", {k: f.repeat(reps, 1, 1, 1)[:n_frames].clone() for k, f in base.items()}, np.arange(n_frames)) for v in range(n_videos)]
+    lens = [10 + (37 * v) % (2 * n_frames - 19) if ragged else n_frames for v in range(n_videos)]
+    reps = (max(lens) + 7) // 8
+    return [(f"Q{v:06d}", {k: f.repeat(reps, 1, 1, 1)[:n].clone() for k, f in base.items()}, np.arange(n)) for v, n in enumerate(lens)]
 
 
 def model_rate(model, frames_u8, dev, batch, steps=3):
@@ -66,7 +68,7 @@ def model_rate(model, frames_u8, dev, batch, steps=3):
     return batch * steps / (time.perf_counter() - t0)
 
 
-def measure(dev, n_videos=52, n_frames=40, u8=True, breakdown=False):
+def measure(dev, n_videos=52, n_frames=40, u8=True, breakdown=False, ragged=False):
     from src.query_pipeline import run_query_videos
     from src.query_postprocess import HipPCA
     t0 = time.perf_counter()
@@ -74,14 +76,14 @@ def measure(dev, n_videos=52, n_frames=40, u8=True, breakdown=False):
     build_s = time.perf_counter() - t0
     encoders = [(s, 256) for s in m["swins"]] + [(m["vit"], 384)]
     pca = HipPCA(_Fitted)
-    vids = videos(m, n_videos, n_frames, u8)
+    vids = videos(m, n_videos, n_frames, u8, ragged)
     run_query_videos(vids, encoders, pca.transform, {}, dev, scorer=m["scorer"])   # warm-up: same shapes as the timed run
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     finals, _ = run_query_videos(vids, encoders, pca.transform, {}, dev, scorer=m["scorer"])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    total = n_videos * n_frames
+    total = sum(len(v[2]) for v in vids)
     out = {"metric": "query frames/s through the reference's ensemble, end to end from uint8 host frames (3 x Swin-V2-B/256 + vit_v68 + CLIP ViT-L/14 "
                      "video-score gate, normalise, concatenate, near-duplicate filter, PCA 2048 -> 512: infer/extract_query_feats.py:143-254, infer/infer_ref.sh:7)",
            "value": round(total / dt, 1), "unit": "frames/s", "videos": n_videos, "frames_per_video": n_frames, "seconds": round(dt, 3),
@@ -128,5 +130,5 @@ if __name__ == "__main__":
     _pos = [a for a in sys.argv[1:] if not a.startswith("--")]
     import json
     r = measure(torch.device("cuda:0"), int(_pos[0]) if _pos else 52, int(_pos[1]) if len(_pos) > 1 else 40,
-                u8="--f32" not in sys.argv, breakdown="--breakdown" in sys.argv)
+                u8="--f32" not in sys.argv, breakdown="--breakdown" in sys.argv, ragged="--ragged" in sys.argv)
     print(json.dumps(r, indent=1))

@@ -1580,15 +1580,25 @@ __global__ __launch_bounds__(256) void upsample_sum4_kernel(UpsampleSumArgs p) {
 
 // softmax(q k^T / sqrt(dh)) v for one (head, query) pair per workgroup, all in fp32 (the video-score head: <= 258 tokens,
 // one video at a time -- 0.1 GFLOP per layer, latency- not throughput-bound).  qkv [tokens, 3 * heads * dh] as q | k | v.
+// row_off (optional): sequences of DIFFERENT lengths back to back, sequence z = rows row_off[z] .. row_off[z + 1] (vsc_attention_f32_varlen;
+// `tokens` is then the longest one: the grid's x extent and the LDS size); a row's arithmetic is the same in every form.
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restrict__ qkv, float *__restrict__ out, int tokens,
-                                                            int heads, int dh) {
+                                                            int heads, int dh, const int32_t *__restrict__ row_off = nullptr) {
     extern __shared__ float sm[];            // [tokens] probabilities, then [4][dh] partial outputs, [dh] query
     float *prob = sm, *part = sm + tokens, *qs = part + 4 * dh;
     __shared__ float red[8];
     const int q = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int width = heads * dh, ld = 3 * width;
+    if (row_off) {
+        const int r0 = row_off[blockIdx.z];
+        tokens = row_off[blockIdx.z + 1] - r0;
+        if (q >= tokens) return;                   // (workgroup-uniform)
+        qkv += (int64_t)r0 * ld;
+        out += (int64_t)r0 * width;
+    } else {
     qkv += (int64_t)blockIdx.z * tokens * ld;      // blockIdx.z: one of several sequences of the same length, back to back
     out += (int64_t)blockIdx.z * tokens * width;
+    }
     for (int d = tid; d < dh; d += 256) qs[d] = qkv[(int64_t)q * ld + hd * dh + d];
     __syncthreads();
     const float scale = rsqrtf((float)dh);
@@ -2043,6 +2053,18 @@ extern "C" int vsc_attention_f32_batch(const float *qkv_dev, float *out_dev, int
     VSC_REQUIRE(smem <= 48 * 1024, "attention_f32: %d tokens x head_dim %d exceeds the kernel's LDS budget", tokens, head_dim);
     hipLaunchKernelGGL(attention_f32_kernel, dim3(tokens, heads, seqs), dim3(256), smem, (hipStream_t)stream_, qkv_dev, out_dev, tokens, heads,
                        head_dim);
+    VSC_CHECK_LAUNCH();
+    return VSC_OK;
+}
+
+extern "C" int vsc_attention_f32_varlen(const float *qkv_dev, float *out_dev, const int32_t *row_offsets_dev, int32_t seqs, int32_t max_tokens,
+                                        int32_t heads, int32_t head_dim, void *stream_) {
+    VSC_REQUIRE(qkv_dev && out_dev && row_offsets_dev && max_tokens > 0 && heads > 0 && head_dim > 0, "attention_f32_varlen: bad arguments");
+    VSC_REQUIRE(max_tokens <= 8192 && heads < 65536 && seqs >= 1 && seqs < 65536, "attention_f32_varlen: %d tokens / %d heads / %d sequences unsupported", max_tokens, heads, seqs);
+    const size_t smem = (size_t)(max_tokens + 5 * head_dim) * 4;
+    VSC_REQUIRE(smem <= 48 * 1024, "attention_f32_varlen: %d tokens x head_dim %d exceeds the kernel's LDS budget", max_tokens, head_dim);
+    hipLaunchKernelGGL(attention_f32_kernel, dim3(max_tokens, heads, seqs), dim3(256), smem, (hipStream_t)stream_, qkv_dev, out_dev, max_tokens, heads,
+                       head_dim, row_offsets_dev);
     VSC_CHECK_LAUNCH();
     return VSC_OK;
 }

@@ -116,6 +116,7 @@ SIGNATURES = {
     "vsc_conv_last_pipe": (c_int32, []),
     "vsc_attention_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "vsc_attention_f32_batch": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "vsc_attention_f32_varlen": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "vsc_knn_last_path": (c_int32, []),
     "vsc_search_release_scratch": (c_int64, []),
     "vsc_video_pair_max_last_path": (c_int32, []),

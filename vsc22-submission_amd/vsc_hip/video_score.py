@@ -77,64 +77,82 @@ class VideoScoreHead:
             })
         self.out_w, self.out_b = f32("output_proj.weight"), f32("output_proj.bias")
 
-    def _attention(self, qkv: torch.Tensor, tokens: int, seqs: int = 1) -> torch.Tensor:
-        lib = _lib.require_device()
-        out = torch.empty((seqs * tokens, self.cfg.hidden), dtype=torch.float32, device=qkv.device)
-        _lib.check(lib.vsc_attention_f32_batch(_lib.ptr(qkv), _lib.ptr(out), tokens, self.cfg.heads, self.cfg.hidden // self.cfg.heads, seqs,
-                                               _lib.current_stream()))
-        return out
-
     def logit(self, clip_cls: torch.Tensor) -> torch.Tensor:
         """clip_cls [n, feat_dim] (device): the CLIP [CLS] feature of each frame of ONE video -> 0-d logit tensor."""
         return self.logits([clip_cls])[0]
 
     def logits(self, videos) -> torch.Tensor:
-        """One [n_v, feat_dim] device tensor per video -> [len(videos)] logits.  Videos with the same number of frames go through the
-        head TOGETHER: every Linear / LayerNorm is row-wise and takes all their tokens in one launch, the attention takes them as
-        back-to-back sequences (vsc_attention_f32_batch) -- the head of one 40-frame video is ~150 launches of a few microseconds of
-        work each, and a group of 26 query videos spent a quarter of its time issuing them one video after the other.  The rows of a
-        video see the same fp32 fma chains whatever else is in the launch: the logits equal the one-at-a-time ones bit for bit."""
+        """One [n_v, feat_dim] device tensor per video -> [len(videos)] logits.  ALL the videos go through the head together, whatever
+        their lengths: every Linear / LayerNorm is row-wise and takes all their tokens in one launch, the attention takes them as
+        back-to-back sequences of their own lengths (vsc_attention_f32_varlen) -- the head of one 40-frame video is ~150 launches of a few
+        microseconds of work each; a group of 26 query videos spent a quarter of its time issuing them one video after the other, and
+        (round 5) a group of videos of 52 DIFFERENT lengths still did, because only equal lengths shared launches.  The rows of a video
+        see the same fp32 fma chains whatever else is in the launch: the logits equal the one-at-a-time ones bit for bit."""
         cfg = self.cfg
-        out = [None] * len(videos)
-        by_len = {}
-        for i, f in enumerate(videos):
+        if not len(videos):
+            return torch.empty(0, device=torch.device("cuda", torch.cuda.current_device()))
+        for f in videos:
             if f.dim() != 2 or f.shape[1] != cfg.feat_dim or f.shape[0] == 0:
                 raise ValueError(f"expected [n >= 1, {cfg.feat_dim}] features, got {tuple(f.shape)}")
             if not f.is_cuda:
                 raise _lib.HipPathUnavailable("video-score features must be on the GPU (no CPU fallback)")
-            by_len.setdefault(min(int(f.shape[0]), cfg.max_frames), []).append(i)
-        for n, idx in by_len.items():
-            vals = self._logits_same_length([videos[i][: cfg.max_frames].float() for i in idx], n)
-            for j, i in enumerate(idx):
-                out[i] = vals[j]
-        return torch.stack(out)
-
-    def _logits_same_length(self, feats, n: int) -> torch.Tensor:
-        cfg = self.cfg
-        V = len(feats)
-        rows, with_sep = compact_tokens(n, cfg.max_frames)
-        f = torch.stack(feats)                                   # [V, n, feat]
-        if rows > n:
-            f = torch.cat([f, torch.zeros(V, rows - n, cfg.feat_dim, device=f.device)], dim=1)
-        f = f.reshape(V * rows, cfg.feat_dim)
+        dev = videos[0].device
+        n_of = [min(int(f.shape[0]), cfg.max_frames) for f in videos]
+        rows_sep = [compact_tokens(n, cfg.max_frames) for n in n_of]
+        T_of = [rows + 1 + int(sep) for rows, sep in rows_sep]
 
         def lin(layer, x, act=None, residual=None):   # [R, in] -> [R, out] through the NHWC convolution entry point
             r = None if residual is None else residual.reshape(1, x.shape[0], 1, -1)
             return layer(x.contiguous().reshape(1, x.shape[0], 1, x.shape[1]), act=act, residual=r).reshape(x.shape[0], -1)
 
-        vision = ops.layernorm(lin(self.proj, f), self.proj_g, self.proj_beta, cfg.proj_ln_eps, out_f32=True).reshape(V, rows, -1)
-        T = rows + 1 + int(with_sep)
-        toks = [self.cls_emb[None, None].expand(V, 1, -1), vision] + ([self.sep_emb[None, None].expand(V, 1, -1)] if with_sep else [])
-        emb = (torch.cat(toks, dim=1) + self.pos_type[:T]).reshape(V * T, -1).contiguous()
+        # frame rows of every video (+ its one padding row, compact_tokens), projected in one launch
+        zero = torch.zeros(1, cfg.feat_dim, device=dev)
+        pieces = []
+        for f, n, (rows, _) in zip(videos, n_of, rows_sep):
+            pieces.append(f[:n].float())
+            if rows > n:
+                pieces.append(zero)
+        vision = ops.layernorm(lin(self.proj, torch.cat(pieces)), self.proj_g, self.proj_beta, cfg.proj_ln_eps, out_f32=True)
+        # token rows: [CLS] + frame rows (+ [SEP]) per video, + position / type embeddings of positions 0 .. T_v - 1
+        off = np.concatenate([[0], np.cumsum(T_of)]).astype(np.int64)
+        total = int(off[-1])
+        vis_pos = np.concatenate([off[v] + 1 + np.arange(rows) for v, (rows, _) in enumerate(rows_sep)])
+        sep_pos = np.asarray([off[v + 1] - 1 for v, (_, sep) in enumerate(rows_sep) if sep], dtype=np.int64)
+        pos_ids = np.concatenate([np.arange(T) for T in T_of])
+        idx = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(dev)
+        emb = torch.empty(total, vision.shape[1], device=dev)
+        emb[idx(off[:-1])] = self.cls_emb
+        emb[idx(vis_pos)] = vision
+        if len(sep_pos):
+            emb[idx(sep_pos)] = self.sep_emb
+        emb = (emb + self.pos_type[idx(pos_ids)]).contiguous()
+        row_off = torch.from_numpy(off.astype(np.int32)).to(dev)
         x, _ = ops.ln_residual(emb, self.emb_g, self.emb_b, cfg.ln_eps)
         for L in self.layers:
-            att = self._attention(lin(L["qkv"], x), T, V)
+            att = self._attention_varlen(lin(L["qkv"], x), row_off, len(videos), max(T_of))
             x, _ = ops.ln_residual(lin(L["o"], att, residual=x), L["ln1_g"], L["ln1_b"], cfg.ln_eps)
             h = lin(L["fc1"], x, act="gelu")
             x, _ = ops.ln_residual(lin(L["fc2"], h, residual=x), L["ln2_g"], L["ln2_b"], cfg.ln_eps)
-        x = x.reshape(V, T, -1)
-        pooled = torch.cat([x[:, 0], x.sum(dim=1) / (T + 1e-5)], dim=1)
-        return (self.out_w[0] * pooled).sum(dim=1) + self.out_b[0]
+        # pooling: [CLS] row | mean over the video's token rows -- per token count (the reduction of a [V, T, hidden] block, as for one video)
+        out = [None] * len(videos)
+        by_T = {}
+        for v, T in enumerate(T_of):
+            by_T.setdefault(T, []).append(v)
+        for T, vs in by_T.items():
+            rows_idx = idx(np.concatenate([off[v] + np.arange(T) for v in vs]))
+            xt = x[rows_idx].reshape(len(vs), T, -1)
+            pooled = torch.cat([xt[:, 0], xt.sum(dim=1) / (T + 1e-5)], dim=1)
+            vals = (self.out_w[0] * pooled).sum(dim=1) + self.out_b[0]
+            for j, v in enumerate(vs):
+                out[v] = vals[j]
+        return torch.stack(out)
+
+    def _attention_varlen(self, qkv: torch.Tensor, row_off: torch.Tensor, seqs: int, max_tokens: int) -> torch.Tensor:
+        lib = _lib.require_device()
+        out = torch.empty((qkv.shape[0], self.cfg.hidden), dtype=torch.float32, device=qkv.device)
+        _lib.check(lib.vsc_attention_f32_varlen(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(row_off), seqs, max_tokens, self.cfg.heads,
+                                                self.cfg.hidden // self.cfg.heads, _lib.current_stream()))
+        return out
 
     def score(self, clip_cls: torch.Tensor) -> float:
         return float(torch.sigmoid(self.logit(clip_cls)))
