@@ -165,6 +165,29 @@ def test_ensemble_on_hip_encoders():
 
 
 @pytest.mark.gpu
+def test_reference_side_extraction_groups_loader_batches():
+    """src.extractor.extract_vsc_feat on the HIP encoder: the valid frames of consecutive loader batches go through the encoder in groups
+    (pinned staging, aligned chunks, one copy back per group) -- the same rows as encoding every video on its own, padding dropped,
+    order kept; a group boundary inside the run (group_frames = 16) and the default single group."""
+    from src.dataset import TensorFrames, collate_fn
+    from src.extractor import extract_vsc_feat
+    from vsc_hip.config import get_config
+    from vsc_hip.encoder import HipEncoder
+    dev = torch.device("cuda", 0)
+    cfg = get_config("tiny")
+    enc = HipEncoder(cfg, synth.encoder_weights(3, cfg), max_batch=8)
+    lens = [5, 11, 1, 7, 9, 3]
+    vids = [(torch.from_numpy(synth.frames(30 + i, n, cfg)), f"R{i:06d}") for i, n in enumerate(lens)]
+    want = np.concatenate([enc(f.to(dev)).cpu().numpy() for f, _ in vids])
+    for group_frames in (16, 2048):
+        loader = torch.utils.data.DataLoader(TensorFrames(vids), batch_size=2, collate_fn=collate_fn)
+        ids, feats, stamps = extract_vsc_feat(enc, loader, dev, group_frames=group_frames)
+        assert ids == [v for (_, v), n in zip(vids, lens) for _ in range(n)]
+        assert stamps.tolist() == [t for n in lens for t in range(n)]
+        assert np.array_equal(feats, want)
+
+
+@pytest.mark.gpu
 def test_group_batched_postprocessing_equals_the_per_video_steps():
     """run_query_videos on the GPU batches normalisation / similarity / PCA per group of videos and keeps the features on the device
     (process_query_group, pinned staging in encode_group): bit for bit the per-video process_query_video on the same features,

@@ -2,7 +2,12 @@
 
 `model` is anything with the reference's call shape -- here a vsc_hip.encoder.HipEncoder.
 A batch is (frames [B,S,3,H,W] padded, mask [B,S], video_ids) exactly as D_vsc.collate_fn
-builds it (infer/src/dataset.py:145-153)."""
+builds it (infer/src/dataset.py:145-153).
+
+The reference encodes loader batch by loader batch (two videos: ~100 frames per call, a synchronous pageable upload in front and a
+device -> host copy behind every one).  Here the valid frames of consecutive loader batches are collected, on the host, into groups of
+>= `group_frames` frames and go through `src.query_pipeline.encode_group`: pinned staging + a copy stream, encoder calls of the
+backbone's aligned chunk, one device -> host copy per group.  The encoders are frame-independent, so the rows are the reference's."""
 from __future__ import annotations
 
 from typing import Iterable, List, Tuple
@@ -11,18 +16,33 @@ import numpy as np
 import torch
 
 
-def extract_vsc_feat(model, batches: Iterable, device) -> Tuple[List[str], np.ndarray, np.ndarray]:
+def extract_vsc_feat(model, batches: Iterable, device, group_frames: int = 2048) -> Tuple[List[str], np.ndarray, np.ndarray]:
+    from src.query_pipeline import encode_group
     feats, vids, stamps = [], [], []
+    group, have = [], 0
+
+    def flush():
+        nonlocal group, have
+        if group:
+            feats.extend(encode_group([model], group, device)[0])
+        group, have = [], 0
+
     for frames, mask, video_id in batches:
-        mask = mask.to(device).bool()
+        mask = mask.bool()
         counts = mask.sum(dim=1).tolist()
-        flat = frames.to(device)[mask]              # drop the padding frames
-        out = model(flat)
-        assert out.shape[0] == sum(counts)
-        feats.append(out.detach().float().cpu().numpy())
-        for v, c in zip(video_id, counts):
-            vids.extend([v] * int(c))
-            stamps.append(np.arange(int(c)))
-    if not feats:
+        for b, (v, c) in enumerate(zip(video_id, counts)):
+            c = int(c)
+            vids.extend([v] * c)
+            stamps.append(np.arange(c))
+            if c:
+                f = frames[b]
+                group.append(f[:c] if bool(mask[b, :c].all()) else f[mask[b]])   # (the collate pads at the end: a view, no copy)
+                have += c
+        if have >= group_frames:
+            flush()
+    flush()
+    if not stamps:
         return [], np.zeros((0, 0), np.float32), np.zeros((0,), np.int64)
+    if not feats:
+        return vids, np.zeros((0, 0), np.float32), np.concatenate(stamps)
     return vids, np.concatenate(feats), np.concatenate(stamps)
