@@ -505,6 +505,35 @@ def test_global_threshold_search_is_the_global_top_k(dev):
         assert all(s == S[i, j] for i, j, s in hits)
 
 
+def test_candidate_generation_fast_path_equals_the_object_path(dev):
+    """CandidateGeneration.query under MaxScoreAggregation (what sscd_baseline.search runs) builds its list from flat hit arrays
+    (VideoIndex.search_pair_maxima); a subclass of the aggregation takes the reference's object path (a PairMatch per frame hit,
+    grouped, aggregated, stably sorted).  Same pairs, same scores, same order -- with a query video glued to a reference video (one
+    row owning far more winners than the adaptive probe holds), exact duplicates across videos (tied maxima) and several
+    global_k, one of them larger than the number of pairs."""
+    from vsc.candidates import CandidateGeneration, MaxScoreAggregation
+    from vsc.index import VideoFeature
+
+    class SameMax(MaxScoreAggregation):      # not `type(...) is MaxScoreAggregation`: the object path
+        pass
+
+    d = 64
+    rb = synth.descriptor_bank(51, 40 * 30, d)
+    qb = synth.descriptor_bank(52, 12 * 10, d)
+    rb[300:330] = qb[25] + 0.01 * synth.normalish(53, (30, d))    # reference video 10 glued to one frame of query video 2
+    rb[600] = rb[30]                                               # duplicate reference frames in two videos
+    qb[77] = rb[30]                                                # ... matched exactly by a query frame (tied maxima 1.0-ish)
+    qb[5] = rb[900]
+    refs = [VideoFeature(f"R{i:03d}", np.arange(30.0), rb[30 * i:30 * i + 30]) for i in range(40)]
+    queries = [VideoFeature(f"Q{i:03d}", np.arange(10.0), qb[10 * i:10 * i + 10]) for i in range(12)]
+    fast, slow = CandidateGeneration(refs, MaxScoreAggregation()), CandidateGeneration(refs, SameMax())
+    for gk in (1, 40, 700, 5000, 10 ** 7):
+        a, b = fast.query(queries, gk), slow.query(queries, gk)
+        assert [(c.query_id, c.ref_id, c.score) for c in a] == [(c.query_id, c.ref_id, c.score) for c in b], gk
+        assert len(a) > 0 and all(x.score >= y.score for x, y in zip(a, a[1:]))
+        assert fast.query(queries, gk, limit=7) == a[:7] and slow.query(queries, gk, limit=7) == b[:7]
+
+
 def test_global_threshold_search_when_the_probe_is_smaller_than_global_k(dev):
     """nq * k' < global_k <= nq * nr (few query rows, the per-row probe capped at MAX_K): the reference returns
     min(global_k, nq * nr) pairs (index.py:145-165); the probe alone would truncate to nq * k'."""

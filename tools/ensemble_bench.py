@@ -68,7 +68,7 @@ def model_rate(model, frames_u8, dev, batch, steps=3):
     return batch * steps / (time.perf_counter() - t0)
 
 
-def measure(dev, n_videos=52, n_frames=40, u8=True, breakdown=False, ragged=False):
+def measure(dev, n_videos=52, n_frames=40, u8=True, breakdown=False, ragged=False, group_frames=None):
     from src.query_pipeline import run_query_videos
     from src.query_postprocess import HipPCA
     t0 = time.perf_counter()
@@ -77,10 +77,11 @@ def measure(dev, n_videos=52, n_frames=40, u8=True, breakdown=False, ragged=Fals
     encoders = [(s, 256) for s in m["swins"]] + [(m["vit"], 384)]
     pca = HipPCA(_Fitted)
     vids = videos(m, n_videos, n_frames, u8, ragged)
-    run_query_videos(vids, encoders, pca.transform, {}, dev, scorer=m["scorer"])   # warm-up: same shapes as the timed run
+    kw = {} if group_frames is None else {"group_frames": group_frames}
+    run_query_videos(vids, encoders, pca.transform, {}, dev, scorer=m["scorer"], **kw)   # warm-up: same shapes as the timed run
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    finals, _ = run_query_videos(vids, encoders, pca.transform, {}, dev, scorer=m["scorer"])
+    finals, _ = run_query_videos(vids, encoders, pca.transform, {}, dev, scorer=m["scorer"], **kw)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     total = sum(len(v[2]) for v in vids)
@@ -130,5 +131,6 @@ if __name__ == "__main__":
     _pos = [a for a in sys.argv[1:] if not a.startswith("--")]
     import json
     r = measure(torch.device("cuda:0"), int(_pos[0]) if _pos else 52, int(_pos[1]) if len(_pos) > 1 else 40,
-                u8="--f32" not in sys.argv, breakdown="--breakdown" in sys.argv, ragged="--ragged" in sys.argv)
+                u8="--f32" not in sys.argv, breakdown="--breakdown" in sys.argv, ragged="--ragged" in sys.argv,
+                group_frames=next((int(a.split("=")[1]) for a in sys.argv if a.startswith("--group=")), None))
     print(json.dumps(r, indent=1))

@@ -28,8 +28,7 @@ logger = logging.getLogger("sscd_baseline.py")
 def search(queries: List[VideoFeature], refs: List[VideoFeature], retrieve_per_query: float = 1200.0,
            candidates_per_query: float = 25.0) -> List[CandidatePair]:
     cg = CandidateGeneration(refs, MaxScoreAggregation())
-    candidates = cg.query(queries, global_k=int(retrieve_per_query * len(queries)))
-    candidates = candidates[: int(candidates_per_query * len(queries))]
+    candidates = cg.query(queries, global_k=int(retrieve_per_query * len(queries)), limit=int(candidates_per_query * len(queries)))
     logger.info("Got %d candidates", len(candidates))
     return candidates
 

@@ -206,6 +206,18 @@ class FlatIPBank:
         return np.take_along_axis(dist, order, 1), np.take_along_axis(I, order, 1)
 
 
+def _best_first(scores: np.ndarray, want: int, descending: bool) -> np.ndarray:
+    """Indices of the `want` best scores, best first, equal scores in their order of appearance: a stable sort -- of host bookkeeping,
+    not of the search -- on the device where there is one (20M pairs: milliseconds), numpy's otherwise (the host-logic tests)."""
+    import torch
+    if len(scores) == 0:
+        return np.zeros(0, np.int64)
+    if not torch.cuda.is_available():
+        return np.argsort(-scores if descending else scores, kind="stable")[:want]
+    t = torch.from_numpy(np.ascontiguousarray(scores)).cuda()
+    return torch.sort(t, descending=descending, stable=True).indices[:want].cpu().numpy()
+
+
 class VideoIndex:
     def __init__(self, dim: int, codec_str: str = "Flat", metric: int = METRIC_INNER_PRODUCT):
         if codec_str != "Flat":
@@ -255,25 +267,62 @@ class VideoIndex:
                 if I[i, j] >= 0]
 
     def _global_threshold_knn_search(self, feats: np.ndarray, global_k: int):
-        """The reference keeps every pair inside an adaptively tightened radius, sorts all of them by score and
+        rows, refs, scores = self._global_threshold_hits(feats, global_k)
+        return [(int(i), int(j), float(sc)) for i, j, sc in zip(rows.tolist(), refs.tolist(), scores.tolist())]
+
+    def search_pair_maxima(self, queries: List[VideoFeature], global_k: int, limit: int = None):
+        """The video pairs that own at least one of the global_k best frame pairs, each with its BEST frame score, best pair first --
+        what `CandidateGeneration.query` makes of `search()` under `MaxScoreAggregation` (reference candidates.py:15-40), without a
+        Python object per frame hit: the hits stay three flat arrays, and because they are sorted best first a video pair's first hit is
+        its maximum and the order of first appearance is the order of the maxima (ties in the order of the hit list, as the stable
+        sort over the grouped hits keeps them).  -> (query ids, ref ids, scores): lists of equal length (the first `limit` pairs)."""
+        if global_k < 0:
+            raise ValueError("search_pair_maxima is the global-threshold form (global_k >= 0)")
+        if not queries:
+            return [], [], []
+        feats = np.concatenate([q.feature for q in queries])
+        rows, refs, scores = self._global_threshold_hits(feats, global_k)
+        if len(rows) == 0:
+            return [], [], []
+        q_of_row = np.repeat(np.arange(len(queries)), [len(q) for q in queries])
+        r_names, r_of_row = np.unique(np.asarray(self.video_clip_to_video_ids), return_inverse=True)
+        key = q_of_row[rows].astype(np.int64) * len(r_names) + r_of_row[refs]
+        _, first = np.unique(key, return_index=True)         # first = index of every pair's first (= best) hit
+        first.sort()
+        first = first[:limit]
+        qv, rv = q_of_row[rows[first]], r_of_row[refs[first]]
+        return [queries[i].video_id for i in qv.tolist()], r_names[rv].tolist(), scores[first].tolist()
+
+    def _global_threshold_hits(self, feats: np.ndarray, global_k: int):
+        """-> (query rows, ref rows, scores): the min(global_k, nq * nr) best frame pairs, best first (ties: lower query row, then lower
+        ref row).  The reference keeps every pair inside an adaptively tightened radius, sorts all of them by score and
         truncates to global_k (index.py:145-165): the result is the min(global_k, nq * nr) best (query row, ref row)
         pairs over ALL pairs.  Here: per-row exact top-k' (k' <= MAX_K), the same sort/truncate on the host, and
         whenever the probe cannot be shown to contain every winner -- a query row may own more than k' of them, or the
         probe holds fewer than global_k pairs in total -- an exact range sweep at a radius found by counting replaces
-        the candidate set.  Exact for inner-product indexes; for METRIC_L2 the distances handed back are recomputed exactly and the
+        the candidate set (since round 5 the probe is as small as the winners-per-row allow, not the fixed 1024).  Exact for inner-product indexes; for METRIC_L2 the distances handed back are recomputed exactly and the
         range sweep is widened by its rounding bound and re-filtered (FlatIPBank.range_search)."""
         sim = self.index.is_similarity
         nr, nq = self.index.ntotal, feats.shape[0]
+        empty = (np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32))
         kk = int(min(global_k, nr, MAX_K))
         if kk <= 0 or nq == 0:
-            return []
+            return empty
         want = int(min(global_k, nq * nr))
+        # The probe only has to hold `want` pairs and to show where the threshold lies; rows that own more winners than it holds are
+        # caught below and answered by a range sweep.  A probe of twice the mean number of winners per row (a power of two, >= 16) keeps
+        # the top-k on its fast path -- the reference's fixed 1024 (exhaustive_search.py:66) is the exact fp32 sweep here, 15 x slower,
+        # and hands nq x 1024 pairs to the host where 2 want / nq suffice.
+        mean = -(-want // nq)
+        kk = int(min(kk, max(16, 1 << (2 * mean - 1).bit_length())))
         D, I = self.index.search(feats, kk)
         valid = I >= 0
         rows = np.broadcast_to(np.arange(I.shape[0])[:, None], I.shape)[valid]
         refs, scores = I[valid], D[valid]
-        key = (lambda s: -s.astype(np.float64)) if sim else (lambda s: s.astype(np.float64))
-        order = np.lexsort((refs, rows, key(scores)))[:want]
+        # best first, ties by (query row, ref row): both hit lists below arrive query-major with equal scores of a row in ascending
+        # ref order (the search's own tie rule / the range sweep's CSR order), so a STABLE sort by score alone is that order -- on
+        # the GPU: a three-key lexsort of 20M probe pairs on the host was 6 of the 8 s this function took at 160k x 1M frames
+        order = _best_first(scores, want, sim)
         if kk < min(global_k, nr):   # the probe was capped: rows may hold winners beyond their k'-th hit
             radius = None
             if len(order) == want:
@@ -283,6 +332,10 @@ class VideoIndex:
                     # some query row owns more than kk of the winners: every pair at least as good as the
                     # provisional threshold (one float32 step outwards: the sweep's comparison is strict)
                     radius = np.nextafter(np.float32(threshold), np.float32(-np.inf if sim else np.inf))
+                    # (a small probe can put that threshold well outside the true one when a few rows own very many winners: if the
+                    # sweep would return far more than asked for, find a tighter radius by counting first)
+                    if self.index.range_count(feats, radius) > 2 * want + (1 << 20):
+                        radius = self._radius_for(feats, want, D[:, kk - 1])
             else:
                 radius = self._radius_for(feats, want, D[:, kk - 1])
             if radius is not None:
@@ -296,8 +349,8 @@ class VideoIndex:
                             break
                         radius, slack = float(radius) + slack, 2.0 * slack
                         rows, refs, scores = self.index.range_search(feats, radius)
-                order = np.lexsort((refs, rows, key(scores)))[:want]
-        return [(int(rows[o]), int(refs[o]), float(scores[o])) for o in order]
+                order = _best_first(scores, want, sim)
+        return rows[order], refs[order], scores[order]
 
     def _radius_for(self, feats: np.ndarray, want: int, kth_scores: np.ndarray) -> float:
         """A radius whose range sweep returns at least `want` pairs and, ties permitting, at most 2 * want (the
