@@ -17,6 +17,15 @@ from vsc_hip.swin_config import get_swin_config
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _reset_swin_switches():
+    """a test that fails between set_option(..., "1") and its reset must not leave the switch on for the tests behind it"""
+    yield
+    from vsc_hip import _lib
+    for name in ("VSC_SWIN_MLP512", "VSC_SWIN_QKV512", "VSC_SWIN_FUSED_MLP"):
+        _lib.set_option(name, None)
+
+
 @pytest.fixture(scope="module")
 def dev():
     from vsc_hip import _lib
@@ -198,6 +207,12 @@ def test_swin_fused_mlp_equals_two_gemm_path(dev):
     w = synth.swin_weights(9, cfg)
     x = torch.from_numpy(synth.swin_frames(10, 6, cfg)).to(dev)
     enc = SwinHipEncoder(cfg, w, max_batch=4, l2_normalize=True)
+    # (4-frame chunks are 8 tiles of the 512-wide stage's fused kernel: by default such calls keep the GEMM launches there -- the kernel
+    # pays from ~0.6 of a round of 256 tiles on; VSC_SWIN_MLP512=1 takes it at every size)
+    enc.set_profiling(True)
+    enc(x)
+    assert enc.profile()["s2.fc1"][1] == 2 * cfg.depths[2] and "s1.fc1" not in enc.profile()
+    _lib.set_option("VSC_SWIN_MLP512", "1")
     enc.set_profiling(True)
     fused = enc(x).cpu().numpy()
     prof = enc.profile()
@@ -222,7 +237,7 @@ def test_swin_fused_mlp_equals_two_gemm_path(dev):
         prof = enc.profile()
         assert "s0.fc1" not in prof and prof["s2.fc1"][1] == 2 * cfg.depths[2]
     finally:
-        _lib.set_option("VSC_SWIN_MLP512", None)
+        _lib.set_option("VSC_SWIN_MLP512", "1")
         enc.set_profiling(False)
     assert np.abs(fused - plain512).max() < 4e-4 and not np.array_equal(fused, plain512)
     # the 512-wide stage with every block launching its own qkv GEMM (VSC_SWIN_QKV512=0; default: blocks 1..17 get their qkv
@@ -238,6 +253,7 @@ def test_swin_fused_mlp_equals_two_gemm_path(dev):
         assert enc.profile()["s2.qkv"][1] == 2 * cfg.depths[2]
     finally:
         _lib.set_option("VSC_SWIN_QKV512", None)
+        _lib.set_option("VSC_SWIN_MLP512", None)
         enc.set_profiling(False)
     assert np.abs(fused - own_qkv).max() < 4e-4
 
@@ -312,6 +328,18 @@ def test_swin_encoder_matches_golden(dev, preset, golden_dir):
     np.testing.assert_allclose(d2, g["desc_l2"], rtol=0, atol=1e-3)
     parity_bounds.check(f"swin/{preset}", d2, g["desc_l2"])     # mean |d| and |mean d| (tests/parity_bounds.py)
     np.testing.assert_allclose(np.linalg.norm(d2, axis=1), 1.0, atol=1e-5)
+    if 512 in [cfg.dim(s) for s in range(cfg.stages)]:
+        # chunks this small take the GEMM launches in the 512-wide stage (its fused kernel would leave most CUs idle): the same fixture
+        # through the fused kernel as well (VSC_SWIN_MLP512=1: at every size)
+        from vsc_hip import _lib
+        _lib.set_option("VSC_SWIN_MLP512", "1")
+        try:
+            d3 = SwinHipEncoder(cfg, w, max_batch=3, l2_normalize=True)(x).cpu().numpy()
+        finally:
+            _lib.set_option("VSC_SWIN_MLP512", None)
+        assert not np.array_equal(d3, d2)
+        np.testing.assert_allclose(d3, g["desc_l2"], rtol=0, atol=1e-3)
+        parity_bounds.check(f"swin/{preset}", d3, g["desc_l2"])
 
 
 def test_swin_encoder_vs_oracle_and_batching(dev):

@@ -424,8 +424,12 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
 #define PROF(cls) SwinProfScope _ps(e, (cls), st)
     const char *fm = vsc_opt(OPT_SWIN_FUSED_MLP);   // diagnostic / test switch: 0 = fc1 and fc2 as two GEMM launches
     const bool unfused_mlp = fm && fm[0] == '0';
-    const char *f5 = vsc_opt(OPT_SWIN_MLP512);      // diagnostic / test switch: 0 = the 512-wide stage keeps fc1 and fc2 as two GEMM launches
-    const bool unfused_mlp512 = f5 && f5[0] == '0';
+    const char *f5 = vsc_opt(OPT_SWIN_MLP512);      // diagnostic / test switch: 0 = the 512-wide stage keeps fc1 and fc2 as two GEMM launches,
+    const bool unfused_mlp512 = f5 && f5[0] == '0';  // 1 = the fused kernel at every size (default: where its 128-row tiles fill the chip)
+    const bool forced_mlp512 = f5 && f5[0] == '1';
+    int cus512 = 256, dev512 = 0;
+    if (hipGetDevice(&dev512) != hipSuccess || hipDeviceGetAttribute(&cus512, hipDeviceAttributeMultiprocessorCount, dev512) != hipSuccess || cus512 <= 0)
+        cus512 = 256;
     const char *f6 = vsc_opt(OPT_SWIN_PROJ512);     // diagnostic / test switch: 0 = the 512-wide stage keeps proj + LayerNorm as their own launch
     const bool unfused_proj512 = f6 && f6[0] == '0';
     const char *f7 = vsc_opt(OPT_SWIN_QKV512);      // diagnostic / test switch: 0 = every block of the 512-wide stage launches its own qkv GEMM
@@ -464,7 +468,13 @@ static int swin_run_chunks(vsc_swin *e, const float *frames, const uint8_t *fram
                 qkv_ready = false;
                 { PROF(pc + VSC_SWIN_PROF_ATTENTION); TRY(launch_window_attention(w.qkv, w.att, K.bias, K.scale, (int)Bs, R, W, e->shift(s, b), H, st)); }
                 // (the 512-wide kernel addresses x through one 4-GiB buffer descriptor: chunks of >= 2^21 rows keep the GEMM launches)
-                const bool mlp512_ok = C != 512 || (!unfused_mlp512 && Ms < (1ll << 21));
+                // ... and small chunks too: the fused kernel gives a CU one 128-row tile at a time (one workgroup per CU, ~200 us per tile
+                // whatever else the chip does), so 40 frames = 80 tiles keep 80 of 256 CUs busy where the GEMMs' 256 x 256 tiles also split
+                // the output width: below 0.6 of a whole number of rounds the launches win (8 frames 2.63 vs 1.96 k frames/s, 40 frames 8.5 vs
+                // 7.3 k, 64 frames 11.1 vs 10.6 k; 96 frames 12.5 vs 13.6 k, 128 frames 13.6 vs 15.8 k: tools/micro/swin_small_batch_ab.sh)
+                const int64_t tiles512 = (Ms + 127) / 128, rounds512 = (tiles512 + cus512 - 1) / cus512;
+                const bool fills512 = forced_mlp512 || 10 * tiles512 >= 6 * rounds512 * cus512;
+                const bool mlp512_ok = C != 512 || (!unfused_mlp512 && fills512 && Ms < (1ll << 21));
                 if (K.fc2_wp && !unfused_mlp && !unfused_proj && swin_proj_mlp_supported(C) && mlp512_ok && !(C == 512 && unfused_proj512)) {
                     // the whole second half of the block -- proj, LayerNorm, residual, MLP, LayerNorm, residual -- in one kernel; its time
                     // is booked under fc2_ln, proj_ln and fc1 stay empty
