@@ -685,6 +685,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "library": _lib.require_device().vsc_version().decode(),     # "... src <hash of csrc/* + include/vsc_hip.h>": which build was measured
             "config": {"workload": f"{cfg.name} bf16 encode of {args.steps * args.batch} synthetic "
                                    f"{cfg.image_size}x{cfg.image_size} frames per GPU in {args.steps} steps of {args.batch} "
                                    "(BASELINE.json configs[1]: 100k frames)",

@@ -24,6 +24,7 @@ def test_bench_json_contract():
     assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert "gfx950" in d["library"] and " src " in d["library"]      # the line says which build it measured (vsc_version())
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["value"] > 0 and abs(d["value"] - 64 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01

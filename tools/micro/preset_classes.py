@@ -1,4 +1,4 @@
-"""Per-class HIP-event times of one ViT-family preset at its aligned chunk (one stream):  python tools/micro/preset_classes.py clip_vit_l14_224"""
+"""Per-class HIP-event times of one ViT-family preset at its aligned chunk (one stream):  python tools/micro/preset_classes.py clip_vit_l14_224 [frames per call]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "vsc22-submission_amd")); sys.path.insert(0, ROOT)
@@ -8,7 +8,7 @@ from vsc_hip.config import aligned_batch, get_config
 from vsc_hip.encoder import HipEncoder
 name = sys.argv[1] if len(sys.argv) > 1 else "clip_vit_l14_224"
 cfg = get_config(name)
-mb = aligned_batch(cfg.tokens)
+mb = int(sys.argv[2]) if len(sys.argv) > 2 else aligned_batch(cfg.tokens)
 enc = HipEncoder(cfg, synth.encoder_weights(3, cfg), max_batch=mb, l2_normalize=True, lanes=2)
 x = torch.from_numpy(synth.frames(1, 8, cfg)).cuda().repeat((mb + 7) // 8, 1, 1, 1)[:mb].contiguous()
 for _ in range(2): enc(x)
