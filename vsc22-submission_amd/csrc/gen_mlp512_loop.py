@@ -17,7 +17,13 @@ script assigns every register of everything else:
                      bp16, bp32 (ds_bpermute addresses of lane ^ 16, lane ^ 32);
                 "s"  w1r, w2r, xr, xbr (buffer descriptors: rows past m lie past the extent -- loads give zeros, stores are dropped),
                      swave = wave * 1024 (source side), sldsw = LDS base + wave * 1024 (destination side), eps
+                     dbgr / dbgoff / bid (timing build), attr / wpr (PROJ: the attention output rows, attn.proj.weight)
     s[40:99] scratch scalars, m0 saved / restored, scc; vcc and exec untouched
+The variants (VARIANTS below; template parameter V of swin_mlp512_kernel): 0 the MLP block; 1 PROJ: attention projection + LayerNorm +
+residual in front of it (proj_gemm, proj_ln); 9 QKV: PROJ + the NEXT block's qkv Linear behind it (qkv_phase) -- no operand was left for
+it (16 VGPRs and ~40 SGPRs survive the clobber list), so the kernel passes Wqkv's descriptor as `dbgr` and the qkv rows' as `xbr`
+(the variant writes no shadow and no timing data) and the row offset is derived from xboff; 2 .. 8 ablations and the cycle-counter
+build of the loop, 10 .. (VSC_GEN_QKV_ABL=1) those of the QKV phase: diagnostic builds only (-DVSC_MLP_ABLATION).
 Wait states the compiler would pad and an asm statement must carry itself (cdna_hip_programming.md 5.7):
     MFMA D (VGPR) -> vector reader: GEMM 1's last MFMA is followed by s_nop 7 + the loop head (>= 12 states);
     MFMA D (AGPR) -> v_accvgpr_read: s_nop 15 behind the last MFMA;
@@ -36,7 +42,8 @@ LDS_W1, LDS_W2 = 0, 2 * SLOT
 NCH = 64
 PF, STAGGER, TIMING, ABL, PROJ, QKV = 8, 0, False, 0, False, False    # defaults; main() builds the variants listed in VARIANTS
 # ABL (diagnostic variants, wrong results): 1 no GELU arithmetic, 2 no LDS-DMA in the loop, 4 no fragment reads, 8 no MFMAs in the loop;
-# in the QKV phase: 16 no LDS-DMA, 32 no chunk barrier, 64 no bias + rounding + store, 128 no fragment reads
+# in the QKV phase: 16 no LDS-DMA, 32 no barrier, 64 no bias + rounding + store, 128 no fragment reads, 1024 cycle stamps, 4096 no stores,
+# 8192 a fragment ring of 10, 16384 ring refills on every other group
 GELU_DEG = 8
 GELU_U = 4.5
 GELU_ZS = 2.0 / (4.5 * 4.5)

@@ -13,14 +13,19 @@
 //   * the hidden axis is walked in chunks of 32: W1[chunk, :] (32 x 512) and W2[:, chunk] (512 x 32), 32 KiB each, in two
 //     two-slot LDS-DMA rings (128 KiB); every fragment read from LDS feeds two MFMAs (the two 16-row tiles of the wave);
 //   * software pipeline across chunks inside the wave, one workgroup barrier per chunk:
-//         iteration i:  [ GELU(i)  ||  GEMM 2 of chunk i-1 ]  then  [ GEMM 1 of chunk i+1 ]
-//     -- the GELU's vector instructions sit between MFMA groups whose operands are already in registers, and the first LDS
-//     round trip behind the barrier is covered by the GELU's first steps;
+//         iteration i:  [ GELU(i): one run of vector instructions ]  then  [ GEMM 2 of chunk i, GEMM 1 of chunk i+1: one run of MFMAs ]
+//     -- the matrix and the vector pipe do not overlap on this part and a vector instruction right behind an MFMA costs 16 cycles
+//     where it costs 5 behind another vector instruction (tools/micro/single_wave_issue.hip), so the two kinds are kept apart; the
+//     first LDS round trip behind the barrier lands under the GELU, the LDS-DMA's scalar set-up sits in MFMA shadows;
 //   * GEMM 1's accumulator layout (row = lane & 15, hidden 16 j + 4 (lane >> 4) + r) is GEMM 2's B operand once the contraction
 //     slots are assigned as in swin_mlp.hip; fc2.weight is packed chunk-major in that order by the host
 //     (swin_mlp512_pack_w2, at model load), so a chunk is one contiguous 32 KiB piece;
 //   * LayerNorm over the wave's own rows (two-pass, a row sits in four lanes), residual rows fetched in blocks under the
 //     statistics, x / shadow written as whole 128- / 64-byte pieces per row.
+// Variants of the body (template parameter V; csrc/gen_mlp512_loop.py): 1 = the attention projection + LayerNorm + residual in front
+// (sixteen 32-column chunks of Wp on GEMM 1's machinery; x1 once through memory as fp32, its shadow in registers only); 9 = that + the
+// NEXT block's qkv Linear behind (24 double chunks of Wqkv; the new shadow is the B operand where it sits, it is not written at all).
+// The kernel is a loop over 128-row tiles (grid = tiles by default).
 // LDS layouts, conflict-free for ds_read_b128 (tools/micro/lds_swizzle_check.py, tests/test_capi_symbols.py):
 //   W1 chunk  [32 rows][1024 B]   16-byte piece index ^= row & 15
 //   W2 chunk  [512 rows][64 B]    16-byte piece index ^= (row & 1) | ((row >> 3) & 1) << 1   (ds_read_b128 serves lanes 0-3, 12-15, 20-27 / 4-11,
