@@ -117,7 +117,7 @@ def parse():
     ap.add_argument("--no-swin", action="store_true")
     ap.add_argument("--no-matching", action="store_true")
     ap.add_argument("--no-ensemble", action="store_true")
-    ap.add_argument("--ensemble-videos", type=int, default=52, help="query videos (40 frames each) of the end-to-end ensemble secondary")
+    ap.add_argument("--ensemble-videos", type=int, default=52, help="query videos (40 frames each; then once more with 10 .. 70 frames each: ensemble.ragged_lengths) of the end-to-end ensemble secondary")
     ap.add_argument("--force-sharded-search", action="store_true",
                     help="run the N > 1 search leg (RCCL all_gather + sweep) even with one rank; needs torchrun's env")
     ap.add_argument("--swin-batch", type=int, default=256)

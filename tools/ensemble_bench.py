@@ -98,6 +98,18 @@ def measure(dev, n_videos=52, n_frames=40, u8=True, breakdown=False, ragged=Fals
         out["models_frames_per_s"] = {k: round(v, 1) for k, v in rates.items()}
         out["encoder_bound_frames_per_s"] = round(1.0 / per_frame, 1)
         out["fraction_of_encoder_bound"] = round(total / dt * per_frame, 3)
+        if not ragged and n_videos >= 8:
+            # the same models on videos of DIFFERENT lengths (what query sets are): 10 .. 2 n_frames - 10 frames each
+            rv = videos(m, n_videos, n_frames, u8, True)
+            run_query_videos(rv, encoders, pca.transform, {}, dev, scorer=m["scorer"], **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_query_videos(rv, encoders, pca.transform, {}, dev, scorer=m["scorer"], **kw)
+            torch.cuda.synchronize()
+            rdt, rtotal = time.perf_counter() - t0, sum(len(v[2]) for v in rv)
+            out["ragged_lengths"] = {"value": round(rtotal / rdt, 1), "unit": "frames/s", "frames": rtotal,
+                                     "frames_per_video": [min(len(v[2]) for v in rv), max(len(v[2]) for v in rv)],
+                                     "fraction_of_encoder_bound": round(rtotal / rdt * per_frame, 3)}
         out["host_bytes_per_frame"] = int(sum(int(np.prod(t.shape[1:])) for t in b.values()))
     if breakdown:
         import src.query_pipeline as qp
