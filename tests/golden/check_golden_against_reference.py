@@ -55,6 +55,14 @@ def check_swin(preset: str) -> float:
     err = max(np.abs(tok[:, :4] - g["tokens_head"]).max(), np.abs(tok[:, -2:] - g["tokens_tail"]).max(),
               np.abs(desc - g["desc"]).max())
     assert err <= ATOL, (preset, err)
+    sp = os.path.join(HERE, f"swin_{preset}_structured.npz")
+    if os.path.exists(sp):      # the second fixture of this preset: frames that differ from one another (synth.structured_frames)
+        from sklearn.preprocessing import normalize
+        gs = np.load(sp)
+        with torch.no_grad():
+            ds = normalize(model(_t(synth.structured_frames(int(gs["frames_seed"]), int(gs["n_frames"]), cfg))).numpy())
+        err = max(err, float(np.abs(ds - gs["desc_l2"]).max()))
+        assert err <= ATOL, (preset, "structured", err)
     return float(err)
 
 

@@ -76,6 +76,17 @@ def gen(preset, n):
                         tokens_head=tok[:, :4].numpy(), tokens_tail=tok[:, -2:].numpy(), desc=desc.numpy(),
                         desc_l2=normalize(desc.numpy()))
     print(f"{path}: tok {tuple(tok.shape)} std {tok.std():.3f} |desc| {desc.abs().mean():.3f} {os.path.getsize(path) / 1024:.1f} KiB")
+    if preset == "swinv2_base_256":
+        # a second fixture on frames that differ from one another (synth.structured_frames): descriptors far from collinear
+        xs = torch.from_numpy(synth.structured_frames(FRAME_SEED, 6, cfg))
+        with torch.no_grad():
+            ts = hf(pixel_values=xs).last_hidden_state
+            ps = ts.clamp(min=1e-6).pow(cfg.gem_p).mean(dim=1).pow(1.0 / cfg.gem_p)
+            ds = normalize((ps @ torch.from_numpy(w["output_proj.weight"]).t() + torch.from_numpy(w["output_proj.bias"])).numpy())
+        c = (ds @ ds.T)[np.triu_indices(6, 1)]
+        np.savez_compressed(os.path.join(HERE, f"swin_{preset}_structured.npz"), weights_seed=WEIGHT_SEED, frames_seed=FRAME_SEED, n_frames=6,
+                            desc_l2=ds, cos_min=float(c.min()), cos_mean=float(c.mean()))
+        print(f"swin_{preset}_structured.npz: cosine between frames min {c.min():.3f} mean {c.mean():.3f}")
 
 
 if __name__ == "__main__":

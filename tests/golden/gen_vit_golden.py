@@ -86,6 +86,16 @@ def gen_vit(preset, n_frames):
         tok = hf(x).last_hidden_state
         gem, desc = _vit_head(tok, w, cfg.gem_p)
     _save(preset, n_frames, tok, gem, desc)
+    if preset == "vit_b16_224":
+        # a second fixture on frames that differ from one another (synth.structured_frames): descriptors far from collinear
+        xs = torch.from_numpy(synth.structured_frames(FRAME_SEED, 6, cfg))
+        with torch.no_grad():
+            _, ds = _vit_head(hf(xs).last_hidden_state, w, cfg.gem_p)
+        d = _l2(ds.numpy())
+        c = (d @ d.T)[np.triu_indices(6, 1)]
+        np.savez_compressed(os.path.join(HERE, f"vit_{preset}_structured.npz"), frames_seed=FRAME_SEED, weights_seed=WEIGHT_SEED, n_frames=6,
+                            desc_l2=d, cos_min=float(c.min()), cos_mean=float(c.mean()))
+        print(f"vit_{preset}_structured.npz: cosine between frames min {c.min():.3f} mean {c.mean():.3f}")
 
 
 def gen_clip(preset, n_frames):

@@ -342,6 +342,26 @@ def test_swin_encoder_matches_golden(dev, preset, golden_dir):
         parity_bounds.check(f"swin/{preset}", d3, g["desc_l2"])
 
 
+def test_swin_encoder_matches_golden_on_frames_that_differ(dev, golden_dir):
+    """Swin-V2-B's second fixture (= the reference's own class, check_golden_against_reference.py): frames of different structure
+    (synth.structured_frames), descriptors with cosine 0.79 .. 0.9 to one another instead of 0.98 -- through the GEMM launches of the
+    512-wide stage (6 frames: the default) and through its fused kernel."""
+    from vsc_hip import _lib
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    g = np.load(os.path.join(golden_dir, "swin_swinv2_base_256_structured.npz"))
+    cfg = get_swin_config("swinv2_base_256")
+    w = synth.swin_weights(int(g["weights_seed"]), cfg)
+    x = torch.from_numpy(synth.structured_frames(int(g["frames_seed"]), int(g["n_frames"]), cfg)).to(dev)
+    ref = g["desc_l2"]
+    cos = (ref @ ref.T)[np.triu_indices(len(ref), 1)]
+    assert cos.min() < 0.85
+    for forced in (None, "1"):
+        _lib.set_option("VSC_SWIN_MLP512", forced)
+        d = SwinHipEncoder(cfg, w, max_batch=4, l2_normalize=True)(x).cpu().numpy()
+        np.testing.assert_allclose(d, ref, rtol=0, atol=1e-3)
+        parity_bounds.check("swin/swinv2_base_256_structured", d, ref)
+
+
 def test_swin_encoder_vs_oracle_and_batching(dev):
     from vsc_hip.swin_encoder import SwinHipEncoder
     cfg = get_swin_config("tiny_swin")

@@ -160,6 +160,34 @@ def swin_frames(seed: int, n: int, cfg) -> np.ndarray:
     return uniform(seed, (n, cfg.channels, cfg.image_size, cfg.image_size))
 
 
+def structured_frames(seed: int, n: int, cfg) -> np.ndarray:
+    """[n, C, H, W] float32 in [-1, 1): frames that DIFFER from one another -- an oriented triangle wave of its own frequency, contrast
+    and offset per frame and channel, a soft blob somewhere, a little noise.  Frames of i.i.d. noise (`frames`) all look alike to a
+    network: their descriptors are near-collinear (cosine 0.98 between frames for the random-weight ViT-B/16), so a 1e-3 tolerance is
+    4 % of the frame-to-frame signal; these give cosines of 0.67-0.9.  Only +, *, abs, floor, min/max in float64 on exactly
+    representable grid values and `uniform` draws: the same array on every platform."""
+    size, ch = cfg.image_size, cfg.channels
+    par = uniform(seed * 7919 + 13, (n, 16)).astype(np.float64)              # per-frame parameters in [-1, 1)
+    pch = uniform(seed * 7919 + 14, (n, ch, 2)).astype(np.float64)           # per-channel phase / offset weight
+    noise = uniform(seed * 7919 + 15, (n, ch, size, size)).astype(np.float64)
+    g = (np.arange(size, dtype=np.float64) + 0.5) / size
+    y, x = g[:, None], g[None, :]
+    out = np.empty((n, ch, size, size), np.float64)
+    for i in range(n):
+        k0 = (0.5 + 4.75 * (par[i, 0] + 1.0)) * (1.0 if par[i, 1] >= 0 else -1.0)      # 0.5 .. 10 cycles per image, either orientation
+        k1 = (0.5 + 4.75 * (par[i, 2] + 1.0)) * (1.0 if par[i, 3] >= 0 else -1.0)
+        amp = 0.15 + 0.4 * (par[i, 4] + 1.0)                                             # contrast 0.15 .. 0.95
+        off = 0.4 * par[i, 5]
+        cx, cy = 0.5 + 0.3 * par[i, 6], 0.5 + 0.3 * par[i, 7]
+        r2 = 0.02 + 0.05 * (par[i, 8] + 1.0)
+        blob = np.maximum(0.0, 1.0 - ((x - cx) ** 2 + (y - cy) ** 2) / r2) ** 2 * (0.8 * par[i, 9])
+        for c in range(ch):
+            t = k0 * x + k1 * y + 0.5 * pch[i, c, 0]
+            tri = 4.0 * np.abs(t - np.floor(t + 0.5)) - 1.0                               # triangle wave in [-1, 1]
+            out[i, c] = amp * tri + off * (0.65 + 0.35 * pch[i, c, 1]) + blob + 0.05 * noise[i, c]
+    return np.minimum(np.maximum(out, -1.0), 0.999).astype(np.float32)
+
+
 def vsm_weights(seed: int, cfg) -> dict:
     """Random-init video-score model weights in the reference's state-dict naming
     (train/train_vid_score/video/model.py:63-75 ``MS``: frame_proj, bert.*, output_proj)."""
