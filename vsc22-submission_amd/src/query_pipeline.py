@@ -41,12 +41,17 @@ class VideoScorer:
     def batch(self, frames_list: Sequence[torch.Tensor]) -> List[float]:
         """Scores of several videos: the CLIP tower runs over all their (first 256) frames as one stream of
         ``chunk``-frame calls, the MS head once per video."""
+        probs = self.batch_device(frames_list)
+        return [] if probs is None else [float(v) for v in probs.cpu().tolist()]                  # one device -> host copy per group
+
+    def batch_device(self, frames_list: Sequence[torch.Tensor]):
+        """``batch`` without the copy back: the sigmoid scores as a device tensor (None for an empty list) -- the caller decides when
+        to wait for them (run_query_videos: after the NEXT group's launches are queued)."""
         clipped = [f[: self.head.cfg.max_frames] for f in frames_list]
         feats = encode_group([self.clip], clipped, self.device, self.chunk, as_numpy=False)[0]   # stay on the device: the head reads them there
         if not feats:
-            return []
-        logits = self.head.logits(feats)     # videos of equal length share the head's launches
-        return [float(v) for v in torch.sigmoid(logits).cpu().tolist()]                          # one device -> host copy per group
+            return None
+        return torch.sigmoid(self.head.logits(feats))     # the videos of a group share the head's launches
 
 
 def encode_many(model, frames_list: Sequence[torch.Tensor], device, chunk: int = None) -> List[np.ndarray]:
@@ -61,6 +66,14 @@ def preferred_chunk(models: Sequence, default: int = 256) -> int:
     expose the frame count that fills whole rounds of GEMM tiles: 332 / 451 / 255 / 256 for ViT-B/16, ViT-B/32-384,
     CLIP ViT-L/14, Swin-V2-B); ``default`` for models that do not say."""
     return min(int(getattr(m, "preferred_batch", default)) for m in models)
+
+
+def preferred_call(models: Sequence, frame_bytes: int, default: int = 256, cap_bytes: int = 512 << 20) -> int:
+    """Frames per staged chunk = per encoder call: the encoders' ``preferred_call`` (a chunk for each of their lanes: a call of ONE chunk
+    runs on one lane alone, 5 % below what the encoder does with both) while a staging buffer of it stays within ``cap_bytes``."""
+    one = preferred_chunk(models, default)
+    many = min(int(getattr(m, "preferred_call", getattr(m, "preferred_batch", default))) for m in models)
+    return many if many * frame_bytes <= cap_bytes else one
 
 
 class _Stager:
@@ -118,7 +131,9 @@ def encode_group(models: Sequence, frames_list: Sequence[torch.Tensor], device, 
     tensors -- the video-score head takes them where they are).  ``chunk`` = None: ``preferred_chunk(models)``.
     On a GPU the chunks go through pinned staging buffers and a copy stream (``_Stager``); the per-model outputs of the whole
     group come back in ONE device -> host copy each."""
-    chunk = chunk or preferred_chunk(models)
+    if not chunk:
+        f0 = frames_list[0] if len(frames_list) else None
+        chunk = preferred_call(models, int(f0[0].numel() * f0.element_size()) if f0 is not None and f0.shape[0] else 1)
     lens = [f.shape[0] for f in frames_list]
     total = sum(lens)
     outs = [[] for _ in models]
@@ -194,24 +209,54 @@ def run_query_videos(videos: Iterable[Tuple[str, Dict[int, torch.Tensor], np.nda
     # on the GPU with the library's own ops the per-video post-processing is batched per group and the features stay on the device
     # in between (process_query_group); anything else (the host-logic tests' numpy ops) takes the reference's per-video steps
     batched = ops is HipOps and torch.device(device).type == "cuda"
+    if batched:
+        # One group of look-ahead: group g + 1's uploads and launches are queued BEFORE the host waits for group g's results (the video
+        # scores' copy back, the similarity blocks, the kept rows) -- the chip used to idle through every group's post-processing and the
+        # next group's first gather.  Same calls in the same order per group: same results.
+        def launch(group):
+            subs_by_model = [None] * len(encoders)
+            for size in dict.fromkeys(sz for _, sz in encoders):
+                idx = [i for i, (_, sz) in enumerate(encoders) if sz == size]
+                for i, per_video in zip(idx, encode_group([encoders[i][0] for i in idx], [v[1][size] for v in group], device, chunk, as_numpy=False)):
+                    subs_by_model[i] = per_video
+            probs = None
+            if scorer is not None:
+                clip_frames = [v[1][VideoScorer.KEY] for v in group]
+                probs = scorer.batch_device(clip_frames) if hasattr(scorer, "batch_device") else \
+                    (scorer.batch(clip_frames) if hasattr(scorer, "batch") else [scorer(f) for f in clip_frames])
+            return group, subs_by_model, probs
+
+        def finish(group, subs_by_model, probs):
+            nonlocal rnd_idx
+            if probs is not None:
+                vals = probs.cpu().tolist() if torch.is_tensor(probs) else list(probs)
+                video_scores.update({v[0]: float(sc) for v, sc in zip(group, vals)})
+            f, pm, rnd_idx = process_query_group([v[0] for v in group], subs_by_model, [np.asarray(v[2]) for v in group],
+                                                 [video_scores.get(v[0], 1.0) for v in group], pca_transform, rnd_idx, score_threshold)
+            finals.extend(f)
+            per_model.extend(pm)
+
+        pending = None
+        for group in _video_groups(videos, group_frames):
+            cur = launch(group)
+            if pending is not None:
+                finish(*pending)
+            pending = cur
+        if pending is not None:
+            finish(*pending)
+        return finals, per_model
+    # anything else (the host-logic tests' numpy ops): the reference's per-video steps
     for group in _video_groups(videos, group_frames):
         # backbones that share an input size share the upload of every chunk
         subs_by_model = [None] * len(encoders)
         for size in dict.fromkeys(sz for _, sz in encoders):
             idx = [i for i, (_, sz) in enumerate(encoders) if sz == size]
-            for i, per_video in zip(idx, encode_group([encoders[i][0] for i in idx], [v[1][size] for v in group], device, chunk,
-                                                      as_numpy=not batched)):
+            for i, per_video in zip(idx, encode_group([encoders[i][0] for i in idx], [v[1][size] for v in group], device, chunk)):
                 subs_by_model[i] = per_video
         if scorer is not None:
             clip_frames = [v[1][VideoScorer.KEY] for v in group]
             scores = scorer.batch(clip_frames) if hasattr(scorer, "batch") else [scorer(f) for f in clip_frames]
             video_scores.update({v[0]: sc for v, sc in zip(group, scores)})
-        if batched:
-            f, pm, rnd_idx = process_query_group([v[0] for v in group], subs_by_model, [np.asarray(v[2]) for v in group],
-                                                 [video_scores.get(v[0], 1.0) for v in group], pca_transform, rnd_idx, score_threshold)
-            finals.extend(f)
-            per_model.extend(pm)
-            continue
         for i, (video_id, frames_by_size, timestamps) in enumerate(group):
             subs = [m[i] for m in subs_by_model]
             feat, sub_feats, rnd_idx = process_query_video(video_id, subs, np.asarray(timestamps), video_scores.get(video_id, 1.0),

@@ -94,6 +94,11 @@ class SwinHipEncoder:
         deepest = max(range(self.cfg.stages), key=lambda s: self.cfg.depths[s])
         return min(self.max_batch, aligned_batch(self.cfg.resolution(deepest) ** 2))
 
+    @property
+    def preferred_call(self) -> int:
+        """Frames per CALL that keep both lanes busy (the chunks of a call alternate over the encoder's two lanes)."""
+        return 2 * self.preferred_batch
+
     def __call__(self, frames: torch.Tensor, return_tokens: bool = False):
         """frames: float32 [n,C,H,W] normalised, or uint8 [n,H,W,C] decoded (normalisation fused on the GPU)."""
         cfg = self.cfg
