@@ -33,6 +33,7 @@ SWIN_SRC = "VSC22-Descriptor-Track-1st/train/train_v115/torch2scripts.py"
 CLIP_SRC = "VSC22-Descriptor-Track-1st/train/train_vid_score/video/clip.py"
 SSCD_SRC = "VSC22-Descriptor-Track-1st/train/train_v68/vsc/baseline/model_factory/backbones/sscd.py"
 VSM_SRC = "VSC22-Descriptor-Track-1st/train/train_vid_score/video/model.py"
+VIT_SRC = "VSC22-Descriptor-Track-1st/train/train_v115/vsc/baseline/model_factory/backbones/vit.py"
 
 _ALLOWED_IMPORT_ROOTS = {"torch", "numpy", "typing", "collections", "math", "transformers"}
 OPT_IN = "VSC_RUN_REFERENCE_CODE"
@@ -42,6 +43,7 @@ _PINNED = {
     CLIP_SRC: "0ed16e443efd547fba54959779a98a6cc0070865d072d0a6aaecd40781a95d03",
     SSCD_SRC: "daf573dca38b65a3c925b4f6cd85d482312270967c0f758e8a179323a81a9654",
     VSM_SRC: "c4e627e3df8564372f571683b602247e40c20682fef6da18cce4c3ab2dc7700d",
+    VIT_SRC: "464fd0c3a398af1794673d2c5e05004845f4474db6afe61b7d46fd6b8e957163",
 }
 
 

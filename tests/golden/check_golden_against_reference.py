@@ -99,6 +99,56 @@ def check_clip(preset: str) -> float:
     return float(err)
 
 
+def reference_vit(cfg, w):
+    """The reference's own `VIT` wrapper (train/train_v115/vsc/baseline/model_factory/backbones/vit.py:12-54: HF ViTModel ->
+    GeM over ALL tokens -> output_proj) instantiated from its source and loaded with tools/synth weights under ITS parameter
+    names (`vit.<HF names>`, `output_proj.*`).  `VIT.__init__` calls ViTConfig / ViTModel.from_pretrained(pretrained): a ViTConfig
+    of the preset's shape and a throw-away ViTModel are saved to a scratch directory and passed as `pretrained` (as check_vsm
+    does for MS); every parameter is then overwritten by the synthetic state dict (strict apart from the unused pooler)."""
+    import tempfile
+    from transformers import ViTConfig, ViTModel
+    import gen_vit_golden
+    ns = refc.load_definitions(refc.VIT_SRC)
+    hc = ViTConfig(hidden_size=cfg.width, num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, intermediate_size=cfg.mlp_dim,
+                   image_size=cfg.image_size, patch_size=cfg.patch_size, layer_norm_eps=cfg.ln_eps, hidden_act="gelu")
+    with tempfile.TemporaryDirectory() as d:
+        ViTModel(hc).save_pretrained(d)
+        model = ns["VIT"](feat_dim=cfg.width, output_dim=cfg.out_dim, pretrained=d, p=cfg.gem_p).eval()
+    st = {"vit." + k: v for k, v in gen_vit_golden._to_hf_vit_state(w, cfg).items()}
+    st["output_proj.weight"], st["output_proj.bias"] = _t(w["head.weight"]), _t(w["head.bias"])
+    res = model.load_state_dict(st, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.startswith("vit.pooler.") for k in res.missing_keys), res.missing_keys      # last_hidden_state does not pass the pooler
+    return model
+
+
+def check_vit(preset: str) -> float:
+    """vit_<preset>.npz (+ its _structured twin) against the reference's `VIT` class: gen_vit_golden.py restates its three head
+    lines on transformers.ViTModel tokens; here the class itself runs."""
+    from sklearn.preprocessing import normalize
+    from vsc_hip.config import get_config
+    g = np.load(os.path.join(HERE, f"vit_{preset}.npz"))
+    cfg = get_config(preset)
+    w = synth.encoder_weights(int(g["weights_seed"]), cfg)
+    model = reference_vit(cfg, w)
+    tokens = {}
+    model.vit.register_forward_hook(lambda m, i, o: tokens.__setitem__("t", o.last_hidden_state))
+    with torch.no_grad():
+        desc = model(_t(synth.frames(int(g["frames_seed"]), int(g["n_frames"]), cfg))).numpy()
+    tok = tokens["t"].numpy()
+    err = max(np.abs(desc - g["desc"]).max(), np.abs(normalize(desc) - g["desc_l2"]).max(),
+              np.abs(tok[:, :4] - g["tokens_head"]).max(), np.abs(tok[:, -2:] - g["tokens_tail"]).max())
+    assert err <= ATOL, (preset, err)
+    sp = os.path.join(HERE, f"vit_{preset}_structured.npz")
+    if os.path.exists(sp):
+        gs = np.load(sp)
+        with torch.no_grad():
+            ds = normalize(model(_t(synth.structured_frames(int(gs["frames_seed"]), int(gs["n_frames"]), cfg))).numpy())
+        err = max(err, float(np.abs(ds - gs["desc_l2"]).max()))
+        assert err <= ATOL, (preset, "structured", err)
+    return float(err)
+
+
 def sscd_head_reference(tokens: torch.Tensor, w: dict, cfg) -> torch.Tensor:
     """The reference's own head of vit_v68 on backbone tokens: `Model.embeddings` with add_head=True =
     Sequential(GlobalGeMPool2d(pool_param, dims), nn.Linear(2048, dims[1])) (sscd.py:25-42, 88-94; the conv width 2048
@@ -159,7 +209,7 @@ def check_vsm(preset: str) -> float:
 
 CHECKS = [("swin", check_swin, "tiny_swin"), ("swin", check_swin, "tiny_swin_w8"), ("swin", check_swin, "swinv2_base_256"),
           ("swin", check_swin, "tiny_swin_w24"), ("swin", check_swin, "swinv2_large_384"),
-          ("clip", check_clip, "tiny_clip"), ("sscd", check_sscd, "vit_v68"), ("vsm", check_vsm, "tiny_vsm")]
+          ("clip", check_clip, "tiny_clip"), ("vit", check_vit, "tiny"), ("vit", check_vit, "vit_b16_224"), ("sscd", check_sscd, "vit_v68"), ("vsm", check_vsm, "tiny_vsm")]
 
 
 def main():
