@@ -37,6 +37,12 @@ const char *vsc_last_error(void);
 /* Number of visible HIP devices whose arch is gfx950; <0 on runtime failure. */
 int vsc_device_count(void);
 const char *vsc_version(void);
+/* The 16-bit operand type of this build of the library: "bf16" (libvsc_hip.so, the configuration BASELINE.json names) or "fp16"
+ * (libvsc_hip_f16.so: same kernels, same MFMA rate and bytes, 11 significand bits instead of 8; the infer/ entry points default to it
+ * because the end-to-end uAP parity needs it).  Every `uint16_t *` tensor of the `*_bf16` kernel-level entry points
+ * below holds THIS type's bit patterns; the entry points keep their names in both builds.  The similarity search and the fp32
+ * convolutions are identical in both libraries (their bf16 stages are bf16 by construction). */
+const char *vsc_operand_dtype(void);
 /* Diagnostic / test switches (path forcing for the parity tests, A/B knobs of tools/micro).  Each switch VSC_<NAME> takes
  * its initial value from the environment variable of the same name, read ONCE per process; after that it changes only
  * through this call (name with or without the VSC_ prefix; value NULL or "" clears it).  No entry point reads the

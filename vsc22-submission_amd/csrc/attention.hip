@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
                     const bf16x8_t kf =
                         *(const bf16x8_t *)(klds + krow * 128 + (((g + 4 * kk) ^ ((krow >> 1) & 7)) << 4));
                     if (ABL & 4) s[t][kk] += (float)kf[0] + (float)qf[qi][kk][1];
-                    else s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi][kk], s[t], 0, 0, 0);
+                    else s[t] = lp_mfma16(kf, qf[qi][kk], s[t]);
                 }
                 // keep the scheduler from hoisting every tile's K fragments (register blow-up)
                 if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -195,12 +195,12 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
                 }
                 union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pk.w[r] = pack_bf16x2(e[2 * r], e[2 * r + 1]);
+                for (int r = 0; r < 4; ++r) pk.w[r] = lp_pack2(e[2 * r], e[2 * r + 1]);
                 pb[u] = pk.v;
             }
             // O^T[dh][query] += V^T[dh][key] . P^T[key][query]; a fifth A operand of ones gives the row sums of the bf16 P the
             // products use (every row of that tile = the sum over the keys: no VALU adds, no cross-lane reduction)
-            const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+            const bf16x8_t ones = LP_ONES;
             f32x4_t osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             f32x4_t o[4];
 #pragma unroll
@@ -211,10 +211,10 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
                 for (int ct = 0; ct < 4; ++ct) {
                     const bf16x8_t vf = *(const bf16x8_t *)(vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 8 * g) * 2);
                     if (ABL & 2) o[ct][u & 3] += (float)vf[0] + (float)pb[u][ct];
-                    else o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[u], o[ct], 0, 0, 0);
+                    else o[ct] = lp_mfma16(vf, pb[u], o[ct]);
                 }
                 if (ABL & 2) osum[0] += (float)pb[u][0];
-                else osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[u], osum, 0, 0, 0);
+                else osum = lp_mfma16(ones, pb[u], osum);
                 if (u & 1) __builtin_amdgcn_sched_barrier(0);
             }
             const float inv = __builtin_amdgcn_rcpf(osum[0]);
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
                     uint2 pk;
-                    pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
-                    pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
+                    pk.x = lp_pack2(o[ct][0] * inv, o[ct][1] * inv);
+                    pk.y = lp_pack2(o[ct][2] * inv, o[ct][3] * inv);
                     const int chunk = 2 * ct + (g >> 1);
                     *(uint2 *)(reg + fr * 128 + ((chunk ^ (fr & 7)) << 4) + ((g ^ (fr >> 3)) & 1) * 8) = pk;
                 }
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(1024) void attention_dma_kernel(const uint16_t *__r
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 128 + (((g + 4 * kk) ^ ((krow >> 1) & 7)) << 4));
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+                s[t] = lp_mfma16(kf, qf[kk], s[t]);
             }
             if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
@@ -380,10 +380,10 @@ __global__ __launch_bounds__(1024) void attention_dma_kernel(const uint16_t *__r
             }
             union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pk.w[r] = pack_bf16x2(e[2 * r], e[2 * r + 1]);
+            for (int r = 0; r < 4; ++r) pk.w[r] = lp_pack2(e[2 * r], e[2 * r + 1]);
             pb[u] = pk.v;
         }
-        const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+        const bf16x8_t ones = LP_ONES;
         f32x4_t osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         f32x4_t o[4];
 #pragma unroll
@@ -396,9 +396,9 @@ __global__ __launch_bounds__(1024) void attention_dma_kernel(const uint16_t *__r
                 union { s16x4_t h[2]; bf16x8_t v; } vf;
                 vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ldstr_t)va);            // keys 32 u + 4 g .. + 3
                 vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ldstr_t)(va + 2048));   // keys 32 u + 16 + 4 g .. + 3
-                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u], o[ct], 0, 0, 0);
+                o[ct] = lp_mfma16(vf.v, pb[u], o[ct]);
             }
-            osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[u], osum, 0, 0, 0);
+            osum = lp_mfma16(ones, pb[u], osum);
             if (u & 1) __builtin_amdgcn_sched_barrier(0);
         }
         const float inv = __builtin_amdgcn_rcpf(osum[0]);
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(1024) void attention_dma_kernel(const uint16_t *__r
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             uint2 pk;
-            pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
-            pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
+            pk.x = lp_pack2(o[ct][0] * inv, o[ct][1] * inv);
+            pk.y = lp_pack2(o[ct][2] * inv, o[ct][3] * inv);
             const int chunk = 2 * ct + (g >> 1);
             *(uint2 *)(reg + fr * 128 + ((chunk ^ (fr & 7)) << 4) + ((g ^ (fr >> 3)) & 1) * 8) = pk;
         }

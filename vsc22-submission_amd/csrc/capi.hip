@@ -19,6 +19,8 @@ extern "C" const char *vsc_last_error(void) { return g_err; }
 #endif
 // "... src <hash>": first 16 hex digits of the SHA-256 over the sources the Makefile lists (HASHED) -- tests/test_capi_symbols.py recomputes it
 extern "C" const char *vsc_version(void) { return "vsc_hip 0.1 (gfx950) src " VSC_SRC_HASH; }
+// "bf16" (libvsc_hip.so) or "fp16" (libvsc_hip_f16.so, built with -DVSC_OPERAND_F16): the 16-bit type of every MFMA operand of the encoders
+extern "C" const char *vsc_operand_dtype(void) { return VSC_LP_NAME; }
 
 extern "C" int vsc_device_count(void) {
     int n = 0;

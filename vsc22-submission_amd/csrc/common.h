@@ -79,6 +79,61 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
     return *(uint32_t *)&b;
 }
 
+// ---- the encoders' 16-bit operand type ("lp") ------------------------------------------------------------------------------
+// Every MFMA operand of the frame -> descriptor path (weights, LayerNorm outputs, qkv, probabilities, attention output, MLP hidden)
+// is ONE 16-bit type per build of the library: bf16 (libvsc_hip.so: the configuration BASELINE.json names) or, with
+// -DVSC_OPERAND_F16, IEEE fp16 (libvsc_hip_f16.so).  Same MFMA rate (v_mfma_f32_16x16x32_{bf16,f16}), same bytes, fp32 accumulation
+// either way; fp16 carries 11 significand bits against 8, which is what the end-to-end uAP parity needs (the weights'
+// bf16 rounding alone moves ViT-B/16 descriptors by 1.3e-4 on average, fp16 by 1.6e-5).  Range: the residual stream, LayerNorm,
+// softmax and pooling stay fp32; what is rounded is bounded by LayerNorm gains / GELU / V rows -- the regime these networks were
+// trained in (the reference runs its CLIP tower under fp16 autocast: extract_query_feats.py:159).  Values past 65504 become inf, as
+// under autocast.  The similarity search (knn.hip) and the matching-track convolutions (conv.hip) are bf16 by CONSTRUCTION (their
+// error bounds are derived for it): they define VSC_TU_BF16 and are the same objects in both libraries.
+#if defined(VSC_OPERAND_F16) && !defined(VSC_TU_BF16)
+#define VSC_LP_F16 1
+#define VSC_LP_NAME "fp16"
+#define VSC_LP_ASM "f16"      // mnemonic suffix in hand-written / generated asm: v_mfma_f32_16x16x32_<>, v_cvt_pk_<>_f32
+typedef __attribute__((ext_vector_type(2))) _Float16 hw_f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 hw_f16x8_t;
+__device__ inline uint32_t lp_pack2(float lo, float hi) {          // one v_cvt_pk_f16_f32 (RNE)
+    f32x2_t v = {lo, hi};
+    hw_f16x2_t b = __builtin_convertvector(v, hw_f16x2_t);
+    return *(uint32_t *)&b;
+}
+__device__ __host__ inline float lp_to_f32(uint16_t h) {
+    union { uint16_t u; _Float16 f; } v;
+    v.u = h;
+    return (float)v.f;
+}
+__device__ __host__ inline uint16_t f32_to_lp(float f) {           // RNE, overflow -> inf
+    union { uint16_t u; _Float16 f; } v;
+    v.f = (_Float16)f;
+    return v.u;
+}
+__device__ __forceinline__ f32x4_t lp_mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(*(hw_f16x8_t *)&a, *(hw_f16x8_t *)&b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float lp_dot2(uint32_t a, uint32_t b, float c) {   // c + a.lo * b.lo + a.hi * b.hi, exact products
+    return __builtin_amdgcn_fdot2(*(hw_f16x2_t *)&a, *(hw_f16x2_t *)&b, c, false);
+}
+#define LP_ONE_BITS 0x3C00
+#else
+#define VSC_LP_F16 0
+#define VSC_LP_NAME "bf16"
+#define VSC_LP_ASM "bf16"
+__device__ inline uint32_t lp_pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+__device__ __host__ inline float lp_to_f32(uint16_t h) { return bf16_to_f32(h); }
+__device__ __host__ inline uint16_t f32_to_lp(float f) { return f32_to_bf16(f); }
+__device__ __forceinline__ f32x4_t lp_mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float lp_dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(*(hw_bf16x2_t *)&a, *(hw_bf16x2_t *)&b, c, false);
+}
+#define LP_ONE_BITS 0x3F80
+#endif
+#define LP_ONES ((bf16x8_t){LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS})
+
 // ---- 16-byte stores through a buffer descriptor with a scalar offset ---------------------------------------------------
 // buffer_store_dwordx4 with an SGPR soffset: on gfx950 the instruction is still reading its four data registers when the next
 // instruction issues, and a VALU write to one of them in that slot reaches memory instead of the value stored (measured: the

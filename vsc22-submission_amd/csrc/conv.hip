@@ -22,6 +22,7 @@
 // output channels per register group: 16-byte stores along the channel axis.
 #include <mutex>
 
+#define VSC_TU_BF16 1   // this file is bf16 by construction in every build of the library (common.h, "the encoders' 16-bit operand type")
 #include "common.h"
 #include "f32_tile.h"
 

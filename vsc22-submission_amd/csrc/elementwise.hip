@@ -52,10 +52,10 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__
             }
         }
         uint4 pk;
-        pk.x = pack_bf16x2(v[0], v[1]);
-        pk.y = pack_bf16x2(v[2], v[3]);
-        pk.z = pack_bf16x2(v[4], v[5]);
-        pk.w = pack_bf16x2(v[6], v[7]);
+        pk.x = lp_pack2(v[0], v[1]);
+        pk.y = lp_pack2(v[2], v[3]);
+        pk.z = lp_pack2(v[4], v[5]);
+        pk.w = lp_pack2(v[6], v[7]);
         *(uint4 *)(patches + row * kpad + k0) = pk;
     }
 }
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restric
          e += (int64_t)gridDim.x * 256) {
         const int64_t r = e / cols_pad;
         const int c = (int)(e - r * cols_pad);
-        dst[e] = c < cols ? f32_to_bf16(src[r * cols + c]) : (uint16_t)0;
+        dst[e] = c < cols ? f32_to_lp(src[r * cols + c]) : (uint16_t)0;
     }
 }
 
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             *(float4 *)((float *)out + row * width + col) = make_float4(y0, y1, y2, y3);
         } else {
             uint2 pk;
-            pk.x = pack_bf16x2(y0, y1);
-            pk.y = pack_bf16x2(y2, y3);
+            pk.x = lp_pack2(y0, y1);
+            pk.y = lp_pack2(y2, y3);
             *(uint2 *)((uint16_t *)out + row * width + col) = pk;
         }
     }
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64) void layernorm_light_kernel(const float *__rest
         if (OUT_F32) {
             buffer_store_b128_soff(__builtin_bit_cast(vsc_u32x4_t, y), ro, off, i * 1024);
         } else {
-            u32x2_t pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3])};
+            u32x2_t pk = {lp_pack2(y[0], y[1]), lp_pack2(y[2], y[3])};
             uint32_t off_o;   // lane * 8, formed per round in a register that is free by now (as a value of the whole kernel it is the 25th)
             asm volatile("v_lshrrev_b32 %0, 1, %1" : "=v"(off_o) : "v"(off_gb));
             __builtin_amdgcn_raw_buffer_store_b64(pk, ro, off_o, i * 512, 0);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void gem_pool_bf16_kernel(const uint16_t *__re
         const bf16x8_t v = *(const bf16x8_t *)(base + (int64_t)t * channels);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float c = fmaxf(bf16_to_f32((uint16_t)v[j]), 1e-6f);
+            const float c = fmaxf(lp_to_f32((uint16_t)v[j]), 1e-6f);
             acc[j] += cube ? c * c * c : __powf(c, gem_p);
         }
     }
@@ -463,10 +463,10 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t *__restr
             }
         }
         uint4 pk;
-        pk.x = pack_bf16x2(v[0], v[1]);
-        pk.y = pack_bf16x2(v[2], v[3]);
-        pk.z = pack_bf16x2(v[4], v[5]);
-        pk.w = pack_bf16x2(v[6], v[7]);
+        pk.x = lp_pack2(v[0], v[1]);
+        pk.y = lp_pack2(v[2], v[3]);
+        pk.z = lp_pack2(v[4], v[5]);
+        pk.w = lp_pack2(v[6], v[7]);
         *(uint4 *)(patches + row * kpad + k0) = pk;
     }
 }

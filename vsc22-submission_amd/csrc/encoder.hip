@@ -99,15 +99,8 @@ int upload_bf16(vsc_encoder *e, const std::string &name, int64_t rows, int cols,
     return rc;
 }
 
-// round-to-nearest-even f32 -> bf16 -> f32, as v_cvt_pk_bf16_f32 / launch_f32_to_bf16 do
-inline float bf16_round(float v) {
-    uint32_t u;
-    memcpy(&u, &v, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    u &= 0xFFFF0000u;
-    memcpy(&v, &u, 4);
-    return v;
-}
+// round-to-nearest-even f32 -> operand type -> f32, as the device packing / launch_f32_to_bf16 do
+inline float bf16_round(float v) { return lp_to_f32(f32_to_lp(v)); }
 
 // LayerNorm folded into the Linear that consumes it:  Linear(LN(x)) = rstd * (x W'^T - mu * colsum) + bias'
 // with W' = gamma o W.  The GEMM then reads bf16(x) itself; colsum is taken over the bf16-rounded W' the MFMA

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = lp_mfma16(wf[j], af[i], acc[i][j]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -205,8 +205,8 @@ gelu4(v);
                     for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
                 }
                 uint2 pk;
-                pk.x = pack_bf16x2(v[0], v[1]);
-                pk.y = pack_bf16x2(v[2], v[3]);
+                pk.x = lp_pack2(v[0], v[1]);
+                pk.y = lp_pack2(v[2], v[3]);
                 *(uint2 *)((uint16_t *)p.out + orow * p.n + n) = pk;
             } else {
                 if (HAS_AUX) v += axv[i][j];
@@ -318,8 +318,8 @@ gelu4(v);
             for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
         }
         uint2 pk;
-        pk.x = pack_bf16x2(v[0], v[1]);
-        pk.y = pack_bf16x2(v[2], v[3]);
+        pk.x = lp_pack2(v[0], v[1]);
+        pk.y = lp_pack2(v[2], v[3]);
         *(uint2 *)((uint16_t *)p.out + orow * p.n + n) = pk;
     } else {
         if (EPI != VSC_EPI_F32) v += *(const f32x4_t *)(auxrow + n);
@@ -377,8 +377,8 @@ gelu4(v);
                     for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
                 }
                 uint2 pk;
-                pk.x = pack_bf16x2(v[0], v[1]);
-                pk.y = pack_bf16x2(v[2], v[3]);
+                pk.x = lp_pack2(v[0], v[1]);
+                pk.y = lp_pack2(v[2], v[3]);
                 const int row = i * 16 + fr, chunk = 2 * j + (fq >> 1);
                 // rows r and r+8 share (r & 7): give them opposite 8-byte halves of the chunk so
                 // the 16 lanes of a ds_write_b64 group hit 16 different bank pairs
@@ -454,8 +454,8 @@ gelu4(v);
                         *(f32x4_t *)((float *)p.out + orow * p.n + n) = v;
                         if (EPI == VSC_EPI_RESADD_STATS_F32) {
                             uint2 pk;
-                            pk.x = pack_bf16x2(v[0], v[1]);
-                            pk.y = pack_bf16x2(v[2], v[3]);
+                            pk.x = lp_pack2(v[0], v[1]);
+                            pk.y = lp_pack2(v[2], v[3]);
                             *(uint2 *)(p.ex.xb + m * p.n + n) = pk;
                         }
                     }
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = lp_mfma16(wf[j], af[i], acc[i][j]);
         }
         __builtin_amdgcn_s_setprio(0);
         VSC_T(3)  // MFMA issue
@@ -834,8 +834,8 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
                         for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
                     }
                     uint2 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]);
-                    pk.y = pack_bf16x2(v[2], v[3]);
+                    pk.x = lp_pack2(v[0], v[1]);
+                    pk.y = lp_pack2(v[2], v[3]);
                     const int row = ii * 16 + fr, chunk = 2 * j + (fq >> 1);
                     // rows r and r+8 share (r & 7): opposite 8-byte halves of the chunk (see epilogue_via_lds)
                     *(uint2 *)(reg + row * 128 + ((chunk ^ (row & 7)) << 4) + ((fq ^ (row >> 3)) & 1) * 8) = pk;
@@ -915,7 +915,7 @@ __device__ __forceinline__ void epilogue_small(const GemmArgs &p, f32x4_t (&acc)
                 if (EPI != VSC_EPI_F32) v += ax[i % 3][it];
                 buffer_store_b128_soff(__builtin_bit_cast(vsc_u32x4_t, v), out_rsrc, off0, (uint32_t)(i * 16 + it * 4) * row_bytes);
                 if (STATS) {
-                    const u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    const u32x2_t pk = {lp_pack2(v[0], v[1]), lp_pack2(v[2], v[3])};
                     __builtin_amdgcn_raw_buffer_store_b64(pk, xb_rsrc, off0 >> 1, ((uint32_t)(i * 16 + it * 4) * row_bytes) >> 1, 0);
                     // two passes on the registers, as the one-tile kernel (epilogue_via_lds)
                     const float mean = row16_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 64.0f);
@@ -1075,7 +1075,7 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8]
             if (res) v += ax[i % 3][it];
             const uint32_t soff = (uint32_t)(i * 16 + it * 4) * row_bytes;
             buffer_store_b128_soff(__builtin_bit_cast(vsc_u32x4_t, v), out_rsrc, off0, soff);
-            const u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            const u32x2_t pk = {lp_pack2(v[0], v[1]), lp_pack2(v[2], v[3])};
             __builtin_amdgcn_raw_buffer_store_b64(pk, xb_rsrc, off0 >> 1, soff >> 1, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = lp_mfma16(wf[j], af[i], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         cur = cur + 1 == STAGES ? 0 : cur + 1;
@@ -1666,8 +1666,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
                 if (m < p.m) {
                     *(f32x4_t *)(p.x_out + m * p.n + n) = v;
                     uint2 pk;
-                    pk.x = pack_bf16x2(v[0], v[1]);
-                    pk.y = pack_bf16x2(v[2], v[3]);
+                    pk.x = lp_pack2(v[0], v[1]);
+                    pk.y = lp_pack2(v[2], v[3]);
                     *(uint2 *)(p.xb_out + m * p.n + n) = pk;
                 }
             }

@@ -899,6 +899,8 @@ def main():
         for l in lines:
             if l.startswith(";"):
                 continue
+            # the operand type is a property of the build (common.h VSC_LP_ASM = "bf16" | "f16"): same instruction classes, same waits
+            l = l.replace("v_mfma_f32_16x16x32_bf16", 'v_mfma_f32_16x16x32_" VSC_LP_ASM "').replace("v_cvt_pk_bf16_f32", 'v_cvt_pk_" VSC_LP_ASM "_f32')
             out.append(f'    "{l}\\n" \\')
         out.append('    ""')
     out.append(f"#define VSC_MLP512_VARIANTS {len(VARIANTS)}")

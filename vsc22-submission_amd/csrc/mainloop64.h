@@ -157,8 +157,7 @@ __device__ __forceinline__ void mfma_quadrant(f32x4_t (&acc)[8][4], const Frags 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                acc[ASUB * 4 + i][WSUB * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    WSUB == 0 ? f.w0[B][j][kh] : f.w1[j][kh], f.af[i][kh], acc[ASUB * 4 + i][WSUB * 2 + j], 0, 0, 0);
+                acc[ASUB * 4 + i][WSUB * 2 + j] = lp_mfma16(WSUB == 0 ? f.w0[B][j][kh] : f.w1[j][kh], f.af[i][kh], acc[ASUB * 4 + i][WSUB * 2 + j]);
     __builtin_amdgcn_s_setprio(0);
 }
 

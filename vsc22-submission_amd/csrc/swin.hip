@@ -13,13 +13,12 @@ constexpr int HD = 32;  // head dim of every Swin-V2 stage (C / heads)
 
 // sum of the squares of 8 bf16 values: four v_dot2c_f32_bf16 (exact products, fp32 accumulation) instead of 8 conversions'
 // worth of multiplies and adds -- the kernel is bound by its vector instructions, and the matrix pipe does not hide them
-typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16pair_t;
 __device__ __forceinline__ float sumsq8(bf16x8_t raw) {
-    union { bf16x8_t v; hw_bf16pair_t p[4]; } u;
+    union { bf16x8_t v; uint32_t p[4]; } u;
     u.v = raw;
     float ss = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ss = __builtin_amdgcn_fdot2_f32_bf16(u.p[j], u.p[j], ss, false);
+    for (int j = 0; j < 4; ++j) ss = lp_dot2(u.p[j], u.p[j], ss);
     return ss;
 }
 
@@ -117,14 +116,14 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
         const bf16x8_t raw = *(const bf16x8_t *)(base + qrow[qi] * ld + g * 8);
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+        for (int j = 0; j < 8; ++j) v[j] = lp_to_f32((uint16_t)raw[j]);
         float ss = sumsq8(raw);
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
         const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // 1 / max(|x|, 1e-12): F.normalize's eps
         union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pk.w[j] = pack_bf16x2(v[2 * j] * inv, v[2 * j + 1] * inv);
+        for (int j = 0; j < 4; ++j) pk.w[j] = lp_pack2(v[2 * j] * inv, v[2 * j + 1] * inv);
         qf[qi] = pk.v;
     }
     // ---- stage K-hat: 4 threads per key row (16 B each), norm over the row by two shuffles
@@ -143,16 +142,16 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
         const bf16x8_t raw = kraw[it];
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+        for (int j = 0; j < 8; ++j) v[j] = lp_to_f32((uint16_t)raw[j]);
         float ss = sumsq8(raw);
         ss += __shfl_xor(ss, 1, 64);
         ss += __shfl_xor(ss, 2, 64);
         const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));   // 1 / max(|x|, 1e-12): F.normalize's eps
         uint4 pk;
-        pk.x = pack_bf16x2(v[0] * inv, v[1] * inv);
-        pk.y = pack_bf16x2(v[2] * inv, v[3] * inv);
-        pk.z = pack_bf16x2(v[4] * inv, v[5] * inv);
-        pk.w = pack_bf16x2(v[6] * inv, v[7] * inv);
+        pk.x = lp_pack2(v[0] * inv, v[1] * inv);
+        pk.y = lp_pack2(v[2] * inv, v[3] * inv);
+        pk.z = lp_pack2(v[4] * inv, v[5] * inv);
+        pk.w = lp_pack2(v[6] * inv, v[7] * inv);
         *(uint4 *)(klds + i * 64 + ((c ^ ((-(i >> 2)) & 3)) << 4)) = pk;
     }
     // ---- stage V transposed: task = (4 keys) x (8 dims); 16 consecutive lanes = 16 key groups
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                 const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
                 f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                 if (ABL & 2) z[0] = (float)kf[0] + (float)qf[qi][1];
-                else z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi], z, 0, 0, 0);
+                else z = lp_mfma16(kf, qf[qi], z);
                 float tb[4];
                 {
                     const int j0 = t * 16 + g * 4;
@@ -246,13 +245,13 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                 }
                 union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
-                for (int h = 0; h < 4; ++h) pk.w[h] = pack_bf16x2(e[h][0], e[h][1]);
+                for (int h = 0; h < 4; ++h) pk.w[h] = lp_pack2(e[h][0], e[h][1]);
                 pb[u] = pk.v;
             }
             // O^T[dh][query] += V^T[dh][key] . P^T[key][query]; a third A operand of ones gives the row sums of the bf16 P the
             // products use (every row of that tile = sum over the keys: no VALU adds, no cross-lane reduction; the matrix pipe
             // is 15 % busy in this kernel, the vector pipe 80 %)
-            const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+            const bf16x8_t ones = LP_ONES;
             f32x4_t o[2], osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -261,19 +260,19 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                 for (int ct = 0; ct < 2; ++ct) {
                     const bf16x8_t vf = *(const bf16x8_t *)(vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 8 * g) * 2);
                     if (ABL & 2) o[ct][u & 3] += (float)vf[0] + (float)pb[u][ct];
-                    else o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[u], o[ct], 0, 0, 0);
+                    else o[ct] = lp_mfma16(vf, pb[u], o[ct]);
                 }
                 if (ABL & 2) osum[0] += (float)pb[u][0];
-                else osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[u], osum, 0, 0, 0);
+                else osum = lp_mfma16(ones, pb[u], osum);
                 if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             const float inv = __builtin_amdgcn_rcpf(osum[0]);
             uint16_t *orow = out + ((int64_t)frame * res * res + qrow[qi]) * C + head * HD + g * 8;
             uint4 pk;
-            pk.x = pack_bf16x2(o[0][0] * inv, o[0][1] * inv);
-            pk.y = pack_bf16x2(o[0][2] * inv, o[0][3] * inv);
-            pk.z = pack_bf16x2(o[1][0] * inv, o[1][1] * inv);
-            pk.w = pack_bf16x2(o[1][2] * inv, o[1][3] * inv);
+            pk.x = lp_pack2(o[0][0] * inv, o[0][1] * inv);
+            pk.y = lp_pack2(o[0][2] * inv, o[0][3] * inv);
+            pk.z = lp_pack2(o[1][0] * inv, o[1][1] * inv);
+            pk.w = lp_pack2(o[1][2] * inv, o[1][3] * inv);
             if (!((ABL & 16) && inv != 12345.f)) *(uint4 *)orow = pk;
         }
     };
@@ -334,14 +333,14 @@ __global__ __launch_bounds__(512, 6) void window_attention_stream_kernel(const u
         const bf16x8_t raw = *(const bf16x8_t *)(base + qrow[qi] * ld + g * 8);
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+        for (int j = 0; j < 8; ++j) v[j] = lp_to_f32((uint16_t)raw[j]);
         float ss = sumsq8(raw);
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
         const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
         union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pk.w[j] = pack_bf16x2(v[2 * j] * inv, v[2 * j + 1] * inv);
+        for (int j = 0; j < 4; ++j) pk.w[j] = lp_pack2(v[2 * j] * inv, v[2 * j + 1] * inv);
         qf[qi] = pk.v;
     }
     {   // K-hat: 4 threads per key row, two rows per thread
@@ -357,16 +356,16 @@ __global__ __launch_bounds__(512, 6) void window_attention_stream_kernel(const u
             const int i = e >> 2, c = e & 3;
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)kraw[it][j]);
+            for (int j = 0; j < 8; ++j) v[j] = lp_to_f32((uint16_t)kraw[it][j]);
             float ss = sumsq8(kraw[it]);
             ss += __shfl_xor(ss, 1, 64);
             ss += __shfl_xor(ss, 2, 64);
             const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
             uint4 pk;
-            pk.x = pack_bf16x2(v[0] * inv, v[1] * inv);
-            pk.y = pack_bf16x2(v[2] * inv, v[3] * inv);
-            pk.z = pack_bf16x2(v[4] * inv, v[5] * inv);
-            pk.w = pack_bf16x2(v[6] * inv, v[7] * inv);
+            pk.x = lp_pack2(v[0] * inv, v[1] * inv);
+            pk.y = lp_pack2(v[2] * inv, v[3] * inv);
+            pk.z = lp_pack2(v[4] * inv, v[5] * inv);
+            pk.w = lp_pack2(v[6] * inv, v[7] * inv);
             *(uint4 *)(klds + i * 64 + ((c ^ ((-(i >> 2)) & 3)) << 4)) = pk;
         }
     }
@@ -391,7 +390,7 @@ __global__ __launch_bounds__(512, 6) void window_attention_stream_kernel(const u
     const bool nomax = scraw < 0.f;   // workgroup-uniform
     const float sc = fabsf(scraw) * LOG2E;
     const f32x2_t sc2 = (f32x2_t){sc, sc};
-    const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8_t ones = LP_ONES;
     auto rows = [&](auto nomax_c) {
         constexpr bool NOMAX = decltype(nomax_c)::value;
 #pragma unroll
@@ -403,7 +402,7 @@ __global__ __launch_bounds__(512, 6) void window_attention_stream_kernel(const u
                 const int krow = t * 16 + fr;
                 const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
                 f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qi], z, 0, 0, 0);
+                z = lp_mfma16(kf, qf[qi], z);
                 const int j0 = t * 16 + g * 4;
                 const f32x4_t b4 = *(const f32x4_t *)(lt - (j0 / WS) * TSTRIDE + (j0 % WS));
                 s[0] = (f32x2_t){z[0], z[1]} * sc2 + (f32x2_t){b4[0], b4[1]};
@@ -436,24 +435,24 @@ __global__ __launch_bounds__(512, 6) void window_attention_stream_kernel(const u
 #pragma unroll
                     for (int x = 0; x < 2; ++x) {
                         const f32x2_t d = NOMAX ? s[x] : s[x] + nm2;
-                        pk.w[2 * h + x] = pack_bf16x2(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
+                        pk.w[2 * h + x] = lp_pack2(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
                     }
                 }
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     const bf16x8_t vf = *(const bf16x8_t *)(vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 8 * g) * 2);
-                    o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pk.v, o[ct], 0, 0, 0);
+                    o[ct] = lp_mfma16(vf, pk.v, o[ct]);
                 }
-                osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pk.v, osum, 0, 0, 0);
+                osum = lp_mfma16(ones, pk.v, osum);
                 if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
             const float inv = __builtin_amdgcn_rcpf(osum[0]);
             uint16_t *orow = out + ((int64_t)frame * res * res + qrow[qi]) * C + head * HD + g * 8;
             uint4 pk;
-            pk.x = pack_bf16x2(o[0][0] * inv, o[0][1] * inv);
-            pk.y = pack_bf16x2(o[0][2] * inv, o[0][3] * inv);
-            pk.z = pack_bf16x2(o[1][0] * inv, o[1][1] * inv);
-            pk.w = pack_bf16x2(o[1][2] * inv, o[1][3] * inv);
+            pk.x = lp_pack2(o[0][0] * inv, o[0][1] * inv);
+            pk.y = lp_pack2(o[0][2] * inv, o[0][3] * inv);
+            pk.z = lp_pack2(o[1][0] * inv, o[1][1] * inv);
+            pk.w = lp_pack2(o[1][2] * inv, o[1][3] * inv);
             *(uint4 *)orow = pk;
         }
     };
@@ -513,16 +512,16 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
         if (i < N) raw = *(const bf16x8_t *)(base + C + rowmap[i] * ld + c * 8);
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+        for (int j = 0; j < 8; ++j) v[j] = lp_to_f32((uint16_t)raw[j]);
         float ss = sumsq8(raw);
         ss += __shfl_xor(ss, 1, 64);
         ss += __shfl_xor(ss, 2, 64);
         const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
         uint4 pk;
-        pk.x = pack_bf16x2(v[0] * inv, v[1] * inv);
-        pk.y = pack_bf16x2(v[2] * inv, v[3] * inv);
-        pk.z = pack_bf16x2(v[4] * inv, v[5] * inv);
-        pk.w = pack_bf16x2(v[6] * inv, v[7] * inv);
+        pk.x = lp_pack2(v[0] * inv, v[1] * inv);
+        pk.y = lp_pack2(v[2] * inv, v[3] * inv);
+        pk.z = lp_pack2(v[4] * inv, v[5] * inv);
+        pk.w = lp_pack2(v[6] * inv, v[7] * inv);
         *(uint4 *)(klds + i * 64 + ((c ^ ((-(i >> 2)) & 3)) << 4)) = pk;
     }
     for (int e = tid; e < (NP / 4) * 4; e += NTHREADS) {
@@ -553,14 +552,14 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
             const bf16x8_t raw = *(const bf16x8_t *)(base + qrow * ld + g * 8);
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+            for (int j = 0; j < 8; ++j) v[j] = lp_to_f32((uint16_t)raw[j]);
             float ss = sumsq8(raw);
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
             const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
             union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pk.w[j] = pack_bf16x2(v[2 * j] * inv, v[2 * j + 1] * inv);
+            for (int j = 0; j < 4; ++j) pk.w[j] = lp_pack2(v[2 * j] * inv, v[2 * j + 1] * inv);
             qf = pk.v;
         }
         const int yq = q / WS, xq = q - yq * WS, rq = region[q];
@@ -572,7 +571,7 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
             const int krow = t * 16 + fr;
             const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
             f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);
+            z = lp_mfma16(kf, qf, z);
             const int j0 = t * 16 + g * 4, yj = j0 / WS, xj = j0 - yj * WS;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -589,7 +588,7 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
             for (int r = 0; r < 4; ++r) s[t][r] = -INFINITY;   // the padding tile: probability 0
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+        const bf16x8_t ones = LP_ONES;
         f32x4_t o[2], osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -598,7 +597,7 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const float *sv = s[2 * u + (h >> 1)] + 2 * (h & 1);
-                pk.w[h] = pack_bf16x2(__builtin_amdgcn_exp2f(sv[0] - mx), __builtin_amdgcn_exp2f(sv[1] - mx));
+                pk.w[h] = lp_pack2(__builtin_amdgcn_exp2f(sv[0] - mx), __builtin_amdgcn_exp2f(sv[1] - mx));
             }
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
@@ -606,9 +605,9 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
                 union { uint2 h[2]; bf16x8_t v; } vf;
                 vf.h[0] = *(const uint2 *)vrow;            // keys 32 u + 4 g .. + 3       (k slots j < 4)
                 vf.h[1] = *(const uint2 *)(vrow + 32);     // keys 32 u + 16 + 4 g .. + 3  (k slots j >= 4)
-                o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk.v, o[ct], 0, 0, 0);
+                o[ct] = lp_mfma16(vf.v, pk.v, o[ct]);
             }
-            osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pk.v, osum, 0, 0, 0);
+            osum = lp_mfma16(ones, pk.v, osum);
             if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         const float inv = __builtin_amdgcn_rcpf(osum[0]);
@@ -616,8 +615,8 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {   // o[ct][r] = context[query fr][dim ct * 16 + 4 g + r]
             uint2 pk;
-            pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
-            pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
+            pk.x = lp_pack2(o[ct][0] * inv, o[ct][1] * inv);
+            pk.y = lp_pack2(o[ct][2] * inv, o[ct][3] * inv);
             *(uint2 *)(orow + ct * 16) = pk;
         }
     }
@@ -682,16 +681,16 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_atte
         const bf16x8_t raw = *(const bf16x8_t *)(base + C + rowmap[i] * ld + c * 8);
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+        for (int j = 0; j < 8; ++j) v[j] = lp_to_f32((uint16_t)raw[j]);
         float ss = sumsq8(raw);
         ss += __shfl_xor(ss, 1, 64);
         ss += __shfl_xor(ss, 2, 64);
         const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
         uint4 pk;
-        pk.x = pack_bf16x2(v[0] * inv, v[1] * inv);
-        pk.y = pack_bf16x2(v[2] * inv, v[3] * inv);
-        pk.z = pack_bf16x2(v[4] * inv, v[5] * inv);
-        pk.w = pack_bf16x2(v[6] * inv, v[7] * inv);
+        pk.x = lp_pack2(v[0] * inv, v[1] * inv);
+        pk.y = lp_pack2(v[2] * inv, v[3] * inv);
+        pk.z = lp_pack2(v[4] * inv, v[5] * inv);
+        pk.w = lp_pack2(v[6] * inv, v[7] * inv);
         *(uint4 *)(klds + i * 64 + ((c ^ ((-(i >> 2)) & 3)) << 4)) = pk;
     }
     for (int e = tid; e < (N / 4) * 4; e += NTHREADS) {   // V^T: task = 4 keys x 8 dims, plain key order
@@ -713,7 +712,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_atte
     const bool nomax = scraw < 0.f;                                          // workgroup-uniform
     const float sc = fabsf(scraw) * LOG2E;
     const f32x2_t sc2 = (f32x2_t){sc, sc};
-    const bf16x8_t ones = (bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bf16x8_t ones = LP_ONES;
     const int fr = lane & 15, g = lane >> 4;
     auto rows = [&](auto nomax_c, auto mask_c) {
         constexpr bool NOMAX = decltype(nomax_c)::value, MASK = decltype(mask_c)::value;
@@ -726,14 +725,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_atte
                 const bf16x8_t raw = *(const bf16x8_t *)(base + qrow * ld + g * 8);
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((uint16_t)raw[j]);
+                for (int j = 0; j < 8; ++j) v[j] = lp_to_f32((uint16_t)raw[j]);
                 float ss = sumsq8(raw);
                 ss += __shfl_xor(ss, 16, 64);
                 ss += __shfl_xor(ss, 32, 64);
                 const float inv = __builtin_amdgcn_rsqf(fmaxf(ss, 1e-24f));
                 union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pk.w[j] = pack_bf16x2(v[2 * j] * inv, v[2 * j + 1] * inv);
+                for (int j = 0; j < 4; ++j) pk.w[j] = lp_pack2(v[2 * j] * inv, v[2 * j + 1] * inv);
                 qf = pk.v;
             }
             const int tcopy = (q + 1) & 3;
@@ -743,7 +742,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_atte
                 const int krow = t * 16 + fr;
                 const bf16x8_t kf = *(const bf16x8_t *)(klds + krow * 64 + ((g ^ ((-(krow >> 2)) & 3)) << 4));
                 f32x4_t z = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);
+                z = lp_mfma16(kf, qf, z);
                 const int a = t * 4 + g, yj = a / (WS / 4), xj = (a - yj * (WS / 4)) * 4;   // keys j0 = 16 t + 4 g .. + 3 = (yj, xj ..)
                 const f32x4_t b4 = *(const f32x4_t *)(lt - yj * TSTRIDE + xj);
                 sv[0] = (f32x2_t){z[0], z[1]} * sc2 + (f32x2_t){b4[0], b4[1]};
@@ -784,7 +783,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_atte
 #pragma unroll
                     for (int x = 0; x < 2; ++x) {
                         const f32x2_t d = NOMAX ? sv[x] : sv[x] + nm2;
-                        pk.w[2 * h + x] = pack_bf16x2(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
+                        pk.w[2 * h + x] = lp_pack2(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
                     }
                 }
 #pragma unroll
@@ -793,17 +792,17 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_atte
                     union { uint2 h[2]; bf16x8_t v; } vf;
                     vf.h[0] = *(const uint2 *)vrow;            // keys 32 u + 4 g .. + 3       (k slots j < 4)
                     vf.h[1] = *(const uint2 *)(vrow + 32);     // keys 32 u + 16 + 4 g .. + 3  (k slots j >= 4)
-                    o[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pk.v, o[ct], 0, 0, 0);
+                    o[ct] = lp_mfma16(vf.v, pk.v, o[ct]);
                 }
-                osum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pk.v, osum, 0, 0, 0);
+                osum = lp_mfma16(ones, pk.v, osum);
             }
             const float inv = __builtin_amdgcn_rcpf(osum[0]);
             uint16_t *orow = out + ((int64_t)frame * res * res + qrow) * C + head * HD + g * 4;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {   // o[ct][r] = context[query fr][dim ct * 16 + 4 g + r]
                 uint2 pk;
-                pk.x = pack_bf16x2(o[ct][0] * inv, o[ct][1] * inv);
-                pk.y = pack_bf16x2(o[ct][2] * inv, o[ct][3] * inv);
+                pk.x = lp_pack2(o[ct][0] * inv, o[ct][1] * inv);
+                pk.y = lp_pack2(o[ct][2] * inv, o[ct][3] * inv);
                 *(uint2 *)(orow + ct * 16) = pk;
             }
         }
@@ -865,8 +864,8 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float *__restric
         }
         *(float4 *)(x_out + row * width + col) = y;
         uint2 pk;
-        pk.x = pack_bf16x2(y.x, y.y);
-        pk.y = pack_bf16x2(y.z, y.w);
+        pk.x = lp_pack2(y.x, y.y);
+        pk.y = lp_pack2(y.z, y.w);
         *(uint2 *)(xb + row * width + col) = pk;
     }
 }

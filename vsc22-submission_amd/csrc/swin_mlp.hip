@@ -77,7 +77,7 @@ __device__ __forceinline__ int w2_swz(int row) { return ((row >> 1) & 1) | (((ro
 // (tools/micro/single_wave_issue.hip)
 template <int C, int NW, int ABL = 0, bool PROJ = false, bool SEQ = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpArgs p) {
-#define MFMA(a, b, c) ((ABL & 2) ? (c) + (f32x4_t){(float)(a)[0], (float)(b)[0], 0.f, 0.f} : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0))
+#define MFMA(a, b, c) ((ABL & 2) ? (c) + (f32x4_t){(float)(a)[0], (float)(b)[0], 0.f, 0.f} : lp_mfma16(a, b, c))
     constexpr int RW = C == 128 ? 32 : 16, MT = RW / 16, R = NW * RW;
     constexpr int KS1 = C / 32, JO = C / 16, H = 4 * C, HC = 64, NCH = H / HC;
     constexpr int W1B = HC * C * 2, W2B = C * HC * 2, CHUNK = W1B + W2B;
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 xres[mt][2 * pp + t] = xin1[mt][2 * pp + t] + nrm[t];
-                pk.w[2 * t] = pack_bf16x2(xres[mt][2 * pp + t][0], xres[mt][2 * pp + t][1]);
-                pk.w[2 * t + 1] = pack_bf16x2(xres[mt][2 * pp + t][2], xres[mt][2 * pp + t][3]);
+                pk.w[2 * t] = lp_pack2(xres[mt][2 * pp + t][0], xres[mt][2 * pp + t][1]);
+                pk.w[2 * t + 1] = lp_pack2(xres[mt][2 * pp + t][2], xres[mt][2 * pp + t][3]);
             }
             xf[mt][pp] = pk.v;   // columns 32 pp + 8 quad .. + 7 of row fr: GEMM 1's B operand of k-step pp
         });
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    hf[mt][jp].w[jj * 2 + 0] = pack_bf16x2(v[mt * 4 + jj * 2][0], v[mt * 4 + jj * 2][1]);
-                    hf[mt][jp].w[jj * 2 + 1] = pack_bf16x2(v[mt * 4 + jj * 2 + 1][0], v[mt * 4 + jj * 2 + 1][1]);
+                    hf[mt][jp].w[jj * 2 + 0] = lp_pack2(v[mt * 4 + jj * 2][0], v[mt * 4 + jj * 2][1]);
+                    hf[mt][jp].w[jj * 2 + 1] = lp_pack2(v[mt * 4 + jj * 2 + 1][0], v[mt * 4 + jj * 2 + 1][1]);
                 }
         };
         // ---- B: GELU(tiles 0, 1) || GEMM 1 (tiles 2, 3): 2 KS1 MFMA groups over the NSTEP steps
@@ -424,10 +424,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
                 *(f32x4_t *)(xr + col + 4 * t) = y[t];
             }
             uint4 pk;
-            pk.x = pack_bf16x2(y[0][0], y[0][1]);
-            pk.y = pack_bf16x2(y[0][2], y[0][3]);
-            pk.z = pack_bf16x2(y[1][0], y[1][1]);
-            pk.w = pack_bf16x2(y[1][2], y[1][3]);
+            pk.x = lp_pack2(y[0][0], y[0][1]);
+            pk.y = lp_pack2(y[0][2], y[0][3]);
+            pk.z = lp_pack2(y[1][0], y[1][1]);
+            pk.w = lp_pack2(y[1][2], y[1][3]);
             *(uint4 *)(xbr + col) = pk;
         }
     });

@@ -25,7 +25,7 @@ import torch
 
 from src.dataset import CLIP_MEAN, CLIP_STD, clip_transform_u8, vit_transform_u8
 from src.matching import calclualte_low_var_dim
-from src.model_zoo import load_encoder, parse_model_spec
+from src.model_zoo import DEFAULT_PRECISION, load_encoder, parse_model_spec
 from src.query_pipeline import VideoScorer, run_query_videos
 from src.query_postprocess import HipPCA, SCORE_THRESHOLD
 from vsc.baseline.score_normalization import query_score_normalize
@@ -86,7 +86,7 @@ def main(args):
     torch.cuda.set_device(0)
     device = torch.device("cuda", 0)
     specs = [parse_model_spec(s) for s in args.models]
-    encoders = [load_encoder(arch, fmt, path, args.max_batch) for arch, fmt, path in specs]
+    encoders = [load_encoder(arch, fmt, path, args.max_batch, precision=args.precision) for arch, fmt, path in specs]
     with open(args.pca_model, "rb") as f:
         pca = HipPCA(pickle.load(f))
     with open(args.input_file, encoding="utf-8") as f:
@@ -95,7 +95,8 @@ def main(args):
     scorer = None
     if args.clip_checkpoint and args.vsm_checkpoint:
         from vsc_hip.video_score import VideoScoreHead, from_reference_state
-        clip, _ = load_encoder("clip_vit_l14_224", "clip", args.clip_checkpoint, args.max_batch, u8_norm=(CLIP_MEAN, CLIP_STD))
+        clip, _ = load_encoder("clip_vit_l14_224", "clip", args.clip_checkpoint, args.max_batch, u8_norm=(CLIP_MEAN, CLIP_STD),
+                               precision=args.precision)
         state = torch.load(args.vsm_checkpoint, map_location="cpu")
         scorer = VideoScorer(clip, VideoScoreHead("vsm_roberta_base", from_reference_state(state.get("state_dict", state))), device)
     videos = zip_videos(vids, args.zip_prefix, sorted({size for _, size in encoders}), with_clip=scorer is not None,
@@ -129,6 +130,8 @@ def build_parser():
     ap.add_argument("--output_dir", default="outputs")
     ap.add_argument("--max_batch", type=int, default=None,
                     help="frames per encoder call; default: each backbone's tile-aligned batch (332 / 451 / 255 / 256)")
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["fp16", "bf16"],
+                    help="16-bit type of the encoders' MFMA operands (same speed; fp16 = 8 x smaller rounding, DESIGN.md 3a)")
     ap.add_argument("--workers", type=int, default=6, help="decode / resize worker processes (the reference uses 6)")
     return ap
 

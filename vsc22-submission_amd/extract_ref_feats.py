@@ -17,7 +17,7 @@ import torch
 from src.dataset import ZipFrames, collate_fn, vit_transform_u8
 from src.extractor import extract_vsc_feat
 from vsc.storage import load_features, store_features
-from src.model_zoo import WEIGHT_FORMATS, load_encoder
+from src.model_zoo import DEFAULT_PRECISION, WEIGHT_FORMATS, load_encoder
 from vsc_hip import distributed as vdist
 
 
@@ -30,7 +30,8 @@ def main(args):
     if distributed:
         dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
     rank, world_size = vdist.world()
-    model, image_size = load_encoder(args.arch, args.weights_format, args.checkpoint_path, args.max_batch)
+    model, image_size = load_encoder(args.arch, args.weights_format, args.checkpoint_path, args.max_batch,
+                                     precision=getattr(args, "precision", DEFAULT_PRECISION))
     with open(args.input_file, encoding="utf-8") as f:
         vids = [x.strip() for x in f if x.strip()]
     lo, hi = vdist.shard_bounds(len(vids), rank, world_size)
@@ -64,4 +65,6 @@ if __name__ == "__main__":
     ap.add_argument("--batch_size", type=int, default=2, help="videos per loader batch")
     ap.add_argument("--max_batch", type=int, default=None,
                     help="frames per encoder step; default: the backbone's tile-aligned batch (ViT-B/16: 332)")
+    ap.add_argument("--precision", default=DEFAULT_PRECISION, choices=["fp16", "bf16"],
+                    help="16-bit type of the encoder's MFMA operands (same speed; fp16 = 8 x smaller rounding, DESIGN.md 3a)")
     main(ap.parse_args())

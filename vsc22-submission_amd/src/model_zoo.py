@@ -34,12 +34,19 @@ def _state_dict(path: str) -> dict:
     return state.state_dict()
 
 
-def load_encoder(arch: str, weights_format: str, checkpoint_path: str, max_batch: int = None, u8_norm=None):
+DEFAULT_PRECISION = "fp16"   # of the infer/ entry points: the operand type whose end-to-end uAP lies within 1e-3 of the fp32 reference chain
+                             # (tests/test_gpu_uap_e2e.py).  "bf16" is the configuration bench.py's headline times.
+
+
+def load_encoder(arch: str, weights_format: str, checkpoint_path: str, max_batch: int = None, u8_norm=None,
+                 precision: str = DEFAULT_PRECISION):
     """-> (encoder, image_size).  ``u8_norm`` = (mean, std) applied to uint8 frames on the GPU (default 0.5 / 0.5, the
     reference's vit_transform; pass dataset.CLIP_MEAN / CLIP_STD for the CLIP tower).  ``max_batch`` = None sizes the
-    workspace for the architecture's tile-aligned batch (vsc_hip.config.aligned_batch).
+    workspace for the architecture's tile-aligned batch (vsc_hip.config.aligned_batch).  ``precision``: "fp16" | "bf16" operands
+    (vsc_hip.encoder.HipEncoder).
     Raises ValueError for an unknown arch / format pairing."""
     kw = {} if u8_norm is None else {"u8_mean": tuple(u8_norm[0]), "u8_std": tuple(u8_norm[1])}
+    kw["precision"] = precision
     if arch in SWIN_PRESETS:
         if weights_format != "swin_ref":
             raise ValueError(f"{arch} is a Swin-V2 preset: weights_format must be swin_ref, not {weights_format}")

@@ -12,6 +12,9 @@ from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_size_t, c_voi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VSC_HIP_LIB: another build of the library (same-box A/B runs of an experimental kernel build, tools/micro/*); default: the in-tree one
 LIB_PATH = os.environ.get("VSC_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libvsc_hip.so")
+# One library per 16-bit operand type of the encoders (vsc_operand_dtype): "bf16" is the configuration BASELINE.json names and the
+# one the search / CNN / kernel-level wrappers use; "fp16" is the same kernels with 11-bit significands (csrc/common.h).
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.environ.get("VSC_HIP_LIB_F16") or os.path.join(os.path.dirname(_HERE), "lib", "libvsc_hip_f16.so")}
 
 EPI_BF16, EPI_GELU_BF16, EPI_QGELU_BF16, EPI_RESADD_F32, EPI_PATCH_F32, EPI_F32 = range(6)
 PROF_CLASSES = ("patchify", "gemm_patch", "layernorm", "gemm_qkv", "attention", "gemm_proj",
@@ -55,6 +58,7 @@ SIGNATURES = {
     "vsc_last_error": (c_char_p, []),
     "vsc_device_count": (c_int32, []),
     "vsc_version": (c_char_p, []),
+    "vsc_operand_dtype": (c_char_p, []),
     "vsc_set_option": (c_int32, [c_char_p, c_char_p]),
     "vsc_get_option": (c_char_p, [c_char_p]),
     "vsc_encoder_create": (c_int32, [POINTER(EncoderConfigC), POINTER(c_void_p)]),
@@ -135,28 +139,37 @@ SIGNATURES = {
                                     c_void_p]),
 }
 
-_lib = None
+_libs = {}
+_options = {}     # switches set through set_option so far: replayed into a library loaded later
 
 
-def load() -> ctypes.CDLL:
-    """Load the shared library (no GPU needed for this step)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def load(precision: str = "bf16") -> ctypes.CDLL:
+    """Load the shared library of that operand type (no GPU needed for this step)."""
+    lib = _libs.get(precision)
+    if lib is None:
+        if precision not in LIB_PATHS:
+            raise ValueError(f"precision must be one of {sorted(LIB_PATHS)}, not {precision!r}")
+        path = LIB_PATHS[precision]
+        if not os.path.exists(path):
             raise HipPathUnavailable(
-                f"{LIB_PATH} is not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C vsc22-submission_amd/csrc`; there is no CPU fallback")
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = lib
-    return _lib
+        got = lib.vsc_operand_dtype().decode()
+        if got != precision:
+            raise HipPathUnavailable(f"{path} reports operand type {got}, expected {precision}: stale or misplaced build")
+        for name, value in _options.items():
+            lib.vsc_set_option(name.encode(), None if value is None else str(value).encode())
+        _libs[precision] = lib
+    return lib
 
 
-def require_device() -> ctypes.CDLL:
-    lib = load()
+def require_device(precision: str = "bf16") -> ctypes.CDLL:
+    lib = load(precision)
     n = lib.vsc_device_count()
     if n < 1:
         raise HipPathUnavailable(
@@ -168,7 +181,10 @@ def require_device() -> ctypes.CDLL:
 def set_option(name: str, value=None) -> None:
     """Set (or, with None, clear) a diagnostic switch of the library -- vsc_set_option in include/vsc_hip.h.  The library
     reads its VSC_* environment variables once per process; changing os.environ afterwards has no effect."""
-    check(load().vsc_set_option(name.encode(), None if value is None else str(value).encode()))
+    load()
+    _options[name] = value
+    for lib in list(_libs.values()):
+        check(lib.vsc_set_option(name.encode(), None if value is None else str(value).encode()))
 
 
 def get_option(name: str):
@@ -196,7 +212,8 @@ class option:
 
 def check(rc: int) -> None:
     if rc != 0:
-        raise VscHipError(f"libvsc_hip status {rc}: {load().vsc_last_error().decode()}")
+        msgs = [m for m in (lib.vsc_last_error().decode() for lib in _libs.values()) if m]
+        raise VscHipError(f"libvsc_hip status {rc}: {' | '.join(msgs)}")
 
 
 def current_stream():

@@ -19,7 +19,10 @@ from .config import EncoderConfig, aligned_batch, get_config
 class HipEncoder:
     def __init__(self, cfg: EncoderConfig | str, weights: dict, *, max_batch: int = 128,
                  l2_normalize: bool = False, lanes: int = 2, fuse_ln: int = 0,
-                 u8_mean=(0.5, 0.5, 0.5), u8_std=(0.5, 0.5, 0.5)):
+                 u8_mean=(0.5, 0.5, 0.5), u8_std=(0.5, 0.5, 0.5), precision: str = "bf16"):
+        """precision: the 16-bit type of the MFMA operands (weights and activations between the fp32 residual stream / LayerNorm /
+        softmax): "bf16" (libvsc_hip.so, the benchmarked configuration) or "fp16" (libvsc_hip_f16.so: same kernels and speed, 8 x
+        smaller rounding; what the infer/ entry points use)."""
         if isinstance(cfg, str):
             cfg = get_config(cfg)
         self.cfg = cfg
@@ -29,7 +32,8 @@ class HipEncoder:
         # Normalize(mean, std) applied to uint8 [n,H,W,C] inputs inside the patchify kernel (vit_transform: 0.5 / 0.5)
         self.u8_mean = (ctypes.c_float * cfg.channels)(*u8_mean[: cfg.channels])
         self.u8_std = (ctypes.c_float * cfg.channels)(*u8_std[: cfg.channels])
-        self._lib = _lib.require_device()
+        self.precision = precision
+        self._lib = _lib.require_device(precision)
         wnames.check_complete(weights, cfg)
         c = EncoderConfigC(
             image_size=cfg.image_size, patch_size=cfg.patch_size, channels=cfg.channels,

@@ -8,6 +8,37 @@ from . import _lib
 from ._lib import check, current_stream, ptr
 
 
+_PRECISION = "bf16"
+
+
+class operands:
+    """with ops.operands("fp16"): ...  -- the kernel-level wrappers below then call libvsc_hip_f16.so and their 16-bit tensors are
+    torch.float16 (vsc_operand_dtype, include/vsc_hip.h).  Default: the bf16 library."""
+
+    def __init__(self, precision: str):
+        assert precision in _lib.LIB_PATHS, precision
+        self.precision, self._saved = precision, None
+
+    def __enter__(self):
+        global _PRECISION
+        self._saved, _PRECISION = _PRECISION, self.precision
+        return self
+
+    def __exit__(self, *exc):
+        global _PRECISION
+        _PRECISION = self._saved
+        return False
+
+
+def lp_dtype():
+    """torch dtype of the current library's 16-bit operands"""
+    return torch.float16 if _PRECISION == "fp16" else lp_dtype()
+
+
+def _rd():
+    return _lib.require_device(_PRECISION)
+
+
 def _dev(t: torch.Tensor, dtype) -> torch.Tensor:
     assert t.is_cuda, "operand must live on the GPU"
     return t.to(dtype).contiguous()
@@ -15,8 +46,8 @@ def _dev(t: torch.Tensor, dtype) -> torch.Tensor:
 
 def gemm_bf16(a, w, bias=None, *, epilogue=_lib.EPI_BF16, aux=None, tokens=0, out=None):
     """out = epi(a @ w.T + bias); a [M,K] bf16, w [N,K] bf16."""
-    lib = _lib.require_device()
-    a, w = _dev(a, torch.bfloat16), _dev(w, torch.bfloat16)
+    lib = _rd()
+    a, w = _dev(a, lp_dtype()), _dev(w, lp_dtype())
     m, k = a.shape
     n = w.shape[0]
     assert w.shape[1] == k
@@ -24,7 +55,7 @@ def gemm_bf16(a, w, bias=None, *, epilogue=_lib.EPI_BF16, aux=None, tokens=0, ou
     aux = None if aux is None else _dev(aux, torch.float32)
     if out is None:
         if epilogue in (_lib.EPI_BF16, _lib.EPI_GELU_BF16, _lib.EPI_QGELU_BF16):
-            out = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+            out = torch.empty((m, n), dtype=lp_dtype(), device=a.device)
         elif epilogue in (_lib.EPI_RESADD_F32, _lib.EPI_F32):
             out = torch.empty((m, n), dtype=torch.float32, device=a.device)
         else:
@@ -36,38 +67,38 @@ def gemm_bf16(a, w, bias=None, *, epilogue=_lib.EPI_BF16, aux=None, tokens=0, ou
 
 
 def attention_bf16(qkv, frames: int, tokens: int, heads: int):
-    lib = _lib.require_device()
-    qkv = _dev(qkv, torch.bfloat16)
+    lib = _rd()
+    qkv = _dev(qkv, lp_dtype())
     assert qkv.shape == (frames * tokens, 3 * heads * 64)
-    out = torch.empty((frames * tokens, heads * 64), dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty((frames * tokens, heads * 64), dtype=lp_dtype(), device=qkv.device)
     check(lib.vsc_attention_bf16(ptr(qkv), ptr(out), frames, tokens, heads, current_stream()))
     return out
 
 
 def layernorm(x, gamma, beta, eps: float, out_f32: bool = False):
-    lib = _lib.require_device()
+    lib = _rd()
     x, gamma, beta = (_dev(t, torch.float32) for t in (x, gamma, beta))
     rows, width = x.shape
-    out = torch.empty((rows, width), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    out = torch.empty((rows, width), dtype=torch.float32 if out_f32 else lp_dtype(), device=x.device)
     check(lib.vsc_layernorm_f32(ptr(x), ptr(gamma), ptr(beta), ptr(out), rows, width, eps,
                                 int(out_f32), current_stream()))
     return out
 
 
 def patchify_bf16(frames, patch: int, kpad: int):
-    lib = _lib.require_device()
+    lib = _rd()
     frames = _dev(frames, torch.float32)
     n, c, h, w = frames.shape
     assert h == w
     g = h // patch
-    out = torch.empty((n * g * g, kpad), dtype=torch.bfloat16, device=frames.device)
+    out = torch.empty((n * g * g, kpad), dtype=lp_dtype(), device=frames.device)
     check(lib.vsc_patchify_bf16(ptr(frames), ptr(out), n, c, h, patch, kpad, current_stream()))
     return out
 
 
 def l2_normalize_(x):
     """In place, sklearn.preprocessing.normalize semantics."""
-    lib = _lib.require_device()
+    lib = _rd()
     assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
     if x.shape[0]:
         check(lib.vsc_l2_normalize_f32(ptr(x), x.shape[0], x.shape[1], current_stream()))
@@ -79,7 +110,7 @@ def knn_ip(q, r, k: int, ref_id_offset: int = 0, floor=None):
     (scores [nq,k] float32 descending, ids [nq,k] int64).  Empty inputs follow
     faiss: nq == 0 -> empty outputs; nr == 0 -> all (-FLT_MAX, -1).
     floor [nq] float32: only references with <q, r> >= floor[q] (vsc_knn_ip_floor_f32; unused slots (-FLT_MAX, -1))."""
-    lib = _lib.require_device()
+    lib = _rd()
     q, r = _dev(q, torch.float32), _dev(r, torch.float32)
     nq, d = q.shape
     nr = r.shape[0]
@@ -105,7 +136,7 @@ def knn_ip(q, r, k: int, ref_id_offset: int = 0, floor=None):
 def knn_merge_parts(scores, ids):
     """scores / ids [parts, nq, k]: per-shard results of knn_ip (each with its ref_id_offset) -> the k best of the union, in the
     search's order (score descending, equal scores by ascending id)."""
-    lib = _lib.require_device()
+    lib = _rd()
     scores, ids = _dev(scores, torch.float32), _dev(ids, torch.int64)
     parts, nq, k = scores.shape
     assert ids.shape == scores.shape and 1 <= parts <= 64
@@ -119,7 +150,7 @@ def range_search_ip(q, r, radius: float, ref_id_offset: int = 0, capacity: int =
     """All pairs with <q, r> > radius.  -> (lims [nq+1] int64, scores, ids), hits of query i in
     lims[i]:lims[i+1], ascending reference id (faiss range_search layout)."""
     import ctypes
-    lib = _lib.require_device()
+    lib = _rd()
     q, r = _dev(q, torch.float32), _dev(r, torch.float32)
     nq, d = q.shape
     nr = r.shape[0]
@@ -144,7 +175,7 @@ def range_search_ip(q, r, radius: float, ref_id_offset: int = 0, capacity: int =
 def range_count_ip(q, r, radius: float) -> int:
     """Number of pairs with <q, r> > radius: the counting pass of vsc_range_search_ip_f32 alone (capacity 0)."""
     import ctypes
-    lib = _lib.require_device()
+    lib = _rd()
     q, r = _dev(q, torch.float32), _dev(r, torch.float32)
     nq, d = q.shape
     nr = r.shape[0]
@@ -163,7 +194,7 @@ def pair_similarity(q, r, pairs):
     q [nq, d], r [nr, d]: frame banks; pairs: int64 [n, 4] rows (q_row0, q_rows, r_row0, r_rows) on the host.
     -> (flat f32 device tensor, offsets int64 numpy [n + 1]); matrix p = flat[off[p]:off[p+1]].view(q_rows, r_rows)."""
     import numpy as np
-    lib = _lib.require_device()
+    lib = _rd()
     q, r = _dev(q, torch.float32), _dev(r, torch.float32)
     assert q.dim() == 2 and r.dim() == 2 and q.shape[1] == r.shape[1], "query / reference dimension mismatch"
     pairs = np.ascontiguousarray(np.asarray(pairs, dtype=np.int64).reshape(-1, 4))
@@ -186,7 +217,7 @@ def video_pair_max(q, q_video, n_q_videos: int, r, r_video, n_r_videos: int, thr
     -> (lims [n_q_videos + 1] int64, ref_video int32, score float32): pairs of query video v in
     lims[v]:lims[v+1], ascending reference video."""
     import ctypes
-    lib = _lib.require_device()
+    lib = _rd()
     q, r = _dev(q, torch.float32), _dev(r, torch.float32)
     assert q.dim() == 2 and r.dim() == 2 and q.shape[1] == r.shape[1], "query / reference dimension mismatch"
     q_video, r_video = _dev(q_video, torch.int32), _dev(r_video, torch.int32)
@@ -216,9 +247,11 @@ def window_attention_bf16(qkv, bias, scale, frames: int, res: int, window: int, 
     """Swin-V2 windowed cosine attention (head_dim 32) on image-ordered tokens.  bounded: fold every head's logit upper bound
     scale + max(bias) into its table and pass -scale where the head's logits span <= 69 (vsc_hip.h: the kernel then skips the
     softmax's row maximum), as vsc_swin_finalize does for its own tables."""
-    lib = _lib.require_device()
-    qkv = _dev(qkv, torch.bfloat16)
+    lib = _rd()
+    qkv = _dev(qkv, lp_dtype())
     bias, scale = _dev(bias, torch.float32), _dev(scale, torch.float32)
+    if bounded and _PRECISION == "fp16":
+        raise ValueError("the bounded softmax needs bf16's exponent range for its probabilities (csrc/swin_encoder.hip): not with fp16 operands")
     if bounded:
         bmax, bmin = bias.max(dim=1).values, bias.min(dim=1).values
         ok = (2 * scale + (bmax - bmin)) <= 69.0
@@ -226,7 +259,7 @@ def window_attention_bf16(qkv, bias, scale, frames: int, res: int, window: int, 
         scale = torch.where(ok, -scale, scale).contiguous()
     assert qkv.shape == (frames * res * res, 3 * heads * 32)
     assert bias.shape == (heads, (2 * window - 1) ** 2) and scale.shape == (heads,)   # compact table
-    out = torch.empty((frames * res * res, heads * 32), dtype=torch.bfloat16, device=qkv.device)
+    out = torch.empty((frames * res * res, heads * 32), dtype=lp_dtype(), device=qkv.device)
     check(lib.vsc_window_attention_bf16(ptr(qkv), ptr(out), ptr(bias), ptr(scale), frames, res, window, shift, heads,
                                         current_stream()))
     return out
@@ -234,12 +267,12 @@ def window_attention_bf16(qkv, bias, scale, frames: int, res: int, window: int, 
 
 def ln_residual(t, gamma, beta, eps: float, x_in=None):
     """-> (x fp32, xb bf16) with x = (x_in or 0) + LayerNorm(t)."""
-    lib = _lib.require_device()
+    lib = _rd()
     t, gamma, beta = (_dev(a, torch.float32) for a in (t, gamma, beta))
     x_in = None if x_in is None else _dev(x_in, torch.float32)
     rows, width = t.shape
     x = torch.empty_like(t)
-    xb = torch.empty((rows, width), dtype=torch.bfloat16, device=t.device)
+    xb = torch.empty((rows, width), dtype=lp_dtype(), device=t.device)
     check(lib.vsc_ln_residual_f32(ptr(t), ptr(gamma), ptr(beta), ptr(x_in), ptr(x), ptr(xb), rows, width, eps,
                                   current_stream()))
     return x, xb
@@ -247,8 +280,8 @@ def ln_residual(t, gamma, beta, eps: float, x_in=None):
 
 def gemm_ln_bf16(a, w, bias, gamma, beta, eps: float, x_in=None):
     """-> (x fp32, xb bf16) with x = (x_in or 0) + LayerNorm(a @ w.T + bias); w is [n, k], n in {128, 256, 512}."""
-    lib = _lib.require_device()
-    a, w = _dev(a, torch.bfloat16), _dev(w, torch.bfloat16)
+    lib = _rd()
+    a, w = _dev(a, lp_dtype()), _dev(w, lp_dtype())
     gamma, beta = _dev(gamma, torch.float32), _dev(beta, torch.float32)
     bias = None if bias is None else _dev(bias, torch.float32)
     x_in = None if x_in is None else _dev(x_in, torch.float32)
@@ -256,7 +289,7 @@ def gemm_ln_bf16(a, w, bias, gamma, beta, eps: float, x_in=None):
     n = w.shape[0]
     assert w.shape[1] == k
     x = torch.empty((m, n), dtype=torch.float32, device=a.device)
-    xb = torch.empty((m, n), dtype=torch.bfloat16, device=a.device)
+    xb = torch.empty((m, n), dtype=lp_dtype(), device=a.device)
     check(lib.vsc_gemm_ln_bf16(ptr(a), ptr(w), ptr(bias), ptr(gamma), ptr(beta), ptr(x_in), ptr(x), ptr(xb), m, n, k,
                                eps, current_stream()))
     return x, xb
@@ -266,16 +299,16 @@ def swin_mlp_bf16(x, w1, b1, w2, b2, gamma, beta, eps: float):
     """Fused Swin-V2 MLP, widths 128 / 256 / 512: -> (x + LayerNorm(gelu(bf16(x) @ w1.T + b1) @ w2.T + b2), its bf16 shadow).
     w1 [4c, c], w2 [c, 4c] as the module holds them (the hidden-axis reordering the kernel wants is done here)."""
     import numpy as np
-    lib = _lib.require_device()
+    lib = _rd()
     x = _dev(x, torch.float32).clone()
     m, c = x.shape
-    xb = x.to(torch.bfloat16)
+    xb = x.to(lp_dtype())
     w2h = np.ascontiguousarray(w2.detach().float().cpu().numpy())
     assert w2h.shape == (c, 4 * c) and tuple(w1.shape) == (4 * c, c)
     w2p = np.empty_like(w2h)
     check(lib.vsc_swin_mlp_permute_hidden_f32(w2h.ctypes.data, w2p.ctypes.data, c))
-    w1d = _dev(w1.to(x.device), torch.bfloat16)
-    w2d = torch.from_numpy(w2p).to(x.device).to(torch.bfloat16)
+    w1d = _dev(w1.to(x.device), lp_dtype())
+    w2d = torch.from_numpy(w2p).to(x.device).to(lp_dtype())
     b1, b2 = _dev(b1.to(x.device), torch.float32), _dev(b2.to(x.device), torch.float32)
     gamma, beta = _dev(gamma.to(x.device), torch.float32), _dev(beta.to(x.device), torch.float32)
     check(lib.vsc_swin_mlp_bf16(ptr(w1d), ptr(b1), ptr(w2d), ptr(b2), ptr(gamma), ptr(beta), ptr(x), ptr(xb), m, c, eps,
@@ -288,17 +321,17 @@ def swin_proj_mlp_bf16(x, att, wp, bp, gamma1, beta1, w1, b1, w2, b2, gamma2, be
     x1 = x + LN(att @ wp.T + bp) * gamma1 + beta1;  -> (x1 + LN(gelu(bf16(x1) @ w1.T + b1) @ w2.T + b2) * gamma2 + beta2, its bf16 shadow).
     att [m, c] (rounded to bf16 here); weights as the module holds them."""
     import numpy as np
-    lib = _lib.require_device()
+    lib = _rd()
     x = _dev(x, torch.float32).clone()
     m, c = x.shape
     dev = x.device
-    xb = torch.empty((m, c), dtype=torch.bfloat16, device=dev)
-    attd = _dev(att.to(dev), torch.bfloat16)
+    xb = torch.empty((m, c), dtype=lp_dtype(), device=dev)
+    attd = _dev(att.to(dev), lp_dtype())
     w2h = np.ascontiguousarray(w2.detach().float().cpu().numpy())
     w2p = np.empty_like(w2h)
     check(lib.vsc_swin_mlp_permute_hidden_f32(w2h.ctypes.data, w2p.ctypes.data, c))
-    wpd, w1d = _dev(wp.to(dev), torch.bfloat16), _dev(w1.to(dev), torch.bfloat16)
-    w2d = torch.from_numpy(w2p).to(dev).to(torch.bfloat16)
+    wpd, w1d = _dev(wp.to(dev), lp_dtype()), _dev(w1.to(dev), lp_dtype())
+    w2d = torch.from_numpy(w2p).to(dev).to(lp_dtype())
     f = [_dev(t.to(dev), torch.float32) for t in (bp, gamma1, beta1, b1, b2, gamma2, beta2)]
     check(lib.vsc_swin_proj_mlp_bf16(ptr(attd), ptr(wpd), ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(w1d), ptr(f[3]), ptr(w2d), ptr(f[4]), ptr(f[5]),
                                      ptr(f[6]), ptr(x), ptr(xb), m, c, eps, current_stream()))
@@ -308,17 +341,17 @@ def swin_proj_mlp_bf16(x, att, wp, bp, gamma1, beta1, w1, b1, w2, b2, gamma2, be
 def swin_proj_mlp_qkv_bf16(x, att, wp, bp, gamma1, beta1, w1, b1, w2, b2, gamma2, beta2, wq, bq, eps: float):
     """swin_proj_mlp_bf16 with the next block's qkv Linear behind it (width 512): -> (x_out fp32, qkv_next = bf16(x_out) @ wq.T + bq as bf16)."""
     import numpy as np
-    lib = _lib.require_device()
+    lib = _rd()
     x = _dev(x, torch.float32).clone()
     m, c = x.shape
     dev = x.device
-    qkv = torch.empty((m, 3 * c), dtype=torch.bfloat16, device=dev)
-    attd = _dev(att.to(dev), torch.bfloat16)
+    qkv = torch.empty((m, 3 * c), dtype=lp_dtype(), device=dev)
+    attd = _dev(att.to(dev), lp_dtype())
     w2h = np.ascontiguousarray(w2.detach().float().cpu().numpy())
     w2p = np.empty_like(w2h)
     check(lib.vsc_swin_mlp_permute_hidden_f32(w2h.ctypes.data, w2p.ctypes.data, c))
-    wpd, w1d, wqd = (_dev(t.to(dev), torch.bfloat16) for t in (wp, w1, wq))
-    w2d = torch.from_numpy(w2p).to(dev).to(torch.bfloat16)
+    wpd, w1d, wqd = (_dev(t.to(dev), lp_dtype()) for t in (wp, w1, wq))
+    w2d = torch.from_numpy(w2p).to(dev).to(lp_dtype())
     f = [_dev(t.to(dev), torch.float32) for t in (bp, gamma1, beta1, b1, b2, gamma2, beta2, bq)]
     check(lib.vsc_swin_proj_mlp_qkv_bf16(ptr(attd), ptr(wpd), ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(w1d), ptr(f[3]), ptr(w2d), ptr(f[4]), ptr(f[5]),
                                          ptr(f[6]), ptr(wqd), ptr(f[7]), ptr(x), ptr(qkv), m, c, eps, current_stream()))
@@ -326,10 +359,10 @@ def swin_proj_mlp_qkv_bf16(x, att, wp, bp, gamma1, beta1, w1, b1, w2, b2, gamma2
 
 
 def merge_gather_bf16(xb, frames: int, res: int):
-    lib = _lib.require_device()
-    xb = _dev(xb, torch.bfloat16)
+    lib = _rd()
+    xb = _dev(xb, lp_dtype())
     c = xb.shape[1]
     assert xb.shape[0] == frames * res * res
-    out = torch.empty((frames * (res // 2) ** 2, 4 * c), dtype=torch.bfloat16, device=xb.device)
+    out = torch.empty((frames * (res // 2) ** 2, 4 * c), dtype=lp_dtype(), device=xb.device)
     check(lib.vsc_merge_gather_bf16(ptr(xb), ptr(out), frames, res, c, current_stream()))
     return out

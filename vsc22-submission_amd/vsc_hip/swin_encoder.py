@@ -43,13 +43,14 @@ def from_reference_state(state: dict) -> dict:
 
 class SwinHipEncoder:
     def __init__(self, cfg: SwinConfig | str, weights: dict, *, max_batch: int = 32, l2_normalize: bool = False,
-                 u8_mean=(0.5, 0.5, 0.5), u8_std=(0.5, 0.5, 0.5)):
+                 u8_mean=(0.5, 0.5, 0.5), u8_std=(0.5, 0.5, 0.5), precision: str = "bf16"):
         if isinstance(cfg, str):
             cfg = get_swin_config(cfg)
         self.cfg, self.max_batch = cfg, max_batch
         self.u8_mean = (ctypes.c_float * cfg.channels)(*u8_mean[: cfg.channels])   # Normalize() of uint8 inputs
         self.u8_std = (ctypes.c_float * cfg.channels)(*u8_std[: cfg.channels])
-        self._lib = _lib.require_device()
+        self.precision = precision                  # 16-bit operand type: "bf16" | "fp16" (HipEncoder's docstring)
+        self._lib = _lib.require_device(precision)
         names = swin_weight_names(cfg)
         missing = [n for n in names if n not in weights]
         if missing:
