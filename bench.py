@@ -115,6 +115,7 @@ def parse():
     ap.add_argument("--search-k", type=int, default=100)
     ap.add_argument("--search-steps", type=int, default=1)
     ap.add_argument("--no-swin", action="store_true")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the fp16-operand secondary (libvsc_hip_f16.so)")
     ap.add_argument("--no-matching", action="store_true")
     ap.add_argument("--no-ensemble", action="store_true")
     ap.add_argument("--ensemble-videos", type=int, default=52, help="query videos (40 frames each; then once more with 10 .. 70 frames each: ensemble.ragged_lengths) of the end-to-end ensemble secondary")
@@ -509,6 +510,57 @@ def bench_swin(dev, args):
             "kernels": kernels}
 
 
+def bench_fp16_operands(dev, args, cfg, weights, frames):
+    """Secondary: the SAME ViT step and the Swin-V2-B step with fp16 instead of bf16 as the 16-bit MFMA operand type (libvsc_hip_f16.so;
+    what the infer/ entry points default to, because the end-to-end uAP parity needs it: tests/test_gpu_uap_e2e.py).
+    Same kernels, same MFMA rate (v_mfma_f32_16x16x32_f16), same bytes: this object exists to show the rate is the same."""
+    from tools import synth
+    from vsc_hip.encoder import HipEncoder
+    from vsc_hip.swin_config import get_swin_config
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    out = {"operands": "fp16", "library": __import__("vsc_hip")._lib.require_device("fp16").vsc_version().decode()}
+    enc = HipEncoder(cfg, weights, max_batch=args.max_batch, l2_normalize=True, lanes=args.lanes, precision="fp16")
+    steps = max(1, min(args.steps, 40))
+    for _ in range(2):
+        enc(frames)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        d = enc(frames)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(d).all()
+    enc.set_profiling(True)
+    for _ in range(4):
+        enc(frames)
+    torch.cuda.synchronize()
+    prof = enc.get_profile()
+    enc.close()
+    fpf = gemm_flops_per_frame(cfg)
+    gemm_ms = sum(prof[k][0] for k in fpf)
+    tf = sum(fpf.values()) * 4 * args.batch / (gemm_ms * 1e-3) / 1e12
+    out["vit"] = {"value": round(steps * args.batch / dt, 1), "unit": "frames/s", "steps": steps, "ms_per_step": round(1e3 * dt / steps, 3),
+                  "gemm_tflops": round(tf, 1), "gemm_frac": round(tf / BF16_PEAK_TFLOPS, 4),
+                  "avg_launch_us": {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in prof.items() if v[1]}}
+    if not args.no_swin:
+        scfg = get_swin_config("swinv2_base_256")
+        senc = SwinHipEncoder(scfg, synth.swin_weights(5, scfg), max_batch=args.swin_batch, l2_normalize=True, precision="fp16")
+        b = 2 * args.swin_batch
+        x = torch.from_numpy(synth.swin_frames(1, 8, scfg)).to(dev).repeat((b + 7) // 8, 1, 1, 1)[:b].contiguous()
+        for _ in range(2):
+            senc(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            d = senc(x)
+        torch.cuda.synchronize()
+        out["swin"] = {"value": round(5 * b / (time.perf_counter() - t0), 1), "unit": "frames/s",
+                       "note": "every head takes the softmax's row maximum (the bounded softmax needs bf16's exponent range)"}
+        assert torch.isfinite(d).all()
+        senc.close()
+    return out
+
+
 def bench_matching(dev, args):
     """Secondary: the matching track's two fp32 networks (infer_matching.py:158-204) at the reference's batch sizes --
     mobilenetv3_small_100 pair classifier on 2048 x 3 x 160 x 160 similarity maps, hrnet_w18 refinement net on
@@ -727,6 +779,11 @@ def main():
         if not args.no_cpu_baseline and secondary:
             line["cpu_baseline"] = cpu_baseline(cfg, weights, base)
         enc.close()
+        if secondary and not args.no_fp16:
+            try:
+                line["fp16_operands"] = bench_fp16_operands(dev, args, cfg, weights, frames)
+            except Exception as exc:  # noqa: BLE001 -- a secondary: the primary line must still be printed
+                line["fp16_operands"] = {"error": f"{type(exc).__name__}: {exc}"}
         del frames
         torch.cuda.empty_cache()
         if not args.no_swin and secondary:

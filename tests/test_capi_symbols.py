@@ -15,20 +15,24 @@ def _declared():
     return set(re.findall(r"\b(vsc_[a-z0-9_]+)\s*\(", text))
 
 
-@pytest.fixture(scope="module")
-def lib():
+@pytest.fixture(scope="module", params=["bf16", "fp16"])
+def lib(request):
+    """both builds of the library: bf16 operands (libvsc_hip.so) and fp16 operands (libvsc_hip_f16.so)"""
     from vsc_hip import _lib
-    if not os.path.exists(_lib.LIB_PATH):
+    if not all(os.path.exists(p) for p in _lib.LIB_PATHS.values()):
         import __graft_entry__
         __graft_entry__.build()
-    return _lib.load()
+    out = _lib.load(request.param)
+    out.precision = request.param
+    return out
 
 
 def test_every_declared_symbol_is_exported(lib):
     from vsc_hip import _lib
     declared = _declared()
     assert declared, "no declarations parsed from the header"
-    nm = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    assert lib.vsc_operand_dtype().decode() == lib.precision
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATHS[lib.precision]], text=True)
     exported = set(re.findall(r" T (vsc_[a-z0-9_]+)", nm))
     assert declared <= exported, f"declared but not exported: {sorted(declared - exported)}"
     assert exported <= declared, f"exported but undeclared: {sorted(exported - declared)}"

@@ -32,7 +32,7 @@ class operands:
 
 def lp_dtype():
     """torch dtype of the current library's 16-bit operands"""
-    return torch.float16 if _PRECISION == "fp16" else lp_dtype()
+    return torch.float16 if _PRECISION == "fp16" else torch.bfloat16
 
 
 def _rd():
