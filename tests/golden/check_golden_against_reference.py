@@ -66,6 +66,47 @@ def check_swin(preset: str) -> float:
     return float(err)
 
 
+def reference_swin(cfg, w):
+    ns = refc.load_definitions(refc.SWIN_SRC)
+    model = ns["SwinTransformerV2"](img_size=cfg.image_size, patch_size=cfg.patch_size, window_size=cfg.window_size,
+                                    num_heads=list(cfg.heads), embed_dim=cfg.embed_dim, depths=list(cfg.depths),
+                                    pretrained_window_sizes=list(cfg.pretrained_window_sizes), mlp_ratio=float(cfg.mlp_ratio),
+                                    drop_path_rate=0.2, pretrained=None, output_dim=cfg.out_dim, p=cfg.gem_p).eval()
+    res = model.load_state_dict({k: _t(v) for k, v in w.items()}, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.endswith(("relative_coords_table", "relative_position_index", "attn_mask")) for k in res.missing_keys), res.missing_keys
+    return model
+
+
+def swin_outlier(preset: str = "swinv2_base_256", write: bool = False) -> float:
+    """swin_<preset>_outlier.npz: the reference's own SwinTransformerV2 on `synth.swin_outlier_weights` (gains x 20, a residual channel
+    at ~100, logit scales at the clamp) and six structured frames.  write=True (re)generates the fixture, else it is compared."""
+    from sklearn.preprocessing import normalize
+    from vsc_hip.swin_config import get_swin_config
+    cfg = get_swin_config(preset)
+    path = os.path.join(HERE, f"swin_{preset}_outlier.npz")
+    wseed, fseed, n = 5, 17, 6
+    model = reference_swin(cfg, synth.swin_outlier_weights(wseed, cfg))
+    taps = {}
+    deepest = max(range(cfg.stages), key=lambda st: cfg.depths[st])
+    model.layers[deepest].blocks[-1].register_forward_hook(lambda m, i, o: taps.__setitem__("s0", o))
+    with torch.no_grad():
+        d = normalize(model(_t(synth.structured_frames(fseed, n, cfg))).numpy())
+    if write:
+        c = (d @ d.T)[np.triu_indices(n, 1)]
+        np.savez_compressed(path, weights_seed=wseed, frames_seed=fseed, n_frames=n, desc_l2=d, residual_absmax_in_deepest_stage=float(taps["s0"].abs().max()))
+        print(f"{path}: cosines {c.min():.3f} .. {c.max():.3f}; |x| max at the end of the deepest stage = {float(taps['s0'].abs().max()):.1f}")
+        return 0.0
+    g = np.load(path)
+    err = float(np.abs(d - g["desc_l2"]).max())
+    assert err <= ATOL, (preset, "outlier", err)
+    return err
+
+
+def check_swinoutlier(preset: str) -> float:
+    return swin_outlier(preset)
+
+
 def clip_reference_state(w, cfg):
     """tools/synth canonical names -> the reference CLIPModel's (OpenAI CLIP visual tower) names."""
     d = cfg.width
@@ -208,7 +249,7 @@ def check_vsm(preset: str) -> float:
 
 
 CHECKS = [("swin", check_swin, "tiny_swin"), ("swin", check_swin, "tiny_swin_w8"), ("swin", check_swin, "swinv2_base_256"),
-          ("swin", check_swin, "tiny_swin_w24"), ("swin", check_swin, "swinv2_large_384"),
+          ("swin", check_swin, "tiny_swin_w24"), ("swin", check_swin, "swinv2_large_384"), ("swinoutlier", check_swinoutlier, "swinv2_base_256"),
           ("clip", check_clip, "tiny_clip"), ("vit", check_vit, "tiny"), ("vit", check_vit, "vit_b16_224"), ("sscd", check_sscd, "vit_v68"), ("vsm", check_vsm, "tiny_vsm")]
 
 

@@ -182,6 +182,39 @@ def test_knn_in_the_benchmarked_regime_single_split_many_items_per_workgroup(dev
     assert (srt[:, 1:] != srt[:, :-1]).all()
 
 
+def test_knn_at_the_full_size_of_configs2(dev):
+    """BASELINE.json configs[2] itself: 1 000 000 queries x 1 000 000 references x 512, k = 100 -- the call bench.py times.  Between
+    262 221 queries (the test above) and this size the candidate lists grow past 4 GiB (1M lists x 1024 keys x 8 B) and the call splits
+    off its last partial round (3 907 query blocks = 15 rounds of 256 + 67: tail balancing): 72 queries from the first / middle / last
+    blocks of the main sweep, the 4-GiB crossing of the list array, and the balanced tail, against knn_oracle, bit for bit; whole-result
+    invariants over every row."""
+    from oracle import knn_oracle
+    from vsc_hip import ops
+    nr = nq = 1_000_000
+    k = 100
+    rt = _device_bank(dev, 5, nr)
+    qt = _device_bank(dev, 6, nq)
+    D, I = ops.knn_ip(qt, rt, k)
+    assert _last_path() == 2
+    nqb = (nq + 255) // 256                      # 3907 query blocks; the tail call owns blocks 3840 .. 3906
+    cross = (4 << 30) // (1024 * 8 * 256)        # first query block whose candidate list lies past byte 2^32 of the list array
+    blocks = [0, 1, 255, 256, cross - 1, cross, cross + 1, nqb // 2, 3839, 3840, 3841, nqb - 2, nqb - 1]
+    rows = np.unique(np.concatenate([np.minimum(b * 256 + np.array([0, 37, 128, 200, 255]), nq - 1) for b in blocks] + [[nq - 1]]))
+    r = rt.cpu().numpy()
+    Dr, Ir = knn_oracle.knn_ip(qt[torch.from_numpy(rows).to(dev)].cpu().numpy(), r, k)
+    Dh, Ih = D[torch.from_numpy(rows).to(dev)].cpu().numpy(), I[torch.from_numpy(rows).to(dev)].cpu().numpy()
+    assert np.array_equal(Ih, Ir), f"ids differ at rows {rows[np.argwhere(Ih != Ir)[:5, 0]]}"
+    assert np.array_equal(Dh.view(np.uint32), Dr.view(np.uint32))
+    # whole result (on the device: 800 MB of ids): sorted scores, ids in range, no duplicate id within a row
+    assert bool((D[:, :-1] >= D[:, 1:]).all()) and int(I.min()) >= 0 and int(I.max()) < nr
+    srt = torch.sort(I[::499], dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())
+    del D, I
+    torch.cuda.empty_cache()
+    from vsc_hip import _lib
+    _lib.require_device().vsc_search_release_scratch()
+
+
 def test_knn_tail_balancing_is_invisible(dev):
     """The query blocks of a call's last partial round are swept as a second, finer-grained sweep (vsc_knn_ip_f32: tail balancing;
     140 000 queries = 547 blocks = two whole rounds of 256 + 35 blocks, which take 7 reference splits each): the same bits as the
@@ -532,6 +565,20 @@ def test_candidate_generation_fast_path_equals_the_object_path(dev):
         assert [(c.query_id, c.ref_id, c.score) for c in a] == [(c.query_id, c.ref_id, c.score) for c in b], gk
         assert len(a) > 0 and all(x.score >= y.score for x, y in zip(a, a[1:]))
         assert fast.query(queries, gk, limit=7) == a[:7] and slow.query(queries, gk, limit=7) == b[:7]
+    # two VideoFeatures under ONE video id (a video stored in two pieces): the object path groups by id -- so must the default path
+    split = queries[:3] + [VideoFeature("Q002", np.arange(10.0), qb[30:40])] + queries[4:]
+    a, b = fast.query(split, 700), slow.query(split, 700)
+    assert [(c.query_id, c.ref_id, c.score) for c in a] == [(c.query_id, c.ref_id, c.score) for c in b]
+    assert len({(c.query_id, c.ref_id) for c in a}) == len(a)
+    # an L2 index: the first hit of a pair in best-first order is its SMALLEST distance, MaxScoreAggregation keeps the largest
+    import vsc.index as vi
+    fast2, slow2 = CandidateGeneration(refs[:6], MaxScoreAggregation()), CandidateGeneration(refs[:6], SameMax())
+    for cg in (fast2, slow2):
+        cg.index = vi.VideoIndex(d, metric=vi.METRIC_L2)
+        cg.index.add(refs[:6])
+    a, b = fast2.query(queries[:4], 300), slow2.query(queries[:4], 300)
+    assert [(c.query_id, c.ref_id) for c in a] == [(c.query_id, c.ref_id) for c in b]
+    np.testing.assert_allclose([c.score for c in a], [c.score for c in b], rtol=0, atol=0)
 
 
 def test_global_threshold_search_when_the_probe_is_smaller_than_global_k(dev):

@@ -379,6 +379,49 @@ def test_swin_encoder_vs_oracle_and_batching(dev):
         SwinHipEncoder(cfg, w2)
 
 
+@pytest.mark.parametrize("precision,bound", [("bf16", 1e-3), ("fp16", 2e-4)])
+def test_swin_outlier_fixture(dev, precision, bound, golden_dir):
+    """Weights with what trained checkpoints have and random init lacks (tools/synth.swin_outlier_weights: LayerNorm gains x 20 in a few
+    channels, a residual channel at ~100 through all 18 blocks of the deepest stage, every other block's heads at the logit-scale clamp
+    of 100, hidden units deep in GELU's linear range); golden = the reference's own SwinTransformerV2 (check_golden_against_reference.
+    swin_outlier, max |fixture - class| 0.0).  Both operand types, both forms of the 512-wide stage."""
+    from vsc_hip import _lib
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    g = np.load(f"{golden_dir}/swin_swinv2_base_256_outlier.npz")
+    cfg = get_swin_config("swinv2_base_256")
+    w = synth.swin_outlier_weights(int(g["weights_seed"]), cfg)
+    x = torch.from_numpy(synth.structured_frames(int(g["frames_seed"]), int(g["n_frames"]), cfg)).to(dev)
+    for fused in ("1", "0"):
+        with _lib.option("VSC_SWIN_MLP512", fused):
+            enc = SwinHipEncoder(cfg, w, max_batch=8, l2_normalize=True, precision=precision)
+            d = enc(x).cpu().numpy()
+            enc.close()
+        assert np.isfinite(d).all()
+        err = np.abs(d - g["desc_l2"])
+        print(f"{precision} operands, outlier fixture (VSC_SWIN_MLP512={fused}): max {err.max():.2e} mean {err.mean():.2e}")
+        assert err.max() <= bound, (precision, fused, float(err.max()))
+
+
+@pytest.mark.parametrize("precision,bound", [("bf16", 3e-4), ("fp16", 6e-5)])
+def test_a_frame_alone_and_inside_a_full_chunk(dev, precision, bound):
+    """The kernel path of the 512-wide stage is chosen per chunk by its row count (swin_encoder.hip: fills512): the same 8 frames
+    encoded alone (GEMM launches) and as rows of a 256-frame call (fused kernels, the next block's qkv inside) agree to rounding-order
+    noise, which is what src/extractor.py documents -- grouping loader batches into 2 048-frame calls does not move a descriptor by
+    more than this."""
+    from vsc_hip.swin_config import get_swin_config
+    from vsc_hip.swin_encoder import SwinHipEncoder
+    cfg = get_swin_config("swinv2_base_256")
+    enc = SwinHipEncoder(cfg, synth.swin_weights(5, cfg), max_batch=256, l2_normalize=True, precision=precision)
+    few = torch.from_numpy(synth.structured_frames(31, 8, cfg))
+    rest = torch.from_numpy(synth.swin_frames(32, 8, cfg)).repeat(31, 1, 1, 1)
+    alone = enc(few.to(dev)).cpu()
+    inside = enc(torch.cat([rest[:100], few, rest[100:]]).to(dev)).cpu()[100:108]
+    err = float((alone - inside).abs().max())
+    print(f"{precision}: the same frames alone / inside a 256-frame call: max |d| {err:.2e}")
+    assert 0 < err <= bound or err == 0.0
+    enc.close()
+
+
 def test_swin_uint8_frames_bit_identical(dev):
     from vsc_hip.swin_config import get_swin_config
     from vsc_hip.swin_encoder import SwinHipEncoder

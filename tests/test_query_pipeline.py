@@ -224,6 +224,17 @@ def test_group_batched_postprocessing_equals_the_per_video_steps():
             assert np.array_equal(got.feature, want.feature) and np.array_equal(got.timestamps, want.timestamps), (group_frames, vid)
             assert all(np.array_equal(a.feature, b.feature) for a, b in zip(subs, want_subs))
     assert len(finals[0].feature) < 11      # the duplicate was dropped
+    # a video WITHOUT frames (an unreadable file) inside a group, and a group made only of such videos: the other videos' results are
+    # untouched and the frameless ones get the placeholder descriptor (the group path indexed an empty list / aborted the group)
+    empty = lambda name: (name, {vcfg.image_size: torch.zeros((0,) + tuple(vids[0][1][vcfg.image_size].shape[1:])),
+                                 scfg.image_size: torch.zeros((0,) + tuple(vids[0][1][scfg.image_size].shape[1:]))}, np.arange(0))
+    mixed = [vids[0], empty("Q000100"), vids[2]]
+    f_mixed, _ = run_query_videos(mixed, enc, pca.transform, {}, dev, chunk=8, group_frames=1024)
+    f_plain, _ = run_query_videos([vids[0], vids[2]], enc, pca.transform, {}, dev, chunk=8, group_frames=1024)
+    assert np.array_equal(f_mixed[0].feature, f_plain[0].feature) and np.array_equal(f_mixed[2].feature, f_plain[1].feature)
+    assert f_mixed[1].feature.shape == (1, 512) and np.abs(f_mixed[1].feature).max() <= 1e-5
+    f_none, pm_none = run_query_videos([empty("Q000101"), empty("Q000102")], enc, pca.transform, {}, dev, chunk=8, group_frames=1024)
+    assert [f.feature.shape for f in f_none] == [(1, 512), (1, 512)] and all(len(sub.feature) == 0 for pm in pm_none for sub in pm)
 
 
 @pytest.mark.gpu

@@ -3,14 +3,14 @@
 # summary of the same command at 3 steps, and separate --pmc passes (FETCH_SIZE / WRITE_SIZE) for the encoder GEMMs and the
 # similarity sweep.  Outputs under gpurun_out/<tag>/; copy what is to be judged into profiles/.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # --lanes 1: under the profiler the two chunks of a step run back to back, so a kernel's average duration is its own (with the
 # default two lanes the launches of the two chunks overlap and stretch each other: rocprofv3 then reports 300 us where the
 # kernel alone takes 207) -- the same serialisation bench.py applies to its per-launch event loop
-SHORT="--steps 3 --warmup 1 --profile-steps 3 --no-cpu-baseline --no-search --no-swin --no-matching --lanes 1"
+SHORT="--steps 3 --warmup 1 --profile-steps 3 --no-cpu-baseline --no-search --no-swin --no-matching --no-ensemble --no-fp16 --lanes 1"   # the ViT step and nothing else: every row of the summary is a ViT kernel
 python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 tail -c 600 "$OUT/bench_default.json"
 (cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o enc -- python $OLDPWD/bench.py $SHORT > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err")

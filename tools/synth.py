@@ -156,6 +156,29 @@ def swin_weights(seed: int, cfg) -> dict:
     return w
 
 
+def swin_outlier_weights(seed: int, cfg) -> dict:
+    """`swin_weights` with what trained checkpoints have and random init lacks: LayerNorm gains with a few channels x 20 (outlier
+    channels of the residual updates), ONE residual channel at magnitude ~100 through the whole deepest stage, heads whose logit_scale
+    sits at the reference's clamp (exp -> 100, torch2scripts.py:161), and a fc1 bias pushing a few hidden units deep into GELU's linear
+    range.  Every choice by index arithmetic: the same dict on every machine."""
+    w = {k: v.copy() for k, v in swin_weights(seed, cfg).items()}
+    deepest = max(range(cfg.stages), key=lambda st: cfg.depths[st])
+    w[f"layers.{deepest}.blocks.0.norm1.bias"][5] = 100.0     # enters the residual stream of the deepest stage and stays for all its blocks
+    for st in range(cfg.stages):
+        c = cfg.dim(st)
+        for b in range(cfg.depths[st]):
+            p = f"layers.{st}.blocks.{b}."
+            if b % 3 == 0:                                   # every third block: three gains x 20 in each post-norm
+                for j in range(3):
+                    w[p + "norm1.weight"][(7 + 11 * j + 13 * b) % c] *= 20.0
+                    w[p + "norm2.weight"][(3 + 17 * j + 5 * b) % c] *= 20.0
+            if b % 2 == 1:                                   # every other block: half of the heads at the clamp
+                w[p + "attn.logit_scale"][::2] = np.log(100.0) + 1.0
+            if b % 4 == 2:
+                w[p + "mlp.fc1.bias"][(19 * b) % (cfg.mlp_ratio * c)] = 40.0
+    return w
+
+
 def swin_frames(seed: int, n: int, cfg) -> np.ndarray:
     return uniform(seed, (n, cfg.channels, cfg.image_size, cfg.image_size))
 

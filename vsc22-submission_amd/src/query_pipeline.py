@@ -51,7 +51,13 @@ class VideoScorer:
         feats = encode_group([self.clip], clipped, self.device, self.chunk, as_numpy=False)[0]   # stay on the device: the head reads them there
         if not feats:
             return None
-        return torch.sigmoid(self.head.logits(feats))     # the videos of a group share the head's launches
+        # a video without frames has no score to compute: it is REJECTED (score 0 < any threshold -> the random placeholder descriptor,
+        # extract_query_feats.py:218-228) instead of aborting the whole group inside the head
+        have = [i for i, f in enumerate(feats) if f.shape[0] > 0]
+        probs = torch.zeros(len(feats), device=self.device)
+        if have:
+            probs[torch.tensor(have, device=self.device)] = torch.sigmoid(self.head.logits([feats[i] for i in have])).reshape(-1).float()
+        return probs
 
 
 def encode_many(model, frames_list: Sequence[torch.Tensor], device, chunk: int = None) -> List[np.ndarray]:
@@ -172,8 +178,8 @@ def encode_group(models: Sequence, frames_list: Sequence[torch.Tensor], device, 
     cuts = np.cumsum(lens)[:-1]
     result = []
     for o in outs:
-        if not o:
-            result.append(np.split(np.zeros((0, 0), np.float32), cuts) if as_numpy else [])
+        if not o:      # a group without a single frame: one empty block per video, in either form
+            result.append(np.split(np.zeros((0, 0), np.float32), cuts) if as_numpy else [torch.empty((0, 0), device=device) for _ in lens])
             continue
         full = torch.cat(o) if len(o) > 1 else o[0]
         assert full.shape[0] == total

@@ -143,8 +143,11 @@ def process_query_group(video_ids: Sequence[str], subs_by_model: Sequence[Sequen
     lens = [int(subs_by_model[0][v].shape[0]) for v in range(n_vid)]
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     subs_dev = []
-    for per_video in subs_by_model:
-        full = torch.cat(list(per_video)).float().contiguous() if n_vid > 1 else per_video[0].float().contiguous().clone()
+    if sum(lens) == 0:      # a group made only of frameless videos: nothing to normalise or compare; every video gets the placeholder below
+        subs_dev = [torch.zeros((0, 1), device=per_video[0].device) for per_video in subs_by_model]
+    for per_video in ([] if sum(lens) == 0 else subs_by_model):
+        per_video = [t for t in per_video if t.shape[0] > 0]     # (an empty block may have width 0: it holds no row to concatenate)
+        full = torch.cat(list(per_video)).float().contiguous() if len(per_video) > 1 else per_video[0].float().contiguous().clone()
         subs_dev.append(ops.l2_normalize_(full))
     features = torch.cat(subs_dev, dim=1).contiguous() if len(subs_dev) > 1 else subs_dev[0]
     accepted = [v for v in range(n_vid) if scores[v] >= score_threshold and lens[v] > 0]
@@ -170,7 +173,7 @@ def process_query_group(video_ids: Sequence[str], subs_by_model: Sequence[Sequen
     finals, per_model, cut = [], [], 0
     for v in range(n_vid):
         ts = np.asarray(timestamps[v])
-        ratio = lens[v] // len(ts)
+        ratio = lens[v] // len(ts) if len(ts) else 1
         stamps = np.asarray(list(ts) * ratio) if ratio != 1 else ts
         assert len(stamps) == lens[v]
         per_model.append([VideoFeature(video_id=video_ids[v], timestamps=stamps, feature=h[offs[v]:offs[v + 1]]) for h in subs_host])

@@ -44,7 +44,11 @@ class CandidateGeneration:
     def query(self, queries: List[VideoFeature], global_k: int, limit: int = None) -> List[CandidatePair]:
         """limit: only the first `limit` candidates (== query(...)[:limit]; the caller that keeps 25 per query video of 1 200 does not pay
         for a CandidatePair object per dropped pair)"""
-        if type(self.aggregation) is MaxScoreAggregation and global_k >= 0:
+        # The fast path equals the object path only (i) on a similarity index -- with METRIC_L2 a pair's FIRST hit in best-first order is its
+        # smallest distance, while MaxScoreAggregation takes the largest, and the final sort runs the other way -- and (ii) when no two
+        # query VideoFeatures share a video_id: the object path groups hits by id, the flat path by position in `queries`.
+        ids = [q.video_id for q in queries]
+        if type(self.aggregation) is MaxScoreAggregation and global_k >= 0 and self.index.index.is_similarity and len(set(ids)) == len(ids):
             # the aggregation the descriptor track uses (sscd_baseline.py:100): the same list as below, built from flat arrays instead
             # of a PairMatch object per frame hit (2.4M hits of 2 000 query videos: 29 s of Python; tools/micro/candidates_bench.py)
             return [CandidatePair(q, r, s) for q, r, s in zip(*self.index.search_pair_maxima(queries, global_k, limit))]

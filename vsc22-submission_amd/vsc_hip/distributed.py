@@ -63,7 +63,8 @@ def gather_rows_pipelined(local: torch.Tensor, always_collective: bool = False):
     """The ranks' row blocks as SEPARATE buffers arriving one after the other: after one size exchange every source rank's shard
     is broadcast on its own (async), so the caller can work on shard s while shard s + 1 is still on the wire.
     -> (shards: per source rank a tensor [n_r, dim] -- this rank's own is `local` itself --, works: per source rank the pending
-    broadcast (None for the own shard / a group of one), offsets [world + 1])."""
+    broadcast (None for an empty shard / a group of one; the OWN shard's entry is this rank's send: nobody has to wait for it before
+    READING `local`, only before the buffer is released or rewritten), offsets [world + 1])."""
     rank, ws = world()
     if ws == 1 and not (always_collective and dist.is_available() and dist.is_initialized()):
         return [local], [None], torch.tensor([0, local.shape[0]])
@@ -142,11 +143,16 @@ def sharded_knn(queries_local: torch.Tensor, refs_local: torch.Tensor, k: int,
         def landed():
             for step in range(len(shards)):
                 r = (rank + step) % len(shards)
-                if works[r] is not None:
+                # the own shard is swept at once: its broadcast only READS `local` (the send side), and broadcasts complete in issue
+                # order 0 .. ws - 1 on the communicator -- waiting for it here made rank r's first sweep wait for the transfers of
+                # ranks 0 .. r - 1, and the time is the maximum over ranks
+                if works[r] is not None and r != rank:
                     works[r].wait()          # orders the caller's stream behind that broadcast only
                 yield shards[r], int(offsets[r])
 
         scores, ids = sweep_shards(queries_local, landed(), k, knn, merge, carry)
+        if rank < len(works) and works[rank] is not None:
+            works[rank].wait()               # the send is complete before `refs_local` may be released or rewritten by the caller
         if scores is None:
             scores, ids = knn(queries_local, refs_local, k)     # an empty bank everywhere: the search's own empty result
     else:
