@@ -119,6 +119,11 @@ def parse():
     ap.add_argument("--no-matching", action="store_true")
     ap.add_argument("--no-ensemble", action="store_true")
     ap.add_argument("--ensemble-videos", type=int, default=52, help="query videos (40 frames each; then once more with 10 .. 70 frames each: ensemble.ragged_lengths) of the end-to-end ensemble secondary")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 launch (nccl = RCCL; gloo only for the "
+                    "--share-device plumbing run)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="plumbing run of the N > 1 code on a box with fewer GPUs than ranks: rank r uses device r %% device_count "
+                         "(RCCL refuses two ranks on one device, so this needs --backend gloo); no scaling claim can be drawn from it")
     ap.add_argument("--force-sharded-search", action="store_true",
                     help="run the N > 1 search leg (RCCL all_gather + sweep) even with one rank; needs torchrun's env")
     ap.add_argument("--swin-batch", type=int, default=256)
@@ -654,12 +659,16 @@ def main():
     from vsc_hip.encoder import HipEncoder
 
     _lib.require_device()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or args.force_sharded_search:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
 
     cfg = get_config(args.preset)
     weights = synth.encoder_weights(7, cfg)
@@ -757,6 +766,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            **({"shared_device_plumbing_run": f"{world} ranks on {torch.cuda.device_count()} device(s), backend {args.backend}: exercises the N > 1 code path, "
+                                              "says nothing about scaling"} if args.share_device else {}),
             "library": _lib.require_device().vsc_version().decode(),     # "... src <hash of csrc/* + include/vsc_hip.h>": which build was measured
             "config": {"workload": f"{cfg.name} bf16 encode of {args.steps * args.batch} synthetic "
                                    f"{cfg.image_size}x{cfg.image_size} frames per GPU in {args.steps} steps of {args.batch} "
