@@ -580,7 +580,7 @@ def bench_fp16_operands(dev, args, cfg, weights, frames):
             d = senc(x)
         torch.cuda.synchronize()
         out["swin"] = {"value": round(5 * b / (time.perf_counter() - t0), 1), "unit": "frames/s",
-                       "note": "every head takes the softmax's row maximum (the bounded softmax needs bf16's exponent range)"}
+                       "note": "q-hat / k-hat and every Linear on fp16 operands; the P . V product of the window attention stays on bf16 (bounded softmax: csrc/swin.hip)"}
         assert torch.isfinite(d).all()
         senc.close()
     return out

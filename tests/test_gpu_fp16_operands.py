@@ -12,8 +12,8 @@ from tools import synth
 
 pytestmark = pytest.mark.gpu
 
-DESC_ATOL_FP16 = 1.5e-4     # maximum over a fixture; measured <= 9.0e-5 (Swin-V2-B on the structured frames)
-MEAN_ATOL_FP16 = 3.0e-5     # mean |d|; measured <= 2.4e-5 (tiny_swin_w24)
+DESC_ATOL_FP16 = 2.0e-4     # maximum over a fixture; measured <= 1.34e-4 (tiny_swin_w8), 1.0e-4 (Swin-V2-B on the structured frames)
+MEAN_ATOL_FP16 = 4.5e-5     # mean |d|; measured <= 3.4e-5 (tiny_swin_w8: the PV product of the window attention is bf16 in both builds)
 
 
 @pytest.fixture(scope="module")
@@ -167,8 +167,13 @@ def test_window_attention_with_fp16_operands(dev, res, window, shift, heads):
     scale = torch.linspace(8.0, 60.0, heads)
     with ops.operands("fp16"):
         out = ops.window_attention_bf16(qkv.to(dev), table.to(dev), scale.to(dev), frames, res, window, shift, heads).float().cpu()
-        with pytest.raises(ValueError):
-            ops.window_attention_bf16(qkv.to(dev), table.to(dev), scale.to(dev), frames, res, window, shift, heads, bounded=True)
+        # the bounded softmax (probabilities down to e^-69) in the fp16 build: P and V go through the PV MFMA as bf16 in both builds
+        small = torch.linspace(6.0, 14.0, heads)
+        a = ops.window_attention_bf16(qkv.to(dev), table.to(dev), small.to(dev), frames, res, window, shift, heads).float().cpu()
+        b = ops.window_attention_bf16(qkv.to(dev), table.to(dev), small.to(dev), frames, res, window, shift, heads, bounded=True).float().cpu()
+        assert torch.isfinite(b).all()
+        torch.testing.assert_close(b, a, rtol=2 ** -6, atol=1e-2)
+        assert (a - b).abs().mean() < 2e-3
     x = qkv.float().reshape(frames, res, res, 3 * c)
     if shift:
         x = torch.roll(x, (-shift, -shift), (1, 2))
@@ -184,7 +189,7 @@ def test_window_attention_with_fp16_operands(dev, res, window, shift, heads):
         o = torch.roll(o, (shift, shift), (1, 2))
     ref = o.reshape(frames * res * res, c)
     assert torch.isfinite(out).all()
-    # q-hat / k-hat / P rounded to fp16 (at scale 60 a 2^-11 error of a cosine is 0.03 in the logit), fp16 output.  The bf16 build's test
-    # holds 2e-2 / mean 4e-3 at scales around 10.
-    torch.testing.assert_close(out, ref, rtol=2 ** -8, atol=2e-2)
-    assert (out - ref).abs().mean() < 8e-4
+    # q-hat / k-hat rounded to fp16 (at scale 60 a 2^-11 error of a cosine is 0.03 in the logit), P and V to bf16, fp16 output.  The bf16
+    # build's test holds 2e-2 / mean 4e-3 at scales around 10.
+    torch.testing.assert_close(out, ref, rtol=2 ** -6, atol=2e-2)
+    assert (out - ref).abs().mean() < 2e-3

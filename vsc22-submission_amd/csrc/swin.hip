@@ -13,6 +13,23 @@ constexpr int HD = 32;  // head dim of every Swin-V2 stage (C / heads)
 
 // sum of the squares of 8 bf16 values: four v_dot2c_f32_bf16 (exact products, fp32 accumulation) instead of 8 conversions'
 // worth of multiplies and adds -- the kernel is bound by its vector instructions, and the matrix pipe does not hide them
+// The P . V product runs on bf16 operands in BOTH builds of the library (fp16 operands everywhere else in libvsc_hip_f16.so): a
+// probability of the bounded softmax, exp(logit - the head's upper bound), may be as small as e^-69 -- bf16 holds it (fp32's exponent
+// range), fp16 flushes it to zero, and a row whose logits all lie far below the bound would sum to 0.  Keeping P in bf16 keeps the
+// one-pass bounded softmax (the streamed kernels otherwise need a first pass over the keys for the row maximum: Swin-V2-B 17.3 ->
+// 16.0 k frames/s); the MFMA needs both operands in one type, so V is rounded to bf16 once while it is staged.  What that costs in
+// accuracy: P's bf16 rounding moves a ViT-B/16 descriptor by 2e-6 on average, V's by < 1e-5 (tools/precision_budget.py: "p", "qkv").
+__device__ __forceinline__ uint32_t v_pair(uint16_t lo, uint16_t hi) {      // two V values of the build's operand type -> a bf16 pair
+#if VSC_LP_F16
+    return pack_bf16x2(lp_to_f32(lo), lp_to_f32(hi));
+#else
+    return (uint32_t)lo | ((uint32_t)hi << 16);
+#endif
+}
+#define pv_pack2 pack_bf16x2
+#define pv_mfma16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define PV_ONES ((bf16x8_t){0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80})
+
 __device__ __forceinline__ float sumsq8(bf16x8_t raw) {
     union { bf16x8_t v; uint32_t p[4]; } u;
     u.v = raw;
@@ -164,8 +181,8 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             uint2 pk;
-            pk.x = (uint32_t)(uint16_t)r[0][j] | ((uint32_t)(uint16_t)r[1][j] << 16);
-            pk.y = (uint32_t)(uint16_t)r[2][j] | ((uint32_t)(uint16_t)r[3][j] << 16);
+            pk.x = v_pair((uint16_t)r[0][j], (uint16_t)r[1][j]);
+            pk.y = v_pair((uint16_t)r[2][j], (uint16_t)r[3][j]);
             // head dim d sits in row 16 ((d >> 2) & 1) + 4 (d >> 3) + (d & 3): the PV accumulators of a lane are then 8
             // CONSECUTIVE head dims of its query (8 g + 4 ct + r) -- one 16-byte store per lane, 64 contiguous bytes per query
             const int d = c8 * 8 + j;
@@ -245,13 +262,13 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                 }
                 union { uint32_t w[4]; bf16x8_t v; } pk;
 #pragma unroll
-                for (int h = 0; h < 4; ++h) pk.w[h] = lp_pack2(e[h][0], e[h][1]);
+                for (int h = 0; h < 4; ++h) pk.w[h] = pv_pack2(e[h][0], e[h][1]);
                 pb[u] = pk.v;
             }
             // O^T[dh][query] += V^T[dh][key] . P^T[key][query]; a third A operand of ones gives the row sums of the bf16 P the
             // products use (every row of that tile = sum over the keys: no VALU adds, no cross-lane reduction; the matrix pipe
             // is 15 % busy in this kernel, the vector pipe 80 %)
-            const bf16x8_t ones = LP_ONES;
+            const bf16x8_t ones = PV_ONES;
             f32x4_t o[2], osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -260,10 +277,10 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
                 for (int ct = 0; ct < 2; ++ct) {
                     const bf16x8_t vf = *(const bf16x8_t *)(vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 8 * g) * 2);
                     if (ABL & 2) o[ct][u & 3] += (float)vf[0] + (float)pb[u][ct];
-                    else o[ct] = lp_mfma16(vf, pb[u], o[ct]);
+                    else o[ct] = pv_mfma16(vf, pb[u], o[ct]);
                 }
                 if (ABL & 2) osum[0] += (float)pb[u][0];
-                else osum = lp_mfma16(ones, pb[u], osum);
+                else osum = pv_mfma16(ones, pb[u], osum);
                 if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             const float inv = __builtin_amdgcn_rcpf(osum[0]);
@@ -379,8 +396,8 @@ __global__ __launch_bounds__(512, 6) void window_attention_stream_kernel(const u
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             uint2 pk;
-            pk.x = (uint32_t)(uint16_t)r[0][j] | ((uint32_t)(uint16_t)r[1][j] << 16);
-            pk.y = (uint32_t)(uint16_t)r[2][j] | ((uint32_t)(uint16_t)r[3][j] << 16);
+            pk.x = v_pair((uint16_t)r[0][j], (uint16_t)r[1][j]);
+            pk.y = v_pair((uint16_t)r[2][j], (uint16_t)r[3][j]);
             const int d = c8 * 8 + j;
             *(uint2 *)(vt + (16 * ((d >> 2) & 1) + 4 * (d >> 3) + (d & 3)) * VSTRIDE + slot * 8) = pk;
         }
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(512, 6) void window_attention_stream_kernel(const u
     const bool nomax = scraw < 0.f;   // workgroup-uniform
     const float sc = fabsf(scraw) * LOG2E;
     const f32x2_t sc2 = (f32x2_t){sc, sc};
-    const bf16x8_t ones = LP_ONES;
+    const bf16x8_t ones = PV_ONES;
     auto rows = [&](auto nomax_c) {
         constexpr bool NOMAX = decltype(nomax_c)::value;
 #pragma unroll
@@ -435,15 +452,15 @@ __global__ __launch_bounds__(512, 6) void window_attention_stream_kernel(const u
 #pragma unroll
                     for (int x = 0; x < 2; ++x) {
                         const f32x2_t d = NOMAX ? s[x] : s[x] + nm2;
-                        pk.w[2 * h + x] = lp_pack2(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
+                        pk.w[2 * h + x] = pv_pack2(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
                     }
                 }
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     const bf16x8_t vf = *(const bf16x8_t *)(vt + (ct * 16 + fr) * VSTRIDE + (32 * u + 8 * g) * 2);
-                    o[ct] = lp_mfma16(vf, pk.v, o[ct]);
+                    o[ct] = pv_mfma16(vf, pk.v, o[ct]);
                 }
-                osum = lp_mfma16(ones, pk.v, osum);
+                osum = pv_mfma16(ones, pk.v, osum);
                 if ((u & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
             const float inv = __builtin_amdgcn_rcpf(osum[0]);
@@ -535,8 +552,8 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             uint2 pk;
-            pk.x = (uint32_t)(uint16_t)r[0][j] | ((uint32_t)(uint16_t)r[1][j] << 16);
-            pk.y = (uint32_t)(uint16_t)r[2][j] | ((uint32_t)(uint16_t)r[3][j] << 16);
+            pk.x = v_pair((uint16_t)r[0][j], (uint16_t)r[1][j]);
+            pk.y = v_pair((uint16_t)r[2][j], (uint16_t)r[3][j]);
             *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + kg * 8) = pk;
         }
     }
@@ -588,7 +605,7 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
             for (int r = 0; r < 4; ++r) s[t][r] = -INFINITY;   // the padding tile: probability 0
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const bf16x8_t ones = LP_ONES;
+        const bf16x8_t ones = PV_ONES;
         f32x4_t o[2], osum = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         o[0] = o[1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -597,7 +614,7 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const float *sv = s[2 * u + (h >> 1)] + 2 * (h & 1);
-                pk.w[h] = lp_pack2(__builtin_amdgcn_exp2f(sv[0] - mx), __builtin_amdgcn_exp2f(sv[1] - mx));
+                pk.w[h] = pv_pack2(__builtin_amdgcn_exp2f(sv[0] - mx), __builtin_amdgcn_exp2f(sv[1] - mx));
             }
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
@@ -605,9 +622,9 @@ __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
                 union { uint2 h[2]; bf16x8_t v; } vf;
                 vf.h[0] = *(const uint2 *)vrow;            // keys 32 u + 4 g .. + 3       (k slots j < 4)
                 vf.h[1] = *(const uint2 *)(vrow + 32);     // keys 32 u + 16 + 4 g .. + 3  (k slots j >= 4)
-                o[ct] = lp_mfma16(vf.v, pk.v, o[ct]);
+                o[ct] = pv_mfma16(vf.v, pk.v, o[ct]);
             }
-            osum = lp_mfma16(ones, pk.v, osum);
+            osum = pv_mfma16(ones, pk.v, osum);
             if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         const float inv = __builtin_amdgcn_rcpf(osum[0]);
@@ -701,8 +718,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_atte
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             uint2 pk;
-            pk.x = (uint32_t)(uint16_t)r[0][j] | ((uint32_t)(uint16_t)r[1][j] << 16);
-            pk.y = (uint32_t)(uint16_t)r[2][j] | ((uint32_t)(uint16_t)r[3][j] << 16);
+            pk.x = v_pair((uint16_t)r[0][j], (uint16_t)r[1][j]);
+            pk.y = v_pair((uint16_t)r[2][j], (uint16_t)r[3][j]);
             *(uint2 *)(vt + (c8 * 8 + j) * VSTRIDE + kg * 8) = pk;
         }
     }
@@ -712,7 +729,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_atte
     const bool nomax = scraw < 0.f;                                          // workgroup-uniform
     const float sc = fabsf(scraw) * LOG2E;
     const f32x2_t sc2 = (f32x2_t){sc, sc};
-    const bf16x8_t ones = LP_ONES;
+    const bf16x8_t ones = PV_ONES;
     const int fr = lane & 15, g = lane >> 4;
     auto rows = [&](auto nomax_c, auto mask_c) {
         constexpr bool NOMAX = decltype(nomax_c)::value, MASK = decltype(mask_c)::value;
@@ -783,7 +800,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_atte
 #pragma unroll
                     for (int x = 0; x < 2; ++x) {
                         const f32x2_t d = NOMAX ? sv[x] : sv[x] + nm2;
-                        pk.w[2 * h + x] = lp_pack2(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
+                        pk.w[2 * h + x] = pv_pack2(__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1]));
                     }
                 }
 #pragma unroll
@@ -792,9 +809,9 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_atte
                     union { uint2 h[2]; bf16x8_t v; } vf;
                     vf.h[0] = *(const uint2 *)vrow;            // keys 32 u + 4 g .. + 3       (k slots j < 4)
                     vf.h[1] = *(const uint2 *)(vrow + 32);     // keys 32 u + 16 + 4 g .. + 3  (k slots j >= 4)
-                    o[ct] = lp_mfma16(vf.v, pk.v, o[ct]);
+                    o[ct] = pv_mfma16(vf.v, pk.v, o[ct]);
                 }
-                osum = lp_mfma16(ones, pk.v, osum);
+                osum = pv_mfma16(ones, pk.v, osum);
             }
             const float inv = __builtin_amdgcn_rcpf(osum[0]);
             uint16_t *orow = out + ((int64_t)frame * res * res + qrow) * C + head * HD + g * 4;

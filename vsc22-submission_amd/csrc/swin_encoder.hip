@@ -343,12 +343,10 @@ extern "C" int vsc_swin_finalize(vsc_swin *e) {
             std::vector<float> pb = position_bias(e->host_w.at(p + "attn.cpb_mlp.0.weight"), e->host_w.at(p + "attn.cpb_mlp.0.bias"),
                                                   e->host_w.at(p + "attn.cpb_mlp.2.weight"), W, c.pretrained_window_sizes[s], H);
             // bounded softmax (vsc_window_attention_bf16): heads whose logits span <= 69 get their upper bound scale + max(bias)
-            // folded into the table and a negative scale.  bf16 operands only: a probability exp(logit - bound) may be as small as
-            // e^-69, which bf16 (fp32's exponent range) holds and fp16 flushes to zero -- a row whose logits all lie far below the
-            // head's bound would sum to 0.  With fp16 operands every head takes the row maximum (probabilities in (0, 1]; what
-            // underflows then is < 6e-8 of the row's largest term).
+            // folded into the table and a negative scale.  (Its probabilities can be as small as e^-69: they are packed to bf16 -- fp32's
+            // exponent range -- in BOTH builds of the library; swin.hip "The P . V product runs on bf16 operands".)
             const size_t side2 = (size_t)(2 * W - 1) * (2 * W - 1);
-            for (int hh = 0; hh < H && !vsc_opt(OPT_SWIN_ROW_MAX) && !VSC_LP_F16; ++hh) {
+            for (int hh = 0; hh < H && !vsc_opt(OPT_SWIN_ROW_MAX); ++hh) {
                 float bmax = -INFINITY, bmin = INFINITY;
                 for (size_t i = 0; i < side2; ++i) {
                     bmax = fmaxf(bmax, pb[hh * side2 + i]);
