@@ -44,7 +44,7 @@ void vsc_set_error(const char *fmt, ...);
     X(ATTN_SKEW) X(ATTN_ABL) X(ATTN_NI) X(ATTN_DMA) X(CONV_IMPLICIT) X(CONV_DIRECT) X(CONV_REMAP) X(CONV_PERSIST) X(CONV_STAGES) X(CONV_WAVES) X(CONV_NARROW_MAX) X(CONV_NARROW_NT) X(CONV_EXPAND) X(DWCONV_SMALL) X(CONV_STEM) X(CONV_STREAM_MIN_COUT) X(CONV_X3)      \
     X(GEMM_GROUP_N) X(GEMM_V4_SKEW) X(GEMM_TIMING_PRINT) X(GEMM_V4) X(GEMM_V4_GRID) X(GEMM_SKEW_NS_PER_K) X(GEMM_CFG)    \
     X(GEMM_V3) X(GEMM_ABL) X(GEMM_V1) X(KNN_TRIG) X(KNN_ABL) X(KNN_PATH) X(KNN_XCD_MAP) X(KNN_DELTA) X(KNN_TAIL) X(RANGE_PATH) X(PAIRMAX_PATH) X(WATTN_ABL)      \
-    X(SWIN_SPLIT_LN) X(SWIN_SPLIT_K) X(GEMM_LN_V4) X(SWIN_FUSED_MLP) X(SWIN_MLP512) X(SWIN_PROJ512) X(SWIN_QKV512) X(SWIN_MLP512_GRID) X(SWIN_FUSED_PROJ) X(SWIN_MLP_ABL) X(SWIN_MLP_SEQ) X(SWIN_FUSED_MERGE) X(SWIN_ROW_MAX) X(LN_LIGHT) X(WATTN_STREAM)
+    X(SWIN_SPLIT_LN) X(SWIN_SPLIT_K) X(GEMM_LN_V4) X(SWIN_FUSED_MLP) X(SWIN_MLP512) X(SWIN_PROJ512) X(SWIN_QKV512) X(SWIN_MLP512_GRID) X(SWIN_FUSED_PROJ) X(SWIN_MLP_ABL) X(SWIN_MLP_SEQ) X(SWIN_MLP_NW4) X(SWIN_FUSED_MERGE) X(SWIN_ROW_MAX) X(LN_LIGHT) X(WATTN_STREAM)
 enum VscOpt {
 #define X(n) OPT_##n,
     VSC_OPT_LIST(X)

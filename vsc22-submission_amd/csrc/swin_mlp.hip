@@ -46,6 +46,7 @@ struct MlpArgs {
     const uint16_t *att;   // [m, C] attention output
     const uint16_t *wp;    // [C, C]
     const float *bp, *gamma1, *beta1;   // [C]
+    int stagger;           // NW = 4 (two workgroups per CU): the second resident workgroup of every CU starts this many x 8 128 cycles late
 };
 
 // Empty volatile asm through which every element of a step's results passes: the step's arithmetic cannot be sunk below it nor
@@ -88,12 +89,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpA
     float *bps = bs + C, *g1s = bps + C, *be1s = g1s + C;   // PROJ: bp, gamma1, beta1
     // PROJ: Wp [C][C] bf16, 2 C-byte rows, chunk ^= row & 15 -- beside the ring at C = 128 (32 KiB); at C = 256 it is as large as the ring
     // (128 KiB) and lives IN it until the projection is done, the MLP's first weight chunk being requested only then
-    constexpr bool WP_IN_RING = PROJ && C * C * 2 > 32 * 1024;
-    char *wps = WP_IN_RING ? ring : (char *)(be1s + C);
+    // (NW = 4: two workgroups per CU -- 2 x (ring + bias rows) = 138 KiB at C = 128 leaves no room for a resident Wp either)
+    // At C = 128 Wp is exactly one ring slot (32 KiB): it takes slot 1 while chunk 0 arrives in slot 0, and chunk 1's request -- issued behind
+    // the first chunk barrier, which every wave reaches with its projection done -- overwrites it.  No extra barrier, no exposed request.
+    constexpr bool WP_SLOT1 = PROJ && NW == 4 && C * C * 2 == CHUNK;
+    constexpr bool WP_IN_RING = PROJ && !WP_SLOT1 && (C * C * 2 > 32 * 1024 || NW == 4);
+    char *wps = WP_SLOT1 ? ring + CHUNK : WP_IN_RING ? ring : (char *)(be1s + C);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, quad = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * R + wave * RW;
+    if (NW == 4 && p.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        // Two workgroups share a CU; they are dispatched together, take the same time and would stay in phase for the whole launch -- both
+        // moving rows, then both computing.  The first round's second workgroups (workgroups 256 .. 511: the dispatcher gives every CU one
+        // workgroup before any gets two) start half a tile late; their successors inherit the offset.
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- LDS-DMA of hidden chunk ch into ring slot `slot`: instruction q of a matrix covers its bytes [1024 q, 1024 q + 1024)
     auto stage = [&](int ch, int slot) {
@@ -448,6 +459,26 @@ int launch_proj_c(const MlpArgs &a, hipStream_t stream) {
     }
     const int64_t grid = (a.m + R - 1) / R;
     VSC_REQUIRE(grid < (1ll << 31), "swin_mlp: grid too large");
+    // C = 128 (round 6): two 4-wave workgroups per CU instead of one 8-wave one -- Wp rides in ring slot 1 (2 x 69 KiB of LDS), 128 rows per
+    // workgroup.  One workgroup's row loads, its first weight request and its stores now sit under the other's chunk loop: 705 -> 638 us per
+    // launch of 256 frames of stage 0 on one stream, the same bits (tools/micro/swin_mlp_nw4_ab.py, profiles/r06_swin_mlp_nw4_ab.txt).  A start
+    // stagger between the two (VSC_SWIN_MLP_NW4=<n> x 8 128 cycles) changes nothing: they are not in lockstep to begin with.  In the
+    // encoder's two-lane step the other lane's launches were already filling those gaps: frames/s unchanged there; one-lane calls gain.
+    // VSC_SWIN_MLP_NW4=-1: the 8-wave form.
+    const char *nw4 = vsc_opt(OPT_SWIN_MLP_NW4);
+    if (C == 128 && !(nw4 && nw4[0] == '-')) {
+        constexpr int R4 = 4 * 32, smem4 = 2 * (2 * 64 * C * 2) + (4 * C + 3 * C + 3 * C) * 4;
+        static bool a4[16] = {};
+        if (dev >= 16 || !a4[dev]) {
+            VSC_CHECK_HIP(hipFuncSetAttribute((const void *)swin_mlp_kernel<128, 4, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem4));
+            if (dev < 16) a4[dev] = true;
+        }
+        MlpArgs b = a;
+        b.stagger = nw4 ? atoi(nw4) : 0;
+        hipLaunchKernelGGL((swin_mlp_kernel<128, 4, 0, true>), dim3((unsigned)((a.m + R4 - 1) / R4)), dim3(256), smem4, stream, b);
+        VSC_CHECK_LAUNCH();
+        return VSC_OK;
+    }
     const char *sq = vsc_opt(OPT_SWIN_MLP_SEQ);   // diagnostic: 1 = the vector work of a chunk as one run (SEQ)
     if (sq && sq[0] == '1') {
         static bool seq_attr[16] = {};
@@ -509,7 +540,7 @@ int launch_swin_mlp(const uint16_t *w1, const float *b1, const uint16_t *w2p, co
     VSC_REQUIRE(w1 && b1 && w2p && b2 && gamma && beta && x && xb && m > 0, "swin_mlp: null/empty");
     VSC_REQUIRE(swin_mlp_supported(c), "swin_mlp: width %d unsupported (128, 256 or 512)", c);
     if (c == 512) return launch_swin_mlp512(w1, b1, w2p, b2, gamma, beta, x, xb, m, eps, stream);
-    const MlpArgs a{w1, b1, w2p, b2, gamma, beta, x, xb, m, eps, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const MlpArgs a{w1, b1, w2p, b2, gamma, beta, x, xb, m, eps, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     return c == 128 ? launch_c<128>(a, stream) : launch_c<256>(a, stream);
 }
 
@@ -522,7 +553,7 @@ int launch_swin_proj_mlp(const uint16_t *att, const uint16_t *wp, const float *b
     VSC_REQUIRE(att && wp && bp && gamma1 && beta1 && w1 && b1 && w2p && b2 && gamma2 && beta2 && x && xb && m > 0, "swin_proj_mlp: null/empty");
     VSC_REQUIRE(swin_proj_mlp_supported(c), "swin_proj_mlp: width %d unsupported (128, 256, 512)", c);
     if (c == 512) return launch_swin_proj_mlp512(att, wp, bp, gamma1, beta1, w1, b1, w2p, b2, gamma2, beta2, x, xb, m, eps, stream);
-    const MlpArgs a{w1, b1, w2p, b2, gamma2, beta2, x, xb, m, eps, att, wp, bp, gamma1, beta1};
+    const MlpArgs a{w1, b1, w2p, b2, gamma2, beta2, x, xb, m, eps, att, wp, bp, gamma1, beta1, 0};
     return c == 128 ? launch_proj_c<128>(a, stream) : launch_proj_c<256>(a, stream);
 }
 
