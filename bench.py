@@ -826,7 +826,8 @@ def main():
         if not args.no_ensemble and secondary:
             try:
                 from tools import ensemble_bench
-                line["ensemble"] = ensemble_bench.measure(dev, args.ensemble_videos, 40)
+                line["ensemble"] = ensemble_bench.measure(dev, args.ensemble_videos, 40)      # at the entry points' default operand type (fp16)
+                line["ensemble"]["value_bf16_operands"] = ensemble_bench.measure(dev, args.ensemble_videos, 40, precision="bf16")["value"]
             except Exception as exc:  # noqa: BLE001 -- a secondary: the primary line must still be printed
                 line["ensemble"] = {"error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.empty_cache()

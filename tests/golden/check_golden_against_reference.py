@@ -107,6 +107,35 @@ def check_swinoutlier(preset: str) -> float:
     return swin_outlier(preset)
 
 
+def check_uape2e(_preset: str = "") -> float:
+    """uap_e2e.npz: (i) the stored per-frame descriptors ARE the reference classes' outputs -- a sample of reference, score-norm and query
+    frames (edited copies included) re-encoded here through SwinTransformerV2 and VIT; (ii) the stored candidate list and uAP follow from the
+    stored descriptors through gen_uap_e2e_golden.chain and the REFERENCE's average_precision.  (The full regeneration is
+    gen_uap_e2e_golden.py itself: five CPU-minutes.)"""
+    import gen_uap_e2e_golden as gen
+    from tools import synth_videos
+    g = np.load(os.path.join(HERE, "uap_e2e.npz"))
+    data = synth_videos.make(int(g["seed"]))
+    assert data["fingerprint"] == str(g["fingerprint"])
+    allf = np.concatenate([f for grp in ("refs", "norm", "queries") for _, f in data[grp]])
+    F = synth_videos.FRAMES
+    nq0 = (len(data["refs"]) + len(data["norm"])) * F
+    rows = np.array([0, 1, 2, 3, len(data["refs"]) * F, len(data["refs"]) * F + 5, nq0 + 1, nq0 + 2, nq0 + 4 * F + 2, nq0 + 4 * F + 3,
+                     nq0 + 43 * F + 1, nq0 + 43 * F + 2, nq0 + 50 * F, len(allf) - 1])
+    err = 0.0
+    for (model, size), key in zip(gen.reference_models(), ("desc_swin", "desc_vit")):
+        err = max(err, float(np.abs(gen.encode(model, size, allf[rows]) - g[key][rows]).max()))
+    assert err <= ATOL, ("uap_e2e descriptors", err)
+    gen.PCA_DIM = int(g["pca_components"].shape[0])
+    cands, pca, kept, low = gen.chain(data, [g["desc_swin"], g["desc_vit"]])
+    assert [c[0] for c in cands] == g["cand_query"].tolist() and [c[1] for c in cands] == g["cand_ref"].tolist()
+    assert np.abs(np.array([c[2] for c in cands], np.float32) - g["cand_score"]).max() <= 1e-6
+    uap, _ = gen.reference_uap(cands, data["gt"])
+    assert abs(uap - float(g["uap"])) < 1e-9, (uap, float(g["uap"]))
+    assert np.abs(pca.components_.astype(np.float32) - g["pca_components"]).max() <= 1e-5 and low == int(g["low_var_dim"])
+    return err
+
+
 def clip_reference_state(w, cfg):
     """tools/synth canonical names -> the reference CLIPModel's (OpenAI CLIP visual tower) names."""
     d = cfg.width
@@ -250,7 +279,7 @@ def check_vsm(preset: str) -> float:
 
 CHECKS = [("swin", check_swin, "tiny_swin"), ("swin", check_swin, "tiny_swin_w8"), ("swin", check_swin, "swinv2_base_256"),
           ("swin", check_swin, "tiny_swin_w24"), ("swin", check_swin, "swinv2_large_384"), ("swinoutlier", check_swinoutlier, "swinv2_base_256"),
-          ("clip", check_clip, "tiny_clip"), ("vit", check_vit, "tiny"), ("vit", check_vit, "vit_b16_224"), ("sscd", check_sscd, "vit_v68"), ("vsm", check_vsm, "tiny_vsm")]
+          ("clip", check_clip, "tiny_clip"), ("vit", check_vit, "tiny"), ("vit", check_vit, "vit_b16_224"), ("sscd", check_sscd, "vit_v68"), ("vsm", check_vsm, "tiny_vsm"), ("uape2e", check_uape2e, "chain")]
 
 
 def main():

@@ -46,6 +46,9 @@ def test_bench_json_contract():
     assert 0.3 < mt["refiner"]["flop_share_on_split_bf16_pipe"] < 1 and 0 < mt["refiner"]["frac_of_per_pipe_roof"] < 1
     # the reference's real workload end to end (3 x Swin-V2-B + vit_v68 + CLIP gate from uint8 host frames)
     en = d["ensemble"]
+    assert en["operands"] == "fp16" and en["value_bf16_operands"] > 0      # measured at the entry points' default operand type, bf16 beside it
+    f16 = d["fp16_operands"]                                                 # the ViT / Swin steps through libvsc_hip_f16.so
+    assert "error" not in f16 and f16["vit"]["value"] > 0 and f16["swin"]["value"] > 0 and f16["vit"]["gemm_tflops"] > 0
     assert en["value"] > 0 and en["encoder_bound_frames_per_s"] > en["value"] and set(en["models_frames_per_s"]) == {"swinv2_base_256", "vit_v68", "clip_vit_l14_224"}
 
 

@@ -25,7 +25,7 @@ class _Fitted:
     whiten = False
 
 
-def build(dev):
+def build(dev, precision="bf16"):
     from src.dataset import CLIP_MEAN, CLIP_STD
     from src.query_pipeline import VideoScorer
     from vsc_hip.config import aligned_batch, get_config
@@ -35,9 +35,9 @@ def build(dev):
     from vsc_hip.video_score import VideoScoreHead
     from vsc_hip.vsm_config import get_vsm_config
     scfg, vcfg, ccfg, mcfg = get_swin_config("swinv2_base_256"), get_config("vit_v68"), get_config("clip_vit_l14_224"), get_vsm_config("vsm_roberta_base")
-    swins = [SwinHipEncoder(scfg, synth.swin_weights(40 + i, scfg), max_batch=256) for i in range(3)]   # 256 = its aligned batch
-    vit = HipEncoder(vcfg, synth.encoder_weights(50, vcfg), max_batch=aligned_batch(vcfg.tokens))
-    clip = HipEncoder(ccfg, synth.encoder_weights(51, ccfg), max_batch=aligned_batch(ccfg.tokens), u8_mean=CLIP_MEAN, u8_std=CLIP_STD)
+    swins = [SwinHipEncoder(scfg, synth.swin_weights(40 + i, scfg), max_batch=256, precision=precision) for i in range(3)]   # 256 = its aligned batch
+    vit = HipEncoder(vcfg, synth.encoder_weights(50, vcfg), max_batch=aligned_batch(vcfg.tokens), precision=precision)
+    clip = HipEncoder(ccfg, synth.encoder_weights(51, ccfg), max_batch=aligned_batch(ccfg.tokens), u8_mean=CLIP_MEAN, u8_std=CLIP_STD, precision=precision)
     scorer = VideoScorer(clip, VideoScoreHead(mcfg, synth.vsm_weights(52, mcfg)), dev)
     return {"swins": swins, "vit": vit, "clip": clip, "scorer": scorer, "cfgs": (scfg, vcfg, ccfg)}
 
@@ -68,11 +68,14 @@ def model_rate(model, frames_u8, dev, batch, steps=3):
     return batch * steps / (time.perf_counter() - t0)
 
 
-def measure(dev, n_videos=52, n_frames=40, u8=True, breakdown=False, ragged=False, group_frames=None):
+def measure(dev, n_videos=52, n_frames=40, u8=True, breakdown=False, ragged=False, group_frames=None, precision=None):
+    """precision: the encoders' 16-bit operand type; None = what the extract_* entry points default to (src.model_zoo.DEFAULT_PRECISION)"""
+    if precision is None:
+        from src.model_zoo import DEFAULT_PRECISION as precision
     from src.query_pipeline import run_query_videos
     from src.query_postprocess import HipPCA
     t0 = time.perf_counter()
-    m = build(dev)
+    m = build(dev, precision)
     build_s = time.perf_counter() - t0
     encoders = [(s, 256) for s in m["swins"]] + [(m["vit"], 384)]
     pca = HipPCA(_Fitted)
@@ -87,7 +90,7 @@ def measure(dev, n_videos=52, n_frames=40, u8=True, breakdown=False, ragged=Fals
     total = sum(len(v[2]) for v in vids)
     out = {"metric": "query frames/s through the reference's ensemble, end to end from uint8 host frames (3 x Swin-V2-B/256 + vit_v68 + CLIP ViT-L/14 "
                      "video-score gate, normalise, concatenate, near-duplicate filter, PCA 2048 -> 512: infer/extract_query_feats.py:143-254, infer/infer_ref.sh:7)",
-           "value": round(total / dt, 1), "unit": "frames/s", "videos": n_videos, "frames_per_video": n_frames, "seconds": round(dt, 3),
+           "value": round(total / dt, 1), "unit": "frames/s", "operands": precision, "videos": n_videos, "frames_per_video": n_frames, "seconds": round(dt, 3),
            "descriptor_dim": int(finals[0].feature.shape[1]), "frames_kept": int(sum(len(f.feature) for f in finals)),
            "input": "uint8 HWC host tensors (pageable), pinned staging + copy stream" if u8 else "fp32 CHW host tensors", "build_seconds": round(build_s, 1)}
     if u8:
