@@ -56,6 +56,20 @@ def test_vit_matches_golden_with_fp16_operands(dev, preset, golden_dir):
     enc.close()
 
 
+def test_vit_layernorm_folding_with_fp16_operands(dev, golden_dir):
+    """fuse_ln = 1 (LayerNorm folded into the neighbouring GEMM epilogues, DESIGN 4.1: W' = lp(gamma * W), column sums of the ROUNDED weights
+    on the host -- `bf16_round` there is the build's operand type) against the same golden fixture."""
+    from vsc_hip.config import get_config
+    from vsc_hip.encoder import HipEncoder
+    g = np.load(f"{golden_dir}/vit_vit_b16_224.npz")
+    cfg = get_config("vit_b16_224")
+    w = synth.encoder_weights(int(g["weights_seed"]), cfg)
+    enc = HipEncoder(cfg, w, max_batch=8, l2_normalize=True, precision="fp16", fuse_ln=1)
+    x = torch.from_numpy(synth.frames(int(g["frames_seed"]), int(g["n_frames"]), cfg)).to(dev)
+    _check("vit/vit_b16_224 fuse_ln", enc(x).cpu().numpy(), g["desc_l2"])
+    enc.close()
+
+
 @pytest.mark.parametrize("preset", ["tiny_swin", "tiny_swin_w8", "tiny_swin_w24", "swinv2_base_256", "swinv2_large_384"])
 def test_swin_matches_golden_with_fp16_operands(dev, preset, golden_dir):
     """Every window-attention kernel (16 x 16 plain / streamed / shifted-streamed, 8 x 8, 24 x 24 and 12 x 12 wide forms), the fused
