@@ -207,3 +207,30 @@ def test_window_attention_with_fp16_operands(dev, res, window, shift, heads):
     # build's test holds 2e-2 / mean 4e-3 at scales around 10.
     torch.testing.assert_close(out, ref, rtol=2 ** -6, atol=2e-2)
     assert (out - ref).abs().mean() < 2e-3
+
+
+def test_fp16_overflow_saturates_instead_of_inf(dev):
+    """A value past fp16's range at a rounding point becomes +-65504, not inf (MODE.FP16_OVFL, csrc/common.h lp_kernel_entry): GEMM
+    write-outs (plain and GELU), the LayerNorm output, and a whole encoder whose fc1 bias drives hidden units to 1e6 -- finite
+    descriptors where inf would turn the next LayerNorm into NaN."""
+    from vsc_hip import _lib, ops
+    from vsc_hip.config import get_config
+    from vsc_hip.encoder import HipEncoder
+    a = torch.full((300, 256), 30.0).half()
+    w = torch.full((128, 256), 10.0).half()
+    w[1] = -10.0
+    with ops.operands("fp16"):
+        out = ops.gemm_bf16(a.to(dev), w.to(dev), None, epilogue=_lib.EPI_BF16).float().cpu()       # 256 * 300 = 76 800 > 65 504
+        gel = ops.gemm_bf16(a.to(dev), w.to(dev), None, epilogue=_lib.EPI_GELU_BF16).float().cpu()
+        big = torch.zeros(4, 768)
+        big[:, 0] = 1.0
+        ln = ops.layernorm(big.to(dev), torch.full((768,), 5000.0).to(dev), torch.zeros(768).to(dev), 1e-6).float().cpu()   # 27.7 * 5000
+    assert torch.isfinite(out).all() and float(out[0, 0]) == 65504.0 and float(out[0, 1]) == -65504.0
+    assert torch.isfinite(gel).all() and float(gel[0, 0]) == 65504.0 and abs(float(gel[0, 1])) < 0.5     # (the GELU polynomial is off by 3.5e-6 |x| at x = -76 800)
+    assert torch.isfinite(ln).all() and float(ln.max()) == 65504.0
+    cfg = get_config("tiny")
+    wts = {k: v.copy() for k, v in synth.encoder_weights(7, cfg).items()}
+    wts["blocks.0.fc1.bias"][:8] = 1.0e6
+    x = torch.from_numpy(synth.frames(11, 3, cfg)).to(dev)
+    d = HipEncoder(cfg, wts, max_batch=4, l2_normalize=True, precision="fp16")(x)
+    assert torch.isfinite(d).all()

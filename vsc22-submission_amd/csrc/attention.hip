@@ -53,6 +53,7 @@ template <int KT, int NI, int ABL = 0>  // key tiles of 32 -> padded token count
 __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__restrict__ qkv,
                                                            uint16_t *__restrict__ out, int tokens,
                                                            int heads, int total, int skew, int ncu) {
+    lp_kernel_entry();
     constexpr int TP = KT * 32;
     // Start skew of the SECOND workgroup of every CU (the first 2 x ncu workgroups start together, two per CU; all have the same
     // duration, so without it the two residents of a CU load together and compute together for the whole launch).
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(512, 2) void attention_kernel(const uint16_t *__res
 template <int KT>
 __global__ __launch_bounds__(1024) void attention_dma_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, int tokens,
                                                              int heads, int total) {
+    lp_kernel_entry();
     typedef __attribute__((address_space(3))) void *lptr_t;
     typedef __attribute__((ext_vector_type(4))) short s16x4_t;
     typedef __attribute__((address_space(3))) s16x4_t *ldstr_t;

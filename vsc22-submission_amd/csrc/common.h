@@ -86,8 +86,8 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
 // either way; fp16 carries 11 significand bits against 8, which is what the end-to-end uAP parity needs (the weights'
 // bf16 rounding alone moves ViT-B/16 descriptors by 1.3e-4 on average, fp16 by 1.6e-5).  Range: the residual stream, LayerNorm,
 // softmax and pooling stay fp32; what is rounded is bounded by LayerNorm gains / GELU / V rows -- the regime these networks were
-// trained in (the reference runs its CLIP tower under fp16 autocast: extract_query_feats.py:159).  Values past 65504 become inf, as
-// under autocast.  The similarity search (knn.hip) and the matching-track convolutions (conv.hip) are bf16 by CONSTRUCTION (their
+// trained in (the reference runs its CLIP tower under fp16 autocast: extract_query_feats.py:159).  Values past 65504 saturate at
+// +-65504 (lp_kernel_entry below; under autocast they would become inf).  The similarity search (knn.hip) and the matching-track convolutions (conv.hip) are bf16 by CONSTRUCTION (their
 // error bounds are derived for it): they define VSC_TU_BF16 and are the same objects in both libraries.
 #if defined(VSC_OPERAND_F16) && !defined(VSC_TU_BF16)
 #define VSC_LP_F16 1
@@ -117,6 +117,10 @@ __device__ __forceinline__ float lp_dot2(uint32_t a, uint32_t b, float c) {   //
     return __builtin_amdgcn_fdot2(*(hw_f16x2_t *)&a, *(hw_f16x2_t *)&b, c, false);
 }
 #define LP_ONE_BITS 0x3C00
+// First statement of every kernel that rounds to the operand type: MODE.FP16_OVFL = 1 -- a conversion that overflows fp16 then yields
+// +-65504 instead of inf (true infinities stay; measured: tools/micro/fp16_ovfl_probe.hip).  A checkpoint whose activations leave
+// fp16's range at some rounding point thereby costs accuracy in that element instead of a NaN descriptor.
+__device__ __forceinline__ void lp_kernel_entry() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
 #else
 #define VSC_LP_F16 0
 #define VSC_LP_NAME "bf16"
@@ -131,6 +135,7 @@ __device__ __forceinline__ float lp_dot2(uint32_t a, uint32_t b, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(*(hw_bf16x2_t *)&a, *(hw_bf16x2_t *)&b, c, false);
 }
 #define LP_ONE_BITS 0x3F80
+__device__ __forceinline__ void lp_kernel_entry() {}
 #endif
 #define LP_ONES ((bf16x8_t){LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS, LP_ONE_BITS})
 

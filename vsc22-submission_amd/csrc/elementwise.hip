@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__
                                                        uint16_t *__restrict__ patches,
                                                        int64_t total_chunks, int channels,
                                                        int image, int patch, int kpad) {
+    lp_kernel_entry();
     const int grid = image / patch;
     const int kc = kpad >> 3;
     const int pp = patch * patch;
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restrict__ src,
                                                           uint16_t *__restrict__ dst, int64_t rows,
                                                           int cols, int cols_pad) {
+    lp_kernel_entry();
     const int64_t total = rows * cols_pad;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
          e += (int64_t)gridDim.x * 256) {
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
                                                         const float *__restrict__ beta,
                                                         void *__restrict__ out, int64_t rows,
                                                         int width, float eps) {
+    lp_kernel_entry();
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -171,6 +174,7 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
 template <bool OUT_F32, int NV>
 __global__ __launch_bounds__(64) void layernorm_light_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                              const float *__restrict__ beta, void *__restrict__ out, float eps) {
+    lp_kernel_entry();
     constexpr int W = NV * 256;
     const uint32_t off = threadIdx.x * 16u;
     const int64_t row = blockIdx.x;
@@ -438,6 +442,7 @@ struct Norm3 {
 __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t *__restrict__ frames, uint16_t *__restrict__ patches,
                                                           int64_t total_chunks, int channels, int image, int patch,
                                                           int kpad, Norm3 nm) {
+    lp_kernel_entry();
     const int grid = image / patch;
     const int kc = kpad >> 3;
     const int pp = patch * patch;

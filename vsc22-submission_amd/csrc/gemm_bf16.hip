@@ -106,6 +106,7 @@ __device__ __forceinline__ float quick_gelu(float x) {
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs p) {
+    lp_kernel_entry();
     __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // A0 W0 A1 W1
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -479,6 +480,7 @@ gelu4(v);
 
 template <int EPI, int WAVES_M, int WAVES_N, int TM, int TN, int STAGES>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(GemmArgs p) {
+    lp_kernel_entry();
     constexpr int NW = WAVES_M * WAVES_N;  // 8: one block per CU, two staggered wave groups;
                                            // 4: two independent blocks per CU (their phases
                                            //    drift apart, so one block's write-out overlaps
@@ -660,6 +662,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64, 2) void gemm_bf16_v2_kernel(
 // LDS-staged write-out as v2.  K % 64 == 0.
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v3_kernel(GemmArgs p) {
+    lp_kernel_entry();
     constexpr int TM = 8, TN = 4;
     extern __shared__ __attribute__((aligned(16))) char lds2[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1085,6 +1088,7 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs &p, f32x4_t (&acc)[8]
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v4_kernel(GemmArgs p) {
+    lp_kernel_entry();
     typedef __attribute__((address_space(3))) void *lptr_t;
     extern __shared__ __attribute__((aligned(16))) char lds2[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1476,6 +1480,7 @@ __device__ unsigned long long g_ln_dbg[8];
 
 template <int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(512, 2) void gemm_ln_kernel(GemmLnArgs p) {
+    lp_kernel_entry();
 #ifdef VSC_GEMM_TIMING
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif

@@ -64,6 +64,7 @@ template <int NT, int ABL = 0>  // 16-key tiles per window: 4 (8x8 window) or 16
 __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
     const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, const float *__restrict__ bias,
     const float *__restrict__ scale, int res, int ws, int shift, int heads) {
+    lp_kernel_entry();
     constexpr int N = NT * 16, NWAVES = NT / 2, NTHREADS = NWAVES * 64;
     // V^T rows: 16-byte aligned, +32 B of padding (conflict-free ds_read_b128 over a 16-lane group's rows); inside a 32-key block
     // the 4-key groups are stored in the order a lane consumes them (group g of the even 16-key tile, then group g of the odd
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(NT * 32, 4) void window_attention_kernel(
 __global__ __launch_bounds__(512, 6) void window_attention_stream_kernel(const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out,
                                                                          const float *__restrict__ bias, const float *__restrict__ scale,
                                                                          int res, int heads) {
+    lp_kernel_entry();
     constexpr int NT = 16, N = 256, NTHREADS = 512, WS = 16, SIDE = 31;
     constexpr int VSTRIDE = N * 2 + 32, TSTRIDE = 36, TCOPY = SIDE * TSTRIDE;
     __shared__ __attribute__((aligned(16))) char smem[N * 64 + HD * VSTRIDE + N * 4 + 4 * TCOPY * 4];
@@ -488,6 +490,7 @@ template <int WS>
 __global__ __launch_bounds__(256, 1) void window_attention_wide_kernel(
     const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, const float *__restrict__ bias,
     const float *__restrict__ scale, int res, int shift, int heads) {
+    lp_kernel_entry();
     constexpr int N = WS * WS, NT = N / 16, NTP = (NT + 1) & ~1, NP = NTP * 16;   // keys padded to whole 32-key PV steps
     constexpr int NTHREADS = 256, NWAVES = 4;   // one wave per SIMD: a 576-key score row is 144 registers of a lane (up to 512 are its own)
     constexpr int SIDE = 2 * WS - 1, VSTRIDE = NP * 2 + 32;
@@ -655,6 +658,7 @@ template <int WS, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 6) void window_attention_wide_stream_kernel(
     const uint16_t *__restrict__ qkv, uint16_t *__restrict__ out, const float *__restrict__ bias,
     const float *__restrict__ scale, int res, int shift, int heads) {
+    lp_kernel_entry();
     constexpr int N = WS * WS, NT = N / 16, NTHREADS = NWAVES * 64, QPW = NT / NWAVES;
     constexpr int SIDE = 2 * WS - 1, VSTRIDE = N * 2 + 32, TSTRIDE = (SIDE + 3 + 3) & ~3, TCOPY = SIDE * TSTRIDE;
     static_assert(N % 32 == 0 && NT % NWAVES == 0 && WS % 4 == 0, "whole 32-key PV steps, whole query tiles per wave, a lane's 4 keys inside one window row");
@@ -843,6 +847,7 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float *__restric
                                                           const float *x_in, float *x_out,
                                                           uint16_t *__restrict__ xb, int64_t rows,
                                                           int width, float eps) {
+    lp_kernel_entry();
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;

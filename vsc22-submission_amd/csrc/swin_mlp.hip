@@ -78,6 +78,7 @@ __device__ __forceinline__ int w2_swz(int row) { return ((row >> 1) & 1) | (((ro
 // (tools/micro/single_wave_issue.hip)
 template <int C, int NW, int ABL = 0, bool PROJ = false, bool SEQ = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void swin_mlp_kernel(MlpArgs p) {
+    lp_kernel_entry();
 #define MFMA(a, b, c) ((ABL & 2) ? (c) + (f32x4_t){(float)(a)[0], (float)(b)[0], 0.f, 0.f} : lp_mfma16(a, b, c))
     constexpr int RW = C == 128 ? 32 : 16, MT = RW / 16, R = NW * RW;
     constexpr int KS1 = C / 32, JO = C / 16, H = 4 * C, HC = 64, NCH = H / HC;

@@ -71,6 +71,7 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 // exist in -DVSC_MLP_ABLATION builds only (make EXTRA=-DVSC_MLP_ABLATION; tools/micro/mlp512_variants.py)
 template <int V>
 __global__ __launch_bounds__(NW * 64, 1) void swin_mlp512_kernel(Mlp512Args p) {
+    lp_kernel_entry();
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float *b1s = (float *)(lds + LDS_B1), *b2s = (float *)(lds + LDS_VEC), *gs = b2s + C, *bs = gs + C;
     const int tid = threadIdx.x, lane = tid & 63;
