@@ -70,3 +70,25 @@ def test_bench_stdout_is_one_line_with_a_process_group():
     assert "all_gather" in d["search"]["metric"] and d["search"]["nr_total"] == 50000
     # configs[3]: score normalisation is in the sharded leg, and the pipelined (shard-by-shard) gather is timed beside the one-gather form
     assert "score normalisation" in d["search"]["metric"] and d["search"]["ms_pipelined"] > 0 and d["search"]["ms_one_gather"] > 0
+
+
+def test_bench_runs_with_world_size_two_on_one_gpu():
+    """`bench.py --gpus 2` under torch.distributed.run with BOTH ranks on the one GPU of the box (--share-device; RCCL refuses two ranks on
+    one device, so the backend is gloo on device tensors): the N > 1 code path -- per-rank frame shards, barrier + max-over-ranks timing, the
+    sharded score-normalised search in its pipelined and one-gather forms, rank 0 alone printing -- executes end to end.  A plumbing check: no
+    scaling claim can be drawn from two ranks time-slicing one GPU (profiles/r06_two_ranks_one_gpu.txt holds a full-size run)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--max-batch", "64",
+           "--search-nq", "2048", "--search-nr", "100000", "--search-steps", "1", "--no-cpu-baseline", "--share-device", "--backend", "gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "shared_device_plumbing_run" in d
+    assert abs(d["value"] - 2 * 64 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01          # whole-job frames over the max-over-ranks time
+    s = d["search"]
+    assert s["n_gpus"] == 2 and s["nr_total"] == 100000 and s["ms_pipelined"] > 0 and s["ms_one_gather"] > 0 and s["form"].startswith("pipelined")
+    assert s["all_gather_bytes_per_rank"] == 50000 * 513 * 4
+    assert "swin" not in d and "fp16_operands" not in d          # secondaries are N = 1 only
