@@ -98,7 +98,14 @@ typedef __attribute__((ext_vector_type(8))) _Float16 hw_f16x8_t;
 __device__ inline uint32_t lp_pack2(float lo, float hi) {          // one v_cvt_pk_f16_f32 (RNE)
     f32x2_t v = {lo, hi};
     hw_f16x2_t b = __builtin_convertvector(v, hw_f16x2_t);
+#ifdef VSC_LP_ACT_MANT
+    // EXPERIMENT (tools/micro/operand_speed_ab.py act): ACTIVATIONS keep only VSC_LP_ACT_MANT explicit significand bits inside their fp16
+    // containers (weights keep all ten: they are rounded by f32_to_lp) -- does the multiplier array's power follow the operands' bit width?
+    constexpr uint32_t DROP = 10 - VSC_LP_ACT_MANT;
+    return (*(uint32_t *)&b + (0x00010001u << (DROP - 1))) & ~(((1u << DROP) - 1u) * 0x00010001u);
+#else
     return *(uint32_t *)&b;
+#endif
 }
 __device__ __host__ inline float lp_to_f32(uint16_t h) {
     union { uint16_t u; _Float16 f; } v;
