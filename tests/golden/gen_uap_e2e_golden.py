@@ -158,9 +158,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cache", default="")
     ap.add_argument("--dry", action="store_true", help="print the numbers, do not write the fixture")
+    ap.add_argument("--large", action="store_true", help="the second fixture (uap_e2e_large.npz): 160 references, 192 queries of which 150 hold copies "
+                    "-- 3.4 x the positives, so one adjacent swap moves the uAP by a third as much; per-frame descriptors are not stored")
     args = ap.parse_args()
     torch.set_num_threads(8)
-    data = synth_videos.make(SEED)
+    sizes = dict(n_ref=160, n_norm=60, n_query=192, n_positive=150) if args.large else {}
+    data = synth_videos.make(SEED + (1 if args.large else 0), **sizes)
     desc = descriptors(data, args.cache)
     cands, pca, kept, low_var_dim = chain(data, desc)
     uap, simple = reference_uap(cands, data["gt"])
@@ -172,15 +175,17 @@ def main():
           sum(len(k) < synth_videos.FRAMES for k in kept.values()))
     if args.dry:
         return
+    extra = {} if args.large else {"desc_swin": desc[0].astype(np.float32), "desc_vit": desc[1].astype(np.float32)}
+    out_path = OUT.replace(".npz", "_large.npz") if args.large else OUT
     np.savez_compressed(
-        OUT, seed=SEED, fingerprint=data["fingerprint"], swin_preset=SWIN_PRESET, swin_weights_seed=SWIN_WEIGHTS,
+        out_path, seed=SEED + (1 if args.large else 0), sizes=np.array([len(data["refs"]), len(data["norm"]), len(data["queries"]), len(data["gt"])]),
+        fingerprint=data["fingerprint"], swin_preset=SWIN_PRESET, swin_weights_seed=SWIN_WEIGHTS,
         vit_preset=VIT_PRESET, vit_weights_seed=VIT_WEIGHTS, pca_mean=pca.mean_.astype(np.float32),
         pca_components=pca.components_.astype(np.float32), pca_explained_variance=pca.explained_variance_.astype(np.float32),
         cand_query=np.array([c[0] for c in cands]), cand_ref=np.array([c[1] for c in cands]),
         cand_score=np.array([c[2] for c in cands], np.float32), uap=uap, simple_ap=simple, low_var_dim=low_var_dim,
-        kept_counts=np.array([len(kept[q]) for q, _ in data["queries"]]),
-        desc_swin=desc[0].astype(np.float32), desc_vit=desc[1].astype(np.float32))
-    print(f"{OUT}: {os.path.getsize(OUT) / 1024:.0f} KiB")
+        kept_counts=np.array([len(kept[q]) for q, _ in data["queries"]]), **extra)
+    print(f"{out_path}: {os.path.getsize(out_path) / 1024:.0f} KiB")
 
 
 if __name__ == "__main__":

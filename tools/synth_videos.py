@@ -96,23 +96,25 @@ def to_u8(x: np.ndarray) -> np.ndarray:
     return np.moveaxis(np.clip(q, 0, 255).astype(np.uint8), -3, -1)
 
 
-def make(seed: int = 2022) -> Dict:
+def make(seed: int = 2022, n_ref: int = None, n_norm: int = None, n_query: int = None, n_positive: int = None) -> Dict:
     """-> {"refs": [(id, u8 [F,S,S,3])], "norm": [...], "queries": [...], "gt": [(query_id, ref_id)], "levels": {query_id: level},
     "fingerprint": hex}.  Ids follow the challenge (Q2xxxxx queries, R2xxxxx references, R1xxxxx the other split's references, which
     the reference normalises scores against: extract_query_feats.py:47-50)."""
-    ref_scenes = scenes(seed * 10 + 1, N_REF * FRAMES).reshape(N_REF, FRAMES, 3, BASE, BASE)
-    norm_scenes = scenes(seed * 10 + 2, N_NORM * FRAMES).reshape(N_NORM, FRAMES, 3, BASE, BASE)
-    q_scenes = scenes(seed * 10 + 3, N_QUERY * FRAMES).reshape(N_QUERY, FRAMES, 3, BASE, BASE)
-    par = synth.uniform(seed * 10 + 4, (N_QUERY, FRAMES, 6)).astype(np.float64)
-    refs = [(f"R2{i:05d}", to_u8(ref_scenes[i])) for i in range(N_REF)]
-    norm = [(f"R1{i:05d}", to_u8(norm_scenes[i])) for i in range(N_NORM)]
+    n_ref, n_norm, n_query, n_positive = (n_ref or N_REF), (n_norm or N_NORM), (n_query or N_QUERY), (n_positive or N_POSITIVE)
+    assert n_positive <= n_query and n_positive <= n_ref and n_ref % 7 != 0      # (the copy walk q -> 7 q + 3 mod n_ref visits every reference once)
+    ref_scenes = scenes(seed * 10 + 1, n_ref * FRAMES).reshape(n_ref, FRAMES, 3, BASE, BASE)
+    norm_scenes = scenes(seed * 10 + 2, n_norm * FRAMES).reshape(n_norm, FRAMES, 3, BASE, BASE)
+    q_scenes = scenes(seed * 10 + 3, n_query * FRAMES).reshape(n_query, FRAMES, 3, BASE, BASE)
+    par = synth.uniform(seed * 10 + 4, (n_query, FRAMES, 6)).astype(np.float64)
+    refs = [(f"R2{i:05d}", to_u8(ref_scenes[i])) for i in range(n_ref)]
+    norm = [(f"R1{i:05d}", to_u8(norm_scenes[i])) for i in range(n_norm)]
     queries, gt, levels = [], [], {}
-    for q in range(N_QUERY):
+    for q in range(n_query):
         qid = f"Q2{q:05d}"
         frames = q_scenes[q].copy()
-        if q < N_POSITIVE:
-            src = (q * 7 + 3) % N_REF                                   # which reference it copies (a permutation walk: 7 and 80 are coprime)
-            level = 0.03 + 0.42 * (q / (N_POSITIVE - 1))                # 0.03 (nearly verbatim) .. 0.45 (zoom to 89 %, 3 x 3 blur, 13 % foreign frame, noise)
+        if q < n_positive:
+            src = (q * 7 + 3) % n_ref                                   # which reference it copies (a permutation walk: 7 and n_ref are coprime)
+            level = 0.03 + 0.42 * (q / (n_positive - 1))                # 0.03 (nearly verbatim) .. 0.45 (zoom to 89 %, 3 x 3 blur, 13 % foreign frame, noise)
             for f in (1, 2):                                            # two of the four frames are copies of reference frames f, f + 1
                 noise = synth.uniform(seed * 1000 + q * 8 + f, (3, BASE, BASE)).astype(np.float64)
                 frames[f] = edit(ref_scenes[src, f], q_scenes[q, f], level, par[q, f], noise)
