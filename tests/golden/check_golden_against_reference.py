@@ -114,6 +114,22 @@ def check_uape2e(_preset: str = "") -> float:
     gen_uap_e2e_golden.py itself: five CPU-minutes.)"""
     import gen_uap_e2e_golden as gen
     from tools import synth_videos
+    if _preset == "large":
+        # uap_e2e_large.npz stores a sample of its descriptors only: those are re-encoded, and the stored candidate list gives the stored uAP
+        # through the reference's average_precision (the chain itself is checked on the small fixture, whose descriptors are all stored)
+        g = np.load(os.path.join(HERE, "uap_e2e_large.npz"))
+        data = synth_videos.make(int(g["seed"]), **dict(zip(("n_ref", "n_norm", "n_query", "n_positive"), (int(v) for v in g["sizes"]))))
+        assert data["fingerprint"] == str(g["fingerprint"])
+        allf = np.concatenate([f for grp in ("refs", "norm", "queries") for _, f in data[grp]])
+        rows = g["sample_rows"]
+        err = 0.0
+        for (model, size), key in zip(gen.reference_models(), ("desc_swin_sample", "desc_vit_sample")):
+            err = max(err, float(np.abs(gen.encode(model, size, allf[rows]) - g[key]).max()))
+        assert err <= ATOL, ("uap_e2e_large descriptors", err)
+        cands = list(zip(g["cand_query"].tolist(), g["cand_ref"].tolist(), g["cand_score"].tolist()))
+        uap, _ = gen.reference_uap(cands, data["gt"])
+        assert abs(uap - float(g["uap"])) < 1e-9
+        return err
     g = np.load(os.path.join(HERE, "uap_e2e.npz"))
     data = synth_videos.make(int(g["seed"]))
     assert data["fingerprint"] == str(g["fingerprint"])
@@ -279,7 +295,7 @@ def check_vsm(preset: str) -> float:
 
 CHECKS = [("swin", check_swin, "tiny_swin"), ("swin", check_swin, "tiny_swin_w8"), ("swin", check_swin, "swinv2_base_256"),
           ("swin", check_swin, "tiny_swin_w24"), ("swin", check_swin, "swinv2_large_384"), ("swinoutlier", check_swinoutlier, "swinv2_base_256"),
-          ("clip", check_clip, "tiny_clip"), ("vit", check_vit, "tiny"), ("vit", check_vit, "vit_b16_224"), ("sscd", check_sscd, "vit_v68"), ("vsm", check_vsm, "tiny_vsm"), ("uape2e", check_uape2e, "chain")]
+          ("clip", check_clip, "tiny_clip"), ("vit", check_vit, "tiny"), ("vit", check_vit, "vit_b16_224"), ("sscd", check_sscd, "vit_v68"), ("vsm", check_vsm, "tiny_vsm"), ("uape2e", check_uape2e, "chain"), ("uape2e", check_uape2e, "large")]
 
 
 def main():

@@ -175,7 +175,9 @@ def main():
           sum(len(k) < synth_videos.FRAMES for k in kept.values()))
     if args.dry:
         return
-    extra = {} if args.large else {"desc_swin": desc[0].astype(np.float32), "desc_vit": desc[1].astype(np.float32)}
+    rows = np.arange(0, len(desc[0]), 67)          # --large: a sample of the per-frame descriptors (every 67th frame), for check_uape2e
+    extra = {"sample_rows": rows, "desc_swin_sample": desc[0][rows].astype(np.float32), "desc_vit_sample": desc[1][rows].astype(np.float32)} if args.large \
+        else {"desc_swin": desc[0].astype(np.float32), "desc_vit": desc[1].astype(np.float32)}
     out_path = OUT.replace(".npz", "_large.npz") if args.large else OUT
     np.savez_compressed(
         out_path, seed=SEED + (1 if args.large else 0), sizes=np.array([len(data["refs"]), len(data["norm"]), len(data["queries"]), len(data["gt"])]),
