@@ -543,7 +543,8 @@ def bench_fp16_operands(dev, args, cfg, weights, frames):
     from vsc_hip.encoder import HipEncoder
     from vsc_hip.swin_config import get_swin_config
     from vsc_hip.swin_encoder import SwinHipEncoder
-    out = {"operands": "fp16", "library": __import__("vsc_hip")._lib.require_device("fp16").vsc_version().decode()}
+    from vsc_hip import _lib
+    out = {"operands": "fp16", "library": _lib.require_device("fp16").vsc_version().decode()}
     enc = HipEncoder(cfg, weights, max_batch=args.max_batch, l2_normalize=True, lanes=args.lanes, precision="fp16")
     steps = max(1, min(args.steps, 40))
     for _ in range(2):
