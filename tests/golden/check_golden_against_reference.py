@@ -235,6 +235,34 @@ def check_vit(preset: str) -> float:
     return float(err)
 
 
+def vit_outlier(preset: str = "vit_b16_224", write: bool = False) -> float:
+    """vit_<preset>_outlier.npz: the reference's own VIT wrapper on `synth.vit_outlier_weights` (a residual channel at ~100 through all
+    blocks, gains x 20, hidden units at 40) and six structured frames.  write=True (re)generates the fixture, else it is compared."""
+    from sklearn.preprocessing import normalize
+    from vsc_hip.config import get_config
+    cfg = get_config(preset)
+    path = os.path.join(HERE, f"vit_{preset}_outlier.npz")
+    wseed, fseed, n = 7, 19, 6
+    model = reference_vit(cfg, synth.vit_outlier_weights(wseed, cfg))
+    taps = {}
+    model.vit.layers[cfg.layers // 2].register_forward_hook(lambda m, i, o: taps.__setitem__("x", o[0] if isinstance(o, tuple) else o))
+    with torch.no_grad():
+        d = normalize(model(_t(synth.structured_frames(fseed, n, cfg))).numpy())
+    if write:
+        c = (d @ d.T)[np.triu_indices(n, 1)]
+        np.savez_compressed(path, weights_seed=wseed, frames_seed=fseed, n_frames=n, desc_l2=d, residual_absmax_mid_network=float(taps["x"].abs().max()))
+        print(f"{path}: cosines {c.min():.3f} .. {c.max():.3f}; |x| max in the middle of the network = {float(taps['x'].abs().max()):.1f}")
+        return 0.0
+    g = np.load(path)
+    err = float(np.abs(d - g["desc_l2"]).max())
+    assert err <= ATOL, (preset, "outlier", err)
+    return err
+
+
+def check_vitoutlier(preset: str) -> float:
+    return vit_outlier(preset)
+
+
 def sscd_head_reference(tokens: torch.Tensor, w: dict, cfg) -> torch.Tensor:
     """The reference's own head of vit_v68 on backbone tokens: `Model.embeddings` with add_head=True =
     Sequential(GlobalGeMPool2d(pool_param, dims), nn.Linear(2048, dims[1])) (sscd.py:25-42, 88-94; the conv width 2048
@@ -295,7 +323,7 @@ def check_vsm(preset: str) -> float:
 
 CHECKS = [("swin", check_swin, "tiny_swin"), ("swin", check_swin, "tiny_swin_w8"), ("swin", check_swin, "swinv2_base_256"),
           ("swin", check_swin, "tiny_swin_w24"), ("swin", check_swin, "swinv2_large_384"), ("swinoutlier", check_swinoutlier, "swinv2_base_256"),
-          ("clip", check_clip, "tiny_clip"), ("vit", check_vit, "tiny"), ("vit", check_vit, "vit_b16_224"), ("sscd", check_sscd, "vit_v68"), ("vsm", check_vsm, "tiny_vsm"), ("uape2e", check_uape2e, "chain"), ("uape2e", check_uape2e, "large")]
+          ("clip", check_clip, "tiny_clip"), ("vit", check_vit, "tiny"), ("vit", check_vit, "vit_b16_224"), ("vitoutlier", check_vitoutlier, "vit_b16_224"), ("sscd", check_sscd, "vit_v68"), ("vsm", check_vsm, "tiny_vsm"), ("uape2e", check_uape2e, "chain"), ("uape2e", check_uape2e, "large")]
 
 
 def main():

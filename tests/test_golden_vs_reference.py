@@ -29,7 +29,7 @@ def _child(code, tmp_path):
 
 @runs_reference_code
 @pytest.mark.parametrize("kind,preset", [("swin", "tiny_swin"), ("swin", "tiny_swin_w8"), ("swin", "swinv2_base_256"), ("swin", "tiny_swin_w24"), ("swinoutlier", "swinv2_base_256"),
-                                         ("clip", "tiny_clip"), ("vit", "tiny"), ("vit", "vit_b16_224"), ("sscd", "vit_v68"), ("vsm", "tiny_vsm"), ("uape2e", "chain"), ("uape2e", "large")])
+                                         ("clip", "tiny_clip"), ("vit", "tiny"), ("vit", "vit_b16_224"), ("vitoutlier", "vit_b16_224"), ("sscd", "vit_v68"), ("vsm", "tiny_vsm"), ("uape2e", "chain"), ("uape2e", "large")])
 def test_fixture_equals_reference_class_output(kind, preset, tmp_path):
     r = _child(f"import check_golden_against_reference as chk; err = chk.check_{kind}({preset!r}); print('ERR', err); "
                f"raise SystemExit(0 if err <= chk.ATOL else 1)", tmp_path)

@@ -71,6 +71,30 @@ def test_encoder_matches_golden_on_frames_that_differ(dev, golden_dir):
     assert np.abs((d @ d.T)[np.triu_indices(len(ref), 1)] - cos).max() < 1e-3      # and the frame-to-frame geometry is the reference's
 
 
+@pytest.mark.parametrize("precision,bound", [("bf16", 1e-3), ("fp16", 2e-4)])
+def test_encoder_outlier_fixture(dev, golden_dir, precision, bound):
+    """Weights with a residual channel riding at ~100 through the whole network (|x| max 104 in the middle), LayerNorm gains x 20, hidden units
+    at 40 (tools/synth.vit_outlier_weights); golden = the reference's own VIT wrapper (check_golden_against_reference.vit_outlier: 0.0).  The
+    default path (explicit fp32 LayerNorm, then the operand rounding) holds its bound in both operand types.  The LayerNorm-FOLDED path
+    (fuse_ln = 1, opt-in) feeds the GEMMs the rounded RAW residual stream: the offset channel's token-to-token variation drowns in the rounding
+    of 100 -- this fixture is why it is not the default; its error is reported, and bounded only loosely."""
+    from vsc_hip.encoder import HipEncoder
+    g = np.load(f"{golden_dir}/vit_vit_b16_224_outlier.npz")
+    cfg = get_config("vit_b16_224")
+    w = synth.vit_outlier_weights(int(g["weights_seed"]), cfg)
+    x = torch.from_numpy(synth.structured_frames(int(g["frames_seed"]), int(g["n_frames"]), cfg)).to(dev)
+    errs = {}
+    for fuse in (0, 1):
+        enc = HipEncoder(cfg, w, max_batch=8, l2_normalize=True, precision=precision, fuse_ln=fuse)
+        d = enc(x).cpu().numpy()
+        enc.close()
+        assert np.isfinite(d).all()
+        errs[fuse] = float(np.abs(d - g["desc_l2"]).max())
+    print(f"{precision} operands, ViT outlier fixture: max |d| {errs[0]:.2e} (explicit LayerNorm), {errs[1]:.2e} (fuse_ln)")
+    assert errs[0] <= bound, errs
+    assert errs[1] <= 5e-2, errs
+
+
 def test_mean_bound_sees_a_one_percent_scale_error(dev, golden_dir):
     """The net itself under test: ONE weight tensor of the HIP encoder off by 1 % (5 % for a bias) passes the 1e-3 maximum bound
     and must FAIL the mean bound of parity_bounds (measured: 1.34e-4 / 1.9e-4 / 1.09e-4 against 1.07e-4)."""

@@ -96,6 +96,24 @@ def encoder_weights(seed: int, cfg) -> dict:
     return w
 
 
+def vit_outlier_weights(seed: int, cfg) -> dict:
+    """`encoder_weights` with what trained ViTs have and random init lacks: ONE residual channel riding at ~100 from the first block on (the
+    "massive activation" channel: a projection bias puts it there, nothing takes it out), LayerNorm gains x 20 in a few channels of every
+    third block, and an fc1 bias that drives a few hidden units deep into GELU's linear range.  Index arithmetic only."""
+    w = {k: v.copy() for k, v in encoder_weights(seed, cfg).items()}
+    d, m = cfg.width, cfg.mlp_dim
+    w["blocks.0.proj.bias"][5 % d] = 100.0
+    for i in range(cfg.layers):
+        b = f"blocks.{i}."
+        if i % 3 == 0:
+            for j in range(3):
+                w[b + "ln1.weight"][(7 + 11 * j + 13 * i) % d] *= 20.0
+                w[b + "ln2.weight"][(3 + 17 * j + 5 * i) % d] *= 20.0
+        if i % 4 == 2:
+            w[b + "fc1.bias"][(19 * i) % m] = 40.0
+    return w
+
+
 def descriptor_bank(seed: int, n: int, dim: int = 512, l2: bool = True) -> np.ndarray:
     """[n, dim] float32 bank; rows L2-normalised like emitted descriptors."""
     x = normalish(seed, (n, dim))
