@@ -21,12 +21,13 @@ def dev():
     return torch.device("cuda:0")
 
 
-def test_vit_encoder_two_lanes_full_chunks(dev):
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_vit_encoder_two_lanes_full_chunks(dev, precision):
     """ViT-B/16 at the benchmarked configuration: 332-frame chunks on two lanes, persistent v4 GEMMs (LDS-DMA ring streaming
-    across tiles), attention, LayerNorm -- 700 frames = two full chunks + a ragged one."""
+    across tiles), attention, LayerNorm -- 700 frames = two full chunks + a ragged one.  Both builds of the library."""
     from vsc_hip.encoder import HipEncoder
     cfg = get_config("vit_b16_224")
-    enc = HipEncoder(cfg, synth.encoder_weights(7, cfg), max_batch=332, l2_normalize=True, lanes=2)
+    enc = HipEncoder(cfg, synth.encoder_weights(7, cfg), max_batch=332, l2_normalize=True, lanes=2, precision=precision)
     base = torch.from_numpy(synth.frames(21, 20, cfg)).to(dev)
     x = (base.repeat(35, 1, 1, 1) + 0.001 * torch.arange(700, device=dev).view(-1, 1, 1, 1)).contiguous()
     first = enc(x).clone()
@@ -78,16 +79,18 @@ def test_range_and_pair_max_sweeps_repeat(dev):
 @pytest.mark.parametrize("name,m,n,k,epi", [("swin s2 fc1", 65536, 2048, 512, "GELU"), ("vit fc1", 65404, 3072, 768, "GELU"),
                                             ("clip fc1", 65535, 4096, 1024, "QGELU"), ("swin s0 qkv (ragged N)", 1048576, 384, 128, "BF16"),
                                             ("vit proj", 65404, 768, 768, "RESADD")])
-def test_persistent_gemm_repeats_and_equals_the_one_tile_kernel(dev, name, m, n, k, epi):
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_persistent_gemm_repeats_and_equals_the_one_tile_kernel(dev, name, m, n, k, epi, precision):
     """The persistent kernel's write-outs at full size: bit-equal to the one-tile-per-workgroup kernel (same K loop, same rounding
     points) and to themselves over 20 launches.  Round 4's first buffer-descriptor write-out stored garbage in ~1 % of the GELU
     tiles, different ones every run (a 16-byte buffer store with a scalar offset whose data register the next pass's first VALU
     instruction overwrote: common.h buffer_store_b128_soff) -- every parity test at small sizes passed."""
     from vsc_hip import _lib, ops
     code = {"GELU": _lib.EPI_GELU_BF16, "QGELU": _lib.EPI_QGELU_BF16, "BF16": _lib.EPI_BF16, "RESADD": _lib.EPI_RESADD_F32}[epi]
+    lp = torch.float16 if precision == "fp16" else torch.bfloat16     # (the fp16 build: v_cvt_pk_f16_f32 in the same write-outs)
     g = torch.Generator(device=dev).manual_seed(11)
-    a = torch.randn(m, k, generator=g, device=dev).to(torch.bfloat16)
-    w = (torch.randn(n, k, generator=g, device=dev) * 0.05).to(torch.bfloat16)
+    a = torch.randn(m, k, generator=g, device=dev).to(lp)
+    w = (torch.randn(n, k, generator=g, device=dev) * 0.05).to(lp)
     b = torch.randn(n, generator=g, device=dev)
     aux0 = torch.randn(m, n, generator=g, device=dev) if epi == "RESADD" else None
 
@@ -95,16 +98,18 @@ def test_persistent_gemm_repeats_and_equals_the_one_tile_kernel(dev, name, m, n,
         aux = aux0.clone() if aux0 is not None else None
         return ops.gemm_bf16(a, w, b, epilogue=code, aux=aux, out=aux).clone()
 
-    with _lib.option("VSC_GEMM_V4", "0"):
-        ref = run()
-    first = run()
-    assert torch.isfinite(first.float()).all()
-    assert torch.equal(first, ref), name
-    for _ in range(20):
-        assert torch.equal(run(), first), name
+    with ops.operands(precision):
+        with _lib.option("VSC_GEMM_V4", "0"):
+            ref = run()
+        first = run()
+        assert torch.isfinite(first.float()).all()
+        assert torch.equal(first, ref), name
+        for _ in range(20):
+            assert torch.equal(run(), first), name
 
 
-def test_swin_mlp512_repeats_at_stage2_size(dev):
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_swin_mlp512_repeats_at_stage2_size(dev, precision):
     """swin_mlp512_kernel (one asm statement with hand-assigned registers and hand-counted waits: csrc/gen_mlp512_loop.py) at Swin-V2-B's
     stage-2 size, 256 frames = 65 536 rows + a ragged tile: five launches from the same input, bit for bit.  A missing wait state or
     a too-early barrier shows as a difference between runs long before it shows in a tolerance."""
@@ -116,11 +121,12 @@ def test_swin_mlp512_repeats_at_stage2_size(dev):
     w2, b2 = torch.randn(c, 4 * c, generator=g) * (4 * c) ** -0.5, torch.randn(c, generator=g) * 0.2
     gam, bet = 0.3 + 0.05 * torch.randn(c, generator=g), 0.05 * torch.randn(c, generator=g)
     xd = x0.to(dev)
-    first, first_b = ops.swin_mlp_bf16(xd, w1, b1, w2, b2, gam, bet, 1e-5)
-    assert torch.isfinite(first).all()
-    for _ in range(REPEATS):
-        y, yb = ops.swin_mlp_bf16(xd, w1, b1, w2, b2, gam, bet, 1e-5)
-        assert torch.equal(y, first) and torch.equal(yb, first_b)
+    with ops.operands(precision):
+        first, first_b = ops.swin_mlp_bf16(xd, w1, b1, w2, b2, gam, bet, 1e-5)
+        assert torch.isfinite(first).all()
+        for _ in range(REPEATS):
+            y, yb = ops.swin_mlp_bf16(xd, w1, b1, w2, b2, gam, bet, 1e-5)
+            assert torch.equal(y, first) and torch.equal(yb, first_b)
 
 
 def test_matching_networks_repeat_at_the_benchmarked_batches(dev):
