@@ -1,3 +1,6 @@
+"""Max / mean |descriptor - fixture| of every golden fixture (tests/golden: outputs of the reference's own classes) through both builds of
+the library: bf16 operands (libvsc_hip.so) and fp16 operands (libvsc_hip_f16.so).  Run on the GPU box: python tools/micro/operand_precision_probe.py
+-> profiles/r06_operand_precision_probe.txt"""
 import sys, os, numpy as np, torch
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/vsc22-submission_amd')
 from tools import synth
