@@ -26,6 +26,13 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 (kernels{}) and the roofline of its GEMM launches (gemm_ln_kernel + gemm_bf16_v4 / v3 / v2).
   matching      secondary: the matching track's fp32 networks (pair classifier, HRNet refinement net), maps/s and the
                 fraction of the fp32 MFMA peak.
+  fp16_operands secondary (round 6): the same ViT step and the Swin-V2-B step through libvsc_hip_f16.so -- the build whose MFMA
+                operands are IEEE fp16 instead of bf16 (same kernels; what the infer/ entry points default to because the end-to-end
+                uAP parity needs it).  `value` above stays the bf16 configuration BASELINE.json names.
+  ensemble      secondary: the reference's whole query-side workload from uint8 host frames, at the entry points' default operand
+                type (fp16), `value_bf16_operands` beside it.
+  search.cpu_baseline.oracle_check_of_the_timed_result: rows of the timed 1M x 1M result compared with oracle/knn_oracle.c, bit for bit.
+With --share-device --backend gloo the N > 1 path runs with several ranks on one GPU (plumbing check; RCCL refuses that).
 """
 import argparse
 import json
