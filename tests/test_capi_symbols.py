@@ -131,3 +131,30 @@ def test_lds_layouts_are_conflict_free():
                    for ct in range(2) for u in range(tp // 32)) == 4
     # and the old V^T row stride (2 TP + 8 bytes) is what a b128 read could NOT have used: misaligned rows
     assert (224 * 2 + 8) % 16 != 0
+
+
+def test_operand_type_plumbing_refuses_what_does_not_exist():
+    """`precision` names a build of the library: anything but "bf16" / "fp16" is refused before any device work, and a library whose
+    vsc_operand_dtype() is not the requested one (a misplaced or stale build) is refused at load."""
+    from vsc_hip import _lib, ops
+    with pytest.raises(ValueError, match="precision must be one of"):
+        _lib.load("fp8")
+    with pytest.raises(AssertionError):
+        ops.operands("fp8")
+    assert set(_lib.LIB_PATHS) == {"bf16", "fp16"}
+    saved = dict(_lib.LIB_PATHS)
+    try:
+        _lib._libs.pop("fp16", None)
+        _lib.LIB_PATHS["fp16"] = saved["bf16"]          # the bf16 library under the fp16 name
+        with pytest.raises(_lib.HipPathUnavailable, match="reports operand type bf16"):
+            _lib.load("fp16")
+    finally:
+        _lib.LIB_PATHS.update(saved)
+        _lib._libs.pop("fp16", None)
+    assert _lib.load("fp16").vsc_operand_dtype() == b"fp16" and _lib.load("bf16").vsc_operand_dtype() == b"bf16"
+    with ops.operands("fp16"):
+        import torch
+        assert ops.lp_dtype() == torch.float16
+    assert ops.lp_dtype() == torch.bfloat16
+    from src.model_zoo import DEFAULT_PRECISION
+    assert DEFAULT_PRECISION == "fp16"
