@@ -97,8 +97,8 @@ def main(args):
         from vsc_hip.video_score import VideoScoreHead, from_reference_state
         clip, _ = load_encoder("clip_vit_l14_224", "clip", args.clip_checkpoint, args.max_batch, u8_norm=(CLIP_MEAN, CLIP_STD),
                                precision=args.precision)
-        state = torch.load(args.vsm_checkpoint, map_location="cpu")
-        scorer = VideoScorer(clip, VideoScoreHead("vsm_roberta_base", from_reference_state(state.get("state_dict", state))), device)
+        from src.model_zoo import _state_dict      # a plain / training checkpoint or the TorchScript archive the reference ships (vsm.torchscript.pt)
+        scorer = VideoScorer(clip, VideoScoreHead("vsm_roberta_base", from_reference_state(_state_dict(args.vsm_checkpoint))), device)
     videos = zip_videos(vids, args.zip_prefix, sorted({size for _, size in encoders}), with_clip=scorer is not None,
                         workers=args.workers)
     finals, per_model = run_query_videos(videos, encoders, pca.transform, scores, device, score_threshold=args.score_threshold,
