@@ -125,7 +125,7 @@ def parse():
     ap.add_argument("--no-fp16", action="store_true", help="skip the fp16-operand secondary (libvsc_hip_f16.so)")
     ap.add_argument("--no-matching", action="store_true")
     ap.add_argument("--no-ensemble", action="store_true")
-    ap.add_argument("--ensemble-videos", type=int, default=52, help="query videos (40 frames each; then once more with 10 .. 70 frames each: ensemble.ragged_lengths) of the end-to-end ensemble secondary")
+    ap.add_argument("--ensemble-videos", type=int, default=208, help="query videos (40 frames each; then once more with 10 .. 70 frames each: ensemble.ragged_lengths) of the end-to-end ensemble secondary")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 launch (nccl = RCCL; gloo only for the "
                     "--share-device plumbing run)")
     ap.add_argument("--share-device", action="store_true",

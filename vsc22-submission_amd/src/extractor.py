@@ -6,7 +6,7 @@ builds it (infer/src/dataset.py:145-153).
 
 The reference encodes loader batch by loader batch (two videos: ~100 frames per call, a synchronous pageable upload in front and a
 device -> host copy behind every one).  Here the valid frames of consecutive loader batches are collected, on the host, into groups of
->= `group_frames` frames and go through `src.query_pipeline.encode_group`: pinned staging + a copy stream, encoder calls of the
+>= `group_frames` frames (4 096: the ragged last chunk of a group is then a percent of it) and go through `src.query_pipeline.encode_group`: pinned staging + a copy stream, encoder calls of the
 backbone's aligned chunk, one device -> host copy per group.  A frame's descriptor does not depend on WHICH frames share its call, but
 the encoders choose kernels by a call's row count (Swin-V2's 512-wide stage: the one-launch second half from 77 frames per chunk on, GEMM
 launches below; the ViT's persistent GEMMs need more tiles than CUs) and the two forms round in different orders: the same frame in a
@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 
-def extract_vsc_feat(model, batches: Iterable, device, group_frames: int = 2048) -> Tuple[List[str], np.ndarray, np.ndarray]:
+def extract_vsc_feat(model, batches: Iterable, device, group_frames: int = 4096) -> Tuple[List[str], np.ndarray, np.ndarray]:
     from src.query_pipeline import encode_group
     feats, vids, stamps = [], [], []
     group, have = [], 0
