@@ -24,11 +24,27 @@ def extract_vsc_feat(model, batches: Iterable, device, group_frames: int = 4096)
     from src.query_pipeline import encode_group
     feats, vids, stamps = [], [], []
     group, have = [], 0
+    pending = None      # the previous group's descriptors, still on the device
+
+    def collect():
+        nonlocal pending
+        if pending is not None:
+            feats.append(torch.cat(pending).cpu().numpy() if len(pending) > 1 else pending[0].cpu().numpy())
+            pending = None
 
     def flush():
-        nonlocal group, have
+        # One group of look-ahead (round 6): a group's uploads and launches are QUEUED here (device tensors back, no wait); its descriptors
+        # are copied back when the next group has been queued behind it -- so the loader's next batches are collated while this group is
+        # encoded, instead of behind it.  On the CPU (host-logic tests with fake encoders) nothing is asynchronous and nothing changes.
+        nonlocal group, have, pending
         if group:
-            feats.extend(encode_group([model], group, device)[0])
+            on_gpu = torch.device(device).type == "cuda"
+            outs = encode_group([model], group, device, as_numpy=not on_gpu)[0]
+            collect()
+            if on_gpu:
+                pending = [o for o in outs if o.shape[0] > 0]
+            else:
+                feats.extend(outs)
         group, have = [], 0
 
     for frames, mask, video_id in batches:
@@ -45,6 +61,7 @@ def extract_vsc_feat(model, batches: Iterable, device, group_frames: int = 4096)
         if have >= group_frames:
             flush()
     flush()
+    collect()
     if not stamps:
         return [], np.zeros((0, 0), np.float32), np.zeros((0,), np.int64)
     if not feats:
