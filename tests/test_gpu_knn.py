@@ -753,6 +753,17 @@ def test_concat_pca_sn_entry_point(dev, tmp_path):
             np.testing.assert_allclose(merged[v].feature, fitted.transform(cat), rtol=1e-4, atol=2e-5)
         sn = load_features(str(tmp_path / f"{name}_sn.npz"))
         assert all(vf.feature.shape[1] == 16 for vf in sn)   # one low-variance dim replaced by the bias column
+    # the videos of a block go through the normalisation and the PCA together: the same bits as one video at a time, for any block size
+    from src.query_postprocess import HipPCA
+    pca = HipPCA(fitted)
+    paths = [str(tmp_path / m / "train_refs.npz") for m in models]
+    whole = C.merge_set(paths, pca.transform)
+    for rows in (1, 7, 14):
+        part = C.merge_set(paths, pca.transform, block_rows=rows)
+        assert [v.video_id for v in part] == [v.video_id for v in whole]
+        assert all(np.array_equal(a.feature, b.feature) and np.array_equal(a.timestamps, b.timestamps) for a, b in zip(part, whole))
+    per_video = [pca.transform(np.concatenate([C.HipOps.normalize(raw[(m, "train_refs")][vi].feature) for m in models], axis=1)) for vi in range(3)]
+    assert all(np.array_equal(a.feature, b) for a, b in zip(whole, per_video))
 
 
 def test_search_scratch_release(dev):

@@ -30,10 +30,32 @@ def concat_models(per_model_features, ops=HipOps):
     return vids, [np.concatenate([ops.normalize(m[v].feature) for m in per_model_features], axis=1) for v in vids]
 
 
-def merge_set(paths, pca_transform, ops=HipOps):
+BLOCK_ROWS = 1 << 18   # frames per device round trip of merge_set (x 2048 floats of concatenated descriptors = 2 GiB)
+
+
+def merge_set(paths, pca_transform, ops=HipOps, block_rows: int = None):
+    """Per video: normalise every model's rows, concatenate, PCA (concat_pca_sn.py:56-68).  The reference does this video by video on the
+    host; video by video through the GPU it was one host -> device -> host round trip per video and model plus one for the PCA -- 200 k of
+    them for the track's 40 k reference videos.  Row normalisation and the PCA product are row-wise, so the videos of a BLOCK go through
+    them together (one round trip per model and block, one for the PCA) and are cut apart again: the same per-row arithmetic, the same
+    bits (tests/test_gpu_knn.py::test_concat_pca_sn_entry_point compares the two forms)."""
     models = [{vf.video_id: vf for vf in load_features(p)} for p in paths]
-    vids, cats = concat_models(models, ops)
-    return [VideoFeature(video_id=v, feature=pca_transform(c), timestamps=models[0][v].timestamps) for v, c in zip(vids, cats)]
+    vids = list(models[0].keys())
+    lens = [len(models[0][v].feature) for v in vids]
+    out, lo = [], 0
+    limit = block_rows or BLOCK_ROWS
+    while lo < len(vids):
+        hi, rows = lo, 0
+        while hi < len(vids) and (hi == lo or rows + lens[hi] <= limit):
+            rows += lens[hi]
+            hi += 1
+        block = vids[lo:hi]
+        cat = np.concatenate([ops.normalize(np.concatenate([m[v].feature for v in block])) for m in models], axis=1)
+        reduced = np.asarray(pca_transform(cat))
+        cuts = np.cumsum([lens[i] for i in range(lo, hi)])[:-1]
+        out.extend(VideoFeature(video_id=v, feature=f, timestamps=models[0][v].timestamps) for v, f in zip(block, np.split(reduced, cuts)))
+        lo = hi
+    return out
 
 
 def main(args):
