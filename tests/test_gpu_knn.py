@@ -688,6 +688,13 @@ def test_eval_entry_point_end_to_end(dev, tmp_path):
         want = np.concatenate([f, -1.2 * D[:, :1]], axis=1)
         np.testing.assert_allclose(qn.feature, want, rtol=0, atol=2e-6)
     assert all(r.feature.shape[1] == dim and (r.feature[:, -1] == 1).all() for r in r2)
+    # the videos are normalised a block at a time (normalize_videos): the same bits as video by video, for any block size, empty videos included
+    plus_empty = queries + [VideoFeature("Q000099", np.arange(0.0), np.zeros((0, dim), np.float32))]
+    one_by_one = sn.transform_features(plus_empty[:-1], sn.normalize)
+    for rows in (1, 13, 1 << 20):
+        blocks = sn.normalize_videos(plus_empty, block_rows=rows)
+        assert len(blocks) == len(plus_empty) and blocks[-1].feature.shape == (0, dim)
+        assert all(np.array_equal(a.feature, b.feature) for a, b in zip(blocks, one_by_one))
     with pytest.raises(Exception, match="against VSC rules"):
         sn.score_normalize(queries, refs, refs)
 
