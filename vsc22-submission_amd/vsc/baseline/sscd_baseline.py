@@ -36,17 +36,14 @@ def search(queries: List[VideoFeature], refs: List[VideoFeature], retrieve_per_q
 def localize_and_verify(queries: List[VideoFeature], refs: List[VideoFeature], candidates: List[CandidatePair],
                         localize_per_query: float = 5.0, score_normalization: bool = False, model=None) -> List[Match]:
     """sscd_baseline.py:107-152: the best `localize_per_query * len(queries)` candidates, aligned in batches of 512."""
-    from sklearn.preprocessing import normalize
-
-    from src.matching import transform_features
     from vsc.baseline.localization import VCSLLocalizationCandidateScore, VCSLLocalizationMaxSim
     candidates = candidates[: int(len(queries) * localize_per_query)]
     if score_normalization:
         alignment = VCSLLocalizationMaxSim(queries, refs, model_type="TN", tn_max_step=5, min_length=4, concurrency=16,
                                            similarity_bias=0.5, model=model)
     else:
-        alignment = VCSLLocalizationCandidateScore(transform_features(queries, normalize),
-                                                   transform_features(refs, normalize), model_type="TN",
+        from vsc.baseline.score_normalization import normalize_videos      # row-wise, a block of videos per device round trip
+        alignment = VCSLLocalizationCandidateScore(normalize_videos(queries), normalize_videos(refs), model_type="TN",
                                                    tn_max_step=5, min_length=4, concurrency=16, model=model)
     matches: List[Match] = []
     logger.info("Aligning %s candidate pairs", len(candidates))
